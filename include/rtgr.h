@@ -1,0 +1,207 @@
+/*
+ * rtgr.h — C ABI of the MI355X-native geodesic ray tracer (librtgr_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of eschnett/RayTraceGR.jl: the per-pixel
+ * geodesic integration + object intersection + colouring that the reference performs in
+ *
+ *     trace_rays(metric, objs::Vector{Object{T}}, c::Canvas{T})   src/RayTraceGR.jl:482-536
+ *
+ * i.e. everything between building the EnsembleProblem (:488-509), the
+ * `solve(probs, Tsit5(), callback=cb, trajectories=N, reltol=tol, abstol=tol)` call (:510-511) and the
+ * colouring loop (:513-533), plus the camera that feeds it (make_canvas, :457-478) and the legacy
+ * single-ray shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:65-79).
+ *
+ * Every entry point is plain C: pointers, sizes, PODs.  No torch / C++ types cross this line.
+ * A Julia `ccall`, a Python `ctypes` or a C caller bind exactly these symbols.
+ *
+ * Conventions
+ *  - Coordinates are (t, x, y, z); D = 4 (src/RayTraceGR.jl:253-254).
+ *  - A ray state is 8 scalars (x^a, u^a) — `r2s(Ray{T}(x,u))` (src/RayTraceGR.jl:345-347).
+ *  - Pixels are indexed as the reference's column-major `pixels[i,j]`: linear index i + j*ni (0-based),
+ *    i fastest.  A slab is the j-range [j0, j1); its local linear index is i + (j-j0)*ni.
+ *  - RGB output is three planes (SoA) of n = ni*(j1-j0) scalars each: rgb[c*n + idx]
+ *    (what `colorview(RGB, R', G', B')` consumes, src/RayTraceGR.jl:566-569).
+ *  - All functions return 0 on success and a negative rtgr_status on failure; they never throw or abort.
+ *    The message of the last failure on the calling thread is rtgr_last_error().
+ *  - The library never keeps a caller pointer after a call returns.
+ */
+#ifndef RTGR_H
+#define RTGR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTGR_ABI_VERSION 1
+#define RTGR_MAX_OBJECTS 16
+
+/* ---- return codes -------------------------------------------------------------------------------------- */
+enum rtgr_status {
+    RTGR_OK = 0,
+    RTGR_ERR_BAD_ARG = -1,     /* null pointer, bad enum, empty/oversized range ...                           */
+    RTGR_ERR_NO_DEVICE = -2,   /* no usable HIP device; the library has NO CPU fallback                       */
+    RTGR_ERR_HIP = -3,         /* a HIP runtime call failed (message has the hipError string)                 */
+    RTGR_ERR_NAN_INPUT = -4,   /* NaN in an input ray — the reference's `@assert !any(isnan,…)` (:279)        */
+    RTGR_ERR_NOT_INIT = -5
+};
+
+/* ---- metric: replaces the `metric` callable argument (src/RayTraceGR.jl:262-264, :274-294) -------------- */
+enum rtgr_metric {
+    RTGR_MINKOWSKI = 0, /* minkowski(x)                                           src/RayTraceGR.jl:262-264   */
+    RTGR_KS_REF = 1,    /* kerr_schild(x) exactly AS WRITTEN, r = sqrt(rho^2-a^2)/2 + sqrt(a^2 z^2+((rho^2-a^2)/2)^2)
+                           (src/RayTraceGR.jl:284); the reference hard-wires M=1, a=0 (:275-276)               */
+    RTGR_KS_TRUE = 2    /* textbook Kerr–Schild radius r^2 = (q + sqrt(q^2 + 4 a^2 z^2))/2, q = rho^2 - a^2
+                           (no reference counterpart; needed for a != 0 configs)                               */
+};
+
+/* ---- objects: replaces Vector{Object{T}} (src/RayTraceGR.jl:374-428); ORDER MATTERS (:518-530) ---------- */
+enum rtgr_object_kind {
+    RTGR_PLANE = 1,  /* Plane{T}(time)            p[0] = time                     src/RayTraceGR.jl:394-404  */
+    RTGR_SPHERE = 2, /* Sphere{T}(pos, vel, radius)  p[0..3]=pos  p[4..7]=vel (unused, :411)  p[8]=radius     */
+    RTGR_DISK = 3    /* thin disk (no reference counterpart): p[0]=half thickness h, p[1]=r_in, p[2]=r_out;
+                        distance = max(|z|-h, r_in-rho_cyl, rho_cyl-r_out) obeying the contract at :377-383    */
+};
+
+typedef struct rtgr_object {
+    uint32_t kind; /* rtgr_object_kind */
+    uint32_t reserved;
+    double p[9];
+} rtgr_object;
+
+typedef struct rtgr_scene {
+    uint32_t metric; /* rtgr_metric */
+    uint32_t nobj;   /* 0..RTGR_MAX_OBJECTS */
+    double M;        /* mass  (reference: 1, :275) */
+    double a;        /* spin  (reference: 0, :276) */
+    rtgr_object obj[RTGR_MAX_OBJECTS];
+} rtgr_scene;
+
+/* ---- solver constants (src/RayTraceGR.jl:485, :497, :510-511, :519, :528; OrdinaryDiffEq 5.38 defaults) -- */
+typedef struct rtgr_solver {
+    double reltol;        /* eps(T)^(3/4)                                       :485               */
+    double abstol;        /* eps(T)^(3/4)                                       :485               */
+    double lambda0;       /* 0                                                  :497               */
+    double lambda1;       /* 100                                                :497               */
+    double hit_threshold; /* 0.01                                               :519               */
+    double miss_rgb[3];   /* (1,0,0)                                            :528               */
+    uint32_t max_steps;   /* step-attempt cap per ray (reference: maxiters, never binds)           */
+    uint32_t interp_points; /* ContinuousCallback interp_points = 10 (DiffEqBase 6.35 default)      */
+} rtgr_solver;
+
+/* ---- camera: arguments of make_canvas (src/RayTraceGR.jl:458-462) ---------------------------------------- */
+typedef struct rtgr_camera {
+    double pos[4];
+    double widthx[4];
+    double widthy[4];
+    double normal[4];
+} rtgr_camera;
+
+/* ---- per-ray status byte (the reference ignores solver retcodes, :502-505; we report them) -------------- */
+enum rtgr_ray_status {
+    RTGR_RAY_EVENT = 0,     /* terminated by the ContinuousCallback (terminate!, :489)      */
+    RTGR_RAY_LAMBDA1 = 1,   /* reached lambda1 without an event                              */
+    RTGR_RAY_MAXSTEPS = 2,  /* hit max_steps                                                 */
+    RTGR_RAY_DTMIN = 3,     /* step size underflow                                           */
+    RTGR_RAY_NAN = 4        /* state became non-finite                                       */
+};
+
+/* ---- counters accumulated over a call (8 x uint64) -------------------------------------------------------- */
+typedef struct rtgr_counters {
+    uint64_t rays;
+    uint64_t accepted;        /* accepted Tsit5 steps                                         */
+    uint64_t rejected;        /* rejected Tsit5 step attempts                                 */
+    uint64_t rhs_evals;       /* geodesic RHS evaluations actually executed                   */
+    uint64_t events;          /* rays terminated by an event                                  */
+    uint64_t events_interior; /* events found only by the interior dense-output sample points */
+    uint64_t not_finished;    /* rays with status >= RTGR_RAY_MAXSTEPS                        */
+    uint64_t reserved;
+} rtgr_counters;
+
+/* optional per-ray outputs; any member may be NULL.  Device or host pointers according to the call. */
+typedef struct rtgr_ray_outputs {
+    void* state_end;      /* n x 8 scalars (AoS)  — `sols.u[i]` (src/RayTraceGR.jl:516)                    */
+    void* lambda_end;     /* n scalars            — `sol.t[end]` (:503)                                     */
+    uint8_t* status;      /* n x rtgr_ray_status                                                            */
+    uint8_t* hit;         /* n: omin of the colouring rule (0 = miss, else 1-based object index, :518-526)  */
+    uint32_t* n_accept;   /* n: accepted steps per ray                                                      */
+    uint32_t* n_reject;   /* n: rejected attempts per ray                                                   */
+} rtgr_ray_outputs;
+
+/* ---- lifecycle --------------------------------------------------------------------------------------------- */
+/* Select the HIP device this process drives (one process per GPU). device < 0 means "current device". */
+int rtgr_init(int device);
+int rtgr_shutdown(void);
+const char* rtgr_last_error(void);
+int rtgr_abi_version(void);
+/* Fill `s` with the reference's constants for T = Float64 (is_f32 = 0) or Float32 (is_f32 = 1). */
+int rtgr_solver_defaults(rtgr_solver* s, int is_f32);
+/* Name / CU count / clock of the active device, for bench reports. */
+int rtgr_device_info(char* name, uint64_t name_len, int* n_cu, int* clock_mhz, int* wavefront);
+
+/* ---- the hot path, device-resident buffers ------------------------------------------------------------------
+ * Replaces the body of trace_rays (src/RayTraceGR.jl:482-536) for rows j in [j0, j1) of an ni x nj canvas.
+ *   d_state0 : n x 8 initial ray states on the DEVICE (n = ni*(j1-j0)), as `input_func(i)` yields (:492-496),
+ *              or NULL — then rays are generated on the device from `cam` exactly as make_canvas does (:464-476).
+ *   d_rgb    : 3*n scalars on the device, plane-major (required).
+ *   out      : optional per-ray device outputs.
+ *   d_counters : optional device pointer to one rtgr_counters; the call ADDS to it (caller zeroes it).
+ *   stream   : hipStream_t to enqueue on (NULL = default stream).  The call is asynchronous: it only enqueues.
+ */
+int rtgr_trace_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* d_state0,
+                          const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1,
+                          double* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
+int rtgr_trace_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const float* d_state0,
+                          const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1,
+                          float* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
+
+/* ---- the hot path, host buffers (what a Julia ccall would pass) ---------------------------------------------
+ * Same semantics with HOST pointers; the library stages through its own device buffers and blocks until done.
+ *   state0 may be NULL (device-side make_canvas from `cam`).  `ctr` (host, optional) is overwritten.
+ */
+int rtgr_trace_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* state0, const rtgr_camera* cam,
+                   uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, double* rgb, const rtgr_ray_outputs* out,
+                   rtgr_counters* ctr);
+int rtgr_trace_f32(const rtgr_scene* scene, const rtgr_solver* opt, const float* state0, const rtgr_camera* cam,
+                   uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, float* rgb, const rtgr_ray_outputs* out,
+                   rtgr_counters* ctr);
+
+/* Accepts the reference's own pixel array: `pointer(c.pixels)` of an Array{Pixel{Float64},2} — 11 doubles per
+ * pixel (pos 4, normal 4, rgb 3; src/RayTraceGR.jl:446-450), column-major ni x nj.  Traces every pixel and
+ * writes rgb back into the same AoS layout of `pixels_out` (may alias pixels_in), as trace_rays does (:532). */
+int rtgr_trace_pixels_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in, uint64_t ni,
+                          uint64_t nj, double* pixels_out, rtgr_counters* ctr);
+
+/* Legacy single-ray shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:76): one pixel in, rgb out. */
+int rtgr_trace_one_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
+                       const double normal[4], double rgb[3], double state_end[8], uint8_t* status);
+
+/* ---- camera: make_canvas (src/RayTraceGR.jl:457-478) on the device ------------------------------------------
+ * Writes n x 8 ray states (pos, null past-directed 4-velocity) for rows [j0, j1).  Device / host variants. */
+int rtgr_make_canvas_device_f64(const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
+                                uint64_t j0, uint64_t j1, double* d_state0, void* stream);
+int rtgr_make_canvas_f64(const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                         uint64_t j1, double* state0);
+
+/* ---- physics kernels exposed for parity tests (test/runtests.jl:12-61 exercises exactly these) -------------
+ * Evaluated ON THE DEVICE for n points (host pointers in/out):
+ *   g   : n x 16  metric g_ab            (minkowski / kerr_schild, :262-294)
+ *   dg  : n x 64  dg[a][b][c] = d_c g_ab (dmetric, :302-313)
+ *   Gam : n x 64  Gamma^a_bc             (christoffel, :321-331)
+ * Any output may be NULL. */
+int rtgr_eval_metric_f64(const rtgr_scene* scene, const double* x /* n x 4 */, uint64_t n, double* g, double* dg,
+                         double* Gam);
+/* geodesic RHS (src/RayTraceGR.jl:358-370): n x 8 states -> n x 8 derivatives, on the device.
+ * path = 0: production path (Kerr–Schild-form closed contraction), 1: generic dual-number path. */
+int rtgr_eval_geodesic_f64(const rtgr_scene* scene, const double* s /* n x 8 */, uint64_t n, int path,
+                           double* ds /* n x 8 */);
+
+/* ---- image output: N0f8 quantisation + transposed PNG layout of `save(file, colorview(...))` (:566-575) ---- */
+/* rgb planes (n = ni*nj, device pointer) -> 8-bit interleaved image[j][i][c] (device pointer, 3*n bytes). */
+int rtgr_quantize_device_f64(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGR_H */

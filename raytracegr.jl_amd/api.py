@@ -1,0 +1,326 @@
+"""Host-side mirror of RayTraceGR.jl's interface for the hot path, over the C ABI of include/rtgr.h.
+
+The reference's host language is Julia, which is absent from this image; this module plays the role of the thin
+Julia `ccall` layer (julia/RayTraceGRHIP.jl ships the actual Julia stub): same names, argument meaning and error
+behaviour as the reference's exported API, so tests read like the reference's own.
+
+    reference (src/RayTraceGR.jl)                       here
+    ------------------------------------------------   --------------------------------------------------
+    minkowski, kerr_schild            :258-294          minkowski, kerr_schild  (+ KerrSchild(M, a, textbook))
+    dmetric, christoffel, geodesic    :298-370          dmetric, christoffel, geodesic   (evaluated on the GPU)
+    Object / Plane / Sphere           :374-428          Plane, Sphere (+ Disk)
+    Pixel / Canvas / make_canvas      :445-478          Pixel (numpy record), Canvas, make_canvas
+    trace_rays(metric, objs, canvas)  :482-536          trace_rays(metric, objs, canvas) -> Canvas
+    trace_ray(metric, objs, cb, p)    test/runtests.jl:76   trace_ray(metric, objs, cb, p) -> Pixel
+    example1(), example2()            :542-612          example1(), example2()  (write scenes/sphere*.png)
+
+Nothing here computes physics on the CPU: every numeric result comes from librtgr_hip.so (HIP kernels).
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import rtgr_camera, rtgr_counters, rtgr_ray_outputs, rtgr_scene, rtgr_solver
+
+D = 4  # src/RayTraceGR.jl:253-254
+
+
+# ---- metrics (callables only as identities: the ABI takes an enum) ---------------------------------
+class Metric:
+    """A built-in metric: enum + (M, a). Calling it evaluates g_ab(x) on the GPU (src/RayTraceGR.jl:262-294)."""
+
+    def __init__(self, kind, M=1.0, a=0.0, name="metric"):
+        self.kind, self.M, self.a, self.__name__ = int(kind), float(M), float(a), name
+
+    def __call__(self, x):
+        g, _, _ = _eval_metric(self, x, want=(True, False, False))
+        return g
+
+    def __repr__(self):
+        return f"{self.__name__}(M={self.M}, a={self.a})"
+
+
+minkowski = Metric(_abi.MINKOWSKI, name="minkowski")          # src/RayTraceGR.jl:262-264
+kerr_schild = Metric(_abi.KS_REF, 1.0, 0.0, name="kerr_schild")  # as written: M=1, a=0 (:275-276), r of :284
+
+
+def KerrSchild(M=1.0, a=0.0, textbook=True):
+    """Parameterised Kerr–Schild metric the reference describes (README "varying mass and spin") but does not
+    have: textbook radius (RTGR_KS_TRUE) or the as-written radius with a != 0 (RTGR_KS_REF)."""
+    return Metric(_abi.KS_TRUE if textbook else _abi.KS_REF, M, a, name="KerrSchild")
+
+
+# ---- objects (src/RayTraceGR.jl:374-428) ------------------------------------------------------------------------
+class Object:
+    kind = 0
+
+    def _pack(self):
+        raise NotImplementedError("Called distance on abstract object")  # :384-386
+
+
+class Plane(Object):
+    """Plane{T}(time)  src/RayTraceGR.jl:394-397"""
+    kind = _abi.PLANE
+
+    def __init__(self, time):
+        self.time = float(time)
+
+    def _pack(self):
+        return [self.time] + [0.0] * 8
+
+
+class Sphere(Object):
+    """Sphere{T}(pos, vel, radius)  src/RayTraceGR.jl:409-413 (vel is stored and unused, as in the reference)"""
+    kind = _abi.SPHERE
+
+    def __init__(self, pos, vel, radius):
+        self.pos = [float(v) for v in pos]
+        self.vel = [float(v) for v in vel]
+        self.radius = float(radius)
+        assert len(self.pos) == D and len(self.vel) == D
+
+    def _pack(self):
+        return self.pos + self.vel + [self.radius]
+
+
+class Disk(Object):
+    """Thin disk |z| <= h, r_in <= sqrt(x^2+y^2) <= r_out. No reference counterpart (BASELINE config 5)."""
+    kind = _abi.DISK
+
+    def __init__(self, half_thickness, r_in, r_out):
+        self.h, self.r_in, self.r_out = float(half_thickness), float(r_in), float(r_out)
+
+    def _pack(self):
+        return [self.h, self.r_in, self.r_out] + [0.0] * 6
+
+
+def make_scene(metric, objs):
+    """(metric, objs::Vector{Object}) -> rtgr_scene (order of objs preserved: it matters, :518-530)."""
+    if not isinstance(metric, Metric):
+        raise TypeError(
+            "only the built-in metrics (minkowski, kerr_schild, KerrSchild(M,a)) cross the C ABI; an arbitrary "
+            "metric callable has to stay on the reference's CPU path (SURVEY §8b)")
+    objs = list(objs)
+    if len(objs) > _abi.RTGR_MAX_OBJECTS:
+        raise ValueError(f"at most {_abi.RTGR_MAX_OBJECTS} objects")
+    sc = rtgr_scene()
+    sc.metric, sc.nobj, sc.M, sc.a = metric.kind, len(objs), metric.M, metric.a
+    for o, obj in enumerate(objs):
+        sc.obj[o].kind = obj.kind
+        p = obj._pack()
+        for q in range(9):
+            sc.obj[o].p[q] = p[q]
+    return sc
+
+
+def solver_defaults(dtype=np.float64, **over):
+    """tol = eps(T)^(3/4), λ∈[0,100], hit threshold 0.01, miss colour (1,0,0)  (src/RayTraceGR.jl:485,:497,:519,:528).
+    Pure constants — filled here so that building a solver struct does not need the GPU library."""
+    s = rtgr_solver()
+    tol = float(np.finfo(dtype).eps) ** 0.75
+    s.reltol = s.abstol = tol
+    s.lambda0, s.lambda1 = 0.0, 100.0
+    s.hit_threshold = 0.01
+    s.miss_rgb[0], s.miss_rgb[1], s.miss_rgb[2] = 1.0, 0.0, 0.0
+    s.max_steps = 100000
+    s.interp_points = 10
+    for k, v in over.items():
+        if k == "miss_rgb":
+            for c in range(3):
+                s.miss_rgb[c] = float(v[c])
+        else:
+            setattr(s, k, v)
+    return s
+
+
+def make_camera(pos, widthx, widthy, normal):
+    cam = rtgr_camera()
+    for a in range(D):
+        cam.pos[a], cam.widthx[a], cam.widthy[a], cam.normal[a] = (float(pos[a]), float(widthx[a]),
+                                                                   float(widthy[a]), float(normal[a]))
+    return cam
+
+
+# ---- Pixel / Canvas (src/RayTraceGR.jl:445-455) -----------------------------------------------------------------
+def pixel_dtype(dtype=np.float64):
+    """Pixel{T}: pos (4), normal (4), rgb (3) — isbits, 88 bytes for Float64 (:446-450)."""
+    return np.dtype([("pos", dtype, 4), ("normal", dtype, 4), ("rgb", dtype, 3)])
+
+
+def Pixel(pos, normal, rgb=(0.0, 0.0, 0.0), dtype=np.float64):
+    p = np.zeros((), dtype=pixel_dtype(dtype))
+    p["pos"], p["normal"], p["rgb"] = pos, normal, rgb
+    return p
+
+
+class Canvas:
+    """Canvas{T}(pixels::Array{Pixel{T},2}) — `pixels` is stored column-major like Julia: pixels[i, j] with i fastest
+    (numpy array of shape (ni, nj), order='F')."""
+
+    def __init__(self, pixels):
+        self.pixels = pixels
+
+    @property
+    def shape(self):
+        return self.pixels.shape
+
+    def rgb_planes(self):
+        """(R, G, B) each (ni, nj) — what `T[p.rgb[c] for p in canvas.pixels]` yields (:566-569)."""
+        return tuple(np.asfortranarray(self.pixels["rgb"][..., c]) for c in range(3))
+
+    def image_u8(self):
+        """8-bit image[j, i, c] as `save(file, colorview(RGB, R', G', B'))` writes it (:566-575; N0f8 rounding)."""
+        rgb = np.stack(self.rgb_planes(), axis=-1)  # [i, j, c]
+        img = np.rint(np.clip(rgb, 0.0, 1.0) * 255.0).astype(np.uint8)
+        return np.ascontiguousarray(np.transpose(img, (1, 0, 2)))
+
+
+def _lib():
+    lib = _abi.load()
+    return lib
+
+
+def make_canvas(metric, pos, widthx, widthy, normal, ni, nj):
+    """make_canvas(metric, pos, widthx, widthy, normal, ni, nj)::Canvas  (src/RayTraceGR.jl:457-478), on the GPU."""
+    lib = _lib()
+    sc = make_scene(metric, [])
+    cam = make_camera(pos, widthx, widthy, normal)
+    st = np.empty((ni * nj, 8), dtype=np.float64)
+    _abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
+    px = np.zeros((ni, nj), dtype=pixel_dtype(), order="F")
+    flat = px.reshape(-1, order="F")
+    flat["pos"] = st[:, :4]
+    flat["normal"] = st[:, 4:]
+    return Canvas(px)
+
+
+def trace_rays(metric, objs, c, opt=None, return_info=False):
+    """trace_rays(metric, objs, c::Canvas)::Canvas  (src/RayTraceGR.jl:482-536).
+
+    Passes the reference's own AoS pixel array across the ABI (rtgr_trace_pixels_f64) and returns a NEW canvas
+    with pos/normal copied and rgb set (:532).  Pure, like the reference."""
+    lib = _lib()
+    sc = make_scene(metric, objs)
+    opt = opt or solver_defaults()
+    ni, nj = c.pixels.shape
+    pin = np.asfortranarray(c.pixels)
+    if pin.dtype != pixel_dtype():
+        raise TypeError("Canvas{Float64} expected")
+    pout = np.empty_like(pin, order="F")
+    ctr = rtgr_counters()
+    _abi.check(lib, lib.rtgr_trace_pixels_f64(C.byref(sc), C.byref(opt), pin.ctypes.data, ni, nj,
+                                              pout.ctypes.data, C.byref(ctr)))
+    out = Canvas(pout)
+    return (out, ctr.as_dict()) if return_info else out
+
+
+def trace_ray(metric, objs, cb, p, opt=None):
+    """Legacy single-pixel shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:65-79).
+    `cb` is accepted for signature parity and ignored: the callback is always
+    ContinuousCallback(min_distance(objs, ·), terminate!) (src/RayTraceGR.jl:488-490)."""
+    lib = _lib()
+    sc = make_scene(metric, objs)
+    opt = opt or solver_defaults()
+    pos = np.ascontiguousarray(p["pos"], dtype=np.float64)
+    nrm = np.ascontiguousarray(p["normal"], dtype=np.float64)
+    rgb = np.zeros(3)
+    se = np.zeros(8)
+    st = C.c_uint8(0)
+    _abi.check(lib, lib.rtgr_trace_one_f64(C.byref(sc), C.byref(opt), pos.ctypes.data, nrm.ctypes.data,
+                                           rgb.ctypes.data, se.ctypes.data, C.addressof(st)))
+    return Pixel(pos, nrm, rgb)
+
+
+# ---- physics kernels for the reference's unit tests (test/runtests.jl:12-61), evaluated on the GPU ------------
+def _eval_metric(metric, x, want=(True, True, True)):
+    lib = _lib()
+    sc = make_scene(metric, [])
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 4)
+    n = x.shape[0]
+    g = np.empty((n, 4, 4)) if want[0] else None
+    dg = np.empty((n, 4, 4, 4)) if want[1] else None
+    G = np.empty((n, 4, 4, 4)) if want[2] else None
+    _abi.check(lib, lib.rtgr_eval_metric_f64(C.byref(sc), x.ctypes.data, n, g.ctypes.data if want[0] else None,
+                                             dg.ctypes.data if want[1] else None,
+                                             G.ctypes.data if want[2] else None))
+    sq = (lambda v: v[0] if (v is not None and n == 1) else v)
+    return sq(g), sq(dg), sq(G)
+
+
+def dmetric(metric, x):
+    """dmetric(metric, x) -> (g[a,b], dg[a,b,c] = ∂_c g_ab)  (src/RayTraceGR.jl:302-313)"""
+    g, dg, _ = _eval_metric(metric, x, (True, True, False))
+    return g, dg
+
+
+def christoffel(metric, x):
+    """christoffel(metric, x) -> Γ[a,b,c] = Γ^a_bc  (src/RayTraceGR.jl:321-331)"""
+    return _eval_metric(metric, x, (False, False, True))[2]
+
+
+def geodesic(s, metric, lam=0.0, path=0):
+    """geodesic(s::SVector{8}, metric, λ) -> ṡ  (src/RayTraceGR.jl:367-370); λ is ignored as in the reference."""
+    lib = _lib()
+    sc = make_scene(metric, [])
+    s = np.ascontiguousarray(s, dtype=np.float64).reshape(-1, 8)
+    ds = np.empty_like(s)
+    _abi.check(lib, lib.rtgr_eval_geodesic_f64(C.byref(sc), s.ctypes.data, s.shape[0], path, ds.ctypes.data))
+    return ds[0] if ds.shape[0] == 1 else ds
+
+
+# ---- example scenes (src/RayTraceGR.jl:542-612) -------------------------------------------------------------------
+outdir = "scenes"  # :540
+
+
+def example1_scene():
+    """Scene of example1(): Minkowski, sky R=-10, plane t=-20, sphere R=1/2 at the origin; camera (0,0,-2,0)
+    (src/RayTraceGR.jl:545-557).  Returns (metric, objs, camera_args)."""
+    caelum = Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10)
+    frustum = Plane(-20)
+    sphere = Sphere((0, 0, 0, 0), (1, 0, 0, 0), 0.5)
+    cam = dict(pos=(0, 0, -2, 0), widthx=(0, 1, 0, 0), widthy=(0, 0, 0, 1), normal=(0, 0, 1, 0))
+    return minkowski, [caelum, frustum, sphere], cam
+
+
+def example2_scene(metric=None):
+    """Scene of example2(): kerr_schild, sky R=-10, plane t=-20, sphere R=1/2 at (0,4,0,0); camera (0,4,-2,0)
+    (src/RayTraceGR.jl:581-593)."""
+    caelum = Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10)
+    frustum = Plane(-20)
+    sphere = Sphere((0, 4, 0, 0), (1, 0, 0, 0), 0.5)
+    cam = dict(pos=(0, 4, -2, 0), widthx=(0, 1, 0, 0), widthy=(0, 0, 0, 1), normal=(0, 0, 1, 0))
+    return (metric or kerr_schild), [caelum, frustum, sphere], cam
+
+
+def _run_example(scene, ni, nj, fname, save):
+    from .png import write_png
+    metric, objs, cam = scene
+    canvas = make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], ni, nj)
+    canvas = trace_rays(metric, objs, canvas)
+    if save:
+        os.makedirs(outdir, exist_ok=True)
+        file = os.path.join(outdir, fname)
+        if os.path.exists(file):
+            os.remove(file)
+        print(f'Output file is "{file}"')
+        write_png(file, canvas.image_u8())
+    return canvas
+
+
+def example1(ni=200, nj=200, save=True):
+    """example1()  src/RayTraceGR.jl:542-576"""
+    return _run_example(example1_scene(), ni, nj, "sphere.png", save)
+
+
+def example2(ni=200, nj=200, save=True):
+    """example2()  src/RayTraceGR.jl:578-612"""
+    return _run_example(example2_scene(), ni, nj, "sphere2.png", save)
+
+
+__all__ = ["D", "Metric", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
+           "make_scene", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
+           "trace_rays", "trace_ray", "dmetric", "christoffel", "geodesic", "example1", "example2",
+           "example1_scene", "example2_scene"]
