@@ -1,0 +1,362 @@
+// rtgr_physics.hpp — device-side physics of the geodesic hot path (gfx950 / CDNA4, wave64).
+//
+// What the reference computes per RHS evaluation (src/RayTraceGR.jl:358-370 -> :321-331 -> :302-313 -> :274-294):
+// forward-mode duals through the metric, a 4x4 inverse, 64 Christoffel symbols, and the contraction
+// u̇^a = -Γ^a_bc u^b u^c.  Two device formulations live here:
+//
+//  * ksform_rhs  (production): both built-in metrics are of Kerr–Schild form g = η + f k⊗k with k_t = 1 and no
+//    t-dependence.  The Jacobian of (f, k_i) is propagated in registers by the chain rule through the two
+//    intermediates (r, z) — the same first-order information the reference's Dual{T,SVector{4}} carries — and the
+//    Christoffel contraction is done BEFORE raising, using the Sherman–Morrison inverse
+//    g^{-1} = η^{-1} - f k♯k♯ / (1 + f k·η^{-1}·k).  No 4x4x4 array is ever formed.
+//  * generic_rhs (validation / API parity): 4-wide forward duals through an arbitrary metric functor, symmetric
+//    g (10) and dg (40), cofactor inverse, contract-then-raise.  This is the "lean generic-metric" form whose flop
+//    count (814) defines the algorithmic work in SURVEY §8(d).  It also feeds rtgr_eval_metric_f64 (g, dg, Γ).
+//
+// Everything is templated on the scalar R (double for the reference's Float64 path, float for config C4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtgr.h"
+
+namespace rtgr {
+
+#define RTGR_DEV __device__ __forceinline__
+
+template <class R>
+struct DevObject {
+    uint32_t kind;
+    uint32_t pad;
+    R p[9];
+};
+
+template <class R>
+struct DevScene {
+    uint32_t metric;
+    uint32_t nobj;
+    R M, a;
+    DevObject<R> obj[RTGR_MAX_OBJECTS];
+};
+
+template <class R>
+struct DevSolver {
+    R reltol, abstol, lambda0, lambda1, hit_threshold;
+    R miss_rgb[3];
+    uint32_t max_steps, interp_points;
+};
+
+template <class R>
+struct DevCamera {
+    R pos[4], widthx[4], widthy[4], normal[4];
+};
+
+// ---- small math helpers -------------------------------------------------------------------------------------------
+template <class R> RTGR_DEV R rfma(R a, R b, R c);
+template <> RTGR_DEV double rfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> RTGR_DEV float rfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <class R> RTGR_DEV R rsqrt_(R x);
+template <> RTGR_DEV double rsqrt_<double>(double x) { return __builtin_sqrt(x); }
+template <> RTGR_DEV float rsqrt_<float>(float x) { return __builtin_sqrtf(x); }
+template <class R> RTGR_DEV R rabs(R x) { return x < R(0) ? -x : x; }
+template <> RTGR_DEV double rabs<double>(double x) { return __builtin_fabs(x); }
+template <> RTGR_DEV float rabs<float>(float x) { return __builtin_fabsf(x); }
+template <class R> RTGR_DEV R rmax(R a, R b) { return a > b ? a : b; }  // operands are never NaN where used
+template <class R> RTGR_DEV R rmin(R a, R b) { return a < b ? a : b; }
+// Julia sign(): ±1, 0 -> 0 (NaN handled by callers)
+template <class R> RTGR_DEV R rsign(R v) { return v > R(0) ? R(1) : (v < R(0) ? R(-1) : R(0)); }
+
+// ---- Kerr–Schild-form field: f, ∇f, k_i, ∂_j k_i at a spatial point ----------------------------------------------
+template <class R>
+struct KSField {
+    R f, df[3];      // f, ∂_j f
+    R k[3];          // k_x, k_y, k_z   (k_t = 1)
+    R dk[3][3];      // dk[i][j] = ∂_j k_i
+};
+
+// METRIC: RTGR_KS_REF — kerr_schild as written (src/RayTraceGR.jl:283-289, r of :284) — or RTGR_KS_TRUE.
+// SPIN = false is the reference's actual configuration (a = 0 hard-wired, :276) and drops the a-terms statically.
+template <class R, int METRIC, bool SPIN>
+RTGR_DEV void ks_field(R x, R y, R z, R M, R a, KSField<R>& F) {
+    const R a2 = SPIN ? a * a : R(0);
+    const R rho2 = rfma(x, x, rfma(y, y, z * z));
+    R r, rq2, rz;  // r, 2*∂r/∂q (so that ∇r = rq2*(x,y,z) + rz*ẑ), explicit ∂r/∂z
+    if constexpr (METRIC == RTGR_KS_REF) {
+        if constexpr (SPIN) {
+            // r = sqrt(q)/2 + sqrt(a² z² + (q/2)²),  q = ρ² - a²                                     :284
+            const R q = rho2 - a2;
+            const R s1 = rsqrt_(q);
+            const R hq = R(0.5) * q;
+            const R s2 = rsqrt_(rfma(a2 * z, z, hq * hq));
+            r = rfma(R(0.5), s1, s2);
+            const R is1 = R(1) / s1, is2 = R(1) / s2;
+            rq2 = R(0.5) * rfma(q, is2, is1);  // 2*(1/(4 s1) + q/(4 s2))
+            rz = a2 * z * is2;
+        } else {
+            // a = 0: r = ρ/2 + ρ²/2
+            const R rho = rsqrt_(rho2);
+            r = R(0.5) * (rho + rho2);
+            rq2 = rfma(R(0.5), R(1) / rho, R(1));  // ∇r = (1/(2ρ) + 1)(x,y,z)
+            rz = R(0);
+        }
+    } else {
+        if constexpr (SPIN) {
+            // textbook: r² = (q + sqrt(q² + 4a²z²))/2
+            const R q = rho2 - a2;
+            const R s = rsqrt_(rfma(q, q, R(4) * a2 * z * z));
+            const R r2 = R(0.5) * (q + s);
+            r = rsqrt_(r2);
+            const R is = R(1) / s, ir = R(1) / r;
+            rq2 = R(0.5) * rfma(q, is, R(1)) * ir;  // 2 * (1+q/s)/2 / (2r)
+            rz = a2 * z * is * ir;
+        } else {
+            r = rsqrt_(rho2);  // a = 0: r = ρ
+            rq2 = R(1) / r;
+            rz = R(0);
+        }
+    }
+    const R dr[3] = {rq2 * x, rq2 * y, rfma(rq2, z, rz)};
+    const R r2 = r * r;
+    if constexpr (SPIN) {
+        // f = 2M r³/(r⁴ + a² z²)                                                                   :285
+        const R a2z = a2 * z;
+        const R den = rfma(r2, r2, a2z * z);
+        const R iden = R(1) / den;
+        const R r3 = r2 * r;
+        const R tm = R(2) * M;
+        F.f = tm * r3 * iden;
+        // ∂f/∂r = 2M r²(3 den − 4 r⁴)/den² ;  ∂f/∂z|_r = −2M r³ 2a²z/den²
+        const R fr = tm * r2 * rfma(R(3), den, R(-4) * r2 * r2) * iden * iden;
+        const R fz = R(-2) * F.f * a2z * iden;
+        F.df[0] = fr * dr[0];
+        F.df[1] = fr * dr[1];
+        F.df[2] = rfma(fr, dr[2], fz);
+        // k = ((r x + a y), (r y − a x))/(r² + a²),  z/r                                           :286-289
+        const R w = R(1) / (r2 + a2);
+        const R ir = R(1) / r;
+        F.k[0] = rfma(r, x, a * y) * w;
+        F.k[1] = rfma(r, y, -a * x) * w;
+        F.k[2] = z * ir;
+        const R kxr = w * rfma(R(-2) * r, F.k[0], x);  // ∂k_x/∂r
+        const R kyr = w * rfma(R(-2) * r, F.k[1], y);
+        const R kzr = -F.k[2] * ir;
+        const R rw = r * w, aw = a * w;
+        F.dk[0][0] = rfma(kxr, dr[0], rw);  F.dk[0][1] = rfma(kxr, dr[1], aw);  F.dk[0][2] = kxr * dr[2];
+        F.dk[1][0] = rfma(kyr, dr[0], -aw); F.dk[1][1] = rfma(kyr, dr[1], rw);  F.dk[1][2] = kyr * dr[2];
+        F.dk[2][0] = kzr * dr[0];           F.dk[2][1] = kzr * dr[1];           F.dk[2][2] = rfma(kzr, dr[2], ir);
+    } else {
+        // a = 0: f = 2M/r, k_i = x_i/r
+        const R ir = R(1) / r;
+        F.f = R(2) * M * ir;
+        const R fr = -F.f * ir;
+        F.df[0] = fr * dr[0]; F.df[1] = fr * dr[1]; F.df[2] = fr * dr[2];
+        F.k[0] = x * ir; F.k[1] = y * ir; F.k[2] = z * ir;
+        const R c0 = -F.k[0] * ir, c1 = -F.k[1] * ir, c2 = -F.k[2] * ir;  // ∂k_i/∂r = −x_i/r²
+        F.dk[0][0] = rfma(c0, dr[0], ir); F.dk[0][1] = c0 * dr[1];          F.dk[0][2] = c0 * dr[2];
+        F.dk[1][0] = c1 * dr[0];          F.dk[1][1] = rfma(c1, dr[1], ir); F.dk[1][2] = c1 * dr[2];
+        F.dk[2][0] = c2 * dr[0];          F.dk[2][1] = c2 * dr[1];          F.dk[2][2] = rfma(c2, dr[2], ir);
+    }
+}
+
+// u̇^a = −Γ^a_bc u^b u^c for g = η + f k⊗k (k_t = 1, stationary).  Replaces christoffel + the contraction of
+// geodesic (src/RayTraceGR.jl:321-331, :361-363) without forming Γ.  pos = (x,y,z), u = (u^t,u^x,u^y,u^z).
+template <class R>
+RTGR_DEV void ksform_accel(const KSField<R>& F, const R u[4], R ud[4]) {
+    const R ut = u[0], ux = u[1], uy = u[2], uz = u[3];
+    const R K = rfma(F.k[0], ux, rfma(F.k[1], uy, rfma(F.k[2], uz, ut)));          // k_a u^a
+    const R Df = rfma(F.df[0], ux, rfma(F.df[1], uy, F.df[2] * uz));               // u·∇f
+    R Dk[3], W[3];
+    for (int i = 0; i < 3; i++) Dk[i] = rfma(F.dk[i][0], ux, rfma(F.dk[i][1], uy, F.dk[i][2] * uz));  // u^j ∂_j k_i
+    for (int d = 0; d < 3; d++) W[d] = rfma(F.dk[0][d], ux, rfma(F.dk[1][d], uy, F.dk[2][d] * uz));   // u^i ∂_d k_i
+    const R A = rfma(ux, Dk[0], rfma(uy, Dk[1], uz * Dk[2]));                      // u^b u^c ∂_b k_c
+    const R P = rfma(K, Df, F.f * A);                                              // L_t
+    const R fK = F.f * K, hK2 = R(-0.5) * K * K;
+    R L[3];
+    for (int i = 0; i < 3; i++) L[i] = rfma(F.k[i], P, rfma(fK, Dk[i] - W[i], hK2 * F.df[i]));
+    const R kk = rfma(F.k[0], F.k[0], rfma(F.k[1], F.k[1], F.k[2] * F.k[2]));
+    const R S = F.f / rfma(F.f, kk - R(1), R(1));                                  // f/(1 + f(|k|²−1))
+    const R kL = rfma(F.k[0], L[0], rfma(F.k[1], L[1], rfma(F.k[2], L[2], -P)));   // k♯^d L_d, k♯ = (−1, k_i)
+    const R SkL = S * kL;
+    ud[0] = P - SkL;
+    for (int i = 0; i < 3; i++) ud[1 + i] = rfma(F.k[i], SkL, -L[i]);
+}
+
+// geodesic RHS, production path.  s = (x^a, u^a) -> (u^a, u̇^a)                       src/RayTraceGR.jl:358-370
+template <class R, int METRIC, bool SPIN>
+RTGR_DEV void rhs(const R s[8], R M, R a, R ds[8]) {
+    ds[0] = s[4]; ds[1] = s[5]; ds[2] = s[6]; ds[3] = s[7];
+    if constexpr (METRIC == RTGR_MINKOWSKI) {
+        ds[4] = ds[5] = ds[6] = ds[7] = R(0);  // Γ ≡ 0
+    } else {
+        KSField<R> F;
+        ks_field<R, METRIC, SPIN>(s[1], s[2], s[3], M, a, F);
+        ksform_accel<R>(F, s + 4, ds + 4);
+    }
+}
+
+// ---- generic forward-mode path ----------------------------------------------------------------------------------------
+// Dual{T,SVector{4,T}} (src/RayTraceGR.jl:11-14) on the device: value + 4 partials, in registers.
+template <class R>
+struct DDual {
+    R v, e[4];
+};
+template <class R> RTGR_DEV DDual<R> dconst(R v) { return DDual<R>{v, {R(0), R(0), R(0), R(0)}}; }
+template <class R> RTGR_DEV DDual<R> operator+(const DDual<R>& x, const DDual<R>& y) {
+    DDual<R> r; r.v = x.v + y.v; for (int i = 0; i < 4; i++) r.e[i] = x.e[i] + y.e[i]; return r; }
+template <class R> RTGR_DEV DDual<R> operator-(const DDual<R>& x, const DDual<R>& y) {
+    DDual<R> r; r.v = x.v - y.v; for (int i = 0; i < 4; i++) r.e[i] = x.e[i] - y.e[i]; return r; }
+template <class R> RTGR_DEV DDual<R> operator+(const DDual<R>& x, R a) { DDual<R> r = x; r.v = x.v + a; return r; }
+template <class R> RTGR_DEV DDual<R> operator-(const DDual<R>& x, R a) { DDual<R> r = x; r.v = x.v - a; return r; }
+template <class R> RTGR_DEV DDual<R> operator*(const DDual<R>& x, const DDual<R>& y) {
+    DDual<R> r; r.v = x.v * y.v; for (int i = 0; i < 4; i++) r.e[i] = rfma(x.e[i], y.v, x.v * y.e[i]); return r; }
+template <class R> RTGR_DEV DDual<R> operator*(R a, const DDual<R>& x) {
+    DDual<R> r; r.v = a * x.v; for (int i = 0; i < 4; i++) r.e[i] = a * x.e[i]; return r; }
+template <class R> RTGR_DEV DDual<R> operator*(const DDual<R>& x, R a) { return a * x; }
+template <class R> RTGR_DEV DDual<R> operator/(const DDual<R>& x, const DDual<R>& y) {
+    const R iy = R(1) / y.v; DDual<R> r; r.v = x.v * iy;
+    for (int i = 0; i < 4; i++) r.e[i] = rfma(-r.v, y.e[i], x.e[i]) * iy; return r; }
+template <class R> RTGR_DEV DDual<R> dsqrt(const DDual<R>& x) {
+    DDual<R> r; r.v = rsqrt_(x.v); const R c = R(0.5) / r.v; for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+
+// metric(x::SVector{4,Dual}) for the built-ins; symmetric result gd[a][b], a<=b filled for all (a,b)
+template <class R>
+RTGR_DEV void metric_dual(uint32_t metric, R M, R a, const DDual<R> xx[4], DDual<R> g[4][4]) {
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; q < 4; q++) g[p][q] = dconst<R>(p == q ? (p == 0 ? R(-1) : R(1)) : R(0));   // η  :263,:282
+    if (metric == RTGR_MINKOWSKI) return;
+    const DDual<R>&x = xx[1], &y = xx[2], &z = xx[3];
+    const R a2 = a * a;
+    DDual<R> rho2 = x * x + y * y + z * z;                                                          // :283
+    DDual<R> r;
+    if (metric == RTGR_KS_REF) {
+        DDual<R> q = rho2 - a2;
+        DDual<R> hq = R(0.5) * q;
+        r = R(0.5) * dsqrt(q) + dsqrt(a2 * (z * z) + hq * hq);                                      // :284
+    } else {
+        DDual<R> q = rho2 - a2;
+        r = dsqrt(R(0.5) * (q + dsqrt(q * q + (R(4) * a2) * (z * z))));
+    }
+    DDual<R> r2 = r * r;
+    DDual<R> f = ((R(2) * M) * (r2 * r)) / (r2 * r2 + a2 * (z * z));                                // :285
+    DDual<R> k[4];
+    DDual<R> den = r2 + a2;
+    k[0] = dconst<R>(R(1));                                                                         // :286-289
+    k[1] = (r * x + a * y) / den;
+    k[2] = (r * y - a * x) / den;
+    k[3] = z / r;
+    for (int p = 0; p < 4; p++)
+        for (int q = p; q < 4; q++) {
+            g[p][q] = g[p][q] + f * k[p] * k[q];                                                    // :291
+            g[q][p] = g[p][q];
+        }
+}
+
+template <class R>
+RTGR_DEV void inv4sym(const R m[4][4], R o[4][4]) {  // cofactor inverse (StaticArrays closed form)
+    const R s0 = m[0][0] * m[1][1] - m[1][0] * m[0][1], s1 = m[0][0] * m[1][2] - m[1][0] * m[0][2];
+    const R s2 = m[0][0] * m[1][3] - m[1][0] * m[0][3], s3 = m[0][1] * m[1][2] - m[1][1] * m[0][2];
+    const R s4 = m[0][1] * m[1][3] - m[1][1] * m[0][3], s5 = m[0][2] * m[1][3] - m[1][2] * m[0][3];
+    const R c5 = m[2][2] * m[3][3] - m[3][2] * m[2][3], c4 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+    const R c3 = m[2][1] * m[3][2] - m[3][1] * m[2][2], c2 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+    const R c1 = m[2][0] * m[3][2] - m[3][0] * m[2][2], c0 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+    const R id = R(1) / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+    o[0][0] = (m[1][1] * c5 - m[1][2] * c4 + m[1][3] * c3) * id;
+    o[0][1] = (-m[0][1] * c5 + m[0][2] * c4 - m[0][3] * c3) * id;
+    o[0][2] = (m[3][1] * s5 - m[3][2] * s4 + m[3][3] * s3) * id;
+    o[0][3] = (-m[2][1] * s5 + m[2][2] * s4 - m[2][3] * s3) * id;
+    o[1][0] = (-m[1][0] * c5 + m[1][2] * c2 - m[1][3] * c1) * id;
+    o[1][1] = (m[0][0] * c5 - m[0][2] * c2 + m[0][3] * c1) * id;
+    o[1][2] = (-m[3][0] * s5 + m[3][2] * s2 - m[3][3] * s1) * id;
+    o[1][3] = (m[2][0] * s5 - m[2][2] * s2 + m[2][3] * s1) * id;
+    o[2][0] = (m[1][0] * c4 - m[1][1] * c2 + m[1][3] * c0) * id;
+    o[2][1] = (-m[0][0] * c4 + m[0][1] * c2 - m[0][3] * c0) * id;
+    o[2][2] = (m[3][0] * s4 - m[3][1] * s2 + m[3][3] * s0) * id;
+    o[2][3] = (-m[2][0] * s4 + m[2][1] * s2 - m[2][3] * s0) * id;
+    o[3][0] = (-m[1][0] * c3 + m[1][1] * c1 - m[1][2] * c0) * id;
+    o[3][1] = (m[0][0] * c3 - m[0][1] * c1 + m[0][2] * c0) * id;
+    o[3][2] = (-m[3][0] * s3 + m[3][1] * s1 - m[3][2] * s0) * id;
+    o[3][3] = (m[2][0] * s3 - m[2][1] * s1 + m[2][2] * s0) * id;
+}
+
+// dmetric (src/RayTraceGR.jl:302-313): g[a][b], dg[a][b][c] = ∂_c g_ab
+template <class R>
+RTGR_DEV void dmetric_dev(uint32_t metric, R M, R a, const R x[4], R g[4][4], R dg[4][4][4]) {
+    DDual<R> xdx[4], gd[4][4];
+    for (int p = 0; p < 4; p++) {
+        xdx[p] = dconst<R>(x[p]);
+        xdx[p].e[p] = R(1);
+    }
+    metric_dual<R>(metric, M, a, xdx, gd);
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; q < 4; q++) {
+            g[p][q] = gd[p][q].v;
+            for (int c = 0; c < 4; c++) dg[p][q][c] = gd[p][q].e[c];
+        }
+}
+
+// generic RHS: contract-then-raise.  L_d = ∂_b g_dc u^b u^c − ½ ∂_d g_bc u^b u^c ;  u̇ = −g^{-1} L
+template <class R>
+RTGR_DEV void generic_rhs(uint32_t metric, R M, R a, const R s[8], R ds[8]) {
+    R g[4][4], dg[4][4][4], gu[4][4];
+    dmetric_dev<R>(metric, M, a, s, g, dg);
+    inv4sym<R>(g, gu);
+    const R* u = s + 4;
+    R L[4];
+    for (int d = 0; d < 4; d++) {
+        R t1 = R(0), t2 = R(0);
+        for (int b = 0; b < 4; b++)
+            for (int c = 0; c < 4; c++) {
+                t1 = rfma(dg[d][c][b] * u[b], u[c], t1);
+                t2 = rfma(dg[b][c][d] * u[b], u[c], t2);
+            }
+        L[d] = rfma(R(-0.5), t2, t1);
+    }
+    for (int p = 0; p < 4; p++) {
+        ds[p] = u[p];
+        ds[4 + p] = -(gu[p][0] * L[0] + gu[p][1] * L[1] + gu[p][2] * L[2] + gu[p][3] * L[3]);
+    }
+}
+
+// christoffel (src/RayTraceGR.jl:321-331): all 64 entries, for rtgr_eval_metric_f64
+template <class R>
+RTGR_DEV void christoffel_dev(const R g[4][4], const R dg[4][4][4], R Gam[4][4][4]) {
+    R gu[4][4];
+    inv4sym<R>(g, gu);
+    for (int p = 0; p < 4; p++)
+        for (int b = 0; b < 4; b++)
+            for (int c = 0; c < 4; c++) {
+                R acc = R(0);
+                for (int d = 0; d < 4; d++) acc = rfma(gu[p][d], R(0.5) * (dg[d][b][c] + dg[d][c][b] - dg[b][c][d]), acc);
+                Gam[p][b][c] = acc;
+            }
+}
+
+// ---- objects (src/RayTraceGR.jl:374-441) -------------------------------------------------------------------------------
+template <class R>
+RTGR_DEV R obj_distance(const DevObject<R>& o, const R pos[4]) {
+    if (o.kind == RTGR_PLANE) return pos[0] - o.p[0];                                    // :399-401
+    if (o.kind == RTGR_SPHERE) {                                                         // :415-419
+        const R dx = pos[1] - o.p[1], dy = pos[2] - o.p[2], dz = pos[3] - o.p[3];
+        const R Rr = o.p[8];
+        const R d = rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, -Rr * Rr)));
+        return Rr < R(0) ? -d : d;  // sign(R)*( … ); R = 0 never used
+    }
+    // RTGR_DISK: max(|z|−h, r_in−ϱ, ϱ−r_out)
+    const R rc = rsqrt_(rfma(pos[1], pos[1], pos[2] * pos[2]));
+    R d = rabs(pos[3]) - o.p[0];
+    d = rmax(d, o.p[1] - rc);
+    d = rmax(d, rc - o.p[2]);
+    return d;
+}
+
+template <class R>
+RTGR_DEV R min_distance(const DevScene<R>& sc, const R pos[4]) {                          // :433-441
+    R dmin = R(__builtin_huge_val());
+    for (uint32_t o = 0; o < sc.nobj; o++) {
+        const R d = obj_distance<R>(sc.obj[o], pos);
+        dmin = (d < dmin || d != d) ? d : dmin;
+    }
+    return dmin;
+}
+
+}  // namespace rtgr
