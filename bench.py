@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: geodesic RK (Tsit5) step attempts/s and rays/s on the Kerr–Schild
+4096² screen (BASELINE.json metric / configs[2]), rows sharded over N GPUs of one node with one RCCL gather.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" of this bench is one full pass of the hot path over the whole screen (every ray integrated to its event and
+coloured, slabs gathered on rank 0).  `value` = Tsit5 step attempts (accepted + rejected, each = 6 RHS evaluations,
+SURVEY §8d) of the whole job per second; rays/s is reported beside it.  Inputs are generated on the device
+(make_canvas fused into the kernel), so nothing crosses PCIe inside the timed region.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_RHS = 814           # algorithmic flop per RHS, lean generic-metric form
+F_STEP = 6 * F_RHS + 520   # = 5404 flop per Tsit5 step attempt
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (½ of the
+#                                157.3 TF fp32 vector figure in MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096, help="screen is size x size")
+    ap.add_argument("--variant", default="ks_ref0",
+                    choices=["ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "mink"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cpu-sample", type=int, default=320, help="CPU baseline renders a sample x sample crop; 0=off")
+    ap.add_argument("--no-gather", action="store_true")
+    return ap.parse_args()
+
+
+def build_scene(rt, variant):
+    _, objs, cam = rt.example2_scene()
+    if variant == "mink":
+        metric, objs, cam = rt.example1_scene()
+    else:
+        metric = {"ks_ref0": rt.kerr_schild, "ks_ref08": rt.KerrSchild(1, 0.8, textbook=False),
+                  "ks_true0": rt.KerrSchild(1, 0.0), "ks_true08": rt.KerrSchild(1, 0.8),
+                  "ks_true0998": rt.KerrSchild(1, 0.998)}[variant]
+    return rt.make_scene(metric, objs), rt.make_camera(**cam)
+
+
+def cpu_baseline(rt, scene, cam, opt, sample):
+    """The CPU oracle (a restatement of the reference's algorithm — kind "port", NOT the Julia code) timed on this
+    host's cores on a bounded sample of the same workload: the central sample x sample pixels' worth of rays of the
+    same camera (a sample² screen of the same scene; step statistics are resolution independent)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    nthreads = int(O.lib().rtgr_oracle_num_threads())
+    O.trace(scene, opt, 32, 32, cam=cam, details=False)  # warm
+    t0 = time.perf_counter()
+    r = O.trace(scene, opt, sample, sample, cam=cam, details=False, nthreads=nthreads)
+    dt = time.perf_counter() - t0
+    c = r["counters"]
+    attempts = c["accepted"] + c["rejected"]
+    return {"value": attempts / dt, "unit": "RK step attempts/s", "cores": nthreads, "kind": "port",
+            "sample": f"{sample}x{sample} screen of the same scene ({c['rays']} rays, {attempts} step attempts) "
+                      f"in {dt:.2f} s; C++/OpenMP restatement of the reference algorithm (Julia absent)",
+            "rays_per_s": c["rays"] / dt, "seconds": dt}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    rt = load_package()
+    from raytracegr_jl_amd import sharded
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if ws > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    lib = rt._abi.load()
+    rt._abi.check(lib, lib.rtgr_init(local))
+
+    npdt = np.float64 if a.dtype == "f64" else np.float32
+    scene, cam = build_scene(rt, a.variant)
+    opt = rt.solver_defaults(npdt)
+    ni = nj = a.size
+    j0, j1 = sharded.slab_bounds(nj, ws, rank)
+    ctr = torch.zeros(8, dtype=torch.int64, device=dev)
+    out = {}
+
+    def one_pass(timed_events=None):
+        if timed_events is not None:
+            timed_events[0].record()
+        sharded.trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device=dev, dtype=npdt, counters=ctr, out=out)
+        if timed_events is not None:
+            timed_events[1].record()
+        if ws > 1 and not a.no_gather:
+            gather(out["rgb"])
+
+    nmax = ni * (sharded.slab_bounds(nj, ws, 0)[1] - sharded.slab_bounds(nj, ws, 0)[0])
+    parts = None
+
+    def gather(slab):
+        nonlocal parts
+        send = slab if slab.shape[1] == nmax else torch.cat([slab, slab.new_zeros((3, nmax - slab.shape[1]))], 1)
+        if rank == 0:
+            if parts is None:
+                parts = [torch.empty((3, nmax), dtype=slab.dtype, device=dev) for _ in range(ws)]
+            dist.gather(send.contiguous(), parts, dst=0)
+        else:
+            dist.gather(send.contiguous(), None, dst=0)
+
+    for _ in range(a.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    ctr.zero_()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        one_pass(evs[k])
+    torch.cuda.synchronize()
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    totals = ctr.clone()
+    kmax = torch.tensor([max(kern_ms)], dtype=torch.float64, device=dev)
+    if ws > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    dt = float(tt[0])
+    rays, acc, rej, nrhs = (int(totals[i]) for i in range(4))
+    attempts = acc + rej
+
+    if rank == 0:
+        # roofline of the dominant (only hot) kernel, this rank's launches: algorithmic flop / measured kernel time
+        my = ctr.cpu().numpy()
+        my_attempts, my_rays = int(my[1] + my[2]) / a.steps, int(my[0]) / a.steps
+        k_avg_s = float(np.mean(kern_ms)) * 1e-3
+        flop_launch = my_attempts * F_STEP + 2 * my_rays * F_RHS
+        achieved = flop_launch / k_avg_s / 1e12
+        roof = {"bound": "valu_f64", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                "kernel": "trace_kernel<double>", "kernel_ms_avg": k_avg_s * 1e3,
+                "algorithmic_flop_per_launch": flop_launch,
+                "flop_model": f"{F_STEP} flop/step attempt + 2x{F_RHS} per ray (SURVEY §8d)",
+                "hbm_GBps_algorithmic": (my_rays * (24 + 1)) / k_avg_s / 1e9}
+        name = C_name(lib)
+        cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if a.cpu_sample > 0 else None
+        line = {
+            "metric": "geodesic RK step attempts/s (Tsit5, 6 RHS each), Kerr-Schild screen, whole job",
+            "value": attempts / dt, "unit": "RK step attempts/s", "n_gpus": ws, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"example2 scene (Kerr-Schild {a.variant}, 3 objects) {ni}x{nj} screen, "
+                                   f"tol=eps^(3/4), lambda in [0,100]; rows sharded over {ws} GPU(s)"
+                                   f"{'' if ws == 1 or a.no_gather else ' + RCCL gather to rank 0'}",
+                       "size": a.size, "variant": a.variant, "parallelism": f"rows/{ws}"},
+            "rays_per_s": rays / dt, "rays": rays // a.steps, "step_attempts_per_pass": attempts // a.steps,
+            "accepted": acc // a.steps, "rejected": rej // a.steps, "rhs_evals_per_pass": nrhs // a.steps,
+            "kernel_ms_max_over_ranks": float(kmax[0]), "device": name,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def C_name(lib):
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    cu, mhz, wf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    lib.rtgr_device_info(buf, 128, ctypes.byref(cu), ctypes.byref(mhz), ctypes.byref(wf))
+    return f"{buf.value.decode()} {cu.value} CU @ {mhz.value} MHz"
+
+
+if __name__ == "__main__":
+    main()

@@ -103,6 +103,23 @@ def _declare(lib):
             getattr(lib, name).restype = i32
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7)
+    next to libtorch; librtgr_hip.so needs `libamdhip64.so.7` too.  If ours resolved to /opt/rocm's copy first, a later
+    `import torch` would bring a second runtime into the process and find "No HIP GPUs".  Loading torch's copy first
+    (by path, without importing torch) makes both bind to the same runtime, whichever is used first."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load(path=None):
     """Load librtgr_hip.so (built by __graft_entry__.build() / raytracegr.jl_amd/build.py).
 
@@ -116,6 +133,7 @@ def load(path=None):
         raise RuntimeError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(p)
     _declare(lib)
     got = lib.rtgr_abi_version()

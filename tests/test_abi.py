@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/rtgr.h declares; argument validation that
+does not need a GPU; the product never falls back to a CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_package
+
+rt = load_package()
+abi = rt._abi
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(abi.LIB_PATH):
+        subprocess.check_call(["python", os.path.join(ROOT, "raytracegr.jl_amd", "build.py")])
+    return abi.load()
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "rtgr.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtgr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_ctypes_agree_on_exports():
+    assert _declared_symbols() == sorted(abi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for s in _declared_symbols():
+        assert hasattr(lib, s), s
+    assert lib.rtgr_abi_version() == abi.RTGR_ABI_VERSION
+
+
+def test_struct_sizes_match_the_header(lib):
+    # layouts in include/rtgr.h: object 8+72, scene 8+16+16*80, solver 8*8+8, camera 128, counters 64, outputs 48
+    assert C.sizeof(abi.rtgr_object) == 80
+    assert C.sizeof(abi.rtgr_scene) == 24 + 16 * 80
+    assert C.sizeof(abi.rtgr_solver) == 72
+    assert C.sizeof(abi.rtgr_camera) == 128
+    assert C.sizeof(abi.rtgr_counters) == 64
+    assert C.sizeof(abi.rtgr_ray_outputs) == 48
+
+
+def test_solver_defaults_are_the_reference_constants(lib):
+    s = abi.rtgr_solver()
+    assert lib.rtgr_solver_defaults(C.byref(s), 0) == 0
+    assert s.reltol == s.abstol == 2.0 ** -39                     # eps(Float64)^(3/4)  src/RayTraceGR.jl:485
+    assert (s.lambda0, s.lambda1, s.hit_threshold) == (0.0, 100.0, 0.01)
+    assert list(s.miss_rgb) == [1.0, 0.0, 0.0]
+    assert s.interp_points == 10
+    p = rt.solver_defaults()
+    assert (p.reltol, p.lambda1, p.hit_threshold, p.interp_points) == (s.reltol, s.lambda1, s.hit_threshold, 10)
+    assert lib.rtgr_solver_defaults(C.byref(s), 1) == 0
+    assert abs(s.reltol - float(np.finfo(np.float32).eps) ** 0.75) < 1e-18
+
+
+def test_no_cpu_fallback_without_a_gpu(lib):
+    """Without a HIP device every compute entry point must FAIL (RTGR_ERR_NO_DEVICE), never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sc = rt.make_scene(rt.minkowski, [])
+    opt = rt.solver_defaults()
+    s0 = np.zeros((1, 8))
+    rgb = np.zeros(3)
+    rc = lib.rtgr_trace_f64(C.byref(sc), C.byref(opt), s0.ctypes.data, None, 1, 1, 0, 1, rgb.ctypes.data, None, None)
+    assert rc == abi.ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.rtgr_last_error()
+    with pytest.raises(abi.RtgrError):
+        rt.christoffel(rt.kerr_schild, [0, 2, 0, 0])
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under raytracegr.jl_amd/ or include/ may mention it."""
+    for base in ("raytracegr.jl_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "librtgr_oracle" not in txt and "oracle_lib" not in txt and "rtgr_oracle_" not in txt, f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        abi.load(str(tmp_path / "nope.so"))
+
+
+def test_arbitrary_metric_callable_is_refused():
+    with pytest.raises(TypeError):
+        rt.make_scene(lambda x: np.eye(4), [])
