@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--variant", default="ks_ref0",
                     choices=["ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "mink"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--cpu-sample", type=int, default=320, help="CPU baseline renders a sample x sample crop; 0=off")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="CPU baseline renders a sample x sample screen; -1 = auto (~15 s of CPU work), 0 = off")
     ap.add_argument("--no-gather", action="store_true")
     return ap.parse_args()
 
@@ -62,7 +63,11 @@ def cpu_baseline(rt, scene, cam, opt, sample):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     nthreads = int(O.lib().rtgr_oracle_num_threads())
-    O.trace(scene, opt, 32, 32, cam=cam, details=False)  # warm
+    t0 = time.perf_counter()
+    O.trace(scene, opt, 64, 64, cam=cam, details=False, nthreads=nthreads)  # warm + pilot
+    pilot = time.perf_counter() - t0
+    if sample <= 0:  # auto: about 15 s of CPU work, bounded
+        sample = int(min(1536, max(64, 64 * (15.0 / max(pilot, 1e-3)) ** 0.5)))
     t0 = time.perf_counter()
     r = O.trace(scene, opt, sample, sample, cam=cam, details=False, nthreads=nthreads)
     dt = time.perf_counter() - t0
@@ -169,7 +174,7 @@ def main():
                 "flop_model": f"{F_STEP} flop/step attempt + 2x{F_RHS} per ray (SURVEY §8d)",
                 "hbm_GBps_algorithmic": (my_rays * (24 + 1)) / k_avg_s / 1e9}
         name = C_name(lib)
-        cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if a.cpu_sample > 0 else None
+        cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if a.cpu_sample != 0 else None
         line = {
             "metric": "geodesic RK step attempts/s (Tsit5, 6 RHS each), Kerr-Schild screen, whole job",
             "value": attempts / dt, "unit": "RK step attempts/s", "n_gpus": ws, "steps": a.steps,

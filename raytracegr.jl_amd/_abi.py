@@ -128,7 +128,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RTGR_LIB") or LIB_PATH  # RTGR_LIB: experiment builds (bench A/B only)
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "

@@ -11,10 +11,11 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
-#include "rtgr_integrator.hpp"
+#include "rtgr_persistent.hpp"
 
 using namespace rtgr;
 
@@ -34,32 +35,6 @@ static int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                       \
             return fail(RTGR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
-
-// ---------------------------------------------------------------------------------------------------------------------
-// kernel arguments
-// ---------------------------------------------------------------------------------------------------------------------
-template <class R>
-struct TraceArgs {
-    DevScene<R> sc;
-    DevSolver<R> opt;
-    DevCamera<R> cam;
-    const R* state0;  // n x 8 or null (camera)
-    uint64_t ni, nj, j0, nrows;
-    R* rgb;           // 3 planes of n
-    R* state_end;     // optional
-    R* lambda_end;
-    uint8_t* status;
-    uint8_t* hit;
-    uint32_t* n_accept;
-    uint32_t* n_reject;
-    unsigned long long* counters;  // rtgr_counters or null
-};
-
-RTGR_DEV unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
 
 // One lane = one ray.  A wave owns an 8x8 pixel tile (lock-step efficiency 0.90 vs 0.45 for 64 consecutive
 // pixels); a 256-thread workgroup owns 4 horizontally adjacent tiles.
@@ -245,6 +220,7 @@ static void convert_camera(const rtgr_camera* c, DevCamera<R>& d) {
     }
 }
 
+static int bind_device(int dev);
 static int ensure_device() {
     if (g_device >= 0) return RTGR_OK;
     int n = 0;
@@ -252,15 +228,60 @@ static int ensure_device() {
         return fail(RTGR_ERR_NO_DEVICE, "no HIP device visible; librtgr_hip has no CPU fallback");
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    g_device = dev;
-    return RTGR_OK;
+    return bind_device(dev);
+}
+
+// ---- launch policy ---------------------------------------------------------------------------------------------
+// RTGR_KERNEL=tile selects the simple tile-per-wave kernel (kept for A/B and as a cross-check); default is the
+// persistent kernel.  RTGR_THRESH = parked lanes that trigger a batched resolve/refill (default 4).
+static int g_num_cu = 0;
+static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per in-flight call
+static unsigned g_queue_next = 0;
+constexpr unsigned RTGR_QUEUE_SLOTS = 256;
+
+static int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+static bool use_tile_kernel() {
+    const char* v = std::getenv("RTGR_KERNEL");
+    return v && std::strcmp(v, "tile") == 0;
 }
 
 template <class R, int METRIC, bool SPIN>
-static void launch_trace(const TraceArgs<R>& A, hipStream_t st) {
+static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
-    const uint64_t blocks = (tiles + 3) / 4;
-    hipLaunchKernelGGL((trace_kernel<R, METRIC, SPIN>), dim3((unsigned)blocks), dim3(256), 0, st, A);
+    if (use_tile_kernel()) {
+        const uint64_t blocks = (tiles + 3) / 4;
+        hipLaunchKernelGGL((trace_kernel<R, METRIC, SPIN>), dim3((unsigned)blocks), dim3(256), 0, st, A);
+        return RTGR_OK;
+    }
+    unsigned long long* q = g_queue_pool + (g_queue_next++ % RTGR_QUEUE_SLOTS);
+    HIP_TRY(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
+    const int waves_per_cu = env_int("RTGR_WAVES_PER_CU", 8);
+    const uint64_t resident = (uint64_t)g_num_cu * (uint64_t)waves_per_cu;
+    const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
+    const int thresh = env_int("RTGR_THRESH", 4);
+    if (A.opt.interp_points == 10)
+        hipLaunchKernelGGL((trace_persistent_kernel<R, METRIC, SPIN, true>), dim3(blocks), dim3(64), 0, st, A, q, thresh);
+    else
+        hipLaunchKernelGGL((trace_persistent_kernel<R, METRIC, SPIN, false>), dim3(blocks), dim3(64), 0, st, A, q, thresh);
+    return RTGR_OK;
+}
+
+static int bind_device(int dev) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTGR_ERR_NO_DEVICE, std::string("librtgr_hip is built for gfx950 only; device is ") + p.gcnArchName);
+    if (g_queue_pool && g_device != dev) { (void)hipFree(g_queue_pool); g_queue_pool = nullptr; }
+    if (!g_queue_pool) {
+        HIP_TRY(hipMalloc((void**)&g_queue_pool, RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_queue_pool, 0, RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
+    }
+    g_num_cu = p.multiProcessorCount;
+    g_device = dev;
+    return RTGR_OK;
 }
 
 template <class R>
@@ -293,13 +314,14 @@ static int trace_device(const rtgr_scene* scene, const rtgr_solver* opt, const R
     hipStream_t st = (hipStream_t)stream;
     const bool spin = scene->a != 0.0;
     switch (scene->metric) {
-        case RTGR_MINKOWSKI: launch_trace<R, RTGR_MINKOWSKI, false>(A, st); break;
+        case RTGR_MINKOWSKI: rc = launch_trace<R, RTGR_MINKOWSKI, false>(A, st); break;
         case RTGR_KS_REF:
-            if (spin) launch_trace<R, RTGR_KS_REF, true>(A, st); else launch_trace<R, RTGR_KS_REF, false>(A, st);
+            rc = spin ? launch_trace<R, RTGR_KS_REF, true>(A, st) : launch_trace<R, RTGR_KS_REF, false>(A, st);
             break;
         default:
-            if (spin) launch_trace<R, RTGR_KS_TRUE, true>(A, st); else launch_trace<R, RTGR_KS_TRUE, false>(A, st);
+            rc = spin ? launch_trace<R, RTGR_KS_TRUE, true>(A, st) : launch_trace<R, RTGR_KS_TRUE, false>(A, st);
     }
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return RTGR_OK;
 }
@@ -381,10 +403,10 @@ int rtgr_init(int device) {
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    g_device = dev;
-    return RTGR_OK;
+    return bind_device(dev);
 }
 int rtgr_shutdown(void) {
+    if (g_queue_pool) { (void)hipFree(g_queue_pool); g_queue_pool = nullptr; }
     g_device = -1;
     return RTGR_OK;
 }

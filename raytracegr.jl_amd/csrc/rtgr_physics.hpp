@@ -66,6 +66,12 @@ template <class R> RTGR_DEV R rmin(R a, R b) { return a < b ? a : b; }
 // Julia sign(): ±1, 0 -> 0 (NaN handled by callers)
 template <class R> RTGR_DEV R rsign(R v) { return v > R(0) ? R(1) : (v < R(0) ? R(-1) : R(0)); }
 
+RTGR_DEV unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
 // ---- Kerr–Schild-form field: f, ∇f, k_i, ∂_j k_i at a spatial point ----------------------------------------------
 template <class R>
 struct KSField {
