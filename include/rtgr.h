@@ -140,6 +140,11 @@ int rtgr_solver_defaults(rtgr_solver* s, int is_f32);
 /* Name / CU count / clock of the active device, for bench reports. */
 int rtgr_device_info(char* name, uint64_t name_len, int* n_cu, int* clock_mhz, int* wavefront);
 
+/* The device entry points are asynchronous and never allocate once the library-owned workspace (event records handed
+ * from the integrate kernel to the resolve kernel: <= 440 B per ray, bounded by a 2^24-ray pipeline chunk) is large
+ * enough.  Call this once up front (e.g. before hipGraph capture) to size it for slabs of n_rays rays. */
+int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32);
+
 /* ---- the hot path, device-resident buffers ------------------------------------------------------------------
  * Replaces the body of trace_rays (src/RayTraceGR.jl:482-536) for rows j in [j0, j1) of an ni x nj canvas.
  *   d_state0 : n x 8 initial ray states on the DEVICE (n = ni*(j1-j0)), as `input_func(i)` yields (:492-496),

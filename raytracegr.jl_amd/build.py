@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rtgr_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "rtgr_persistent.hpp"), os.path.join(HERE, "csrc", "rtgr_physics.hpp"), os.path.join(HERE, "csrc", "rtgr_integrator.hpp"),
+DEPS = [SRC, os.path.join(HERE, "csrc", "rtgr_persistent.hpp"), os.path.join(HERE, "csrc", "rtgr_tsit5_tables.hpp"), os.path.join(HERE, "csrc", "rtgr_physics.hpp"), os.path.join(HERE, "csrc", "rtgr_integrator.hpp"),
         os.path.join(HERE, "..", "include", "rtgr.h")]
 OUT = os.path.join(HERE, "librtgr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,8 +1,10 @@
 // rtgr_hip.hip — HIP kernels + the C ABI of include/rtgr.h  (gfx950 only; no CPU fallback, no compatibility paths).
 //
 // Kernel inventory
-//   trace_kernel<R,METRIC,SPIN>   the hot path: one wavefront lane per ray, 8x8-pixel tile per wave, whole adaptive
-//                                 Tsit5 loop + event finder + colouring in registers; coalesced-by-tile stores.
+//   integrate_kernel / resolve_kernel (rtgr_persistent.hpp)   THE HOT PATH: persistent waves with lane refill,
+//                                 then one thread per ray for root-find + colouring
+//   trace_kernel<R,METRIC,SPIN>   simple variant (RTGR_KERNEL=tile): one lane per ray, 8x8-pixel tile per wave, whole
+//                                 adaptive loop + event finder + colouring inline — an independent formulation
 //   canvas_kernel<R>              make_canvas (src/RayTraceGR.jl:457-478)
 //   eval_metric_kernel / eval_geodesic_kernel   parity hooks for the reference's unit tests
 //   quantize_kernel               N0f8 rounding + transposed image layout of save() (:566-575)
@@ -93,13 +95,14 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
 
 template <class R>
 __global__ __launch_bounds__(256) void canvas_kernel(DevScene<R> sc, DevCamera<R> cam, uint64_t ni, uint64_t nj,
-                                                     uint64_t j0, uint64_t nrows, R* state0) {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= ni * nrows) return;
+                                                     uint64_t j0, uint64_t first, uint64_t count, R* state0) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= count) return;
+    const uint64_t idx = first + w;  // linear index inside the slab: i + (j - j0) * ni
     R s[8];
     make_pixel<R>(sc, cam, ni, nj, idx % ni, j0 + idx / ni, s);
 #pragma unroll
-    for (int c = 0; c < 8; c++) state0[idx * 8 + c] = s[c];
+    for (int c = 0; c < 8; c++) state0[w * 8 + c] = s[c];
 }
 
 __global__ __launch_bounds__(256) void eval_metric_kernel(DevScene<double> sc, const double* x, uint64_t n, double* g,
@@ -232,12 +235,16 @@ static int ensure_device() {
 }
 
 // ---- launch policy ---------------------------------------------------------------------------------------------
-// RTGR_KERNEL=tile selects the simple tile-per-wave kernel (kept for A/B and as a cross-check); default is the
-// persistent kernel.  RTGR_THRESH = parked lanes that trigger a batched resolve/refill (default 4).
+// Default: canvas -> integrate (persistent waves) -> resolve.  RTGR_KERNEL=tile selects the simple tile-per-wave
+// kernel (kept as an independent formulation for A/B and cross-checks).  Tunables (experiments only):
+//   RTGR_WAVES_PER_CU  resident waves per CU of the integrate kernel (default 8 = 2 per SIMD)
+//   RTGR_CHUNK         rays per pipeline chunk (default 2^24); bounds the library-owned workspace
 static int g_num_cu = 0;
-static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per in-flight call
+static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per launch in flight
 static unsigned g_queue_next = 0;
 constexpr unsigned RTGR_QUEUE_SLOTS = 256;
+static void* g_ws = nullptr;  // library-owned workspace (event records, per-ray meta, generated ray states)
+static size_t g_ws_bytes = 0;
 
 static int env_int(const char* name, int dflt) {
     const char* v = std::getenv(name);
@@ -247,25 +254,71 @@ static bool use_tile_kernel() {
     const char* v = std::getenv("RTGR_KERNEL");
     return v && std::strcmp(v, "tile") == 0;
 }
+static uint64_t chunk_rays() {
+    const char* v = std::getenv("RTGR_CHUNK");
+    uint64_t c = (v && *v) ? std::strtoull(v, nullptr, 10) : (1ull << 24);
+    return c < 64 ? 64 : c;
+}
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+static int ensure_workspace(size_t bytes) {
+    if (bytes <= g_ws_bytes) return RTGR_OK;
+    if (g_ws) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
+    HIP_TRY(hipMalloc(&g_ws, bytes));
+    g_ws_bytes = bytes;
+    return RTGR_OK;
+}
+template <class R>
+static size_t workspace_bytes(uint64_t rays, bool with_state, bool with_canvas) {
+    const int recw = with_state ? REC_W_STATE : REC_W;
+    return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
+           (with_canvas ? align256(rays * 8 * sizeof(R)) : 0);
+}
+
+template <class R, int METRIC, bool SPIN>
+static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, unsigned blocks, hipStream_t st) {
+    if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true>), dim3(blocks), dim3(64), 0, st, IA);
+    else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, false>), dim3(blocks), dim3(64), 0, st, IA);
+    return RTGR_OK;
+}
 
 template <class R, int METRIC, bool SPIN>
 static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
-    const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
     if (use_tile_kernel()) {
+        const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
         const uint64_t blocks = (tiles + 3) / 4;
         hipLaunchKernelGGL((trace_kernel<R, METRIC, SPIN>), dim3((unsigned)blocks), dim3(256), 0, st, A);
         return RTGR_OK;
     }
-    unsigned long long* q = g_queue_pool + (g_queue_next++ % RTGR_QUEUE_SLOTS);
-    HIP_TRY(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
-    const int waves_per_cu = env_int("RTGR_WAVES_PER_CU", 8);
-    const uint64_t resident = (uint64_t)g_num_cu * (uint64_t)waves_per_cu;
-    const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
-    const int thresh = env_int("RTGR_THRESH", 4);
-    if (A.opt.interp_points == 10)
-        hipLaunchKernelGGL((trace_persistent_kernel<R, METRIC, SPIN, true>), dim3(blocks), dim3(64), 0, st, A, q, thresh);
-    else
-        hipLaunchKernelGGL((trace_persistent_kernel<R, METRIC, SPIN, false>), dim3(blocks), dim3(64), 0, st, A, q, thresh);
+    const uint64_t n = A.ni * A.nrows;
+    const uint64_t chunk = n < chunk_rays() ? n : chunk_rays();
+    const bool with_state = A.state_end != nullptr, with_canvas = A.state0 == nullptr;
+    int rc = ensure_workspace(workspace_bytes<R>(chunk, with_state, with_canvas));
+    if (rc) return rc;
+    const int recw = with_state ? REC_W_STATE : REC_W;
+    char* base = (char*)g_ws;
+    R* rec = (R*)base;
+    uint32_t* meta = (uint32_t*)(base + align256(chunk * recw * sizeof(R)));
+    R* gen = (R*)(base + align256(chunk * recw * sizeof(R)) + align256(chunk * 3 * sizeof(uint32_t)));
+    const int waves_per_cu = env_int("RTGR_WAVES_PER_CU", 4 * RTGR_WAVES_PER_SIMD);
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
+        const R* s0 = A.state0 ? A.state0 + off * 8 : gen;
+        if (with_canvas)
+            hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
+                               A.nj, A.j0, off, m, gen);
+        unsigned long long* q = g_queue_pool + (g_queue_next++ % RTGR_QUEUE_SLOTS);
+        HIP_TRY(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
+        IntegrateArgs<R> IA;
+        IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
+        IA.queue = q; IA.counters = A.counters;
+        const uint64_t waves = (m + 63) / 64, resident = (uint64_t)g_num_cu * (uint64_t)waves_per_cu;
+        launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, (unsigned)(waves < resident ? waves : resident), st);
+        ResolveArgs<R> RA;
+        RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = off;
+        RA.n_slab = n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
+        RA.status = A.status; RA.hit = A.hit; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
+        hipLaunchKernelGGL(resolve_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, RA);
+    }
     return RTGR_OK;
 }
 
@@ -274,7 +327,10 @@ static int bind_device(int dev) {
     HIP_TRY(hipGetDeviceProperties(&p, dev));
     if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
         return fail(RTGR_ERR_NO_DEVICE, std::string("librtgr_hip is built for gfx950 only; device is ") + p.gcnArchName);
-    if (g_queue_pool && g_device != dev) { (void)hipFree(g_queue_pool); g_queue_pool = nullptr; }
+    if (g_queue_pool && g_device != dev) {
+        (void)hipFree(g_queue_pool); g_queue_pool = nullptr;
+        if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
+    }
     if (!g_queue_pool) {
         HIP_TRY(hipMalloc((void**)&g_queue_pool, RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(g_queue_pool, 0, RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
@@ -407,6 +463,7 @@ int rtgr_init(int device) {
 }
 int rtgr_shutdown(void) {
     if (g_queue_pool) { (void)hipFree(g_queue_pool); g_queue_pool = nullptr; }
+    if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
     g_device = -1;
     return RTGR_OK;
 }
@@ -435,6 +492,14 @@ int rtgr_device_info(char* name, uint64_t name_len, int* n_cu, int* clock_mhz, i
     if (clock_mhz) *clock_mhz = p.clockRate / 1000;
     if (wavefront) *wavefront = p.warpSize;
     return RTGR_OK;
+}
+
+int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const uint64_t chunk = n_rays < chunk_rays() ? n_rays : chunk_rays();
+    return ensure_workspace(is_f32 ? workspace_bytes<float>(chunk, with_state_end != 0, true)
+                                   : workspace_bytes<double>(chunk, with_state_end != 0, true));
 }
 
 int rtgr_trace_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* d_state0,
@@ -514,7 +579,7 @@ int rtgr_make_canvas_device_f64(const rtgr_scene* scene, const rtgr_camera* cam,
     convert_camera<double>(cam, c);
     const uint64_t n = ni * (j1 - j0);
     hipLaunchKernelGGL(canvas_kernel<double>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, sc, c, ni, nj, j0,
-                       j1 - j0, d_state0);
+                       (uint64_t)0, n, d_state0);
     HIP_TRY(hipGetLastError());
     return RTGR_OK;
 }

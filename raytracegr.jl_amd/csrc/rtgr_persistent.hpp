@@ -1,18 +1,29 @@
-// rtgr_persistent.hpp — the production trace kernel: persistent waves, lane refill, batched event resolution.
+// rtgr_persistent.hpp — the production trace pipeline: integrate (persistent waves) -> resolve (one thread per ray).
 //
-// Why: in the tile-per-wave kernel (trace_kernel, kept as the simple variant) a wave runs until its LONGEST ray ends
-// (27…991 step attempts inside one image) and every ray's event episode (root-find, dense output,
-// colouring) is executed by the whole wave with one lane active.  Here a wave is a pool of 64 independent ray
-// slots:
-//   * a lane whose ray has ended parks (state EVENT/DONE); a wavefront ballot counts the parked lanes and when
-//     >= `thresh` of them have accumulated they are resolved together (root-find on the dense output, end state,
-//     colouring rule, stores) and re-filled from a global ray queue (one wave-aggregated atomic per batch);
-//   * the two RHS evaluations of the Hairer initial-step estimate of a fresh ray ride in the k2/k3 evaluation slots
-//     of the neighbours' regular Tsit5 step (an "init pseudo-step"), so initialisation costs no extra wave-wide RHS;
-//   * the ContinuousCallback's interior sample points use compile-time dense-output weights b_i(j/9).
-// The numerical algorithm per ray is unchanged; only the schedule differs.
+// Why three kernels instead of one loop per ray (the simple tile kernel in rtgr_hip.hip keeps that shape):
+//   * rays need 27…991 Tsit5 step attempts inside one image; a wave that owns 64 fixed rays idles until
+//     its longest ray ends, and each ray's end-of-life episode (bracketed root-find on the dense output, colouring,
+//     next ray's camera set-up) would run with one lane active;
+//   * so the integrate kernel treats a wave as a pool of 64 ray slots: a lane whose ray has ended writes a small
+//     EVENT RECORD (the position polynomial of its last step) to HBM, and is re-filled from a global ray queue on the
+//     next iteration — a wavefront ballot finds the free lanes, one wave-aggregated atomic pops their work ids;
+//   * everything that happens once per ray and diverges — root-finding, the colouring rule with its acos/atan2 —
+//     runs afterwards in the resolve kernel with every lane busy; the camera (make_canvas) runs before, likewise.
+//   HBM traffic of the hand-off: 64 B (state0) + 204 B (record) per ray, against ≈1.1 Mflop of integration per ray.
+//
+// Step body (per lane, registers only):
+//   * Nyström form: since ẋ = u (src/RayTraceGR.jl:360) stage positions are x + h c_s u + h² Σ A2[s][l] k_l — only the
+//     seven acceleration 4-vectors k_l are stored (28 scalars), not the 7 x 8 stage derivatives;
+//   * the two RHS evaluations of the Hairer initial step of a fresh ray ride in the k2/k3 slots of its neighbours'
+//     regular step ("init pseudo-step");
+//   * error norm, PI controller and initial-dt formula run in f32 on the (otherwise idle) f32 VALU/transcendental
+//     path; they only steer the step size — the state arithmetic is all R (f64);
+//   * ContinuousCallback: the position interpolant is put in polynomial form once per accepted step and evaluated at
+//     the 8 interior sample points θ = j/9; distances are evaluated object-major so each object's
+//     parameters are fetched once.
 #pragma once
 #include "rtgr_integrator.hpp"
+#include "rtgr_tsit5_tables.hpp"
 
 #ifndef RTGR_WAVES_PER_SIMD
 #define RTGR_WAVES_PER_SIMD 2  // 2 -> <=256 VGPR+AGPR per lane; 1 -> the whole 512-entry file
@@ -20,7 +31,19 @@
 
 namespace rtgr {
 
-enum LaneState : int { L_FREE = 0, L_INIT = 1, L_RUN = 2, L_EVENT = 3, L_DONE = 4, L_EXIT = 5 };
+enum LaneState : int { L_FREE = 0, L_INIT = 1, L_RUN = 2, L_EXIT = 3 };
+
+// event record layout (scalars of type R per ray)
+constexpr int REC_X = 0;      // x[4]   position at the start of the last step
+constexpr int REC_C = 4;      // c[m][q], m = 0..3 (θ¹..θ⁴), q = 0..3
+constexpr int REC_PS = 20;    // sign of the callback condition at the step start (0: no event, use θ = top = 0)
+constexpr int REC_TOP = 21;   // bracket top θ
+constexpr int REC_T = 22;     // λ at the step start
+constexpr int REC_H = 23;     // step size
+constexpr int REC_U = 24;     // u[4] and cu[m][q] (only when the caller wants state_end)
+constexpr int REC_CU = 28;
+constexpr int REC_W = 24;
+constexpr int REC_W_STATE = 44;
 
 template <class R>
 struct TraceArgs {
@@ -39,91 +62,443 @@ struct TraceArgs {
     unsigned long long* counters;  // rtgr_counters or null
 };
 
-// b_i(θ) for θ = j/(N-1), evaluated at compile time (Tsit5 dense output)
 template <class R>
-constexpr R dense_w(int i, int j, int nm1) {
-    const R th = R(j) / R(nm1);
-    return th * (Tsit5C<R>::r[i][0] + th * (Tsit5C<R>::r[i][1] + th * (Tsit5C<R>::r[i][2] + th * Tsit5C<R>::r[i][3])));
-}
-
-// position at interior sample point J of NPTS (compile-time weights): x0 + h Σ b_i k_i
-template <class R, int J, int NM1>
-RTGR_DEV void dense_pos_const(const R y[8], R h, const R k[7][8], R x[4]) {
-    constexpr R b0 = dense_w<R>(0, J, NM1), b1 = dense_w<R>(1, J, NM1), b2 = dense_w<R>(2, J, NM1),
-                b3 = dense_w<R>(3, J, NM1), b4 = dense_w<R>(4, J, NM1), b5 = dense_w<R>(5, J, NM1),
-                b6 = dense_w<R>(6, J, NM1);
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        R acc = b0 * k[0][c];
-        acc = rfma(b1, k[1][c], acc);
-        acc = rfma(b2, k[2][c], acc);
-        acc = rfma(b3, k[3][c], acc);
-        acc = rfma(b4, k[4][c], acc);
-        acc = rfma(b5, k[5][c], acc);
-        acc = rfma(b6, k[6][c], acc);
-        x[c] = rfma(h, acc, y[c]);
-    }
-}
-
-template <class R, int J, int NM1>
-struct InteriorScan {
-    // first J (1..NM1-1) whose sample has the opposite sign of ps; recursion unrolled at compile time
-    static RTGR_DEV void run(const DevScene<R>& sc, const R y[8], R h, const R k[7][8], R ps, bool& found, R& top) {
-        R xi[4];
-        dense_pos_const<R, J, NM1>(y, h, k, xi);
-        const R c = min_distance<R>(sc, xi);
-        const bool hit = (ps * rsign(c) < R(0)) && !found;
-        top = hit ? R(J) / R(NM1) : top;
-        found = found || hit;
-        if constexpr (J + 1 < NM1) InteriorScan<R, J + 1, NM1>::run(sc, y, h, k, ps, found, top);
-    }
+struct IntegrateArgs {
+    DevScene<R> sc;
+    DevSolver<R> opt;
+    const R* state0;        // n x 8
+    uint64_t n;             // rays in this chunk
+    R* rec;                 // n x recw
+    uint32_t* meta;         // n x 3: accepted, rejected, status | interior << 8
+    int recw;               // REC_W or REC_W_STATE
+    unsigned long long* queue;
+    unsigned long long* counters;
 };
 
-// polynomial form of the position interpolant: x(θ) = y + θ c1 + θ² c2 + θ³ c3 + θ⁴ c4
-template <class R>
-RTGR_DEV void dense_pos_coeffs(R h, const R k[7][8], R c[4][4]) {
-    using C = Tsit5C<R>;
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            R acc = C::r[0][m] * k[0][q];
-#pragma unroll
-            for (int i = 1; i < 7; i++) acc = rfma(C::r[i][m], k[i][q], acc);
-            c[m][q] = h * acc;
-        }
+// fast f32 helpers for the step-size machinery
+RTGR_DEV float flog2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+RTGR_DEV float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+
+// lanes below `lane` set in mask
+RTGR_DEV uint32_t mask_rank(unsigned long long mask, uint32_t lane) {
+    return (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }
+
+// distances of one object at P sample positions folded into dmin[] (object-major: parameters fetched once)
+template <class R, int P>
+RTGR_DEV void fold_distances(const DevObject<R>& o, const R (&pos)[P][4], R (&dmin)[P]) {
+    if (o.kind == RTGR_PLANE) {                                                        // src/RayTraceGR.jl:399-401
+        const R tm = o.p[0];
+#pragma unroll
+        for (int p = 0; p < P; p++) dmin[p] = rmin(dmin[p], pos[p][0] - tm);
+    } else if (o.kind == RTGR_SPHERE) {                                                // :415-419
+        const R cx = o.p[1], cy = o.p[2], cz = o.p[3], Rr = o.p[8];
+        const R nR2 = -Rr * Rr;
+        if (Rr < R(0)) {
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const R dx = pos[p][1] - cx, dy = pos[p][2] - cy, dz = pos[p][3] - cz;
+                dmin[p] = rmin(dmin[p], -rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, nR2))));
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const R dx = pos[p][1] - cx, dy = pos[p][2] - cy, dz = pos[p][3] - cz;
+                dmin[p] = rmin(dmin[p], rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, nR2))));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; p++) dmin[p] = rmin(dmin[p], obj_distance<R>(o, pos[p]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// integrate kernel
+// ---------------------------------------------------------------------------------------------------------------------
+template <class R, int METRIC, bool SPIN, bool NPTS10>
+__global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(const IntegrateArgs<R> A) {
+    using N = Tsit5N<R>;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t total = A.n;
+    const R M = A.sc.M, aspin = A.sc.a;
+    const R reltol = A.opt.reltol, abstol = A.opt.abstol;
+    const R t0 = A.opt.lambda0, t1 = A.opt.lambda1, dtmax = A.opt.lambda1 - A.opt.lambda0;
+    const float igamma = 1.0f / 0.9f, qmin_inv = 5.0f, qmax_inv = 0.1f;
+    const float lq_init = -13.287712379549449f;  // log2(qoldinit = 1e-4)
+    const float beta1 = 0.14f, beta2 = 0.08f;
+    const int npts = (int)A.opt.interp_points;
+    const R eps = sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7);
+
+    int state = L_FREE;
+    bool exhausted = false;
+    R x[4], u[4], k[7][4];  // k[l] = acceleration at stage l+1 (k[0] is the FSAL slot)
+    R t = t0, dt = R(0), ps = R(0);
+    float lq = lq_init;
+    uint64_t idx = 0;
+    uint32_t nacc = 0, nrej = 0;
+    uint32_t c_rays = 0, c_acc = 0, c_rej = 0, c_ev = 0, c_int = 0, c_nf = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        x[q] = R(1); u[q] = R(0);
+#pragma unroll
+        for (int s = 0; s < 7; s++) k[s][q] = R(0);
+    }
+
+    for (;;) {
+        // ================= refill: free lanes pop ray ids from the global queue (one atomic per wave) ===========
+        unsigned long long m_need = __ballot(state == L_FREE);
+        if (m_need != 0ull) {
+            if (!exhausted) {
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(m_need);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(A.queue, (unsigned long long)cnt);
+                base = __shfl(base, 0, 64);
+                if (state == L_FREE) {
+                    const uint64_t w = base + mask_rank(m_need, lane);
+                    if (w < total) {
+                        idx = w;
+                        const R* s0 = A.state0 + w * 8;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { x[q] = s0[q]; u[q] = s0[4 + q]; k[0][q] = R(0); }
+                        t = t0; nacc = 0; nrej = 0;
+                        state = L_INIT;
+                    }
+                }
+                if (base + cnt >= total) exhausted = true;
+            }
+            if (state == L_FREE && exhausted) state = L_EXIT;
+        }
+        if (__ballot(state == L_INIT || state == L_RUN) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ================= one Tsit5 attempt (or the init pseudo-step) per runnable lane ==========================
+        const bool init = (state == L_INIT);
+        const unsigned long long m_init = __ballot(init);
+        if (state == L_RUN || state == L_INIT) {
+            if (!init) dt = rmin(dt, t1 - t);
+            const R h = init ? R(0) : dt;
+            const R h2 = h * h;
+            R X[3], U[4];
+            // ---- stage 2 -------------------------------------------------------------------------------------
+            {
+                const R ha = h * N::a[1][0], hc = h * N::c[1];
+#pragma unroll
+                for (int q = 0; q < 4; q++) U[q] = rfma(ha, k[0][q], u[q]);
+#pragma unroll
+                for (int q = 0; q < 3; q++) X[q] = rfma(hc, u[1 + q], x[1 + q]);
+            }
+            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[1]);   // init lanes (h = 0): k[1] = u̇(y0), f0 = (u, k[1])
+            R dt0 = R(0);
+            float d1f = 0.0f;
+            if (m_init != 0ull) {
+                if (init) {  // Hairer initial step, first half; norms in f32
+                    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float iskx = __builtin_amdgcn_rcpf((float)rfma(rabs(x[q]), reltol, abstol));
+                        const float isku = __builtin_amdgcn_rcpf((float)rfma(rabs(u[q]), reltol, abstol));
+                        const float a0 = (float)x[q] * iskx, b0 = (float)u[q] * isku;
+                        const float a1 = (float)u[q] * iskx, b1 = (float)k[1][q] * isku;
+                        acc0 = __builtin_fmaf(a0, a0, __builtin_fmaf(b0, b0, acc0));
+                        acc1 = __builtin_fmaf(a1, a1, __builtin_fmaf(b1, b1, acc1));
+                    }
+                    const float d0f = __builtin_sqrtf(acc0 * 0.125f);
+                    d1f = __builtin_sqrtf(acc1 * 0.125f);
+                    const float dt0f = (d0f < 1e-5f || d1f < 1e-5f) ? 1e-6f : (d0f / d1f) * 0.01f;
+                    dt0 = rmin((R)dt0f, dtmax);
+                }
+            }
+            // ---- stage 3 (init lanes: y0 + dt0 f0) -----------------------------------------------------------
+            {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const R ur = rfma(h, rfma(N::a[2][1], k[1][q], N::a[2][0] * k[0][q]), u[q]);
+                    U[q] = init ? rfma(dt0, k[1][q], u[q]) : ur;
+                }
+                const R hc = init ? dt0 : h * N::c[2];
+                const R h2a = h2 * N::A2[2][0];
+#pragma unroll
+                for (int q = 0; q < 3; q++) X[q] = rfma(h2a, k[0][1 + q], rfma(hc, u[1 + q], x[1 + q]));
+            }
+            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[2]);   // init lanes: k[2] = u̇(y0 + dt0 f0)
+            R dt_init = R(0);
+            if (m_init != 0ull) {
+                if (init) {  // second half: f1 − f0 = (dt0·k[1], k[2] − k[1])
+                    float acc2 = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float iskx = __builtin_amdgcn_rcpf((float)rfma(rabs(x[q]), reltol, abstol));
+                        const float isku = __builtin_amdgcn_rcpf((float)rfma(rabs(u[q]), reltol, abstol));
+                        const float a2 = (float)(dt0 * k[1][q]) * iskx, b2 = (float)(k[2][q] - k[1][q]) * isku;
+                        acc2 = __builtin_fmaf(a2, a2, __builtin_fmaf(b2, b2, acc2));
+                    }
+                    const float d2f = __builtin_sqrtf(acc2 * 0.125f) / (float)dt0;
+                    const float md = fmaxf(d1f, d2f);
+                    // dt1 = 10^(-(2 + log10 md)/5) = 2^(-(2 log2 10 + log2 md)/5)
+                    const float dt1f = (md <= 1e-15f) ? fmaxf(1e-6f, (float)dt0 * 1e-3f)
+                                                      : fexp2(-0.2f * (6.643856189774724f + flog2(md)));
+                    dt_init = rmin(rmin(R(100) * dt0, (R)dt1f), dtmax);
+                }
+            }
+            // ---- stages 4, 5, 6 ----------------------------------------------------------------------------------
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                U[q] = rfma(h, rfma(N::a[3][2], k[2][q], rfma(N::a[3][1], k[1][q], N::a[3][0] * k[0][q])), u[q]);
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                X[q] = rfma(h2, rfma(N::A2[3][1], k[1][1 + q], N::A2[3][0] * k[0][1 + q]),
+                            rfma(h * N::c[3], u[1 + q], x[1 + q]));
+            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[3]);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                U[q] = rfma(h, rfma(N::a[4][3], k[3][q], rfma(N::a[4][2], k[2][q], rfma(N::a[4][1], k[1][q],
+                            N::a[4][0] * k[0][q]))), u[q]);
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                X[q] = rfma(h2, rfma(N::A2[4][2], k[2][1 + q], rfma(N::A2[4][1], k[1][1 + q], N::A2[4][0] * k[0][1 + q])),
+                            rfma(h * N::c[4], u[1 + q], x[1 + q]));
+            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[4]);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                U[q] = rfma(h, rfma(N::a[5][4], k[4][q], rfma(N::a[5][3], k[3][q], rfma(N::a[5][2], k[2][q],
+                            rfma(N::a[5][1], k[1][q], N::a[5][0] * k[0][q])))), u[q]);
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                X[q] = rfma(h2, rfma(N::A2[5][3], k[3][1 + q], rfma(N::A2[5][2], k[2][1 + q], rfma(N::A2[5][1], k[1][1 + q],
+                            N::A2[5][0] * k[0][1 + q]))), rfma(h * N::c[5], u[1 + q], x[1 + q]));
+            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[5]);
+            // ---- stage 7 = the step result (FSAL) ----------------------------------------------------------------
+            R xn[4], un[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                un[q] = rfma(h, rfma(N::a[6][5], k[5][q], rfma(N::a[6][4], k[4][q], rfma(N::a[6][3], k[3][q],
+                             rfma(N::a[6][2], k[2][q], rfma(N::a[6][1], k[1][q], N::a[6][0] * k[0][q]))))), u[q]);
+                xn[q] = rfma(h2, rfma(N::A2[6][4], k[4][q], rfma(N::A2[6][3], k[3][q], rfma(N::A2[6][2], k[2][q],
+                             rfma(N::A2[6][1], k[1][q], N::A2[6][0] * k[0][q])))), rfma(h * N::c[6], u[q], x[q]));
+            }
+            accel<R, METRIC, SPIN, true>(xn + 1, un, M, aspin, k[6]);
+
+            if (init) {
+                // the fresh ray is ready: FSAL slot <- u̇(y0), controller state reset        
+#pragma unroll
+                for (int q = 0; q < 4; q++) k[0][q] = k[1][q];
+                dt = dt_init;
+                lq = lq_init;
+                ps = rsign(min_distance<R>(A.sc, x));
+                state = L_RUN;
+            } else {
+                // ---- embedded error, residual norm in f32 ----------------------------------------
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const R eu = h * rfma(N::bt[6], k[6][q], rfma(N::bt[5], k[5][q], rfma(N::bt[4], k[4][q],
+                                     rfma(N::bt[3], k[3][q], rfma(N::bt[2], k[2][q], rfma(N::bt[1], k[1][q], N::bt[0] * k[0][q]))))));
+                    const R ex = h * rfma(h, rfma(N::BT2[5], k[5][q], rfma(N::BT2[4], k[4][q], rfma(N::BT2[3], k[3][q],
+                                     rfma(N::BT2[2], k[2][q], rfma(N::BT2[1], k[1][q], N::BT2[0] * k[0][q]))))), N::sbt * u[q]);
+                    const float isku = __builtin_amdgcn_rcpf((float)rfma(rmax(rabs(u[q]), rabs(un[q])), reltol, abstol));
+                    const float iskx = __builtin_amdgcn_rcpf((float)rfma(rmax(rabs(x[q]), rabs(xn[q])), reltol, abstol));
+                    const float ru = (float)eu * isku, rx = (float)ex * iskx;
+                    acc = __builtin_fmaf(ru, ru, __builtin_fmaf(rx, rx, acc));
+                }
+                const float EEst = __builtin_sqrtf(acc * 0.125f);
+                uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
+                bool is_event = false, is_interior = false;
+                R top = R(0);
+                R cc[4][4] = {};  // position polynomial of this step (set when the step is accepted)
+                if (EEst != EEst) {
+                    done = RTGR_RAY_NAN;
+                } else {
+                    // ---- PI controller in log2 space: q = EEst^β1 / qold^β2 / γ ----------------------
+                    const float le = flog2(fmaxf(EEst, 1e-30f));
+                    const float q11 = fexp2(beta1 * le);
+                    float qf = fexp2(__builtin_fmaf(beta1, le, -beta2 * lq)) * igamma;
+                    qf = (EEst == 0.0f) ? qmax_inv : fmaxf(qmax_inv, fminf(qmin_inv, qf));
+                    if (EEst <= 1.0f) {
+                        nacc++;
+                        lq = fmaxf(le, lq_init);  // log2(max(EEst, qoldinit))
+                        const R dtnew = dt * (R)__builtin_amdgcn_rcpf(qf);
+                        R tnew = t + dt;
+                        if (rabs(tnew - t1) < R(10) * eps * rmax(rabs(tnew), rabs(t1))) tnew = t1;
+                        // ---- ContinuousCallback ----------------------------------------------------
+                        // x(θ) = x + θ c1 + θ² c2 + θ³ c3 + θ⁴ c4 ;  c1 = h u,  c_m = h² Σ_l R2[l][m] k_l
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            cc[0][q] = h * u[q];
+#pragma unroll
+                            for (int m = 1; m < 4; m++)
+                                cc[m][q] = h2 * rfma(N::R2[5][m], k[5][q], rfma(N::R2[4][m], k[4][q], rfma(N::R2[3][m], k[3][q],
+                                                rfma(N::R2[2][m], k[2][q], rfma(N::R2[1][m], k[1][q], N::R2[0][m] * k[0][q])))));
+                        }
+                        bool found = false;
+                        R nextc;
+                        if constexpr (NPTS10) {
+                            // two blocks (θ = 1/9…5/9, then 6/9…8/9 + the end point) keep the live set inside the
+                            // 256-register budget; each object's parameters are fetched once per block
+                            {
+                                R pos[5][4], dmin[5];
+#pragma unroll
+                                for (int j = 0; j < 5; j++) {
+                                    const R th = R(j + 1) / R(9);
+                                    dmin[j] = R(__builtin_huge_val());
+#pragma unroll
+                                    for (int q = 0; q < 4; q++)
+                                        pos[j][q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
+                                }
+                                for (uint32_t o = 0; o < A.sc.nobj; o++) fold_distances<R, 5>(A.sc.obj[o], pos, dmin);
+#pragma unroll
+                                for (int j = 0; j < 5; j++) {
+                                    const bool hit = (ps * rsign(dmin[j]) < R(0)) && !found;
+                                    top = hit ? R(j + 1) / R(9) : top;
+                                    found = found || hit;
+                                }
+                            }
+                            {
+                                R pos[4][4], dmin[4];
+#pragma unroll
+                                for (int j = 0; j < 3; j++) {
+                                    const R th = R(j + 6) / R(9);
+                                    dmin[j] = R(__builtin_huge_val());
+#pragma unroll
+                                    for (int q = 0; q < 4; q++)
+                                        pos[j][q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
+                                }
+                                dmin[3] = R(__builtin_huge_val());
+#pragma unroll
+                                for (int q = 0; q < 4; q++) pos[3][q] = xn[q];
+                                for (uint32_t o = 0; o < A.sc.nobj; o++) fold_distances<R, 4>(A.sc.obj[o], pos, dmin);
+                                nextc = dmin[3];
+#pragma unroll
+                                for (int j = 0; j < 3; j++) {
+                                    const bool hit = (ps * rsign(dmin[j]) < R(0)) && !found;
+                                    top = hit ? R(j + 6) / R(9) : top;
+                                    found = found || hit;
+                                }
+                            }
+                        } else {
+                            nextc = min_distance<R>(A.sc, xn);
+                            const R dth = npts > 1 ? R(1) / R(npts - 1) : R(1);
+                            for (int j = 1; j + 1 < npts; j++) {
+                                const R th = R(j) * dth;
+                                R xi[4];
+#pragma unroll
+                                for (int q = 0; q < 4; q++)
+                                    xi[q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
+                                const bool hit = (ps * rsign(min_distance<R>(A.sc, xi)) < R(0)) && !found;
+                                top = hit ? th : top;
+                                found = found || hit;
+                            }
+                        }
+                        const bool endpoint = (ps != R(0)) && (ps * rsign(nextc) <= R(0));
+                        found = found && (ps != R(0)) && !endpoint;
+                        if (endpoint || found) {
+                            top = endpoint ? R(1) : top;
+                            is_event = true;
+                            is_interior = found;
+                            done = RTGR_RAY_EVENT;
+                        } else {
+                            ps = rsign(nextc);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k[0][q] = k[6][q]; }
+                            t = tnew;
+                            dt = rmin(dtmax, dtnew);
+                            if (!(t < t1)) done = RTGR_RAY_LAMBDA1;
+                            else if (nacc + nrej >= A.opt.max_steps) done = RTGR_RAY_MAXSTEPS;
+                            else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
+                        }
+                    } else {
+                        nrej++;
+                        dt = dt * (R)__builtin_amdgcn_rcpf(fminf(qmin_inv, q11 * igamma));
+                        if (nacc + nrej >= A.opt.max_steps) done = RTGR_RAY_MAXSTEPS;
+                        else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
+                    }
+                }
+                if (done != 0xffu) {
+                    // ---- hand the ray over to the resolve kernel ---------------------------------------------------------
+                    R* rec = A.rec + idx * (uint64_t)A.recw;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) rec[REC_X + q] = x[q];
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) rec[REC_C + 4 * m + q] = is_event ? cc[m][q] : R(0);
+                    rec[REC_PS] = is_event ? ps : R(0);
+                    rec[REC_TOP] = top;
+                    rec[REC_T] = t;
+                    rec[REC_H] = is_event ? h : R(0);
+                    if (A.recw == REC_W_STATE) {
+                        // u(θ) = u + h Σ_j b_j(θ) k_j  (all seven stages)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            rec[REC_U + q] = u[q];
+#pragma unroll
+                            for (int m = 0; m < 4; m++) {
+                                const R cu = h * rfma(N::r[6][m], k[6][q], rfma(N::r[5][m], k[5][q], rfma(N::r[4][m], k[4][q],
+                                                 rfma(N::r[3][m], k[3][q], rfma(N::r[2][m], k[2][q], rfma(N::r[1][m], k[1][q], N::r[0][m] * k[0][q]))))));
+                                rec[REC_CU + 4 * m + q] = is_event ? cu : R(0);
+                            }
+                        }
+                    }
+                    uint32_t* mt = A.meta + idx * 3;
+                    mt[0] = nacc;
+                    mt[1] = nrej;
+                    mt[2] = done | (is_interior ? 0x100u : 0u);
+                    c_rays += 1; c_acc += nacc; c_rej += nrej;
+                    c_ev += is_event; c_int += is_interior; c_nf += (done >= RTGR_RAY_MAXSTEPS);
+                    state = L_FREE;
+                }
+            }
+        }
+    }
+    if (A.counters) {
+        const unsigned long long s0 = wave_sum(c_rays), s1 = wave_sum(c_acc), s2 = wave_sum(c_rej),
+                                 s4 = wave_sum(c_ev), s5 = wave_sum(c_int), s6 = wave_sum(c_nf);
+        if (lane == 0) {
+            atomicAdd(&A.counters[0], s0);
+            atomicAdd(&A.counters[1], s1);
+            atomicAdd(&A.counters[2], s2);
+            atomicAdd(&A.counters[3], 6ull * (s1 + s2) + 2ull * s0);  // RHS evaluations: 6 per attempt + 2 per ray
+            atomicAdd(&A.counters[4], s4);
+            atomicAdd(&A.counters[5], s5);
+            atomicAdd(&A.counters[6], s6);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// resolve kernel: one thread per ray — root of cond(x(θ)) on [0, top], end state, colouring rule, stores
+// ---------------------------------------------------------------------------------------------------------------------
 template <class R>
-RTGR_DEV R cond_at(const DevScene<R>& sc, const R y[8], const R c[4][4], R th) {
+RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th) {
     R x[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) x[q] = rfma(th, rfma(th, rfma(th, rfma(th, c[3][q], c[2][q]), c[1][q]), c[0][q]), y[q]);
+    for (int q = 0; q < 4; q++) x[q] = rfma(th, rfma(th, rfma(th, rfma(th, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
     return min_distance<R>(sc, x);
 }
 
-// Bracketed root of cond(x(θ)) on [0, top] with sign(cond(0)) = ps: Ridders' method (quadratic convergence, every
-// iterate stays inside the bracket, both ends move) finished by bisection; returns the pre-crossing end of the
-// final bracket — the reference's prevfloat(find_zero(...)).
+// Bracketed root of g(θ) = ps·cond(x(θ)) on [0, top], g(0) > 0 >= g(top): Ridders' method (every iterate stays inside
+// the bracket and both ends move; quadratic convergence) with a bisection step built in; returns the pre-crossing
+// end of the final bracket — the reference's prevfloat(find_zero(...)).
 template <class R>
-RTGR_DEV R event_root(const DevScene<R>& sc, const R y[8], const R c[4][4], R ps, R top) {
+RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R ps, R top) {
     R lo = R(0), hi = top;
-    R fhi = cond_at<R>(sc, y, c, hi) * ps;   // work with g = ps*cond: g(lo) > 0, g(hi) <= 0
+    R fhi = cond_poly<R>(sc, x0, c, hi) * ps;
     if (fhi == R(0)) return hi;
-    R flo = cond_at<R>(sc, y, c, R(0)) * ps;
-    if (!(flo > R(0))) return R(0);
+    R flo = cond_poly<R>(sc, x0, c, R(0)) * ps;
+    if (!(flo > R(0)) || !(fhi < R(0))) return R(0);
     const R eps = sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7);
-    for (int it = 0; it < 100; it++) {
+    for (int it = 0; it < 128; it++) {
         const R width = hi - lo;
         if (!(width > R(2) * eps * hi)) break;
         const R mid = rfma(R(0.5), width, lo);
         if (!(mid > lo && mid < hi)) break;
-        const R fm = cond_at<R>(sc, y, c, mid) * ps;
-        // Ridders: x4 = mid + (mid-lo) * sign(flo-fhi) * fm / sqrt(fm² - flo fhi); flo > 0 >= fhi so sign = +1
+        const R fm = cond_poly<R>(sc, x0, c, mid) * ps;
         const R den = rsqrt_(rfma(fm, fm, -flo * fhi));
         R x4 = den > R(0) ? rfma(mid - lo, fm / den, mid) : mid;
         if (!(x4 > lo && x4 < hi)) x4 = mid;
-        const R f4 = (x4 == mid) ? fm : cond_at<R>(sc, y, c, x4) * ps;
-        // re-bracket with the tightest pair around the sign change among {lo, mid, x4, hi}
+        const R f4 = (x4 == mid) ? fm : cond_poly<R>(sc, x0, c, x4) * ps;
         const R a = rmin(mid, x4), b = rmax(mid, x4);
         const R fa = (mid <= x4) ? fm : f4, fb = (mid <= x4) ? f4 : fm;
         if (fa > R(0)) {
@@ -136,279 +511,64 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R y[8], const R c[4][4], R ps
     return lo;
 }
 
-// lanes below `lane` set in mask
-RTGR_DEV uint32_t mask_rank(unsigned long long mask, uint32_t lane) {
-    return (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-}
+template <class R>
+struct ResolveArgs {
+    DevScene<R> sc;
+    DevSolver<R> opt;
+    const R* rec;
+    const uint32_t* meta;
+    int recw;
+    uint64_t n;        // rays in this chunk
+    uint64_t offset;   // first ray of the chunk in the caller's slab
+    uint64_t n_slab;   // rays in the slab (plane stride of rgb)
+    R* rgb;
+    R* state_end;
+    R* lambda_end;
+    uint8_t* status;
+    uint8_t* hit;
+    uint32_t* n_accept;
+    uint32_t* n_reject;
+};
 
-template <class R, int METRIC, bool SPIN, bool NPTS10>
-__global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void trace_persistent_kernel(const TraceArgs<R> A, unsigned long long* queue,
-                                                                 int thresh) {
-    using C = Tsit5C<R>;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t n = A.ni * A.nrows;
-    const uint64_t tiles_i = (A.ni + 7) >> 3, tiles_j = (A.nrows + 7) >> 3;
-    const uint64_t total = tiles_i * tiles_j * 64;  // work ids in 8x8-tile order (some ids fall outside ragged edges)
-    const R M = A.sc.M, aspin = A.sc.a;
-    const R reltol = A.opt.reltol, abstol = A.opt.abstol;
-    const R t0 = A.opt.lambda0, t1 = A.opt.lambda1, dtmax = A.opt.lambda1 - A.opt.lambda0;
-    const R igamma = R(1) / R(0.9L), qmin_inv = R(5), qmax_inv = R(0.1L), qoldinit = R(1e-4L);
-    const R beta1 = R(0.14L), beta2 = R(0.08L);
-    const int npts = (int)A.opt.interp_points;
-
-    int state = L_FREE;
-    bool exhausted = false;
-    R y[8], k[7][8];
-    R t = t0, dt = R(0), qold = qoldinit, prev_cond = R(0), top = R(1), hstep = R(0);
-    uint64_t idx = 0;
-    uint32_t nacc = 0, nrej = 0;
-    uint8_t status = 0, interior = 0;
-    // per-lane totals, reduced once at exit
-    unsigned long long c_rays = 0, c_acc = 0, c_rej = 0, c_rhs = 0, c_ev = 0, c_int = 0, c_nf = 0;
+template <class R>
+__global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= A.n) return;
+    const R* rec = A.rec + w * (uint64_t)A.recw;
+    R x0[4], c[4][4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        y[i] = R(0);
+    for (int q = 0; q < 4; q++) x0[q] = rec[REC_X + q];
 #pragma unroll
-        for (int s = 0; s < 7; s++) k[s][i] = R(0);
-    }
-
-    for (;;) {
-        // ================= service phase: resolve parked lanes, refill from the ray queue ======================
-        const unsigned long long m_wait = __ballot(state == L_EVENT || state == L_DONE);
-        const unsigned long long m_free = __ballot(state == L_FREE);
-        const unsigned long long m_run = __ballot(state == L_RUN || state == L_INIT);
-        const int need = exhausted ? 65 : thresh;
-        if (m_free != 0ull || m_run == 0ull || __builtin_popcountll(m_wait) >= need) {
-            if (state == L_EVENT || state == L_DONE) {
-                R se[8], lam, col[3];
-                if (state == L_EVENT) {
-                    R cc[4][4];
-                    dense_pos_coeffs<R>(hstep, k, cc);
-                    const R Theta = event_root<R>(A.sc, y, cc, rsign(prev_cond), top);
-                    dense_full<R>(y, hstep, k, Theta, se);
-                    lam = rfma(hstep, Theta, t);
-                } else {
+    for (int m = 0; m < 4; m++)
 #pragma unroll
-                    for (int i = 0; i < 8; i++) se[i] = y[i];
-                    lam = t;
-                }
-                const uint8_t hit = colour_pixel<R>(A.sc, A.opt, se, col);
-                A.rgb[idx] = col[0];
-                A.rgb[n + idx] = col[1];
-                A.rgb[2 * n + idx] = col[2];
-                if (A.state_end) {
+        for (int q = 0; q < 4; q++) c[m][q] = rec[REC_C + 4 * m + q];
+    const R ps = rec[REC_PS], top = rec[REC_TOP], t = rec[REC_T], h = rec[REC_H];
+    const R Theta = (ps != R(0)) ? event_root<R>(A.sc, x0, c, ps, top) : R(0);
+    R xe[4];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) A.state_end[idx * 8 + i] = se[i];
-                }
-                if (A.lambda_end) A.lambda_end[idx] = lam;
-                if (A.status) A.status[idx] = status;
-                if (A.hit) A.hit[idx] = hit;
-                if (A.n_accept) A.n_accept[idx] = nacc;
-                if (A.n_reject) A.n_reject[idx] = nrej;
-                c_rays += 1; c_acc += nacc; c_rej += nrej;
-                c_ev += (status == RTGR_RAY_EVENT); c_int += interior; c_nf += (status >= RTGR_RAY_MAXSTEPS);
-                state = L_FREE;
-            }
-            // ---- refill: wave-aggregated pop from the global queue ------------------------------------------
-            unsigned long long m_need = __ballot(state == L_FREE);
-            while (m_need != 0ull && !exhausted) {  // loops only to skip work ids that fall outside a ragged edge
-                const uint32_t cnt = (uint32_t)__builtin_popcountll(m_need);
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(queue, (unsigned long long)cnt);
-                base = __shfl(base, 0, 64);
-                if (state == L_FREE) {
-                    const uint64_t w = base + mask_rank(m_need, lane);
-                    if (w < total) {
-                        const uint64_t tile = w >> 6, l = w & 63;
-                        const uint64_t i = (tile % tiles_i) * 8 + (l & 7), jl = (tile / tiles_i) * 8 + (l >> 3);
-                        if (i < A.ni && jl < A.nrows) {
-                            idx = i + jl * A.ni;
-                            if (A.state0) {
+    for (int q = 0; q < 4; q++)
+        xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
+    R col[3];
+    const uint8_t hit = colour_pixel<R>(A.sc, A.opt, xe, col);
+    const uint64_t idx = A.offset + w;
+    A.rgb[idx] = col[0];
+    A.rgb[A.n_slab + idx] = col[1];
+    A.rgb[2 * A.n_slab + idx] = col[2];
+    const uint32_t* mt = A.meta + w * 3;
+    if (A.state_end) {
+        R* se = A.state_end + idx * 8;
 #pragma unroll
-                                for (int q = 0; q < 8; q++) y[q] = A.state0[idx * 8 + q];
-                            } else {
-                                make_pixel<R>(A.sc, A.cam, A.ni, A.nj, i, A.j0 + jl, y);
-                            }
-#pragma unroll
-                            for (int q = 0; q < 8; q++) k[0][q] = R(0);
-                            t = t0; nacc = 0; nrej = 0; status = 0; interior = 0; top = R(1);
-                            state = L_INIT;
-                        }
-                    }
-                }
-                if (base + cnt >= total) exhausted = true;
-                m_need = __ballot(state == L_FREE);
-            }
-            if (state == L_FREE) state = L_EXIT;
-            if (__ballot(state == L_INIT || state == L_RUN) == 0ull) break;
-        }
-
-        // ================= step phase: one Tsit5 attempt (or the init pseudo-step) per runnable lane =============
-        const bool init = (state == L_INIT);
-        const unsigned long long m_init = __ballot(init);
-        if (state == L_RUN || state == L_INIT) {
-            if (!init) dt = rmin(dt, t1 - t);
-            const R h = init ? R(0) : dt;
-            R Y[8], yn[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) Y[i] = rfma(h * C::a21, k[0][i], y[i]);
-            rhs<R, METRIC, SPIN>(Y, M, aspin, k[1]);            // init lanes: k2 = f(y0) = f0
-            R dt0 = R(0), d1 = R(0);
-            if (m_init != 0ull) {
-                if (init) {  // Hairer initial step, first half
-                    R acc0 = R(0), acc1 = R(0);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const R isk = R(1) / rfma(rabs(y[i]), reltol, abstol);
-                        const R a0 = y[i] * isk, a1 = k[1][i] * isk;
-                        acc0 = rfma(a0, a0, acc0);
-                        acc1 = rfma(a1, a1, acc1);
-                    }
-                    const R d0 = rsqrt_(acc0 * R(0.125));
-                    d1 = rsqrt_(acc1 * R(0.125));
-                    dt0 = (d0 < R(1e-5) || d1 < R(1e-5)) ? R(1e-6) : (d0 / d1) * R(0.01);
-                    dt0 = rmin(dt0, dtmax);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const R yr = rfma(h, rfma(C::a32, k[1][i], C::a31 * k[0][i]), y[i]);
-                Y[i] = init ? rfma(dt0, k[1][i], y[i]) : yr;
-            }
-            rhs<R, METRIC, SPIN>(Y, M, aspin, k[2]);            // init lanes: k3 = f(y0 + dt0 f0) = f1
-            R dt_init = R(0);
-            if (m_init != 0ull) {
-                if (init) {  // second half
-                    R acc2 = R(0);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const R isk = R(1) / rfma(rabs(y[i]), reltol, abstol);
-                        const R a2 = (k[2][i] - k[1][i]) * isk;
-                        acc2 = rfma(a2, a2, acc2);
-                    }
-                    const R d2 = rsqrt_(acc2 * R(0.125)) / dt0;
-                    const R md = rmax(d1, d2);
-                    R dt1;
-                    if (md <= R(1e-15)) dt1 = rmax(R(1e-6), dt0 * R(1e-3));
-                    else dt1 = rpow<R>(R(10), -(R(2) + rlog10<R>(md)) * R(0.2));
-                    dt_init = rmin(rmin(R(100) * dt0, dt1), dtmax);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                Y[i] = rfma(h, rfma(C::a43, k[2][i], rfma(C::a42, k[1][i], C::a41 * k[0][i])), y[i]);
-            rhs<R, METRIC, SPIN>(Y, M, aspin, k[3]);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                Y[i] = rfma(h, rfma(C::a54, k[3][i], rfma(C::a53, k[2][i], rfma(C::a52, k[1][i], C::a51 * k[0][i]))), y[i]);
-            rhs<R, METRIC, SPIN>(Y, M, aspin, k[4]);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                Y[i] = rfma(h, rfma(C::a65, k[4][i], rfma(C::a64, k[3][i], rfma(C::a63, k[2][i],
-                            rfma(C::a62, k[1][i], C::a61 * k[0][i])))), y[i]);
-            rhs<R, METRIC, SPIN>(Y, M, aspin, k[5]);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                yn[i] = rfma(h, rfma(C::a76, k[5][i], rfma(C::a75, k[4][i], rfma(C::a74, k[3][i], rfma(C::a73, k[2][i],
-                             rfma(C::a72, k[1][i], C::a71 * k[0][i]))))), y[i]);
-            rhs<R, METRIC, SPIN>(yn, M, aspin, k[6]);
-
-            if (init) {
-                // the fresh ray is ready: FSAL slot <- f0, controller state reset            
-#pragma unroll
-                for (int i = 0; i < 8; i++) k[0][i] = k[1][i];
-                dt = dt_init;
-                qold = qoldinit;
-                prev_cond = min_distance<R>(A.sc, y);
-                c_rhs += 2;
-                state = L_RUN;
-            } else {
-                c_rhs += 6;
-                R acc = R(0);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const R ut = h * rfma(C::bt7, k[6][i], rfma(C::bt6, k[5][i], rfma(C::bt5, k[4][i],
-                                     rfma(C::bt4, k[3][i], rfma(C::bt3, k[2][i], rfma(C::bt2, k[1][i], C::bt1 * k[0][i]))))));
-                    const R res = ut / rfma(rmax(rabs(y[i]), rabs(yn[i])), reltol, abstol);
-                    acc = rfma(res, res, acc);
-                }
-                const R EEst = rsqrt_(acc * R(0.125));
-                if (EEst != EEst) {
-                    status = RTGR_RAY_NAN;
-                    state = L_DONE;
-                } else {
-                    R q, q11 = R(0);
-                    if (EEst == R(0)) q = qmax_inv;
-                    else {
-                        q11 = rpow<R>(EEst, beta1);
-                        q = q11 / rpow<R>(qold, beta2);
-                        q = rmax(qmax_inv, rmin(qmin_inv, q * igamma));
-                    }
-                    if (EEst <= R(1)) {
-                        nacc++;
-                        qold = rmax(EEst, qoldinit);
-                        const R dtnew = dt / q;
-                        R tnew = t + dt;
-                        if (rabs(tnew - t1) < R(10) * R(sizeof(R) == 8 ? 2.220446049250313e-16 : 1.1920929e-7) * rmax(rabs(tnew), rabs(t1)))
-                            tnew = t1;
-                        // ---- ContinuousCallback ------------------------------------------------
-                        const R next_cond = min_distance<R>(A.sc, yn);
-                        const R ps = rsign(prev_cond);
-                        bool found = false;
-                        R tp = R(1);
-                        const bool endpoint = (ps != R(0)) && (ps * rsign(next_cond) <= R(0));
-                        if constexpr (NPTS10) {
-                            InteriorScan<R, 1, 9>::run(A.sc, y, h, k, ps, found, tp);
-                        } else {
-                            const R dth = npts > 1 ? R(1) / R(npts - 1) : R(1);
-                            for (int j = 1; j + 1 < npts; j++) {
-                                R xi[4];
-                                dense_pos<R>(y, h, k, R(j) * dth, xi);
-                                const bool hit = (ps * rsign(min_distance<R>(A.sc, xi)) < R(0)) && !found;
-                                tp = hit ? R(j) * dth : tp;
-                                found = found || hit;
-                            }
-                        }
-                        found = found && (ps != R(0)) && !endpoint;
-                        if (endpoint || found) {
-                            top = endpoint ? R(1) : tp;
-                            interior = found ? 1 : 0;
-                            hstep = h;
-                            status = RTGR_RAY_EVENT;
-                            state = L_EVENT;  // y, k[0..6], t stay frozen for the batched root-find
-                        } else {
-                            prev_cond = next_cond;
-#pragma unroll
-                            for (int i = 0; i < 8; i++) { y[i] = yn[i]; k[0][i] = k[6][i]; }
-                            t = tnew;
-                            dt = rmin(dtmax, dtnew);
-                            if (!(t < t1)) { status = RTGR_RAY_LAMBDA1; state = L_DONE; }
-                            else if (nacc + nrej >= A.opt.max_steps) { status = RTGR_RAY_MAXSTEPS; state = L_DONE; }
-                            else if (!(t + dt > t)) { status = RTGR_RAY_DTMIN; state = L_DONE; }
-                        }
-                    } else {
-                        nrej++;
-                        dt = dt / rmin(qmin_inv, q11 * igamma);
-                        if (nacc + nrej >= A.opt.max_steps) { status = RTGR_RAY_MAXSTEPS; state = L_DONE; }
-                        else if (!(t + dt > t)) { status = RTGR_RAY_DTMIN; state = L_DONE; }
-                    }
-                }
-            }
+        for (int q = 0; q < 4; q++) {
+            se[q] = xe[q];
+            const R* cu = rec + REC_CU;
+            se[4 + q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, cu[12 + q], cu[8 + q]), cu[4 + q]), cu[q]), rec[REC_U + q]);
         }
     }
-    if (A.counters) {
-        const unsigned long long s0 = wave_sum(c_rays), s1 = wave_sum(c_acc), s2 = wave_sum(c_rej), s3 = wave_sum(c_rhs),
-                                 s4 = wave_sum(c_ev), s5 = wave_sum(c_int), s6 = wave_sum(c_nf);
-        if (lane == 0) {
-            atomicAdd(&A.counters[0], s0);
-            atomicAdd(&A.counters[1], s1);
-            atomicAdd(&A.counters[2], s2);
-            atomicAdd(&A.counters[3], s3);
-            atomicAdd(&A.counters[4], s4);
-            atomicAdd(&A.counters[5], s5);
-            atomicAdd(&A.counters[6], s6);
-        }
-    }
+    if (A.lambda_end) A.lambda_end[idx] = rfma(h, Theta, t);
+    if (A.status) A.status[idx] = (uint8_t)(mt[2] & 0xffu);
+    if (A.hit) A.hit[idx] = hit;
+    if (A.n_accept) A.n_accept[idx] = mt[0];
+    if (A.n_reject) A.n_reject[idx] = mt[1];
 }
 
 }  // namespace rtgr
