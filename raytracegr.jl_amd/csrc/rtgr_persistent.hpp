@@ -211,15 +211,14 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                     dt0 = rmin((R)dt0f, dtmax);
                 }
             }
-            // ---- stage 3 (init lanes: y0 + dt0 f0) -----------------------------------------------------------
+            // ---- stage 3 (init lanes: y0 + dt0 f0 — k[0] = 0 there, so only the scalar multipliers differ) ---------
             {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const R ur = rfma(h, rfma(N::a[2][1], k[1][q], N::a[2][0] * k[0][q]), u[q]);
-                    U[q] = init ? rfma(dt0, k[1][q], u[q]) : ur;
-                }
+                const R w1 = init ? dt0 : h * N::a[2][1];
+                const R w0 = h * N::a[2][0];
                 const R hc = init ? dt0 : h * N::c[2];
                 const R h2a = h2 * N::A2[2][0];
+#pragma unroll
+                for (int q = 0; q < 4; q++) U[q] = rfma(w1, k[1][q], rfma(w0, k[0][q], u[q]));
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(h2a, k[0][1 + q], rfma(hc, u[1 + q], x[1 + q]));
             }
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
                 bool is_event = false, is_interior = false;
                 R top = R(0);
-                R cc[4][4] = {};  // position polynomial of this step (set when the step is accepted)
+                R cc[4][4];  // position polynomial of this step (set when the step is accepted; read only on events)
                 if (EEst != EEst) {
                     done = RTGR_RAY_NAN;
                 } else {
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                                 for (uint32_t o = 0; o < A.sc.nobj; o++) fold_distances<R, 5>(A.sc.obj[o], pos, dmin);
 #pragma unroll
                                 for (int j = 0; j < 5; j++) {
-                                    const bool hit = (ps * rsign(dmin[j]) < R(0)) && !found;
+                                    const bool hit = (ps * dmin[j] < R(0)) && !found;
                                     top = hit ? R(j + 1) / R(9) : top;
                                     found = found || hit;
                                 }
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                                 nextc = dmin[3];
 #pragma unroll
                                 for (int j = 0; j < 3; j++) {
-                                    const bool hit = (ps * rsign(dmin[j]) < R(0)) && !found;
+                                    const bool hit = (ps * dmin[j] < R(0)) && !found;
                                     top = hit ? R(j + 6) / R(9) : top;
                                     found = found || hit;
                                 }
@@ -386,12 +385,12 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
 #pragma unroll
                                 for (int q = 0; q < 4; q++)
                                     xi[q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
-                                const bool hit = (ps * rsign(min_distance<R>(A.sc, xi)) < R(0)) && !found;
+                                const bool hit = (ps * min_distance<R>(A.sc, xi) < R(0)) && !found;
                                 top = hit ? th : top;
                                 found = found || hit;
                             }
                         }
-                        const bool endpoint = (ps != R(0)) && (ps * rsign(nextc) <= R(0));
+                        const bool endpoint = (ps != R(0)) && (ps * nextc <= R(0));
                         found = found && (ps != R(0)) && !endpoint;
                         if (endpoint || found) {
                             top = endpoint ? R(1) : top;
@@ -420,26 +419,32 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                     R* rec = A.rec + idx * (uint64_t)A.recw;
 #pragma unroll
                     for (int q = 0; q < 4; q++) rec[REC_X + q] = x[q];
-#pragma unroll
-                    for (int m = 0; m < 4; m++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) rec[REC_C + 4 * m + q] = is_event ? cc[m][q] : R(0);
-                    rec[REC_PS] = is_event ? ps : R(0);
                     rec[REC_TOP] = top;
                     rec[REC_T] = t;
-                    rec[REC_H] = is_event ? h : R(0);
-                    if (A.recw == REC_W_STATE) {
-                        // u(θ) = u + h Σ_j b_j(θ) k_j  (all seven stages)
+                    const bool want_state = (A.recw == REC_W_STATE);
+                    if (want_state) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            rec[REC_U + q] = u[q];
+                        for (int q = 0; q < 4; q++) rec[REC_U + q] = u[q];
+                    }
+                    if (is_event) {
 #pragma unroll
-                            for (int m = 0; m < 4; m++) {
-                                const R cu = h * rfma(N::r[6][m], k[6][q], rfma(N::r[5][m], k[5][q], rfma(N::r[4][m], k[4][q],
-                                                 rfma(N::r[3][m], k[3][q], rfma(N::r[2][m], k[2][q], rfma(N::r[1][m], k[1][q], N::r[0][m] * k[0][q]))))));
-                                rec[REC_CU + 4 * m + q] = is_event ? cu : R(0);
-                            }
+                        for (int m = 0; m < 4; m++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) rec[REC_C + 4 * m + q] = cc[m][q];
+                        rec[REC_PS] = ps;
+                        rec[REC_H] = h;
+                        if (want_state) {  // u(θ) = u + h Σ_j b_j(θ) k_j  (all seven stages)
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+#pragma unroll
+                                for (int m = 0; m < 4; m++)
+                                    rec[REC_CU + 4 * m + q] = h * rfma(N::r[6][m], k[6][q], rfma(N::r[5][m], k[5][q],
+                                        rfma(N::r[4][m], k[4][q], rfma(N::r[3][m], k[3][q], rfma(N::r[2][m], k[2][q],
+                                        rfma(N::r[1][m], k[1][q], N::r[0][m] * k[0][q]))))));
                         }
+                    } else {
+                        rec[REC_PS] = R(0);  // no event: the resolve kernel takes θ = 0, i.e. the state as stored
+                        rec[REC_H] = R(0);
                     }
                     uint32_t* mt = A.meta + idx * 3;
                     mt[0] = nacc;
@@ -535,19 +540,22 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= A.n) return;
     const R* rec = A.rec + w * (uint64_t)A.recw;
-    R x0[4], c[4][4];
+    R x0[4], xe[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) x0[q] = rec[REC_X + q];
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) c[m][q] = rec[REC_C + 4 * m + q];
+    for (int q = 0; q < 4; q++) xe[q] = x0[q] = rec[REC_X + q];
     const R ps = rec[REC_PS], top = rec[REC_TOP], t = rec[REC_T], h = rec[REC_H];
-    const R Theta = (ps != R(0)) ? event_root<R>(A.sc, x0, c, ps, top) : R(0);
-    R xe[4];
+    R Theta = R(0);
+    if (ps != R(0)) {  // an event: the polynomial part of the record is valid
+        R c[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[m][q] = rec[REC_C + 4 * m + q];
+        Theta = event_root<R>(A.sc, x0, c, ps, top);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
+    }
     R col[3];
     const uint8_t hit = colour_pixel<R>(A.sc, A.opt, xe, col);
     const uint64_t idx = A.offset + w;
@@ -560,8 +568,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             se[q] = xe[q];
-            const R* cu = rec + REC_CU;
-            se[4 + q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, cu[12 + q], cu[8 + q]), cu[4 + q]), cu[q]), rec[REC_U + q]);
+            R ue = rec[REC_U + q];
+            if (ps != R(0)) {
+                const R* cu = rec + REC_CU;
+                ue = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, cu[12 + q], cu[8 + q]), cu[4 + q]), cu[q]), ue);
+            }
+            se[4 + q] = ue;
         }
     }
     if (A.lambda_end) A.lambda_end[idx] = rfma(h, Theta, t);

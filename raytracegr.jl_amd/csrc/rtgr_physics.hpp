@@ -61,8 +61,13 @@ template <> RTGR_DEV float rsqrt_<float>(float x) { return __builtin_sqrtf(x); }
 template <class R> RTGR_DEV R rabs(R x) { return x < R(0) ? -x : x; }
 template <> RTGR_DEV double rabs<double>(double x) { return __builtin_fabs(x); }
 template <> RTGR_DEV float rabs<float>(float x) { return __builtin_fabsf(x); }
-template <class R> RTGR_DEV R rmax(R a, R b) { return a > b ? a : b; }  // operands are never NaN where used
-template <class R> RTGR_DEV R rmin(R a, R b) { return a < b ? a : b; }
+// v_max_f64 / v_min_f64 (one instruction; IEEE maxNum/minNum — operands are never NaN where used)
+template <class R> RTGR_DEV R rmax(R a, R b);
+template <> RTGR_DEV double rmax<double>(double a, double b) { return __builtin_fmax(a, b); }
+template <> RTGR_DEV float rmax<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <class R> RTGR_DEV R rmin(R a, R b);
+template <> RTGR_DEV double rmin<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <> RTGR_DEV float rmin<float>(float a, float b) { return __builtin_fminf(a, b); }
 // ---- fast reciprocal / reciprocal square root: hardware seed (v_rcp_f64 / v_rsq_f64) + two Newton steps on the FMA
 // pipe.  No denormal / inf fix-up (operands here are O(1e-3 … 1e3)); result within ~1 ulp.  The IEEE expansions hipcc
 // emits for `1.0/x` and `sqrt(x)` cost 11 and ~14 instructions; these cost 5 and 7.
