@@ -145,6 +145,13 @@ int rtgr_device_info(char* name, uint64_t name_len, int* n_cu, int* clock_mhz, i
  * enough.  Call this once up front (e.g. before hipGraph capture) to size it for slabs of n_rays rays. */
 int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32);
 
+/* Optional per-kernel timing for benchmarks: when enabled the library brackets every kernel it launches with HIP
+ * events on the caller's stream.  rtgr_timing_read waits for them and returns, since the previous read, the summed
+ * milliseconds and launch counts of [0] the camera kernel, [1] the integrate kernel (the hot kernel), [2] the resolve
+ * kernel.  Not for use during hipGraph capture. */
+int rtgr_timing_enable(int on);
+int rtgr_timing_read(double ms[3], uint64_t launches[3]);
+
 /* ---- the hot path, device-resident buffers ------------------------------------------------------------------
  * Replaces the body of trace_rays (src/RayTraceGR.jl:482-536) for rows j in [j0, j1) of an ni x nj canvas.
  *   d_state0 : n x 8 initial ray states on the DEVICE (n = ni*(j1-j0)), as `input_func(i)` yields (:492-496),

@@ -57,7 +57,7 @@ class rtgr_ray_outputs(C.Structure):
 # Every symbol include/rtgr.h declares (tests check the .so exports exactly this list).
 EXPORTS = [
     "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version", "rtgr_solver_defaults",
-    "rtgr_device_info", "rtgr_reserve_workspace", "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_f64", "rtgr_trace_f32",
+    "rtgr_device_info", "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read", "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_f64", "rtgr_trace_f32",
     "rtgr_trace_pixels_f64", "rtgr_trace_one_f64", "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64",
     "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", "rtgr_quantize_device_f64",
 ]
@@ -86,6 +86,8 @@ def _declare(lib):
     lib.rtgr_solver_defaults.argtypes = [P(rtgr_solver), i32]
     lib.rtgr_device_info.argtypes = [C.c_char_p, u64, P(i32), P(i32), P(i32)]
     lib.rtgr_reserve_workspace.argtypes = [u64, i32, i32]
+    lib.rtgr_timing_enable.argtypes = [i32]
+    lib.rtgr_timing_read.argtypes = [P(C.c_double * 3), P(C.c_uint64 * 3)]
     for suf in ("f64", "f32"):
         getattr(lib, f"rtgr_trace_device_{suf}").argtypes = [
             P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "rtgr_persistent.hpp"
 
@@ -246,6 +247,27 @@ constexpr unsigned RTGR_QUEUE_SLOTS = 256;
 static void* g_ws = nullptr;  // library-owned workspace (event records, per-ray meta, generated ray states)
 static size_t g_ws_bytes = 0;
 
+// optional per-kernel timing (bench.py's roofline leg): hipEvents around each kernel of the pipeline
+struct TimedLaunch { hipEvent_t a, b; int which; };
+static bool g_timing = false;
+static std::vector<TimedLaunch> g_timed;
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t take_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct KernelTimer {  // RAII: records start now, stop at scope exit
+    hipStream_t st; int which; hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(hipStream_t s, int w) : st(s), which(w) {
+        if (g_timing) { a = take_event(); b = take_event(); (void)hipEventRecord(a, st); }
+    }
+    ~KernelTimer() {
+        if (a) { (void)hipEventRecord(b, st); g_timed.push_back({a, b, which}); }
+    }
+};
+
 static int env_int(const char* name, int dflt) {
     const char* v = std::getenv(name);
     return (v && *v) ? std::atoi(v) : dflt;
@@ -286,6 +308,7 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     if (use_tile_kernel()) {
         const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
         const uint64_t blocks = (tiles + 3) / 4;
+        KernelTimer tm(st, 1);
         hipLaunchKernelGGL((trace_kernel<R, METRIC, SPIN>), dim3((unsigned)blocks), dim3(256), 0, st, A);
         return RTGR_OK;
     }
@@ -303,21 +326,29 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
         const R* s0 = A.state0 ? A.state0 + off * 8 : gen;
-        if (with_canvas)
+        if (with_canvas) {
+            KernelTimer tm(st, 0);
             hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
                                A.nj, A.j0, off, m, gen);
+        }
         unsigned long long* q = g_queue_pool + (g_queue_next++ % RTGR_QUEUE_SLOTS);
         HIP_TRY(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
         IntegrateArgs<R> IA;
         IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
         IA.queue = q; IA.counters = A.counters;
         const uint64_t waves = (m + 63) / 64, resident = (uint64_t)g_num_cu * (uint64_t)waves_per_cu;
-        launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, (unsigned)(waves < resident ? waves : resident), st);
+        {
+            KernelTimer tm(st, 1);
+            launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, (unsigned)(waves < resident ? waves : resident), st);
+        }
         ResolveArgs<R> RA;
         RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = off;
         RA.n_slab = n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
         RA.status = A.status; RA.hit = A.hit; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
-        hipLaunchKernelGGL(resolve_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, RA);
+        {
+            KernelTimer tm(st, 2);
+            hipLaunchKernelGGL(resolve_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, RA);
+        }
     }
     return RTGR_OK;
 }
@@ -491,6 +522,26 @@ int rtgr_device_info(char* name, uint64_t name_len, int* n_cu, int* clock_mhz, i
     if (n_cu) *n_cu = p.multiProcessorCount;
     if (clock_mhz) *clock_mhz = p.clockRate / 1000;
     if (wavefront) *wavefront = p.warpSize;
+    return RTGR_OK;
+}
+
+int rtgr_timing_enable(int on) {
+    g_timing = on != 0;
+    return RTGR_OK;
+}
+int rtgr_timing_read(double ms[3], uint64_t launches[3]) {
+    if (!ms || !launches) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    for (int w = 0; w < 3; w++) { ms[w] = 0.0; launches[w] = 0; }
+    for (auto& t : g_timed) {
+        HIP_TRY(hipEventSynchronize(t.b));
+        float e = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, t.a, t.b));
+        ms[t.which] += e;
+        launches[t.which] += 1;
+        g_event_pool.push_back(t.a);
+        g_event_pool.push_back(t.b);
+    }
+    g_timed.clear();
     return RTGR_OK;
 }
 

@@ -1,0 +1,73 @@
+"""world_size-2 run of the row-sharded driver on the gloo backend (CPU): slab bounds, the gather of unequal slabs and
+rank-0 assembly.  No GPU here, so the oracle is injected as the slab tracer (test-only injection point of
+sharded.trace_sharded); the gathered image must equal the single-process oracle image bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, ws, port, ni, nj, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    import oracle_lib as O
+    from scenes import example, rt
+    from raytracegr_jl_amd import sharded
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+
+    def oracle_slab(scene, o, camera, ni_, nj_, j0, j1):
+        r = O.trace(scene, o, ni_, nj_, j0=j0, j1=j1, cam=camera, details=False, nthreads=2)
+        return torch.from_numpy(r["rgb"])
+
+    full = sharded.trace_sharded(sc, opt, cam, ni, nj, trace_slab=oracle_slab)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ni,nj", [(24, 17), (16, 16)])
+def test_sharded_gather_world_size_2(tmp_path, ni, nj):
+    import oracle_lib as O
+    from scenes import example, rt
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(2, _free_port(), ni, nj, out), nprocs=2, join=True)
+    got = np.load(out)
+    sc, cam = example(2)
+    ref = O.trace(sc, rt.solver_defaults(), ni, nj, cam=cam, details=False)["rgb"]
+    assert got.shape == (3, ni * nj)
+    assert np.array_equal(got, ref)
+
+
+def test_slab_bounds_tile_the_frame():
+    from conftest import load_package
+    load_package()
+    from raytracegr_jl_amd import sharded
+    for nj in (1, 7, 8, 200, 4096, 4099):
+        for ws in (1, 2, 3, 8):
+            b = [sharded.slab_bounds(nj, ws, r) for r in range(ws)]
+            assert b[0][0] == 0 and b[-1][1] == nj
+            assert all(b[i][1] == b[i + 1][0] for i in range(ws - 1))
+            sizes = [j1 - j0 for j0, j1 in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
