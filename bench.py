@@ -185,6 +185,7 @@ def main():
                 "other_kernels_ms_avg": {"canvas": float(kms[0]) / max(int(kln[0]), 1),
                                          "resolve": float(kms[2]) / max(int(kln[2]), 1)},
                 "hbm_algorithmic_GBps": (my_rays * (64 + 204 + 25)) / k_avg_s / 1e9}
+        roof["traffic"] = load_traffic(a)
         name = C_name(lib)
         cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if a.cpu_sample != 0 else None
         line = {
@@ -205,6 +206,21 @@ def main():
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def load_traffic(a):
+    """HBM bytes per launch of the dominant kernel from the latest committed PMC profile of the SAME configuration
+    (profiles/rNN/traffic.json; PMC counters cannot be collected from inside the bench), else None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        c = t.get("config", {})
+        if (c.get("size"), c.get("variant"), c.get("dtype")) == (a.size, a.variant, a.dtype) and a.gpus == 1:
+            return t["traffic_bytes_per_launch"]
+    return None
 
 
 def C_name(lib):
