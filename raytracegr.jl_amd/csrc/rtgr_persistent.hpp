@@ -108,8 +108,16 @@ RTGR_DEV void fold_distances(const DevObject<R>& o, const R (&pos)[P][4], R (&dm
             }
         }
     } else {
+        // RTGR_DISK.  The asm barrier pins the operands inside this branch: without it LLVM hoists the (loop-invariant)
+        // sqrt(x²+y²) of every sample point out of the object loop and executes P IEEE square roots per step for
+        // scenes that contain no disk at all.
 #pragma unroll
-        for (int p = 0; p < P; p++) dmin[p] = rmin(dmin[p], obj_distance<R>(o, pos[p]));
+        for (int p = 0; p < P; p++) {
+            R px = pos[p][1], py = pos[p][2];
+            asm volatile("" : "+v"(px), "+v"(py));
+            const R xs[4] = {pos[p][0], px, py, pos[p][3]};
+            dmin[p] = rmin(dmin[p], obj_distance<R>(o, xs));
+        }
     }
 }
 
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                 }
                 const float EEst = __builtin_sqrtf(acc * 0.125f);
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
-                bool is_event = false, is_interior = false;
+                bool is_event = false, is_interior = false, commit = false;
                 R top = R(0);
                 R cc[4][4];  // position polynomial of this step (set when the step is accepted; read only on events)
                 if (EEst != EEst) {
@@ -399,8 +407,7 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                             done = RTGR_RAY_EVENT;
                         } else {
                             ps = rsign(nextc);
-#pragma unroll
-                            for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k[0][q] = k[6][q]; }
+                            commit = true;
                             t = tnew;
                             dt = rmin(dtmax, dtnew);
                             if (!(t < t1)) done = RTGR_RAY_LAMBDA1;
@@ -414,37 +421,57 @@ __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD) void integrate_kernel(cons
                         else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
                     }
                 }
-                if (done != 0xffu) {
-                    // ---- hand the ray over to the resolve kernel ---------------------------------------------------------
+                // ---- an event: hand the step's position polynomial to the resolve kernel (built from the step-START state,
+                // so it has to happen before the commit below) -----------------------------------------------------------------
+                const bool want_state = (A.recw == REC_W_STATE);
+                if (is_event) {
                     R* rec = A.rec + idx * (uint64_t)A.recw;
 #pragma unroll
                     for (int q = 0; q < 4; q++) rec[REC_X + q] = x[q];
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) rec[REC_C + 4 * m + q] = cc[m][q];
+                    rec[REC_PS] = ps;
                     rec[REC_TOP] = top;
                     rec[REC_T] = t;
-                    const bool want_state = (A.recw == REC_W_STATE);
-                    if (want_state) {
+                    rec[REC_H] = h;
+                    if (want_state) {  // u(θ) = u + h Σ_j b_j(θ) k_j  (all seven stages)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) rec[REC_U + q] = u[q];
-                    }
-                    if (is_event) {
+                        for (int q = 0; q < 4; q++) {
+                            rec[REC_U + q] = u[q];
 #pragma unroll
-                        for (int m = 0; m < 4; m++)
-#pragma unroll
-                            for (int q = 0; q < 4; q++) rec[REC_C + 4 * m + q] = cc[m][q];
-                        rec[REC_PS] = ps;
-                        rec[REC_H] = h;
-                        if (want_state) {  // u(θ) = u + h Σ_j b_j(θ) k_j  (all seven stages)
-#pragma unroll
-                            for (int q = 0; q < 4; q++)
-#pragma unroll
-                                for (int m = 0; m < 4; m++)
-                                    rec[REC_CU + 4 * m + q] = h * rfma(N::r[6][m], k[6][q], rfma(N::r[5][m], k[5][q],
-                                        rfma(N::r[4][m], k[4][q], rfma(N::r[3][m], k[3][q], rfma(N::r[2][m], k[2][q],
-                                        rfma(N::r[1][m], k[1][q], N::r[0][m] * k[0][q]))))));
+                            for (int m = 0; m < 4; m++)
+                                rec[REC_CU + 4 * m + q] = h * rfma(N::r[6][m], k[6][q], rfma(N::r[5][m], k[5][q],
+                                    rfma(N::r[4][m], k[4][q], rfma(N::r[3][m], k[3][q], rfma(N::r[2][m], k[2][q],
+                                    rfma(N::r[1][m], k[1][q], N::r[0][m] * k[0][q]))))));
                         }
-                    } else {
-                        rec[REC_PS] = R(0);  // no event: the resolve kernel takes θ = 0, i.e. the state as stored
+                    }
+                }
+                // ---- commit the accepted step.  Event lanes are done with their state (re-filled next iteration), so only a
+                // REJECTED (or NaN) lane must keep its old state: rare (no rejection in the reference scenes), hence a
+                // wave-uniform fast path of 12 plain register moves instead of 24 selects.
+                if (__ballot(!commit && !is_event) == 0ull) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k[0][q] = k[6][q]; }
+                } else if (commit) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k[0][q] = k[6][q]; }
+                }
+                if (done != 0xffu) {
+                    if (!is_event) {
+                        // ended without an event (λ1, step cap, dt underflow, NaN): the state as it stands, θ = 0
+                        R* rec = A.rec + idx * (uint64_t)A.recw;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) rec[REC_X + q] = x[q];
+                        rec[REC_PS] = R(0);
+                        rec[REC_TOP] = R(0);
+                        rec[REC_T] = t;
                         rec[REC_H] = R(0);
+                        if (want_state) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) rec[REC_U + q] = u[q];
+                        }
                     }
                     uint32_t* mt = A.meta + idx * 3;
                     mt[0] = nacc;

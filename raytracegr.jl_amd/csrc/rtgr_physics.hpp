@@ -68,32 +68,30 @@ template <> RTGR_DEV float rmax<float>(float a, float b) { return __builtin_fmax
 template <class R> RTGR_DEV R rmin(R a, R b);
 template <> RTGR_DEV double rmin<double>(double a, double b) { return __builtin_fmin(a, b); }
 template <> RTGR_DEV float rmin<float>(float a, float b) { return __builtin_fminf(a, b); }
-// ---- fast reciprocal / reciprocal square root: hardware seed (v_rcp_f64 / v_rsq_f64) + two Newton steps on the FMA
-// pipe.  No denormal / inf fix-up (operands here are O(1e-3 … 1e3)); result within ~1 ulp.  The IEEE expansions hipcc
-// emits for `1.0/x` and `sqrt(x)` cost 11 and ~14 instructions; these cost 5 and 7.
+// ---- fast reciprocal / reciprocal square root: hardware seed + ONE third-order correction on the FMA pipe.
+// Measured on gfx950 (tools/micro/rcp_accuracy.hip): v_rcp_f64 / v_rsq_f64 seeds are good to 2^-24.4 / 2^-24.2, so a
+// cubically convergent step (error e³ ≈ 2^-73) lands on full double precision: max relative error 1.1e-16 / 1.4e-16
+// over 2^20 operands in [2^-10, 2^10].  No denormal / inf fix-up (operands here are O(1e-3 … 1e3)).  The IEEE
+// expansions hipcc emits for `1.0/x` and `sqrt(x)` cost 11 and ~14 instructions; these cost 4 and 6.
 template <class R> RTGR_DEV R frcp(R x);
 template <> RTGR_DEV double frcp<double>(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);              // 1 − x r
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);      // r (1 + e + e²)
 }
 template <> RTGR_DEV float frcp<float>(float x) {
-    float r = __builtin_amdgcn_rcpf(x);
+    const float r = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, r, 1.0f);
     return __builtin_fmaf(r, e, r);
 }
 template <class R> RTGR_DEV R frsq(R x);  // 1/sqrt(x)
 template <> RTGR_DEV double frsq<double>(double x) {
-    double r = __builtin_amdgcn_rsq(x);
-    double e = __builtin_fma(-x * r, r, 1.0);
-    r = __builtin_fma(0.5 * r, e, r);
-    e = __builtin_fma(-x * r, r, 1.0);
-    return __builtin_fma(0.5 * r, e, r);
+    const double r = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * r, r, 1.0);          // 1 − x r²
+    return __builtin_fma(r * e, __builtin_fma(0.375, e, 0.5), r);  // r (1 + e/2 + 3e²/8)
 }
 template <> RTGR_DEV float frsq<float>(float x) {
-    float r = __builtin_amdgcn_rsqf(x);
+    const float r = __builtin_amdgcn_rsqf(x);
     const float e = __builtin_fmaf(-x * r, r, 1.0f);
     return __builtin_fmaf(0.5f * r, e, r);
 }
