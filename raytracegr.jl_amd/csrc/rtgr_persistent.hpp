@@ -25,6 +25,9 @@
 #include "rtgr_integrator.hpp"
 #include "rtgr_tsit5_tables.hpp"
 
+#ifndef RTGR_ROOT_SHORTCUT
+#define RTGR_ROOT_SHORTCUT 1
+#endif
 #ifndef RTGR_WAVES_PER_SIMD
 #define RTGR_WAVES_PER_SIMD 2  // 2 -> <=256 VGPR+AGPR per lane; 1 -> the whole 512-entry file
 #endif
@@ -510,37 +513,67 @@ RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th
     return min_distance<R>(sc, x);
 }
 
-// Bracketed root of g(θ) = ps·cond(x(θ)) on [0, top], g(0) > 0 >= g(top): Ridders' method (every iterate stays inside
-// the bracket and both ends move; quadratic convergence) with a bisection step built in; returns the pre-crossing
-// end of the final bracket — the reference's prevfloat(find_zero(...)).
+// Bracketed root of g(θ) = ps·cond(x(θ)) on [0, top], g(0) > 0 >= g(top).  Ridders' method: every iterate stays inside
+// the bracket, the estimate x4 converges quadratically (the bracket WIDTH only halves per iteration, so convergence is
+// judged on successive estimates).  Once the estimate has settled, a probe 16 ulp before it pins the pre-crossing side:
+// the result is a point with g > 0 within ~16 ulp of the crossing — the reference's prevfloat(find_zero(...))
+//  up to a few ulp.  If the probe fails (estimate was off) the loop simply continues on the
+// tightened bracket; the bisection point `mid` guarantees progress.
 template <class R>
 RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R ps, R top) {
     R lo = R(0), hi = top;
     R fhi = cond_poly<R>(sc, x0, c, hi) * ps;
-    if (fhi == R(0)) return hi;
     R flo = cond_poly<R>(sc, x0, c, R(0)) * ps;
-    if (!(flo > R(0)) || !(fhi < R(0))) return R(0);
+    R result = R(0);
+    bool done = false;
+    if (fhi == R(0)) { result = hi; done = true; }
+    else if (!(flo > R(0)) || !(fhi < R(0))) { result = R(0); done = true; }
     const R eps = sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7);
-    for (int it = 0; it < 128; it++) {
+    R est_prev = R(-1);
+    for (int it = 0; it < 96 && !done; it++) {
         const R width = hi - lo;
-        if (!(width > R(2) * eps * hi)) break;
         const R mid = rfma(R(0.5), width, lo);
-        if (!(mid > lo && mid < hi)) break;
-        const R fm = cond_poly<R>(sc, x0, c, mid) * ps;
-        const R den = rsqrt_(rfma(fm, fm, -flo * fhi));
-        R x4 = den > R(0) ? rfma(mid - lo, fm / den, mid) : mid;
-        if (!(x4 > lo && x4 < hi)) x4 = mid;
-        const R f4 = (x4 == mid) ? fm : cond_poly<R>(sc, x0, c, x4) * ps;
-        const R a = rmin(mid, x4), b = rmax(mid, x4);
-        const R fa = (mid <= x4) ? fm : f4, fb = (mid <= x4) ? f4 : fm;
-        if (fa > R(0)) {
-            lo = a; flo = fa;
-            if (fb > R(0)) { lo = b; flo = fb; } else { hi = b; fhi = fb; }
+        if (!(width > R(2) * eps * hi) || !(mid > lo && mid < hi)) {
+            result = lo; done = true;
         } else {
-            hi = a; fhi = fa;
+            const R fm = cond_poly<R>(sc, x0, c, mid) * ps;
+            const R rad = rfma(fm, fm, -flo * fhi);  // > 0 since flo > 0 > fhi
+            R x4 = rfma((mid - lo) * fm, frsq<R>(rad), mid);
+            if (!(x4 > lo && x4 < hi)) x4 = mid;
+            const R f4 = (x4 == mid) ? fm : cond_poly<R>(sc, x0, c, x4) * ps;
+            // An exact zero is common (a plane at a representable time makes g vanish on a whole ulp-interval of θ):
+            // "directly at zero" is an accepted result, so stop there.
+            if (fm == R(0)) { result = mid; done = true; }
+            else if (f4 == R(0)) { result = x4; done = true; }
+            const R a = rmin(mid, x4), b = rmax(mid, x4);
+            const R fa = (mid <= x4) ? fm : f4, fb = (mid <= x4) ? f4 : fm;
+            if (fa > R(0)) {
+                lo = a; flo = fa;
+                if (fb > R(0)) { lo = b; flo = fb; } else { hi = b; fhi = fb; }
+            } else {
+                hi = a; fhi = fa;
+            }
+            const bool settled = RTGR_ROOT_SHORTCUT && (rabs(x4 - est_prev) <= R(8) * eps * x4);
+            est_prev = x4;
+            if (settled && !done) {
+                // verify the settled estimate two-sidedly, 16 ulp before and after
+                const R pm = rmax(x4 * (R(1) - R(16) * eps), lo), pp = rmin(x4 * (R(1) + R(16) * eps), hi);
+                const R fpm = (pm > lo) ? cond_poly<R>(sc, x0, c, pm) * ps : flo;
+                const R fpp = (pp < hi) ? cond_poly<R>(sc, x0, c, pp) * ps : fhi;
+                if (!(fpm < R(0)) && !(fpp > R(0))) {
+                    result = pm; done = true;      // the sign change (or an exact zero at pm) is inside [pm, pp]
+                } else if (fpp == R(0)) {
+                    result = pp; done = true;
+                } else {
+                    // the crossing is elsewhere: tighten the bracket with what was learnt and keep iterating
+                    if (fpm > R(0)) { lo = pm; flo = fpm; } else { hi = pm; fhi = fpm; }
+                    if (fpp > R(0)) { if (pp > lo) { lo = pp; flo = fpp; } } else if (pp < hi) { hi = pp; fhi = fpp; }
+                    est_prev = R(-1);
+                }
+            }
         }
     }
-    return lo;
+    return done ? result : lo;
 }
 
 template <class R>

@@ -98,6 +98,12 @@ template <> RTGR_DEV float frsq<float>(float x) {
 template <bool FAST, class R> RTGR_DEV R rcp_(R x) { if constexpr (FAST) return frcp<R>(x); else return R(1) / x; }
 template <bool FAST, class R> RTGR_DEV R sqrt_(R x) { if constexpr (FAST) return x * frsq<R>(x); else return rsqrt_(x); }
 
+// s = sqrt(x) and is = 1/sqrt(x) from ONE reciprocal-square-root (FAST) or the IEEE pair
+template <bool FAST, class R> RTGR_DEV void sqrt_inv(R x, R& s, R& is) {
+    if constexpr (FAST) { is = frsq<R>(x); s = x * is; }
+    else { s = rsqrt_(x); is = R(1) / s; }
+}
+
 // Julia sign(): ±1, 0 -> 0 (NaN handled by callers)
 template <class R> RTGR_DEV R rsign(R v) { return v > R(0) ? R(1) : (v < R(0) ? R(-1) : R(0)); }
 
@@ -122,37 +128,41 @@ RTGR_DEV void ks_field(R x, R y, R z, R M, R a, KSField<R>& F) {
     const R a2 = SPIN ? a * a : R(0);
     const R rho2 = rfma(x, x, rfma(y, y, z * z));
     R r, rq2, rz;  // r, 2*∂r/∂q (so that ∇r = rq2*(x,y,z) + rz*ẑ), explicit ∂r/∂z
+    R ir;  // 1/r
     if constexpr (METRIC == RTGR_KS_REF) {
         if constexpr (SPIN) {
             // r = sqrt(q)/2 + sqrt(a² z² + (q/2)²),  q = ρ² - a²                                     :284
             const R q = rho2 - a2;
-            const R s1 = sqrt_<FAST>(q);
+            R s1, is1, s2, is2;
+            sqrt_inv<FAST>(q, s1, is1);
             const R hq = R(0.5) * q;
-            const R s2 = sqrt_<FAST>(rfma(a2 * z, z, hq * hq));
+            sqrt_inv<FAST>(rfma(a2 * z, z, hq * hq), s2, is2);
             r = rfma(R(0.5), s1, s2);
-            const R is1 = rcp_<FAST>(s1), is2 = rcp_<FAST>(s2);
+            ir = rcp_<FAST>(r);
             rq2 = R(0.5) * rfma(q, is2, is1);  // 2*(1/(4 s1) + q/(4 s2))
             rz = a2 * z * is2;
         } else {
             // a = 0: r = ρ/2 + ρ²/2
-            const R rho = sqrt_<FAST>(rho2);
+            R rho, irho;
+            sqrt_inv<FAST>(rho2, rho, irho);
             r = R(0.5) * (rho + rho2);
-            rq2 = rfma(R(0.5), rcp_<FAST>(rho), R(1));  // ∇r = (1/(2ρ) + 1)(x,y,z)
+            ir = R(2) * irho * rcp_<FAST>(R(1) + rho);
+            rq2 = rfma(R(0.5), irho, R(1));  // ∇r = (1/(2ρ) + 1)(x,y,z)
             rz = R(0);
         }
     } else {
         if constexpr (SPIN) {
             // textbook: r² = (q + sqrt(q² + 4a²z²))/2
             const R q = rho2 - a2;
-            const R s = sqrt_<FAST>(rfma(q, q, R(4) * a2 * z * z));
-            const R r2 = R(0.5) * (q + s);
-            r = sqrt_<FAST>(r2);
-            const R is = rcp_<FAST>(s), ir = rcp_<FAST>(r);
+            R sq, is;
+            sqrt_inv<FAST>(rfma(q, q, R(4) * a2 * z * z), sq, is);
+            const R r2 = R(0.5) * (q + sq);
+            sqrt_inv<FAST>(r2, r, ir);
             rq2 = R(0.5) * rfma(q, is, R(1)) * ir;  // 2 * (1+q/s)/2 / (2r)
             rz = a2 * z * is * ir;
         } else {
-            r = sqrt_<FAST>(rho2);  // a = 0: r = ρ
-            rq2 = rcp_<FAST>(r);
+            sqrt_inv<FAST>(rho2, r, ir);  // a = 0: r = ρ
+            rq2 = ir;
             rz = R(0);
         }
     }
@@ -174,7 +184,6 @@ RTGR_DEV void ks_field(R x, R y, R z, R M, R a, KSField<R>& F) {
         F.df[2] = rfma(fr, dr[2], fz);
         // k = ((r x + a y), (r y − a x))/(r² + a²),  z/r                                           :286-289
         const R w = rcp_<FAST>(r2 + a2);
-        const R ir = rcp_<FAST>(r);
         F.k[0] = rfma(r, x, a * y) * w;
         F.k[1] = rfma(r, y, -a * x) * w;
         F.k[2] = z * ir;
@@ -187,7 +196,6 @@ RTGR_DEV void ks_field(R x, R y, R z, R M, R a, KSField<R>& F) {
         F.dk[2][0] = kzr * dr[0];           F.dk[2][1] = kzr * dr[1];           F.dk[2][2] = rfma(kzr, dr[2], ir);
     } else {
         // a = 0: f = 2M/r, k_i = x_i/r
-        const R ir = rcp_<FAST>(r);
         F.f = R(2) * M * ir;
         const R fr = -F.f * ir;
         F.df[0] = fr * dr[0]; F.df[1] = fr * dr[1]; F.df[2] = fr * dr[2];
