@@ -240,6 +240,7 @@ static int ensure_device() {
 // kernel (kept as an independent formulation for A/B and cross-checks).  Tunables (experiments only):
 //   RTGR_WAVES_PER_CU  resident waves per CU of the integrate kernel (default 8 = 2 per SIMD)
 //   RTGR_CHUNK         rays per pipeline chunk (default 2^24); bounds the library-owned workspace
+//   RTGR_SPLIT=0       one FULL integrate pass instead of the FAR + NEAR pair
 static int g_num_cu = 0;
 static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per launch in flight
 static unsigned g_queue_next = 0;
@@ -293,13 +294,28 @@ template <class R>
 static size_t workspace_bytes(uint64_t rays, bool with_state, bool with_canvas) {
     const int recw = with_state ? REC_W_STATE : REC_W;
     return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
+           align256(rays * HAND_W * sizeof(R)) +
            (with_canvas ? align256(rays * 8 * sizeof(R)) : 0);
 }
 
 template <class R, int METRIC, bool SPIN>
-static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, unsigned blocks, hipStream_t st) {
-    if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true>), dim3(blocks), dim3(64), 0, st, IA);
-    else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, false>), dim3(blocks), dim3(64), 0, st, IA);
+static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split, uint64_t waves, hipStream_t st) {
+    auto grid = [&](int per_simd) {
+        const uint64_t resident = (uint64_t)g_num_cu * (uint64_t)env_int("RTGR_WAVES_PER_CU", 4 * per_simd);
+        return dim3((unsigned)(waves < resident ? waves : resident));
+    };
+    if (npts10 && split) {
+        // FAR pass over every ray, then the NEAR pass over the rays it handed over
+        { KernelTimer tm(st, 1);
+          hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
+                             grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, IA); }
+        { KernelTimer tm(st, 1);
+          hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA); }
+    } else {
+        KernelTimer tm(st, 1);
+        if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
+        else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, false, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
+    }
     return RTGR_OK;
 }
 
@@ -320,9 +336,13 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     const int recw = with_state ? REC_W_STATE : REC_W;
     char* base = (char*)g_ws;
     R* rec = (R*)base;
-    uint32_t* meta = (uint32_t*)(base + align256(chunk * recw * sizeof(R)));
-    R* gen = (R*)(base + align256(chunk * recw * sizeof(R)) + align256(chunk * 3 * sizeof(uint32_t)));
-    const int waves_per_cu = env_int("RTGR_WAVES_PER_CU", 4 * RTGR_WAVES_PER_SIMD);
+    char* cur = base + align256(chunk * recw * sizeof(R));
+    uint32_t* meta = (uint32_t*)cur;
+    cur += align256(chunk * 3 * sizeof(uint32_t));
+    R* hand = (R*)cur;
+    cur += align256(chunk * HAND_W * sizeof(R));
+    R* gen = (R*)cur;
+    const bool split = env_int("RTGR_SPLIT", 1) != 0;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
         const R* s0 = A.state0 ? A.state0 + off * 8 : gen;
@@ -331,16 +351,12 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
             hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
                                A.nj, A.j0, off, m, gen);
         }
-        unsigned long long* q = g_queue_pool + (g_queue_next++ % RTGR_QUEUE_SLOTS);
-        HIP_TRY(hipMemsetAsync(q, 0, sizeof(unsigned long long), st));
+        unsigned long long* q = g_queue_pool + 4 * (g_queue_next++ % RTGR_QUEUE_SLOTS);
+        HIP_TRY(hipMemsetAsync(q, 0, 4 * sizeof(unsigned long long), st));
         IntegrateArgs<R> IA;
         IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
-        IA.queue = q; IA.counters = A.counters;
-        const uint64_t waves = (m + 63) / 64, resident = (uint64_t)g_num_cu * (uint64_t)waves_per_cu;
-        {
-            KernelTimer tm(st, 1);
-            launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, (unsigned)(waves < resident ? waves : resident), st);
-        }
+        IA.hand = hand; IA.ctrl = q; IA.counters = A.counters;
+        launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
         ResolveArgs<R> RA;
         RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = off;
         RA.n_slab = n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
@@ -363,8 +379,8 @@ static int bind_device(int dev) {
         if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
     }
     if (!g_queue_pool) {
-        HIP_TRY(hipMalloc((void**)&g_queue_pool, RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(g_queue_pool, 0, RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&g_queue_pool, 4 * RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_queue_pool, 0, 4 * RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
     }
     g_num_cu = p.multiProcessorCount;
     g_device = dev;
