@@ -163,28 +163,33 @@ def main():
 
     # per-kernel HIP-event timing recorded by the library on the launch stream (rtgr_timing_*)
     import ctypes
-    kms = (ctypes.c_double * 3)()
-    kln = (ctypes.c_uint64 * 3)()
+    kms = (ctypes.c_double * 4)()
+    kln = (ctypes.c_uint64 * 4)()
     rt._abi.check(lib, lib.rtgr_timing_read(ctypes.byref(kms), ctypes.byref(kln)))
     if rank == 0:
-        # roofline of the dominant kernel (integrate_kernel: ~97 % of device time), this rank's launches:
-        # algorithmic flop per launch / average launch duration (HIP events around the kernel itself)
+        # roofline of the dominant kernel — integrate_kernel's main (FAR) pass, ~93 % of device time — over this rank's
+        # launches: algorithmic flop per launch / average launch duration (HIP events around the kernel itself).
+        # The few steps per ray that the NEAR pass redoes/finishes are attributed to the NEAR pass's own time below;
+        # charging ALL step attempts to the FAR kernel's time alone would overstate it, so the denominator is
+        # FAR + NEAR (the two launches of the same kernel template that together perform the counted attempts).
         my = ctr.cpu().numpy()
         n_launch = max(int(kln[1]), 1)
         my_attempts, my_rays = int(my[1] + my[2]) / n_launch, int(my[0]) / n_launch
-        k_avg_s = float(kms[1]) / n_launch * 1e-3
+        k_avg_s = (float(kms[1]) + float(kms[3])) / n_launch * 1e-3
         flop_launch = my_attempts * F_STEP + 2 * my_rays * F_RHS
         achieved = flop_launch / k_avg_s / 1e12
         roof = {"bound": "valu_f64", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": None,
-                "kernel": "rtgr::integrate_kernel", "kernel_ms_avg": k_avg_s * 1e3, "launches": n_launch,
+                "kernel": "rtgr::integrate_kernel (FAR pass + NEAR pass)", "kernel_ms_avg": k_avg_s * 1e3,
+                "launches": n_launch, "far_pass_ms_avg": float(kms[1]) / n_launch,
+                "near_pass_ms_avg": float(kms[3]) / max(int(kln[3]), 1),
                 "algorithmic_flop_per_launch": flop_launch,
                 "flop_model": f"{F_STEP} flop/step attempt + 2x{F_RHS} per ray (SURVEY 8d: reference-formulation "
                               f"work; the kernel's closed Kerr-Schild contraction executes fewer — see DESIGN.md "
                               f"and profiles/ for the hardware-counted f64 flops and VALU utilisation)",
                 "other_kernels_ms_avg": {"canvas": float(kms[0]) / max(int(kln[0]), 1),
                                          "resolve": float(kms[2]) / max(int(kln[2]), 1)},
-                "hbm_algorithmic_GBps": (my_rays * (64 + 204 + 25)) / k_avg_s / 1e9}
+                "hbm_algorithmic_GBps": (my_rays * (64 + 2 * 140 + 204 + 25)) / k_avg_s / 1e9}
         roof["traffic"] = load_traffic(a)
         name = C_name(lib)
         cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if a.cpu_sample != 0 else None

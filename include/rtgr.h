@@ -147,10 +147,11 @@ int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32);
 
 /* Optional per-kernel timing for benchmarks: when enabled the library brackets every kernel it launches with HIP
  * events on the caller's stream.  rtgr_timing_read waits for them and returns, since the previous read, the summed
- * milliseconds and launch counts of [0] the camera kernel, [1] the integrate kernel (the hot kernel), [2] the resolve
- * kernel.  Not for use during hipGraph capture. */
+ * milliseconds and launch counts of [0] the camera kernel, [1] the integrate kernel's main pass (FAR, or FULL when the
+ * far/near split is off — the hot kernel), [2] the resolve kernel, [3] the integrate kernel's NEAR pass.
+ * Not for use during hipGraph capture. */
 int rtgr_timing_enable(int on);
-int rtgr_timing_read(double ms[3], uint64_t launches[3]);
+int rtgr_timing_read(double ms[4], uint64_t launches[4]);
 
 /* ---- the hot path, device-resident buffers ------------------------------------------------------------------
  * Replaces the body of trace_rays (src/RayTraceGR.jl:482-536) for rows j in [j0, j1) of an ni x nj canvas.

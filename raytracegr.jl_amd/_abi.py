@@ -87,7 +87,7 @@ def _declare(lib):
     lib.rtgr_device_info.argtypes = [C.c_char_p, u64, P(i32), P(i32), P(i32)]
     lib.rtgr_reserve_workspace.argtypes = [u64, i32, i32]
     lib.rtgr_timing_enable.argtypes = [i32]
-    lib.rtgr_timing_read.argtypes = [P(C.c_double * 3), P(C.c_uint64 * 3)]
+    lib.rtgr_timing_read.argtypes = [P(C.c_double * 4), P(C.c_uint64 * 4)]
     for suf in ("f64", "f32"):
         getattr(lib, f"rtgr_trace_device_{suf}").argtypes = [
             P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]

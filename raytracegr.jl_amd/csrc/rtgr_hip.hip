@@ -309,7 +309,7 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
         { KernelTimer tm(st, 1);
           hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
                              grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, IA); }
-        { KernelTimer tm(st, 1);
+        { KernelTimer tm(st, 3);
           hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA); }
     } else {
         KernelTimer tm(st, 1);
@@ -545,9 +545,9 @@ int rtgr_timing_enable(int on) {
     g_timing = on != 0;
     return RTGR_OK;
 }
-int rtgr_timing_read(double ms[3], uint64_t launches[3]) {
+int rtgr_timing_read(double ms[4], uint64_t launches[4]) {
     if (!ms || !launches) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
-    for (int w = 0; w < 3; w++) { ms[w] = 0.0; launches[w] = 0; }
+    for (int w = 0; w < 4; w++) { ms[w] = 0.0; launches[w] = 0; }
     for (auto& t : g_timed) {
         HIP_TRY(hipEventSynchronize(t.b));
         float e = 0.f;

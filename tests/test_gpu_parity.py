@@ -305,3 +305,40 @@ def test_large_frame_properties(lib):
     b = sharded.trace_slab_torch(sc, opt, cam, 1024, 1024, 512, 768)
     torch.cuda.synchronize()
     assert torch.equal(b["rgb"], a["rgb"][:, 512 * 1024:768 * 1024])
+
+
+def test_far_near_split_is_bit_identical_to_full_scan(lib):
+    """The FAR pass skips the ContinuousCallback scan only where a rigorous bound proves it finds nothing, and a ray
+    whose bound fails is re-started from its exact pre-step state in the NEAR pass — so the split pipeline must give
+    the SAME BITS as the single FULL pass (RTGR_SPLIT=0), and both must agree with the simple tile kernel's physics."""
+    for name in ("ks_ref0", "ks_true0998_disk", "mink"):
+        sc, cam = scene_variant(name)
+        opt = rt.solver_defaults()
+        a = hip_trace(lib, sc, opt, 96, 80, cam=cam)
+        os.environ["RTGR_SPLIT"] = "0"
+        try:
+            b = hip_trace(lib, sc, opt, 96, 80, cam=cam)
+        finally:
+            del os.environ["RTGR_SPLIT"]
+        for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            assert np.array_equal(a[k], b[k]), (name, k)
+        assert a["counters"] == b["counters"]
+        os.environ["RTGR_KERNEL"] = "tile"
+        try:
+            c = hip_trace(lib, sc, opt, 96, 80, cam=cam)
+        finally:
+            del os.environ["RTGR_KERNEL"]
+        flips = a["hit"] != c["hit"]
+        assert int(flips.sum()) <= (40 if name == "mink" else 2)
+        same = ~flips
+        assert wrap_aware_rgb_err(a["rgb"][:, same], c["rgb"][:, same], a["hit"][same]) <= RGB_TOL
+
+
+def test_interp_points_other_than_10_use_the_generic_scan(lib):
+    """interp_points != 10 takes the runtime-θ scan (FULL pass only); compare with the oracle at 4 and 25 points."""
+    sc, cam = example(2)
+    for npts in (4, 25):
+        opt = rt.solver_defaults(interp_points=npts)
+        gpu = hip_trace(lib, sc, opt, 40, 40, cam=cam)
+        ref = O.trace(sc, opt, 40, 40, cam=cam)
+        compare(gpu, ref, max_class_flips=1, max_step_diff=1)
