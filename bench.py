@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="CPU baseline renders a sample x sample screen; -1 = auto (~15 s of CPU work), 0 = off")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1: nccl (= RCCL over xGMI, the real thing) or gloo (CPU-staged; lets "
+                         "the multi-rank logic be rehearsed with several ranks sharing one GPU)")
     return ap.parse_args()
 
 
@@ -92,11 +95,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # (gloo rehearsal: several ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")  # where collective buffers live
     if ws > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
     lib = rt._abi.load()
     rt._abi.check(lib, lib.rtgr_init(local))
@@ -124,12 +133,13 @@ def main():
     def gather(slab):
         nonlocal parts
         send = slab if slab.shape[1] == nmax else torch.cat([slab, slab.new_zeros((3, nmax - slab.shape[1]))], 1)
+        send = send.contiguous().to(cdev)
         if rank == 0:
             if parts is None:
-                parts = [torch.empty((3, nmax), dtype=slab.dtype, device=dev) for _ in range(ws)]
-            dist.gather(send.contiguous(), parts, dst=0)
+                parts = [torch.empty((3, nmax), dtype=slab.dtype, device=cdev) for _ in range(ws)]
+            dist.gather(send, parts, dst=0)
         else:
-            dist.gather(send.contiguous(), None, dst=0)
+            dist.gather(send, None, dst=0)
 
     for _ in range(a.warmup):
         one_pass()
@@ -150,9 +160,9 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]  # whole pipeline (3 kernels) per pass, torch events
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    totals = ctr.clone()
-    kmax = torch.tensor([max(kern_ms)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    totals = ctr.clone().to(cdev)
+    kmax = torch.tensor([max(kern_ms)], dtype=torch.float64, device=cdev)
     if ws > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)

@@ -241,6 +241,7 @@ static int ensure_device() {
 //   RTGR_WAVES_PER_CU  resident waves per CU of the integrate kernel (default 8 = 2 per SIMD)
 //   RTGR_CHUNK         rays per pipeline chunk (default 2^24); bounds the library-owned workspace
 //   RTGR_SPLIT=0       one FULL integrate pass instead of the FAR + NEAR pair
+//   RTGR_ORDER=0       keep the natural ray order (default: longest-expected-first, see rtgr_persistent.hpp)
 static int g_num_cu = 0;
 static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per launch in flight
 static unsigned g_queue_next = 0;
@@ -294,7 +295,7 @@ template <class R>
 static size_t workspace_bytes(uint64_t rays, bool with_state, bool with_canvas) {
     const int recw = with_state ? REC_W_STATE : REC_W;
     return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
-           align256(rays * HAND_W * sizeof(R)) +
+           align256(rays * HAND_W * sizeof(R)) + align256(rays * sizeof(uint32_t)) + align256(rays) + 4096 +
            (with_canvas ? align256(rays * 8 * sizeof(R)) : 0);
 }
 
@@ -341,7 +342,15 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     cur += align256(chunk * 3 * sizeof(uint32_t));
     R* hand = (R*)cur;
     cur += align256(chunk * HAND_W * sizeof(R));
+    uint32_t* order = (uint32_t*)cur;
+    cur += align256(chunk * sizeof(uint32_t));
+    uint8_t* keys = (uint8_t*)cur;
+    cur += align256(chunk);
+    uint32_t* hist = (uint32_t*)cur;  // 256 bins + 256 running offsets
+    cur += 4096;
     R* gen = (R*)cur;
+    // longest-expected-first queue order: pays off when a lane gets few rays (see rtgr_persistent.hpp); RTGR_ORDER=0/1 forces
+    const int order_mode = env_int("RTGR_ORDER", -1);
     const bool split = env_int("RTGR_SPLIT", 1) != 0;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
@@ -351,11 +360,26 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
             hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
                                A.nj, A.j0, off, m, gen);
         }
+        const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 &&
+                               (order_mode != 0);
+        if (use_order) {
+            KernelTimer tm(st, 0);
+            HIP_TRY(hipMemsetAsync(hist, 0, 2048, st));
+            hipLaunchKernelGGL(order_key_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, s0, m, keys, hist);
+            hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, st, hist, hist + 256);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys, m, hist + 256, order);
+        }
         unsigned long long* q = g_queue_pool + 4 * (g_queue_next++ % RTGR_QUEUE_SLOTS);
         HIP_TRY(hipMemsetAsync(q, 0, 4 * sizeof(unsigned long long), st));
         IntegrateArgs<R> IA;
-        IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
+        IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.order = use_order ? order : nullptr; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
         IA.hand = hand; IA.ctrl = q; IA.counters = A.counters;
+        {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [16, RTGR_QUEUE_CHUNK]
+            const uint64_t per_wave = m / ((uint64_t)g_num_cu * 12 + 1);
+            uint64_t qc = per_wave / 16;
+            qc = qc < 16 ? 16 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
+            IA.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK", (int)qc);
+        }
         launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
         ResolveArgs<R> RA;
         RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = off;
