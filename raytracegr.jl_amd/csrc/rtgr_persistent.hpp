@@ -1,15 +1,19 @@
-// rtgr_persistent.hpp — the production trace pipeline: integrate (persistent waves) -> resolve (one thread per ray).
+// rtgr_persistent.hpp — the production trace pipeline:
+//     canvas -> [order] -> integrate<FAR> -> integrate<NEAR> -> resolve          (rtgr_hip.hip: launch_trace)
 //
-// Why three kernels instead of one loop per ray (the simple tile kernel in rtgr_hip.hip keeps that shape):
+// Why a pipeline instead of one loop per ray (the simple tile kernel in rtgr_hip.hip keeps that shape):
 //   * rays need 27…991 Tsit5 step attempts inside one image; a wave that owns 64 fixed rays idles until
 //     its longest ray ends, and each ray's end-of-life episode (bracketed root-find on the dense output, colouring,
 //     next ray's camera set-up) would run with one lane active;
 //   * so the integrate kernel treats a wave as a pool of 64 ray slots: a lane whose ray has ended writes a small
 //     EVENT RECORD (the position polynomial of its last step) to HBM, and is re-filled from a global ray queue on the
-//     next iteration — a wavefront ballot finds the free lanes, one wave-aggregated atomic pops their work ids;
+//     next iteration — a wavefront ballot finds the free lanes, which take ids from the wave's slice of the queue;
 //   * everything that happens once per ray and diverges — root-finding, the colouring rule with its acos/atan2 —
-//     runs afterwards in the resolve kernel with every lane busy; the camera (make_canvas) runs before, likewise.
-//   HBM traffic of the hand-off: 64 B (state0) + 204 B (record) per ray, against ≈1.1 Mflop of integration per ray.
+//     runs afterwards in the resolve kernel with every lane busy; the camera (make_canvas) runs before, likewise;
+//   * the ContinuousCallback scan (8 interior samples per accepted step) is replaced, while a ray is out of reach of
+//     every object, by a rigorous bound (FAR pass); rays within reach are handed to the NEAR pass (full scan);
+//   * the queue is ordered longest-expected-first so that few rays per lane still balance (order_* kernels).
+//   HBM traffic of the hand-offs: ≈ 1 kB per ray, against ≈ 0.23 Mflop of integration per ray.
 //
 // Step body (per lane, registers only):
 //   * Nyström form: since ẋ = u (src/RayTraceGR.jl:360) stage positions are x + h c_s u + h² Σ A2[s][l] k_l — only the
@@ -18,9 +22,9 @@
 //     regular step ("init pseudo-step");
 //   * error norm, PI controller and initial-dt formula run in f32 on the (otherwise idle) f32 VALU/transcendental
 //     path; they only steer the step size — the state arithmetic is all R (f64);
-//   * ContinuousCallback: the position interpolant is put in polynomial form once per accepted step and evaluated at
-//     the 8 interior sample points θ = j/9; distances are evaluated object-major so each object's
-//     parameters are fetched once.
+//   * ContinuousCallback (NEAR / FULL): the position interpolant is put in polynomial form once per accepted step and
+//     evaluated at the 8 interior sample points θ = j/9; distances are evaluated object-major so
+//     each object's parameters are fetched once per block of sample points.
 #pragma once
 #include "rtgr_integrator.hpp"
 #include "rtgr_tsit5_tables.hpp"
