@@ -394,14 +394,17 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                             const R guard = R(1) + R(1e-6);
                             for (uint32_t o = 0; o < A.sc.nobj; o++) {
                                 const DevObject<R>& ob = A.sc.obj[o];
+                                // (+ an absolute floor of a few hundred ulp of the operands: a distance that is itself
+                                //  rounding noise must go through the real scan)
                                 if (ob.kind == RTGR_PLANE) {
-                                    safe = safe && (rabs(x[0] - ob.p[0]) > guard * dl[0]);
+                                    safe = safe && (rabs(x[0] - ob.p[0]) > rfma(guard, dl[0], R(256) * eps * (rabs(x[0]) + rabs(ob.p[0]))));
                                 } else if (ob.kind == RTGR_SPHERE) {
                                     const R X0 = x[1] - ob.p[1], X1 = x[2] - ob.p[2], X2 = x[3] - ob.p[3], Rr = ob.p[8];
                                     const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
                                     const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
                                                      rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
-                                    safe = safe && (rabs(D0) > guard * B);
+                                    const R mag = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, Rr * Rr)));
+                                    safe = safe && (rabs(D0) > rfma(guard, B, R(256) * eps * mag));
                                 } else {
                                     R px = x[1], py = x[2];
                                     asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's sqrt inside this branch
