@@ -373,3 +373,59 @@ def test_f32_step_statistics_match_f32_oracle(lib):
     r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
     assert 0.7 * r <= g <= 1.1 * r, (gpu["counters"], ref["counters"])
     assert gpu["counters"]["events"] == ref["counters"]["events"] == 96 * 96
+
+
+def _random_scene(seed):
+    """Seeded random scene: 1-6 objects (spheres incl. inside-out ones, planes, disks), random metric variant, random
+    camera, random solver constants — exercises rays that start inside objects, end by λ1, miss everything, fall into
+    the hole until the step cap, graze disks, …"""
+    rng = np.random.default_rng(seed)
+    metric = [rt.minkowski, rt.kerr_schild, rt.KerrSchild(1.0, 0.6), rt.KerrSchild(0.7, 0.9, textbook=False),
+              rt.KerrSchild(1.3, 0.0)][seed % 5]
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -rng.uniform(9, 14))] if seed % 3 else []
+    for _ in range(rng.integers(1, 6)):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            objs.append(rt.Plane(-rng.uniform(5, 30)))
+        elif kind in (1, 2) or metric is rt.minkowski:
+            c = rng.normal(size=3) * 3 + np.array([4, 1, 0])
+            objs.append(rt.Sphere((0, *c), (1, 0, 0, 0), rng.uniform(0.2, 1.5)))
+        else:
+            objs.append(rt.Disk(rng.uniform(0.02, 0.2), rng.uniform(2.5, 4), rng.uniform(5, 8)))
+    pos = (0, 4 + rng.normal(), -3 + rng.normal(), rng.normal() * 0.5)
+    cam = rt.make_camera(pos, (0, 1, 0, 0), (0, 0, 0, 1), (0, 0.1 * rng.normal(), 1, 0.1 * rng.normal()))
+    opt = rt.solver_defaults(lambda1=float(rng.choice([100.0, 15.0])), reltol=float(rng.choice([2.0 ** -39, 1e-9])),
+                             hit_threshold=float(rng.choice([0.01, 0.05])), miss_rgb=(0.25, 0.5, 0.75),
+                             max_steps=5000)
+    return rt.make_scene(metric, objs), cam, opt, len(objs)
+
+
+@pytest.mark.parametrize("seed", range(15))
+def test_random_scenes_match_oracle(lib, seed):
+    """Stated bounds.  Rays that do not finish (they spiral into the singular region until the step cap or dt
+    underflow) are chaotic: only their COUNT is compared (±5 % + 3).  In Minkowski the step sequence is rounding noise
+    (SURVEY §4.3), so up to 3 % of the pixels may change class; elsewhere ≤ 6 (silhouettes).  Of the remaining pixels
+    at most 2 (grazing events on a non-smooth disk edge are ill-conditioned) may exceed the 1e-6 wrap-aware RGB bound."""
+    sc, cam, opt, nobj = _random_scene(seed)
+    gpu = hip_trace(lib, sc, opt, 40, 32, cam=cam)
+    ref = O.trace(sc, opt, 40, 32, cam=cam)
+    unfin_g, unfin_r = gpu["status"] >= 2, ref["status"] >= 2
+    assert abs(int(unfin_g.sum()) - int(unfin_r.sum())) <= 0.05 * unfin_r.sum() + 3
+    ok = ~unfin_g & ~unfin_r
+    flips = (gpu["hit"] != ref["hit"]) & ok
+    nflip_max = 0.03 * 1280 if sc.metric == abi.MINKOWSKI else 6
+    assert int(flips.sum()) <= nflip_max, int(flips.sum())
+    assert int(((gpu["status"] != ref["status"]) & ok).sum()) <= nflip_max  # event <-> λ1 is the same coin toss
+    same = ok & ~flips & (gpu["status"] == ref["status"])
+    d = np.abs(gpu["rgb"][:, same] - ref["rgb"][:, same])
+    per = gpu["hit"][same].astype(np.float64) / max(nobj, 1)   # sawtooth period of a coloured hit (:427, :530)
+    per = np.where(per > 0, per, 1.0)[None, :]
+    e = np.minimum(d, np.abs(per - d)).max(axis=0) if same.any() else np.zeros(0)
+    bad = e > RGB_TOL
+    # rays that orbit the hole many times before they hit something (>= 500 step attempts) amplify rounding differences
+    # exponentially (unstable photon orbit); they are the only ones allowed over the bound, and only a few
+    long_orbit = (ref["n_accept"][same] + ref["n_reject"][same]) >= 500
+    assert int((bad & ~long_orbit).sum()) <= 2, np.sort(e[~long_orbit])[-4:]
+    assert int(bad.sum()) <= 0.02 * 1280 and (e[bad] < 1e-2).all()
+    sd = np.abs((gpu["n_accept"] + gpu["n_reject"]).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))
+    assert np.percentile(sd[same], 99) <= 3 if same.any() else True
