@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="CPU baseline renders a sample x sample screen; -1 = auto (~15 s of CPU work), 0 = off")
+    ap.add_argument("--rhs", default="closed", choices=["closed", "generic"],
+                    help="closed = Kerr-Schild-form contraction (production); generic = reference-style dual-number RHS "
+                         "(RTGR_METRIC_GENERIC): its executed flops equal the algorithmic count of the roofline model")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real thing) or gloo (CPU-staged; lets "
@@ -48,7 +51,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_scene(rt, variant):
+def build_scene(rt, variant, generic=False):
     _, objs, cam = rt.example2_scene()
     if variant == "mink":
         metric, objs, cam = rt.example1_scene()
@@ -56,7 +59,10 @@ def build_scene(rt, variant):
         metric = {"ks_ref0": rt.kerr_schild, "ks_ref08": rt.KerrSchild(1, 0.8, textbook=False),
                   "ks_true0": rt.KerrSchild(1, 0.0), "ks_true08": rt.KerrSchild(1, 0.8),
                   "ks_true0998": rt.KerrSchild(1, 0.998)}[variant]
-    return rt.make_scene(metric, objs), rt.make_camera(**cam)
+    sc = rt.make_scene(metric, objs)
+    if generic and variant != "mink":
+        sc.metric |= rt._abi.METRIC_GENERIC
+    return sc, rt.make_camera(**cam)
 
 
 def cpu_baseline(rt, scene, cam, opt, sample):
@@ -111,7 +117,7 @@ def main():
     rt._abi.check(lib, lib.rtgr_init(local))
 
     npdt = np.float64 if a.dtype == "f64" else np.float32
-    scene, cam = build_scene(rt, a.variant)
+    scene, cam = build_scene(rt, a.variant, a.rhs == "generic")
     opt = rt.solver_defaults(npdt)
     ni = nj = a.size
     j0, j1 = sharded.slab_bounds(nj, ws, rank)
@@ -211,7 +217,7 @@ def main():
             "config": {"workload": f"example2 scene (Kerr-Schild {a.variant}, 3 objects) {ni}x{nj} screen, "
                                    f"tol=eps^(3/4), lambda in [0,100]; rows sharded over {ws} GPU(s)"
                                    f"{'' if ws == 1 or a.no_gather else ' + RCCL gather to rank 0'}",
-                       "size": a.size, "variant": a.variant, "parallelism": f"rows/{ws}"},
+                       "size": a.size, "variant": a.variant, "rhs": a.rhs, "parallelism": f"rows/{ws}"},
             "rays_per_s": rays / dt, "rays": rays // a.steps, "step_attempts_per_pass": attempts // a.steps,
             "accepted": acc // a.steps, "rejected": rej // a.steps, "rhs_evals_per_pass": nrhs // a.steps,
             "pipeline_ms_max_over_ranks": float(kmax[0]), "device": name,
@@ -233,7 +239,8 @@ def load_traffic(a):
         except Exception:
             continue
         c = t.get("config", {})
-        if (c.get("size"), c.get("variant"), c.get("dtype")) == (a.size, a.variant, a.dtype) and a.gpus == 1:
+        if (c.get("size"), c.get("variant"), c.get("dtype")) == (a.size, a.variant, a.dtype) and a.gpus == 1 \
+                and a.rhs == "closed":
             return t["traffic_bytes_per_launch"]
     return None
 

@@ -56,6 +56,13 @@ enum rtgr_metric {
                            (no reference counterpart; needed for a != 0 configs)                               */
 };
 
+/* OR-ed into rtgr_scene.metric: evaluate the geodesic RHS the way the reference does for ANY metric callable — 4-wide
+ * forward duals through the metric, symmetric g / dg, 4x4 inverse, Christoffel contraction (the "generic" path of
+ * DESIGN.md §4.2) — instead of the closed Kerr–Schild contraction.  Same results to rounding; ~5x the flops.  It is the
+ * path a new (non-Kerr–Schild-form) metric functor would take, and the one whose executed flops equal the algorithmic
+ * count of SURVEY §8(d). */
+#define RTGR_METRIC_GENERIC 0x100u
+
 /* ---- objects: replaces Vector{Object{T}} (src/RayTraceGR.jl:374-428); ORDER MATTERS (:518-530) ---------- */
 enum rtgr_object_kind {
     RTGR_PLANE = 1,  /* Plane{T}(time)            p[0] = time                     src/RayTraceGR.jl:394-404  */

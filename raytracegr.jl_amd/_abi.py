@@ -12,6 +12,7 @@ RTGR_ABI_VERSION = 1
 
 # enum rtgr_metric
 MINKOWSKI, KS_REF, KS_TRUE = 0, 1, 2
+METRIC_GENERIC = 0x100  # RTGR_METRIC_GENERIC flag
 # enum rtgr_object_kind
 PLANE, SPHERE, DISK = 1, 2, 3
 # enum rtgr_ray_status

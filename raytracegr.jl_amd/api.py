@@ -32,8 +32,9 @@ D = 4  # src/RayTraceGR.jl:253-254
 class Metric:
     """A built-in metric: enum + (M, a). Calling it evaluates g_ab(x) on the GPU (src/RayTraceGR.jl:262-294)."""
 
-    def __init__(self, kind, M=1.0, a=0.0, name="metric"):
+    def __init__(self, kind, M=1.0, a=0.0, name="metric", generic=False):
         self.kind, self.M, self.a, self.__name__ = int(kind), float(M), float(a), name
+        self.generic = bool(generic)  # True: trace with the generic dual-number RHS (RTGR_METRIC_GENERIC)
 
     def __call__(self, x):
         g, _, _ = _eval_metric(self, x, want=(True, False, False))
@@ -47,10 +48,11 @@ minkowski = Metric(_abi.MINKOWSKI, name="minkowski")          # src/RayTraceGR.j
 kerr_schild = Metric(_abi.KS_REF, 1.0, 0.0, name="kerr_schild")  # as written: M=1, a=0 (:275-276), r of :284
 
 
-def KerrSchild(M=1.0, a=0.0, textbook=True):
+def KerrSchild(M=1.0, a=0.0, textbook=True, generic=False):
     """Parameterised Kerr–Schild metric the reference describes (README "varying mass and spin") but does not
-    have: textbook radius (RTGR_KS_TRUE) or the as-written radius with a != 0 (RTGR_KS_REF)."""
-    return Metric(_abi.KS_TRUE if textbook else _abi.KS_REF, M, a, name="KerrSchild")
+    have: textbook radius (RTGR_KS_TRUE) or the as-written radius with a != 0 (RTGR_KS_REF).  generic=True traces with
+    the reference-style dual-number RHS instead of the closed contraction (same results, ~5x the flops)."""
+    return Metric(_abi.KS_TRUE if textbook else _abi.KS_REF, M, a, name="KerrSchild", generic=generic)
 
 
 # ---- objects (src/RayTraceGR.jl:374-428) ------------------------------------------------------------------------
@@ -107,7 +109,8 @@ def make_scene(metric, objs):
     if len(objs) > _abi.RTGR_MAX_OBJECTS:
         raise ValueError(f"at most {_abi.RTGR_MAX_OBJECTS} objects")
     sc = rtgr_scene()
-    sc.metric, sc.nobj, sc.M, sc.a = metric.kind, len(objs), metric.M, metric.a
+    sc.metric = metric.kind | (_abi.METRIC_GENERIC if metric.generic else 0)
+    sc.nobj, sc.M, sc.a = len(objs), metric.M, metric.a
     for o, obj in enumerate(objs):
         sc.obj[o].kind = obj.kind
         p = obj._pack()

@@ -183,10 +183,10 @@ __global__ __launch_bounds__(256) void pixels_out_kernel(const double* px_in, co
 template <class R>
 static int convert_scene(const rtgr_scene* s, DevScene<R>& d) {
     if (!s) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
-    if (s->metric > RTGR_KS_TRUE) return fail(RTGR_ERR_BAD_ARG, "unknown metric enum");
+    if ((s->metric & ~RTGR_METRIC_GENERIC) > RTGR_KS_TRUE) return fail(RTGR_ERR_BAD_ARG, "unknown metric enum");
     if (s->nobj > RTGR_MAX_OBJECTS) return fail(RTGR_ERR_BAD_ARG, "too many objects");
     std::memset(&d, 0, sizeof d);
-    d.metric = s->metric;
+    d.metric = s->metric & ~RTGR_METRIC_GENERIC;
     d.nobj = s->nobj;
     d.M = (R)s->M;
     d.a = (R)s->a;
@@ -302,6 +302,7 @@ static size_t workspace_bytes(uint64_t rays, bool with_state, bool with_canvas) 
 template <class R, int METRIC, bool SPIN>
 static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split, uint64_t waves, hipStream_t st) {
     auto grid = [&](int per_simd) {
+        if (METRIC >= RTGR_GENERIC_BASE) per_simd = RTGR_WAVES_PER_SIMD_GENERIC;
         const uint64_t resident = (uint64_t)g_num_cu * (uint64_t)env_int("RTGR_WAVES_PER_CU", 4 * per_simd);
         return dim3((unsigned)(waves < resident ? waves : resident));
     };
@@ -322,7 +323,7 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
 
 template <class R, int METRIC, bool SPIN>
 static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
-    if (use_tile_kernel()) {
+    if constexpr (METRIC < RTGR_GENERIC_BASE) if (use_tile_kernel()) {
         const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
         const uint64_t blocks = (tiles + 3) / 4;
         KernelTimer tm(st, 1);
@@ -411,6 +412,13 @@ static int bind_device(int dev) {
     return RTGR_OK;
 }
 
+// generic dual-number RHS (RTGR_METRIC_GENERIC): Float64, metric kind as a template value 100 + kind
+static int launch_generic(const TraceArgs<double>& A, hipStream_t st) {
+    if (A.sc.metric == RTGR_KS_REF) return launch_trace<double, RTGR_GENERIC_BASE + RTGR_KS_REF, true>(A, st);
+    return launch_trace<double, RTGR_GENERIC_BASE + RTGR_KS_TRUE, true>(A, st);
+}
+static int launch_generic(const TraceArgs<float>&, hipStream_t) { return RTGR_ERR_BAD_ARG; }
+
 template <class R>
 static int trace_device(const rtgr_scene* scene, const rtgr_solver* opt, const R* d_state0, const rtgr_camera* cam,
                         uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* d_rgb, const rtgr_ray_outputs* out,
@@ -440,7 +448,16 @@ static int trace_device(const rtgr_scene* scene, const rtgr_solver* opt, const R
     A.counters = (unsigned long long*)d_counters;
     hipStream_t st = (hipStream_t)stream;
     const bool spin = scene->a != 0.0;
-    switch (scene->metric) {
+    const bool generic = (scene->metric & RTGR_METRIC_GENERIC) != 0 && A.sc.metric != RTGR_MINKOWSKI;
+    if (generic) {
+        if (sizeof(R) != 8) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC is compiled for Float64 only");
+        if (use_tile_kernel()) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC needs the persistent pipeline");
+        rc = launch_generic(A, st);
+        if (rc) return rc;
+        HIP_TRY(hipGetLastError());
+        return RTGR_OK;
+    }
+    switch (A.sc.metric) {
         case RTGR_MINKOWSKI: rc = launch_trace<R, RTGR_MINKOWSKI, false>(A, st); break;
         case RTGR_KS_REF:
             rc = spin ? launch_trace<R, RTGR_KS_REF, true>(A, st) : launch_trace<R, RTGR_KS_REF, false>(A, st);

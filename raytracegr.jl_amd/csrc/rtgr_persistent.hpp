@@ -32,6 +32,9 @@
 #ifndef RTGR_ROOT_SHORTCUT
 #define RTGR_ROOT_SHORTCUT 1
 #endif
+#ifndef RTGR_WAVES_PER_SIMD_GENERIC
+#define RTGR_WAVES_PER_SIMD_GENERIC 2  // generic dual-number RHS: ~270 registers wanted; 2 waves with a small spill beat 1 wave (measured 6.72 vs 6.22 Gstep/s)
+#endif
 #ifndef RTGR_WAVES_PER_SIMD_FAR
 #define RTGR_WAVES_PER_SIMD_FAR 3  // the FAR pass has no sample-point arrays: <=168 registers, three waves per SIMD
 #endif
@@ -151,7 +154,8 @@ RTGR_DEV void fold_distances(const DevObject<R>& o, const R (&pos)[P][4], R (&dm
 // integrate kernel
 // ---------------------------------------------------------------------------------------------------------------------
 template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE>
-__global__ __launch_bounds__(64, MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4) : RTGR_WAVES_PER_SIMD)
+__global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? RTGR_WAVES_PER_SIMD_GENERIC
+                                 : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4) : RTGR_WAVES_PER_SIMD))
 void integrate_kernel(const IntegrateArgs<R> A) {
     using N = Tsit5N<R>;
     const uint32_t lane = threadIdx.x & 63;

@@ -266,9 +266,14 @@ RTGR_DEV void accel_radial(const R xs[3], const R u[4], R M, R ud[4]) {
 }
 
 // acceleration only (the ẋ = u half is handled by the caller):  u̇ = accel(x_spatial, u)
+template <class R> RTGR_DEV void accel_generic(uint32_t metric, const R xs[3], const R u[4], R M, R a, R ud[4]);
+constexpr int RTGR_GENERIC_BASE = 100;  // METRIC template value 100 + kind selects the generic dual-number RHS
+
 template <class R, int METRIC, bool SPIN, bool FAST>
 RTGR_DEV void accel(const R xs[3], const R u[4], R M, R a, R ud[4]) {
-    if constexpr (METRIC == RTGR_MINKOWSKI) {
+    if constexpr (METRIC >= RTGR_GENERIC_BASE) {
+        accel_generic<R>((uint32_t)(METRIC - RTGR_GENERIC_BASE), xs, u, M, a, ud);
+    } else if constexpr (METRIC == RTGR_MINKOWSKI) {
         ud[0] = ud[1] = ud[2] = ud[3] = R(0);
     } else if constexpr (!SPIN) {
         accel_radial<R, METRIC, FAST>(xs, u, M, ud);
@@ -413,6 +418,17 @@ RTGR_DEV void generic_rhs(uint32_t metric, R M, R a, const R s[8], R ds[8]) {
         ds[p] = u[p];
         ds[4 + p] = -(gu[p][0] * L[0] + gu[p][1] * L[1] + gu[p][2] * L[2] + gu[p][3] * L[3]);
     }
+}
+
+// acceleration through the GENERIC dual-number path (what the reference does for any metric callable): used by the
+// integrate kernel when the scene asks for it (RTGR_METRIC_GENERIC flag) — the measured counterpart of the 814-flop
+// RHS that defines the algorithmic work in SURVEY §8(d).
+template <class R>
+RTGR_DEV void accel_generic(uint32_t metric, const R xs[3], const R u[4], R M, R a, R ud[4]) {
+    const R s[8] = {R(0), xs[0], xs[1], xs[2], u[0], u[1], u[2], u[3]};
+    R ds[8];
+    generic_rhs<R>(metric, M, a, s, ds);
+    ud[0] = ds[4]; ud[1] = ds[5]; ud[2] = ds[6]; ud[3] = ds[7];
 }
 
 // christoffel (src/RayTraceGR.jl:321-331): all 64 entries, for rtgr_eval_metric_f64

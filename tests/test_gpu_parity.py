@@ -429,3 +429,16 @@ def test_random_scenes_match_oracle(lib, seed):
     assert int(bad.sum()) <= 0.02 * 1280 and (e[bad] < 1e-2).all()
     sd = np.abs((gpu["n_accept"] + gpu["n_reject"]).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))
     assert np.percentile(sd[same], 99) <= 3 if same.any() else True
+
+
+@pytest.mark.parametrize("name", ["ks_ref0", "ks_true08"])
+def test_generic_dual_number_rhs_traces_the_same_image(lib, name):
+    """RTGR_METRIC_GENERIC: the integrate kernel with the reference-style RHS (4-wide forward duals through the metric,
+    inverse, Christoffel contraction) must reproduce the oracle as the closed contraction does."""
+    sc, cam = scene_variant(name)
+    sc.metric |= abi.METRIC_GENERIC
+    opt = rt.solver_defaults()
+    gpu = hip_trace(lib, sc, opt, 64, 64, cam=cam)
+    sc0, _ = scene_variant(name)
+    ref = O.trace(sc0, opt, 64, 64, cam=cam)
+    compare(gpu, ref, max_class_flips=2, max_step_diff=2)
