@@ -265,6 +265,70 @@ RTGR_DEV void accel_radial(const R xs[3], const R u[4], R M, R ud[4]) {
     ud[1] = xs[0] * g; ud[2] = xs[1] * g; ud[3] = xs[2] * g;
 }
 
+// a != 0: fused field + contraction.  ∂_j k_i = kr_i ∂_j r + E_ij with the sparse explicit part
+// E = [[r w, a w, 0], [−a w, r w, 0], [0, 0, 1/r]] (w = 1/(r²+a²)), and ∇f = f_r ∇r + f_z ẑ, so the two contractions
+// Dk_i = u^j ∂_j k_i and W_d = u^i ∂_d k_i come from D = u·∇r, kr·u, E u and Eᵀu without forming the 3x3 Jacobian.
+template <class R, int METRIC, bool FAST>
+RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
+    const R x = xs[0], y = xs[1], z = xs[2];
+    const R a2 = a * a;
+    const R rho2 = rfma(x, x, rfma(y, y, z * z));
+    const R q = rho2 - a2;
+    R r, ir, rq2, rz;  // r, 1/r, ∇r = rq2 (x,y,z) + rz ẑ
+    if constexpr (METRIC == RTGR_KS_REF) {
+        R s1, is1, s2, is2;                                   // r = sqrt(q)/2 + sqrt(a² z² + (q/2)²)            :284
+        sqrt_inv<FAST>(q, s1, is1);
+        const R hq = R(0.5) * q;
+        sqrt_inv<FAST>(rfma(a2 * z, z, hq * hq), s2, is2);
+        r = rfma(R(0.5), s1, s2);
+        ir = rcp_<FAST>(r);
+        rq2 = R(0.5) * rfma(q, is2, is1);
+        rz = a2 * z * is2;
+    } else {
+        R sq, is;                                             // r² = (q + sqrt(q² + 4a²z²))/2
+        sqrt_inv<FAST>(rfma(q, q, R(4) * a2 * z * z), sq, is);
+        sqrt_inv<FAST>(R(0.5) * (q + sq), r, ir);
+        const R hir = R(0.5) * ir;
+        rq2 = rfma(q * is, hir, hir);
+        rz = a2 * z * is * ir;
+    }
+    const R dr0 = rq2 * x, dr1 = rq2 * y, dr2 = rfma(rq2, z, rz);
+    const R r2 = r * r, a2z = a2 * z;
+    const R iden = rcp_<FAST>(rfma(r2, r2, a2z * z));          // 1/(r⁴ + a² z²)
+    const R r3 = r2 * r;
+    const R f = (R(2) * M) * r3 * iden;                         // f = 2M r³/(r⁴+a²z²)                             :285
+    const R f_r = f * rfma(R(-4) * r3, iden, R(3) * ir);        // ∂f/∂r = f (3/r − 4r³/den)
+    const R f_z = R(-2) * f * a2z * iden;                       // ∂f/∂z at fixed r
+    const R w = rcp_<FAST>(r2 + a2);
+    const R k0 = rfma(r, x, a * y) * w, k1 = rfma(r, y, -a * x) * w, k2 = z * ir;            // :286-289
+    const R m2r = R(-2) * r;
+    const R kr0 = w * rfma(m2r, k0, x), kr1 = w * rfma(m2r, k1, y), kr2 = -k2 * ir;          // ∂k_i/∂r
+    const R rw = r * w, aw = a * w;
+    const R ut = u[0], ux = u[1], uy = u[2], uz = u[3];
+    const R D = rfma(dr0, ux, rfma(dr1, uy, dr2 * uz));        // u·∇r
+    const R Df = rfma(f_r, D, f_z * uz);                        // u·∇f
+    const R Ku = rfma(k0, ux, rfma(k1, uy, k2 * uz));
+    const R K = ut + Ku;                                        // k_a u^a
+    const R kru = rfma(kr0, ux, rfma(kr1, uy, kr2 * uz));
+    const R p0 = rw * ux, p1 = aw * uy, p2 = aw * ux, p3 = rw * uy, e2 = ir * uz;
+    const R Dk0 = rfma(kr0, D, p0 + p1), Dk1 = rfma(kr1, D, p3 - p2), Dk2 = rfma(kr2, D, e2);   // u^j ∂_j k_i
+    const R W0 = rfma(kru, dr0, p0 - p1), W1 = rfma(kru, dr1, p2 + p3), W2 = rfma(kru, dr2, e2); // u^i ∂_d k_i
+    const R A = rfma(ux, Dk0, rfma(uy, Dk1, uz * Dk2));
+    const R P = rfma(K, Df, f * A);                             // L_t
+    const R fK = f * K, g2 = R(-0.5) * K * K * f_r, g3 = R(-0.5) * K * K * f_z;
+    const R L0 = rfma(k0, P, rfma(fK, Dk0 - W0, g2 * dr0));
+    const R L1 = rfma(k1, P, rfma(fK, Dk1 - W1, g2 * dr1));
+    const R L2 = rfma(k2, P, rfma(fK, Dk2 - W2, rfma(g2, dr2, g3)));
+    const R kk = rfma(k0, k0, rfma(k1, k1, k2 * k2));
+    const R S = f * rcp_<FAST>(rfma(f, kk - R(1), R(1)));
+    const R kL = rfma(k0, L0, rfma(k1, L1, rfma(k2, L2, -P)));
+    const R SkL = S * kL;
+    ud[0] = P - SkL;
+    ud[1] = rfma(k0, SkL, -L0);
+    ud[2] = rfma(k1, SkL, -L1);
+    ud[3] = rfma(k2, SkL, -L2);
+}
+
 // acceleration only (the ẋ = u half is handled by the caller):  u̇ = accel(x_spatial, u)
 template <class R> RTGR_DEV void accel_generic(uint32_t metric, const R xs[3], const R u[4], R M, R a, R ud[4]);
 constexpr int RTGR_GENERIC_BASE = 100;  // METRIC template value 100 + kind selects the generic dual-number RHS
@@ -278,9 +342,7 @@ RTGR_DEV void accel(const R xs[3], const R u[4], R M, R a, R ud[4]) {
     } else if constexpr (!SPIN) {
         accel_radial<R, METRIC, FAST>(xs, u, M, ud);
     } else {
-        KSField<R> F;
-        ks_field<R, METRIC, SPIN, FAST>(xs[0], xs[1], xs[2], M, a, F);
-        ksform_accel<R, FAST>(F, u, ud);
+        accel_spin<R, METRIC, FAST>(xs, u, M, a, ud);
     }
 }
 

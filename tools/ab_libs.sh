@@ -1,0 +1,6 @@
+for rep in 1 2 3; do for lib in raytracegr.jl_amd/build/librtgr_hip_prev.so raytracegr.jl_amd/librtgr_hip.so; do echo "### $lib"; RTGR_LIB=$lib python bench.py --size ${1:-4096} --steps 3 --warmup 1 --cpu-sample 0 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('   steps/s %.4g  ms/pass %.3f  far %.3f near %.3f other %s' % (d['value'], d['ms_per_step'], d['roofline']['far_pass_ms_avg'], d['roofline']['near_pass_ms_avg'], d['roofline']['other_kernels_ms_avg']))
+"; done; done
