@@ -363,15 +363,14 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         }
         const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 &&
                                (order_mode != 0);
+        unsigned long long* q = g_queue_pool + 4 * (g_queue_next++ % RTGR_QUEUE_SLOTS);
+        hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, st, q, use_order ? hist : (uint32_t*)nullptr);
         if (use_order) {
             KernelTimer tm(st, 0);
-            HIP_TRY(hipMemsetAsync(hist, 0, 2048, st));
             hipLaunchKernelGGL(order_key_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, s0, m, keys, hist);
             hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, st, hist, hist + 256);
             hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys, m, hist + 256, order);
         }
-        unsigned long long* q = g_queue_pool + 4 * (g_queue_next++ % RTGR_QUEUE_SLOTS);
-        HIP_TRY(hipMemsetAsync(q, 0, 4 * sizeof(unsigned long long), st));
         IntegrateArgs<R> IA;
         IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.order = use_order ? order : nullptr; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
         IA.hand = hand; IA.ctrl = q; IA.counters = A.counters;

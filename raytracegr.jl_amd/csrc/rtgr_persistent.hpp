@@ -608,6 +608,14 @@ void integrate_kernel(const IntegrateArgs<R> A) {
     }
 }
 
+// Per-launch reset of the queue heads and of the ordering histogram.  A kernel rather than hipMemsetAsync: memset nodes
+// of a captured HIP graph were observed not to re-run on later replays (ROCm 7.0 runtime bundled with PyTorch), which
+// left stale queue heads / histograms and sent the scatter out of bounds; kernel nodes replay reliably.
+__global__ __launch_bounds__(256) void reset_kernel(unsigned long long* ctrl, uint32_t* hist512) {
+    if (threadIdx.x < 4) ctrl[threadIdx.x] = 0ull;
+    if (hist512) { hist512[threadIdx.x] = 0u; hist512[256 + threadIdx.x] = 0u; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // ray ordering: longest-expected-first (LPT) queue order
 //

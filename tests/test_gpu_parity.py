@@ -442,3 +442,25 @@ def test_generic_dual_number_rhs_traces_the_same_image(lib, name):
     sc0, _ = scene_variant(name)
     ref = O.trace(sc0, opt, 64, 64, cam=cam)
     compare(gpu, ref, max_class_flips=2, max_step_diff=2)
+
+
+def test_pipeline_is_hipgraph_capturable(lib):
+    """The device entry point only enqueues (memset + kernels) once the workspace is reserved, so the whole pipeline can
+    be captured into a HIP graph and replayed; replays must reproduce the eager result bit for bit."""
+    import torch
+    from raytracegr_jl_amd import sharded
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+    ni = nj = 192
+    abi.check(lib, lib.rtgr_reserve_workspace(ni * nj, 0, 0))
+    eager = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj)["rgb"].clone()
+    torch.cuda.synchronize()
+    out = {"rgb": torch.zeros((3, ni * nj), dtype=torch.float64, device="cuda")}
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, out=out)
+    for _ in range(3):
+        out["rgb"].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out["rgb"], eager)
