@@ -45,6 +45,7 @@ def parse():
                     help="closed = Kerr-Schild-form contraction (production); generic = reference-style dual-number RHS "
                          "(RTGR_METRIC_GENERIC): its executed flops equal the algorithmic count of the roofline model")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--layout", default="cyclic", choices=["cyclic", "slab"], help="row distribution over ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real thing) or gloo (CPU-staged; lets "
                          "the multi-rank logic be rehearsed with several ranks sharing one GPU)")
@@ -120,21 +121,24 @@ def main():
     scene, cam = build_scene(rt, a.variant, a.rhs == "generic")
     opt = rt.solver_defaults(npdt)
     ni = nj = a.size
-    j0, j1 = sharded.slab_bounds(nj, ws, rank)
+    # rows are dealt cyclically (rank r: rows r, r+N, …): contiguous slabs of a black-hole image are unbalanced
+    j0, jstride, nrows = sharded.row_assignment(nj, ws, rank, a.layout)
     ctr = torch.zeros(8, dtype=torch.int64, device=dev)
     out = {}
 
     def one_pass(timed_events=None):
         if timed_events is not None:
             timed_events[0].record()
-        sharded.trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device=dev, dtype=npdt, counters=ctr, out=out)
+        sharded.trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device=dev, dtype=npdt, counters=ctr,
+                                 out=out)
         if timed_events is not None:
             timed_events[1].record()
         if ws > 1 and not a.no_gather:
             gather(out["rgb"])
 
-    nmax = ni * (sharded.slab_bounds(nj, ws, 0)[1] - sharded.slab_bounds(nj, ws, 0)[0])
+    nmax = ni * max(sharded.row_assignment(nj, ws, r, a.layout)[2] for r in range(ws))
     parts = None
+    image = None
 
     def gather(slab):
         nonlocal parts
@@ -144,6 +148,8 @@ def main():
             if parts is None:
                 parts = [torch.empty((3, nmax), dtype=slab.dtype, device=cdev) for _ in range(ws)]
             dist.gather(send, parts, dst=0)
+            nonlocal image
+            image = sharded.assemble_rows(parts, ni, nj, ws, a.layout)  # the gathered frame, rows back in place
         else:
             dist.gather(send, None, dst=0)
 
@@ -215,8 +221,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"example2 scene (Kerr-Schild {a.variant}, 3 objects) {ni}x{nj} screen, "
-                                   f"tol=eps^(3/4), lambda in [0,100]; rows sharded over {ws} GPU(s)"
-                                   f"{'' if ws == 1 or a.no_gather else ' + RCCL gather to rank 0'}",
+                                   f"tol=eps^(3/4), lambda in [0,100]; rows dealt {a.layout} over {ws} GPU(s)"
+                                   f"{'' if ws == 1 or a.no_gather else ' + ' + ('RCCL' if a.backend == 'nccl' else 'gloo') + ' gather to rank 0'}",
                        "size": a.size, "variant": a.variant, "rhs": a.rhs, "parallelism": f"rows/{ws}"},
             "rays_per_s": rays / dt, "rays": rays // a.steps, "step_attempts_per_pass": attempts // a.steps,
             "accepted": acc // a.steps, "rejected": rej // a.steps, "rhs_evals_per_pass": nrhs // a.steps,

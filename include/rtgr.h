@@ -176,6 +176,17 @@ int rtgr_trace_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const
                           const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1,
                           float* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
 
+/* Strided rows: traces image rows j0, j0+jstride, …, j0+(nrows-1)*jstride of the camera's ni x nj canvas (rays generated
+ * on the device); local row k of the output planes (n = ni*nrows) is image row j0 + k*jstride.  jstride = 1 is a
+ * contiguous slab; jstride = N, j0 = rank is the CYCLIC row split used for multi-GPU runs — contiguous slabs of a
+ * black-hole image are unbalanced (rows through the hole cost ~1.8x the edge rows), cyclic rows are not. */
+int rtgr_trace_rows_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
+                               uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, double* d_rgb,
+                               const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
+int rtgr_trace_rows_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
+                               uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, float* d_rgb,
+                               const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
+
 /* ---- the hot path, host buffers (what a Julia ccall would pass) ---------------------------------------------
  * Same semantics with HOST pointers; the library stages through its own device buffers and blocks until done.
  *   state0 may be NULL (device-side make_canvas from `cam`).  `ctr` (host, optional) is overwritten.

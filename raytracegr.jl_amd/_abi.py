@@ -58,7 +58,7 @@ class rtgr_ray_outputs(C.Structure):
 # Every symbol include/rtgr.h declares (tests check the .so exports exactly this list).
 EXPORTS = [
     "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version", "rtgr_solver_defaults",
-    "rtgr_device_info", "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read", "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_f64", "rtgr_trace_f32",
+    "rtgr_device_info", "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read", "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_rows_device_f64", "rtgr_trace_rows_device_f32", "rtgr_trace_f64", "rtgr_trace_f32",
     "rtgr_trace_pixels_f64", "rtgr_trace_one_f64", "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64",
     "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", "rtgr_quantize_device_f64",
 ]
@@ -92,6 +92,8 @@ def _declare(lib):
     for suf in ("f64", "f32"):
         getattr(lib, f"rtgr_trace_device_{suf}").argtypes = [
             P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]
+        getattr(lib, f"rtgr_trace_rows_device_{suf}").argtypes = [
+            P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]
         getattr(lib, f"rtgr_trace_{suf}").argtypes = [
             P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs),
             P(rtgr_counters)]

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
 #pragma unroll
             for (int c = 0; c < 8; c++) s0[c] = A.state0[idx * 8 + c];
         } else {
-            make_pixel<R>(A.sc, A.cam, A.ni, A.nj, i, A.j0 + jl, s0);
+            make_pixel<R>(A.sc, A.cam, A.ni, A.nj, i, A.j0 + jl * A.jstride, s0);
         }
         st = integrate_ray<R, METRIC, SPIN>(A.sc, A.opt, s0, se, lam);
         const uint8_t hit = colour_pixel<R>(A.sc, A.opt, se, col);
@@ -96,12 +96,12 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
 
 template <class R>
 __global__ __launch_bounds__(256) void canvas_kernel(DevScene<R> sc, DevCamera<R> cam, uint64_t ni, uint64_t nj,
-                                                     uint64_t j0, uint64_t first, uint64_t count, R* state0) {
+                                                     uint64_t j0, uint64_t jstride, uint64_t first, uint64_t count, R* state0) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= count) return;
-    const uint64_t idx = first + w;  // linear index inside the slab: i + (j - j0) * ni
+    const uint64_t idx = first + w;  // linear index inside the slab: i + k * ni, image row j = j0 + k * jstride
     R s[8];
-    make_pixel<R>(sc, cam, ni, nj, idx % ni, j0 + idx / ni, s);
+    make_pixel<R>(sc, cam, ni, nj, idx % ni, j0 + (idx / ni) * jstride, s);
 #pragma unroll
     for (int c = 0; c < 8; c++) state0[w * 8 + c] = s[c];
 }
@@ -359,7 +359,7 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         if (with_canvas) {
             KernelTimer tm(st, 0);
             hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
-                               A.nj, A.j0, off, m, gen);
+                               A.nj, A.j0, A.jstride, off, m, gen);
         }
         const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 &&
                                (order_mode != 0);
@@ -421,7 +421,7 @@ static int launch_generic(const TraceArgs<float>&, hipStream_t) { return RTGR_ER
 template <class R>
 static int trace_device(const rtgr_scene* scene, const rtgr_solver* opt, const R* d_state0, const rtgr_camera* cam,
                         uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* d_rgb, const rtgr_ray_outputs* out,
-                        rtgr_counters* d_counters, void* stream) {
+                        rtgr_counters* d_counters, void* stream, uint64_t jstride = 1, uint64_t nrows_strided = 0) {
     int rc = ensure_device();
     if (rc) return rc;
     TraceArgs<R> A;
@@ -429,12 +429,20 @@ static int trace_device(const rtgr_scene* scene, const rtgr_solver* opt, const R
     if ((rc = convert_scene<R>(scene, A.sc))) return rc;
     if ((rc = convert_solver<R>(opt, A.opt))) return rc;
     if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
-    if (ni == 0 || nj == 0 || j1 <= j0 || j1 > nj) return fail(RTGR_ERR_BAD_ARG, "bad canvas range: need 0 <= j0 < j1 <= nj, ni > 0");
+    uint64_t nrows = j1 - j0;
+    if (jstride != 1 || nrows_strided != 0) {  // rows j0, j0+jstride, … (nrows_strided of them)
+        if (jstride == 0 || nrows_strided == 0 || j0 >= nj || j0 + (nrows_strided - 1) * jstride >= nj)
+            return fail(RTGR_ERR_BAD_ARG, "bad strided row range: need j0 + (nrows-1)*jstride < nj");
+        nrows = nrows_strided;
+    } else if (j1 <= j0 || j1 > nj) {
+        return fail(RTGR_ERR_BAD_ARG, "bad canvas range: need 0 <= j0 < j1 <= nj, ni > 0");
+    }
+    if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "bad canvas range: need 0 <= j0 < j1 <= nj, ni > 0");
     if (!d_state0 && !cam) return fail(RTGR_ERR_BAD_ARG, "need state0 or a camera");
-    if (ni * (j1 - j0) > (1ull << 40)) return fail(RTGR_ERR_BAD_ARG, "canvas too large");
+    if (ni * nrows > (1ull << 40)) return fail(RTGR_ERR_BAD_ARG, "canvas too large");
     if (cam) convert_camera<R>(cam, A.cam);
     A.state0 = d_state0;
-    A.ni = ni; A.nj = nj; A.j0 = j0; A.nrows = j1 - j0;
+    A.ni = ni; A.nj = nj; A.j0 = j0; A.nrows = nrows; A.jstride = jstride;
     A.rgb = d_rgb;
     if (out) {
         A.state_end = (R*)out->state_end;
@@ -619,6 +627,18 @@ int rtgr_trace_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const
                           const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream) {
     return trace_device<float>(scene, opt, d_state0, cam, ni, nj, j0, j1, d_rgb, out, d_counters, stream);
 }
+int rtgr_trace_rows_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
+                               uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, double* d_rgb,
+                               const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream) {
+    if (!cam) return fail(RTGR_ERR_BAD_ARG, "camera is NULL");
+    return trace_device<double>(scene, opt, nullptr, cam, ni, nj, j0, j0 + 1, d_rgb, out, d_counters, stream, jstride, nrows);
+}
+int rtgr_trace_rows_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
+                               uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, float* d_rgb,
+                               const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream) {
+    if (!cam) return fail(RTGR_ERR_BAD_ARG, "camera is NULL");
+    return trace_device<float>(scene, opt, nullptr, cam, ni, nj, j0, j0 + 1, d_rgb, out, d_counters, stream, jstride, nrows);
+}
 int rtgr_trace_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* state0, const rtgr_camera* cam,
                    uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, double* rgb, const rtgr_ray_outputs* out,
                    rtgr_counters* ctr) {
@@ -686,7 +706,7 @@ int rtgr_make_canvas_device_f64(const rtgr_scene* scene, const rtgr_camera* cam,
     convert_camera<double>(cam, c);
     const uint64_t n = ni * (j1 - j0);
     hipLaunchKernelGGL(canvas_kernel<double>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, sc, c, ni, nj, j0,
-                       (uint64_t)0, n, d_state0);
+                       (uint64_t)1, (uint64_t)0, n, d_state0);
     HIP_TRY(hipGetLastError());
     return RTGR_OK;
 }

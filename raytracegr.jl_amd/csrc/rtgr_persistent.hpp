@@ -65,6 +65,7 @@ struct TraceArgs {
     DevCamera<R> cam;
     const R* state0;  // n x 8 or null (camera)
     uint64_t ni, nj, j0, nrows;
+    uint64_t jstride; // local row k is image row j0 + k*jstride (1 = contiguous slab; N = cyclic rows of an N-way split)
     R* rgb;           // 3 planes of n
     R* state_end;     // optional
     R* lambda_end;

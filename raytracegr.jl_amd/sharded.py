@@ -1,11 +1,12 @@
 """Row-sharded tracing across the GPUs of one node: one process per GPU (torch.distributed, backend "nccl" = RCCL),
-image rows j split into contiguous slabs, one gather of the RGB slabs to rank 0 over xGMI.
+image rows j dealt cyclically to the ranks (rank r traces rows r, r+N, …), one gather of the RGB rows to rank 0 over
+xGMI.
 
 torch is plumbing here (device memory, streams, the process group); the compute is librtgr_hip.so through
 rtgr_trace_device_f64 with raw device pointers.
 
-The reference has no counterpart (threads only, README.md:129-135); the slab decomposition follows from the
-column-major `pixels[i,j]` layout (src/RayTraceGR.jl:463-464): a j-slab is contiguous.
+The reference has no counterpart (threads only, README.md:129-135); rows are the natural unit because a row is
+contiguous in the column-major `pixels[i,j]` layout (src/RayTraceGR.jl:463-464).
 """
 import ctypes as C
 
@@ -62,37 +63,70 @@ def trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device="cuda", dtype=np.fl
     return res
 
 
-def trace_sharded(scene, opt, cam, ni, nj, group=None, device=None, dtype=np.float64, trace_slab=None,
-                  gather=True, counters=None):
-    """Every rank traces its slab; rank 0 receives the whole image [3, ni*nj] (None elsewhere).
+def row_assignment(nj, world_size, rank, layout="cyclic"):
+    """(j0, jstride, nrows) of `rank`.  "cyclic": rows rank, rank+N, … — every rank gets a statistically identical
+    sample of the image, which matters because rows through the hole cost ~1.8x the edge rows (measured: contiguous
+    slabs of example2 at N=8 take 10.9 … 19.2 ms).  "slab": the contiguous range of slab_bounds()."""
+    if layout == "cyclic":
+        return rank, world_size, len(range(rank, nj, world_size))
+    j0, j1 = slab_bounds(nj, world_size, rank)
+    return j0, 1, j1 - j0
 
-    `trace_slab(scene, opt, cam, ni, nj, j0, j1) -> tensor[3, n]` is an injection point for the world_size-2 gloo
-    tests on CPU-only hosts; the default is the HIP path (fails loudly without a GPU).
+
+def trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device="cuda", dtype=np.float64, counters=None,
+                     out=None):
+    """Trace image rows j0, j0+jstride, … (nrows of them) into a device tensor rgb[3, ni*nrows]; asynchronous."""
+    import torch
+    lib = _abi.load()
+    n = ni * nrows
+    td = _torch_dtype(dtype)
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        res = out if out is not None else {}
+        if "rgb" not in res:
+            res["rgb"] = torch.empty((3, n), dtype=td, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        fn = lib.rtgr_trace_rows_device_f64 if dtype == np.float64 else lib.rtgr_trace_rows_device_f32
+        _abi.check(lib, fn(C.byref(scene), C.byref(opt), C.byref(cam), ni, nj, j0, jstride, nrows,
+                           res["rgb"].data_ptr(), None, counters.data_ptr() if counters is not None else None, stream))
+    return res
+
+
+def assemble_rows(parts, ni, nj, world_size, layout="cyclic"):
+    """Rank-0 side of the gather: parts[r] = rgb[3, >= ni*nrows_r] of rank r  ->  full image rgb[3, ni*nj]."""
+    full = parts[0].new_empty((3, nj, ni))
+    for r in range(world_size):
+        j0, st, nr = row_assignment(nj, world_size, r, layout)
+        full[:, j0:j0 + (nr - 1) * st + 1:st, :] = parts[r][:, :ni * nr].reshape(3, nr, ni)
+    return full.reshape(3, nj * ni)
+
+
+def trace_sharded(scene, opt, cam, ni, nj, group=None, device=None, dtype=np.float64, trace_rows=None,
+                  gather=True, counters=None, layout="cyclic"):
+    """Every rank traces its rows; rank 0 receives the whole image [3, ni*nj] (None elsewhere).
+
+    `trace_rows(scene, opt, cam, ni, nj, j0, jstride, nrows) -> tensor[3, ni*nrows]` is an injection point for the
+    world_size-2 gloo tests on CPU-only hosts; the default is the HIP path (fails loudly without a GPU).
     """
     import torch
     import torch.distributed as dist
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    j0, j1 = slab_bounds(nj, ws, rank)
-    if trace_slab is None:
-        slab = trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device=device or "cuda", dtype=dtype,
+    j0, st, nr = row_assignment(nj, ws, rank, layout)
+    if trace_rows is None:
+        mine = trace_rows_torch(scene, opt, cam, ni, nj, j0, st, nr, device=device or "cuda", dtype=dtype,
                                 counters=counters)["rgb"]
     else:
-        slab = trace_slab(scene, opt, cam, ni, nj, j0, j1)
+        mine = trace_rows(scene, opt, cam, ni, nj, j0, st, nr)
     if ws == 1 or not gather:
-        return slab
-    # gather of unequal slabs: pad to the largest slab (rows differ by at most one)
-    nmax = ni * (slab_bounds(nj, ws, 0)[1] - slab_bounds(nj, ws, 0)[0])
-    send = slab if slab.shape[1] == nmax else torch.cat(
-        [slab, slab.new_zeros((3, nmax - slab.shape[1]))], dim=1)
+        return mine
+    # gather of unequal shares: pad to the largest (row counts differ by at most one)
+    nmax = ni * max(row_assignment(nj, ws, r, layout)[2] for r in range(ws))
+    send = mine if mine.shape[1] == nmax else torch.cat([mine, mine.new_zeros((3, nmax - mine.shape[1]))], dim=1)
     send = send.contiguous()
     if rank == 0:
         parts = [torch.empty_like(send) for _ in range(ws)]
         dist.gather(send, parts, dst=0, group=group)
-        full = slab.new_empty((3, ni * nj))
-        for r in range(ws):
-            a, b = slab_bounds(nj, ws, r)
-            full[:, a * ni:b * ni] = parts[r][:, :ni * (b - a)]
-        return full
+        return assemble_rows(parts, ni, nj, ws, layout)
     dist.gather(send, None, dst=0, group=group)
     return None

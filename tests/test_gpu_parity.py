@@ -464,3 +464,24 @@ def test_pipeline_is_hipgraph_capturable(lib):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out["rgb"], eager)
+
+
+def test_strided_rows_equal_the_rows_of_the_full_frame(lib):
+    """rtgr_trace_rows_device_f64 (cyclic multi-GPU split): rows j0, j0+stride, … must be bit-identical to the same rows
+    of the full frame, and reassembling all N shares must give the frame back."""
+    import torch
+    from raytracegr_jl_amd import sharded
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+    ni, nj = 72, 50
+    full = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj)["rgb"].clone()
+    for ws in (2, 3, 8):
+        parts = []
+        for r in range(ws):
+            j0, st, nr = sharded.row_assignment(nj, ws, r, "cyclic")
+            part = sharded.trace_rows_torch(sc, opt, cam, ni, nj, j0, st, nr)["rgb"]
+            assert torch.equal(part.reshape(3, nr, ni), full.reshape(3, nj, ni)[:, j0::st, :])
+            parts.append(part)
+        assert torch.equal(sharded.assemble_rows(parts, ni, nj, ws, "cyclic"), full)
+    bad = lib.rtgr_trace_rows_device_f64(C.byref(sc), C.byref(opt), C.byref(cam), ni, nj, 3, 8, 7, full.data_ptr(), None, None, None)
+    assert bad == abi.ERR_BAD_ARG   # 3 + 6*8 = 51 >= nj

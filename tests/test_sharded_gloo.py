@@ -1,5 +1,5 @@
-"""world_size-2 run of the row-sharded driver on the gloo backend (CPU): slab bounds, the gather of unequal slabs and
-rank-0 assembly.  No GPU here, so the oracle is injected as the slab tracer (test-only injection point of
+"""world_size-2 run of the row-sharded driver on the gloo backend (CPU): row assignment (cyclic and contiguous), the
+gather of unequal shares and rank-0 assembly.  No GPU here, so the oracle is injected as the slab tracer (test-only injection point of
 sharded.trace_sharded); the gathered image must equal the single-process oracle image bit for bit."""
 import os
 import socket
@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, ws, port, ni, nj, out_path):
+def _worker(rank, ws, port, ni, nj, out_path, layout):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,11 +34,12 @@ def _worker(rank, ws, port, ni, nj, out_path):
     sc, cam = example(2)
     opt = rt.solver_defaults()
 
-    def oracle_slab(scene, o, camera, ni_, nj_, j0, j1):
-        r = O.trace(scene, o, ni_, nj_, j0=j0, j1=j1, cam=camera, details=False, nthreads=2)
-        return torch.from_numpy(r["rgb"])
+    def oracle_rows(scene, o, camera, ni_, nj_, j0, jstride, nrows):
+        rows = [O.trace(scene, o, ni_, nj_, j0=j, j1=j + 1, cam=camera, details=False, nthreads=2)["rgb"]
+                for j in range(j0, j0 + nrows * jstride, jstride)]
+        return torch.from_numpy(np.concatenate(rows, axis=1))
 
-    full = sharded.trace_sharded(sc, opt, cam, ni, nj, trace_slab=oracle_slab)
+    full = sharded.trace_sharded(sc, opt, cam, ni, nj, trace_rows=oracle_rows, layout=layout)
     if rank == 0:
         np.save(out_path, full.numpy())
     else:
@@ -47,12 +48,12 @@ def _worker(rank, ws, port, ni, nj, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ni,nj", [(24, 17), (16, 16)])
-def test_sharded_gather_world_size_2(tmp_path, ni, nj):
+@pytest.mark.parametrize("ni,nj,layout", [(24, 17, "cyclic"), (16, 16, "cyclic"), (24, 17, "slab")])
+def test_sharded_gather_world_size_2(tmp_path, ni, nj, layout):
     import oracle_lib as O
     from scenes import example, rt
     out = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(2, _free_port(), ni, nj, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ni, nj, out, layout), nprocs=2, join=True)
     got = np.load(out)
     sc, cam = example(2)
     ref = O.trace(sc, rt.solver_defaults(), ni, nj, cam=cam, details=False)["rgb"]
@@ -71,3 +72,17 @@ def test_slab_bounds_tile_the_frame():
             assert all(b[i][1] == b[i + 1][0] for i in range(ws - 1))
             sizes = [j1 - j0 for j0, j1 in b]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_row_assignments_cover_every_row_once():
+    from conftest import load_package
+    load_package()
+    from raytracegr_jl_amd import sharded
+    for layout in ("cyclic", "slab"):
+        for nj in (1, 7, 8, 200, 4099):
+            for ws in (1, 2, 3, 8):
+                rows = []
+                for r in range(ws):
+                    j0, st, nr = sharded.row_assignment(nj, ws, r, layout)
+                    rows += list(range(j0, j0 + nr * st, st))
+                assert sorted(rows) == list(range(nj)), (layout, nj, ws)
