@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096, help="screen is size x size")
     ap.add_argument("--variant", default="ks_ref0",
-                    choices=["ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "mink"])
+                    choices=["ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk", "mink"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="CPU baseline renders a sample x sample screen; -1 = auto (~15 s of CPU work), 0 = off")
@@ -59,7 +59,9 @@ def build_scene(rt, variant, generic=False):
     else:
         metric = {"ks_ref0": rt.kerr_schild, "ks_ref08": rt.KerrSchild(1, 0.8, textbook=False),
                   "ks_true0": rt.KerrSchild(1, 0.0), "ks_true08": rt.KerrSchild(1, 0.8),
-                  "ks_true0998": rt.KerrSchild(1, 0.998)}[variant]
+                  "ks_true0998": rt.KerrSchild(1, 0.998), "ks_true0998_disk": rt.KerrSchild(1, 0.998)}[variant]
+        if variant == "ks_true0998_disk":  # BASELINE config 5: thin accretion disk instead of the small sphere
+            objs = objs[:2] + [rt.Disk(0.05, 2.0, 4.0)]  # camera (cylindrical radius 4.5) stays outside the disk
     sc = rt.make_scene(metric, objs)
     if generic and variant != "mink":
         sc.metric |= rt._abi.METRIC_GENERIC

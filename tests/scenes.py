@@ -21,7 +21,7 @@ def scene_variant(name):
     if name == "mink":
         return example(1)
     if name == "ks_true0998_disk":
-        objs = objs[:2] + [rt.Disk(0.05, 2.0, 6.0)]
+        objs = objs[:2] + [rt.Disk(0.05, 2.0, 4.0)]  # camera (cylindrical radius 4.5) stays outside the disk
     return rt.make_scene(m, objs), rt.make_camera(**cam)
 
 

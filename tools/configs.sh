@@ -1,0 +1,19 @@
+#!/bin/bash
+# The five BASELINE.json configurations on one GPU (config 1 is the CPU-runnable 200² Minkowski case; config 3 is the
+# bench default).  usage: tools/configs.sh <outfile>
+OUT=${1:-gpurun_out/configs.log}
+run() { echo "### $1" | tee -a $OUT; shift; python bench.py --cpu-sample 0 --steps 2 --warmup 1 "$@" 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); r = d['roofline']
+        print('   steps/s %.4g  rays/s %.4g  ms/pass %.3f  steps/ray %.1f  rejected %d  (far %.2f near %.2f ms)' % (d['value'], d['rays_per_s'], d['ms_per_step'], d['step_attempts_per_pass']/d['rays'], d['rejected'], r['far_pass_ms_avg'], r['near_pass_ms_avg']))
+" | tee -a $OUT; }
+run "C1 example1 Minkowski 200x200" --variant mink --size 200
+run "C2 example2 as written (KS_REF a=0) 1024x1024" --variant ks_ref0 --size 1024
+run "C2' Kerr-Schild a=0.8 (textbook r) 1024x1024" --variant ks_true08 --size 1024
+run "C3 example2 as written 4096x4096 (bench default)" --variant ks_ref0 --size 4096
+run "C3' Kerr-Schild a=0.8 4096x4096" --variant ks_true08 --size 4096
+run "C4 Kerr-Schild a=0.8 2048x2048 Float32" --variant ks_true08 --size 2048 --dtype f32
+run "C4' example2 as written 2048x2048 Float32" --variant ks_ref0 --size 2048 --dtype f32
+run "C5 Kerr a=0.998 + thin disk 8192x8192" --variant ks_true0998_disk --size 8192
