@@ -177,7 +177,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
     R t = t0, dt = R(0), ps = R(0);
     float lq = lq_init;
     uint64_t idx = 0;
-    uint32_t nacc = 0, nrej = 0;
+    uint32_t nacc = 0, nrej = 0, nacc0 = 0, c_maxnear = 0;
     uint32_t c_rays = 0, c_acc = 0, c_rej = 0, c_ev = 0, c_int = 0, c_nf = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -219,6 +219,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                         for (int q = 0; q < 4; q++) { x[q] = hd[q]; u[q] = hd[4 + q]; k[0][q] = hd[8 + q]; }
                         t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
                         nacc = A.meta[w * 3]; nrej = A.meta[w * 3 + 1];
+                        nacc0 = nacc;
                         state = L_RUN;
                     }
                 } else {
@@ -382,7 +383,8 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                     float qf = fexp2(__builtin_fmaf(beta1, le, -beta2 * lq)) * igamma;
                     qf = (EEst == 0.0f) ? qmax_inv : fmaxf(qmax_inv, fminf(qmin_inv, qf));
                     bool hand_over = false;
-                    if constexpr (MODE == MODE_FAR) {
+                    bool need_scan = true;  // NEAR: false when no lane of the wave can see a sign change in this step
+                    if constexpr (MODE == MODE_FAR || MODE == MODE_NEAR) {
                         if (EEst <= 1.0f) {
                             // ---- can ANY object's distance change sign anywhere in this step?  |x_q(θ) − x_q| <= δ_q for all
                             // θ in [0,1] (Nyström form of the dense output, beta[l] = max|B2_l(θ)|); a plane's distance then
@@ -417,8 +419,13 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                                     safe = safe && (rabs(obj_distance<R>(ob, xs)) > guard * (dl[1] + dl[2] + dl[3]));
                                 }
                             }
-                            hand_over = !safe || (ps == R(0));
+                            if constexpr (MODE == MODE_FAR) hand_over = !safe || (ps == R(0));
+                            else need_scan = !safe || (ps == R(0));
                         }
+                        // NEAR pass: a ray stays here until it ends, also after it has left every object's reach; its
+                        // wave then runs with few lanes (the longest stays are 150-370 steps), so the scan is skipped
+                        // whenever NO active lane needs it — a wave-uniform decision, same results by the same bound.
+                        if constexpr (MODE == MODE_NEAR) need_scan = __ballot((EEst <= 1.0f) && need_scan) != 0ull;
                     }
                     if (hand_over) {
                         // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
@@ -437,7 +444,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                         // ---- ContinuousCallback ----------------------------------------------------
                         // x(θ) = x + θ c1 + θ² c2 + θ³ c3 + θ⁴ c4 ;  c1 = h u,  c_m = h² Σ_l R2[l][m] k_l
                         // (FAR pass: proven above that no object's distance changes sign in this step — nothing to scan)
-                        if constexpr (MODE != MODE_FAR) {
+                        if (MODE != MODE_FAR && need_scan) {
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             cc[0][q] = h * u[q];
@@ -514,7 +521,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                             done = RTGR_RAY_EVENT;
                         }
                         if (!is_event) ps = rsign(nextc);
-                        }  // MODE != MODE_FAR
+                        }  // scan
                         if (!is_event) {
                             commit = true;
                             t = tnew;
@@ -587,6 +594,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                     mt[0] = nacc;
                     mt[1] = nrej;
                     mt[2] = done | (is_interior ? 0x100u : 0u);
+                    if (MODE == MODE_NEAR) c_maxnear = c_maxnear > (nacc - nacc0) ? c_maxnear : (nacc - nacc0);
                     c_rays += 1; c_acc += nacc; c_rej += nrej;
                     c_ev += is_event; c_int += is_interior; c_nf += (done >= RTGR_RAY_MAXSTEPS);
                     state = L_FREE;
@@ -605,6 +613,12 @@ void integrate_kernel(const IntegrateArgs<R> A) {
             atomicAdd(&A.counters[4], s4);
             atomicAdd(&A.counters[5], s5);
             atomicAdd(&A.counters[6], s6);
+        }
+        if (MODE == MODE_NEAR) {  // diagnostics: the longest stay of any ray in the NEAR pass (accepted steps)
+            unsigned long long mx = c_maxnear;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(mx, off, 64); mx = mx > o ? mx : o; }
+            if (lane == 0) atomicMax(&A.counters[7], mx);
         }
     }
 }
