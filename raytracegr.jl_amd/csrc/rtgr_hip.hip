@@ -307,12 +307,25 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
         return dim3((unsigned)(waves < resident ? waves : resident));
     };
     if (npts10 && split) {
-        // FAR pass over every ray, then the NEAR pass over the rays it handed over
-        { KernelTimer tm(st, 1);
-          hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
-                             grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, IA); }
-        { KernelTimer tm(st, 3);
-          hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA); }
+        // round 0: FAR over the camera rays, NEAR over what it hands over (the NEAR pass keeps a ray to its end).
+        // RTGR_ROUNDS=2 (experiment, measured SLOWER: 9.9 -> 11.8 ms at 1024², 99.3 -> 101.9 ms at 4096²): the NEAR pass
+        // hands rays that have left every object's reach back, and a second FAR + NEAR round carries them on — the
+        // extra passes' own start-up and tails cost more than the NEAR tail they remove.  Each pass has its own queue
+        // head (ctrl[0..7]).
+        const int rounds = env_int("RTGR_ROUNDS", 1);
+        IntegrateArgs<R> P = IA;
+        for (int r = 0; r < rounds; r++) {
+            P.ctrl = IA.ctrl + 2 * r;
+            P.pick_flag = r == 0 ? 0u : META_HANDBACK;
+            if (r > 0) P.order = nullptr;
+            { KernelTimer tm(st, 1);
+              hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
+                                 grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, P); }
+            P.pick_flag = META_HANDED;
+            P.allow_handback = (r + 1 < rounds) ? 1u : 0u;
+            { KernelTimer tm(st, 3);
+              hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, P); }
+        }
     } else {
         KernelTimer tm(st, 1);
         if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
@@ -363,7 +376,7 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         }
         const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 &&
                                (order_mode != 0);
-        unsigned long long* q = g_queue_pool + 4 * (g_queue_next++ % RTGR_QUEUE_SLOTS);
+        unsigned long long* q = g_queue_pool + 8 * (g_queue_next++ % RTGR_QUEUE_SLOTS);
         hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, st, q, use_order ? hist : (uint32_t*)nullptr);
         if (use_order) {
             KernelTimer tm(st, 0);
@@ -373,7 +386,7 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         }
         IntegrateArgs<R> IA;
         IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.order = use_order ? order : nullptr; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
-        IA.hand = hand; IA.ctrl = q; IA.counters = A.counters;
+        IA.hand = hand; IA.ctrl = q; IA.counters = A.counters; IA.pick_flag = 0; IA.allow_handback = 0;
         {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [16, RTGR_QUEUE_CHUNK]
             const uint64_t per_wave = m / ((uint64_t)g_num_cu * 12 + 1);
             uint64_t qc = per_wave / 16;
@@ -403,8 +416,8 @@ static int bind_device(int dev) {
         if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
     }
     if (!g_queue_pool) {
-        HIP_TRY(hipMalloc((void**)&g_queue_pool, 4 * RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(g_queue_pool, 0, 4 * RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&g_queue_pool, 8 * RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_queue_pool, 0, 8 * RTGR_QUEUE_SLOTS * sizeof(unsigned long long)));
     }
     g_num_cu = p.multiProcessorCount;
     g_device = dev;

@@ -87,7 +87,9 @@ struct IntegrateArgs {
     uint32_t* meta;         // n x 3: accepted, rejected, status | interior << 8
     int recw;               // REC_W or REC_W_STATE
     R* hand;                // n x HAND_W: rays handed from the FAR pass to the NEAR pass
-    unsigned long long* ctrl;  // [0] ray queue head of the FULL / FAR pass, [2] queue head of the NEAR pass
+    unsigned long long* ctrl;  // [0] ray queue head of the FULL / FAR pass, [1] queue head of the NEAR pass (per round)
+    uint32_t pick_flag;     // passes that resume rays (NEAR, FAR of round >= 1): meta flag of the rays to pick up; 0 = camera rays
+    uint32_t allow_handback;  // NEAR: hand a ray back to the next round's FAR pass once it has left every object's reach
     uint32_t queue_chunk;   // ray ids popped per atomic: <= RTGR_QUEUE_CHUNK, smaller when a wave gets few rays in total
     unsigned long long* counters;
 };
@@ -100,7 +102,8 @@ struct IntegrateArgs {
 // where it provably finds nothing); rays spend >90 % of their steps in the FAR pass, which is ~30 % cheaper per step.
 enum IntegrateMode : int { MODE_FULL = 0, MODE_FAR = 1, MODE_NEAR = 2 };
 constexpr int HAND_W = 16;  // x[4] u[4] k0[4] t dt ps lq
-constexpr uint32_t META_HANDED = 0xffff0000u;  // meta[3*idx+2] of a ray waiting for the NEAR pass
+constexpr uint32_t META_HANDED = 0xffff0000u;    // meta[3*idx+2] of a ray waiting for a NEAR pass
+constexpr uint32_t META_HANDBACK = 0xffff0001u;  // … of a ray a NEAR pass handed back to the next round's FAR pass
 #ifndef RTGR_QUEUE_CHUNK
 #define RTGR_QUEUE_CHUNK 256ull
 #endif
@@ -161,7 +164,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
     using N = Tsit5N<R>;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t total = A.n;  // NEAR visits every ray id too and picks up the ones flagged META_HANDED
-    unsigned long long* const queue = (MODE == MODE_NEAR) ? A.ctrl + 2 : A.ctrl;
+    unsigned long long* const queue = (MODE == MODE_NEAR) ? A.ctrl + 1 : A.ctrl;
     const R M = A.sc.M, aspin = A.sc.a;
     const R reltol = A.opt.reltol, abstol = A.opt.abstol;
     const R t0 = A.opt.lambda0, t1 = A.opt.lambda1, dtmax = A.opt.lambda1 - A.opt.lambda0;
@@ -177,7 +180,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
     R t = t0, dt = R(0), ps = R(0);
     float lq = lq_init;
     uint64_t idx = 0;
-    uint32_t nacc = 0, nrej = 0, nacc0 = 0, c_maxnear = 0;
+    uint32_t nacc = 0, nrej = 0, nacc0 = 0, c_maxnear = 0, safe_streak = 0;
     uint32_t c_rays = 0, c_acc = 0, c_rej = 0, c_ev = 0, c_int = 0, c_nf = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -210,9 +213,9 @@ void integrate_kernel(const IntegrateArgs<R> A) {
             const uint32_t rank = mask_rank(m_need, lane);
             if (state == L_FREE && rank < avail) {
                 const uint64_t w = q_next + rank;
-                if constexpr (MODE == MODE_NEAR) {
-                    // every ray id is visited; only rays the FAR pass handed over are picked up
-                    if (A.meta[w * 3 + 2] == META_HANDED) {
+                if (MODE == MODE_NEAR || A.pick_flag != 0u) {
+                    // a resuming pass visits every ray id and picks up the rays flagged for it
+                    if (A.meta[w * 3 + 2] == A.pick_flag) {
                         idx = w;
                         const R* hd = A.hand + w * HAND_W;
 #pragma unroll
@@ -220,6 +223,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                         t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
                         nacc = A.meta[w * 3]; nrej = A.meta[w * 3 + 1];
                         nacc0 = nacc;
+                        safe_streak = 0;
                         state = L_RUN;
                     }
                 } else {
@@ -371,7 +375,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                 }
                 const float EEst = __builtin_sqrtf(acc * 0.125f);
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
-                bool is_event = false, is_interior = false, commit = false, handed = false;
+                bool is_event = false, is_interior = false, commit = false, handed = false, hand_back = false;
                 R top = R(0);
                 R cc[4][4];  // position polynomial of this step (set when the step is accepted; read only on events)
                 if (EEst != EEst) {
@@ -420,7 +424,10 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                                 }
                             }
                             if constexpr (MODE == MODE_FAR) hand_over = !safe || (ps == R(0));
-                            else need_scan = !safe || (ps == R(0));
+                            else {
+                                need_scan = !safe || (ps == R(0));
+                                safe_streak = need_scan ? 0u : safe_streak + 1u;
+                            }
                         }
                         // NEAR pass: a ray stays here until it ends, also after it has left every object's reach; its
                         // wave then runs with few lanes (the longest stays are 150-370 steps), so the scan is skipped
@@ -529,6 +536,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                             if (!(t < t1)) done = RTGR_RAY_LAMBDA1;
                             else if (nacc + nrej >= A.opt.max_steps) done = RTGR_RAY_MAXSTEPS;
                             else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
+                            else if (MODE == MODE_NEAR && A.allow_handback && safe_streak >= 2u) hand_back = true;
                         }
                     } else {
                         nrej++;
@@ -575,6 +583,17 @@ void integrate_kernel(const IntegrateArgs<R> A) {
                     for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k[0][q] = k[6][q]; }
                 }
                 if (handed) state = L_FREE;
+                if (hand_back) {
+                    // NEAR -> next round's FAR pass: the ray has been out of every object's reach for two steps; its
+                    // committed state goes back into the hand-over record and the cheaper pass carries it on
+                    R* hd = A.hand + idx * HAND_W;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k[0][q]; }
+                    hd[12] = t; hd[13] = dt; hd[14] = ps; hd[15] = (R)lq;
+                    A.meta[idx * 3] = nacc; A.meta[idx * 3 + 1] = nrej; A.meta[idx * 3 + 2] = META_HANDBACK;
+                    if (MODE == MODE_NEAR) c_maxnear = c_maxnear > (nacc - nacc0) ? c_maxnear : (nacc - nacc0);
+                    state = L_FREE;
+                }
                 if (done != 0xffu) {
                     if (!is_event) {
                         // ended without an event (λ1, step cap, dt underflow, NaN): the state as it stands, θ = 0
@@ -627,7 +646,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
 // of a captured HIP graph were observed not to re-run on later replays (ROCm 7.0 runtime bundled with PyTorch), which
 // left stale queue heads / histograms and sent the scatter out of bounds; kernel nodes replay reliably.
 __global__ __launch_bounds__(256) void reset_kernel(unsigned long long* ctrl, uint32_t* hist512) {
-    if (threadIdx.x < 4) ctrl[threadIdx.x] = 0ull;
+    if (threadIdx.x < 8) ctrl[threadIdx.x] = 0ull;
     if (hist512) { hist512[threadIdx.x] = 0u; hist512[256 + threadIdx.x] = 0u; }
 }
 

@@ -485,3 +485,18 @@ def test_strided_rows_equal_the_rows_of_the_full_frame(lib):
         assert torch.equal(sharded.assemble_rows(parts, ni, nj, ws, "cyclic"), full)
     bad = lib.rtgr_trace_rows_device_f64(C.byref(sc), C.byref(opt), C.byref(cam), ni, nj, 3, 8, 7, full.data_ptr(), None, None, None)
     assert bad == abi.ERR_BAD_ARG   # 3 + 6*8 = 51 >= nj
+
+
+def test_hand_back_rounds_do_not_change_results(lib):
+    """RTGR_ROUNDS=2 (NEAR hands rays that left every object's reach back to a second FAR/NEAR round): an evaluated
+    schedule variant; like every schedule change it must not change a single bit."""
+    sc, cam = scene_variant("ks_true08")
+    opt = rt.solver_defaults()
+    a = hip_trace(lib, sc, opt, 96, 80, cam=cam)
+    os.environ["RTGR_ROUNDS"] = "2"
+    try:
+        b = hip_trace(lib, sc, opt, 96, 80, cam=cam)
+    finally:
+        del os.environ["RTGR_ROUNDS"]
+    for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+        assert np.array_equal(a[k], b[k]), k
