@@ -666,15 +666,24 @@ __global__ __launch_bounds__(256) void order_key_kernel(const R* state0, uint64_
     lh[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t b = 0xffffffffu;
     if (w < n) {
         const R* s = state0 + w * 8;
         const R x = s[1], y = s[2], z = s[3], ux = s[5], uy = s[6], uz = s[7];
         const R xx = x * x + y * y + z * z, uu = ux * ux + uy * uy + uz * uz, xu = x * ux + y * uy + z * uz;
         float sin2 = 1.0f;
         if (xu < R(0) && xx > R(0) && uu > R(0)) sin2 = fmaxf(0.0f, 1.0f - (float)(xu * xu / (xx * uu)));
-        const uint32_t b = (uint32_t)fminf(255.0f, 256.0f * __builtin_sqrtf(sin2));  // moving away -> last bucket
+        b = (uint32_t)fminf(255.0f, 256.0f * __builtin_sqrtf(sin2));  // moving away -> last bucket
         keys[w] = (uint8_t)b;
-        atomicAdd(&lh[b], 1u);
+    }
+    // neighbouring rays share a handful of buckets: one LDS atomic per distinct bucket per wave, not one per ray
+    unsigned long long todo = __ballot(w < n);
+    while (todo != 0ull) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t b0 = __shfl(b, (int)leader, 64);
+        const unsigned long long m = __ballot(w < n && b == b0);
+        if ((threadIdx.x & 63) == leader) atomicAdd(&lh[b0], (uint32_t)__builtin_popcountll(m));
+        todo &= ~m;
     }
     __syncthreads();
     if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
@@ -699,9 +708,20 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* keys,
     __syncthreads();
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = w < n;
-    const uint32_t b = valid ? keys[w] : 0u;
+    const uint32_t b = valid ? keys[w] : 0xffffffffu;
+    const uint32_t lane = threadIdx.x & 63;
     uint32_t r = 0;
-    if (valid) r = atomicAdd(&lcount[b], 1u);
+    unsigned long long todo = __ballot(valid);
+    while (todo != 0ull) {  // one LDS atomic per distinct bucket per wave; lanes rank themselves inside the ballot mask
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t b0 = __shfl(b, (int)leader, 64);
+        const unsigned long long m = __ballot(valid && b == b0);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&lcount[b0], (uint32_t)__builtin_popcountll(m));
+        base = __shfl(base, (int)leader, 64);
+        if (valid && b == b0) r = base + mask_rank(m, lane);
+        todo &= ~m;
+    }
     __syncthreads();
     if (lcount[threadIdx.x]) gbase[threadIdx.x] = atomicAdd(&offsets[threadIdx.x], lcount[threadIdx.x]);
     __syncthreads();
