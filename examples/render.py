@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Drop-in demo: the reference's example1() / example2() (src/RayTraceGR.jl:542-612) through the HIP library.
+
+    python examples/render.py 2 [ni nj]     # writes scenes/sphere2.png (example2: black hole), default 200 x 200
+    python examples/render.py 1             # writes scenes/sphere.png  (example1: flat space)
+
+The code below is what a user of RayTraceGR.jl writes, with `RayTraceGR.` replaced by the host mirror `rt.`.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+
+rt = load_package()
+
+
+def main():
+    which = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    ni = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    nj = int(sys.argv[3]) if len(sys.argv) > 3 else ni
+    metric = rt.minkowski if which == 1 else rt.kerr_schild
+    caelum = rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10)                       # background sky, inside-out
+    frustum = rt.Plane(-20)                                                    # cut-off plane in the past
+    sphere = rt.Sphere((0, 0 if which == 1 else 4, 0, 0), (1, 0, 0, 0), 0.5)   # the visible sphere
+    objs = [caelum, frustum, sphere]
+    pos = (0, 0 if which == 1 else 4, -2, 0)
+    canvas = rt.make_canvas(metric, pos, (0, 1, 0, 0), (0, 0, 0, 1), (0, 0, 1, 0), ni, nj)
+    canvas, info = rt.trace_rays(metric, objs, canvas, return_info=True)
+    from raytracegr_jl_amd.png import write_png
+    os.makedirs(rt.api.outdir, exist_ok=True)
+    file = os.path.join(rt.api.outdir, "sphere.png" if which == 1 else "sphere2.png")
+    write_png(file, canvas.image_u8())
+    print(f'Output file is "{file}"  ({info["rays"]} rays, {info["accepted"] + info["rejected"]} RK step attempts)')
+
+
+if __name__ == "__main__":
+    main()

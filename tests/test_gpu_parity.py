@@ -500,3 +500,15 @@ def test_hand_back_rounds_do_not_change_results(lib):
         del os.environ["RTGR_ROUNDS"]
     for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_example_script_writes_the_golden_png(lib, tmp_path, monkeypatch):
+    """examples/render.py 2 — the user-level program — writes a PNG whose pixels equal the reference's sphere2.png."""
+    import runpy
+    import sys
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(sys, "argv", ["render.py", "2"])
+    runpy.run_path(os.path.join(ROOT, "examples", "render.py"), run_name="__main__")
+    from raytracegr_jl_amd.png import read_png
+    img = read_png(str(tmp_path / "scenes" / "sphere2.png"))
+    assert int((img != _golden("sphere2.png")).any(axis=2).sum()) == 0
