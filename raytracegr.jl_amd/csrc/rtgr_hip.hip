@@ -387,10 +387,10 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         IntegrateArgs<R> IA;
         IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.order = use_order ? order : nullptr; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
         IA.hand = hand; IA.ctrl = q; IA.counters = A.counters; IA.pick_flag = 0; IA.allow_handback = 0;
-        {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [16, RTGR_QUEUE_CHUNK]
+        {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [8, RTGR_QUEUE_CHUNK]
             const uint64_t per_wave = m / ((uint64_t)g_num_cu * 12 + 1);
             uint64_t qc = per_wave / 16;
-            qc = qc < 16 ? 16 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
+            qc = qc < 8 ? 8 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
             IA.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK", (int)qc);
         }
         launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);

@@ -194,6 +194,7 @@ void integrate_kernel(const IntegrateArgs<R> A) {
     // stalled the FAR pass 5x — so waves pop up to RTGR_QUEUE_CHUNK ids at a time; fewer when the whole job is only a few
     // hundred rays per wave, or the last chunks would unbalance the waves.)
     uint64_t q_next = 0, q_end = 0;
+    bool first_pop = true;
     const unsigned long long qchunk = A.queue_chunk;
     for (;;) {
         // ================= refill: free lanes take ray ids from the wave's slice of the queue ====================
@@ -201,12 +202,17 @@ void integrate_kernel(const IntegrateArgs<R> A) {
         while (m_need != 0ull) {
             if (q_next == q_end) {
                 if (exhausted) break;
+                // The FIRST pop takes exactly the ids the wave can start right away: in longest-first order the head of
+                // the queue holds the long rays, and ids parked in a wave's slice would only start when one of its
+                // (equally long) first rays ends — simulated makespan 1978 vs 1213 steps at 5 rays per lane.
+                const unsigned long long amount = first_pop ? (unsigned long long)__builtin_popcountll(m_need) : qchunk;
+                first_pop = false;
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(queue, qchunk);
+                if (lane == 0) base = atomicAdd(queue, amount);
                 base = __shfl(base, 0, 64);
                 q_next = base < total ? base : total;
-                q_end = (base + qchunk) < total ? (base + qchunk) : total;
-                if (base + qchunk >= total) exhausted = true;
+                q_end = (base + amount) < total ? (base + amount) : total;
+                if (base + amount >= total) exhausted = true;
                 if (q_next == q_end) break;
             }
             const uint64_t avail = q_end - q_next;
