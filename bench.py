@@ -216,7 +216,7 @@ def main():
                 "hbm_algorithmic_GBps": (my_rays * (64 + 2 * 140 + 204 + 25)) / k_avg_s / 1e9}
         roof["traffic"] = load_traffic(a)
         name = C_name(lib)
-        cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if a.cpu_sample != 0 else None
+        cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and ws == 1) else None  # N=1 only
         line = {
             "metric": "geodesic RK step attempts/s (Tsit5, 6 RHS each), Kerr-Schild screen, whole job",
             "value": attempts / dt, "unit": "RK step attempts/s", "n_gpus": ws, "steps": a.steps,
