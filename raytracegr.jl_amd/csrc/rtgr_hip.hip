@@ -312,7 +312,8 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
         // hands rays that have left every object's reach back, and a second FAR + NEAR round carries them on — the
         // extra passes' own start-up and tails cost more than the NEAR tail they remove.  Each pass has its own queue
         // head (ctrl[0..7]).
-        const int rounds = env_int("RTGR_ROUNDS", 1);
+        int rounds = env_int("RTGR_ROUNDS", 1);
+        rounds = rounds < 1 ? 1 : (rounds > 4 ? 4 : rounds);  // 2 queue heads per round, 8 per launch
         IntegrateArgs<R> P = IA;
         for (int r = 0; r < rounds; r++) {
             P.ctrl = IA.ctrl + 2 * r;
