@@ -41,9 +41,10 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="CPU baseline renders a sample x sample screen; -1 = auto (~15 s of CPU work), 0 = off")
-    ap.add_argument("--rhs", default="closed", choices=["closed", "generic"],
+    ap.add_argument("--rhs", default="closed", choices=["closed", "generic", "user"],
                     help="closed = Kerr-Schild-form contraction (production); generic = reference-style dual-number RHS "
-                         "(RTGR_METRIC_GENERIC): its executed flops equal the algorithmic count of the roofline model")
+                         "(RTGR_METRIC_GENERIC): its executed flops equal the algorithmic count of the roofline model; "
+                         "user = the same metric typed as run-time compiled source (api.UserMetric; ks_true* variants)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--layout", default="cyclic", choices=["cyclic", "slab"], help="row distribution over ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -62,6 +63,12 @@ def build_scene(rt, variant, generic=False):
                   "ks_true0998": rt.KerrSchild(1, 0.998), "ks_true0998_disk": rt.KerrSchild(1, 0.998)}[variant]
         if variant == "ks_true0998_disk":  # BASELINE config 5: thin accretion disk instead of the small sphere
             objs = objs[:2] + [rt.Disk(0.05, 2.0, 4.0)]  # camera (cylindrical radius 4.5) stays outside the disk
+    if generic == "user":
+        assert variant.startswith("ks_true"), "--rhs user: the example source is the textbook Kerr-Schild metric"
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import user_metrics
+        metric = rt.UserMetric(user_metrics.KERR_SCHILD, M=metric.M, a=metric.a)
+        generic = False
     sc = rt.make_scene(metric, objs)
     if generic and variant != "mink":
         sc.metric |= rt._abi.METRIC_GENERIC
@@ -120,7 +127,7 @@ def main():
     rt._abi.check(lib, lib.rtgr_init(local))
 
     npdt = np.float64 if a.dtype == "f64" else np.float32
-    scene, cam = build_scene(rt, a.variant, a.rhs == "generic")
+    scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user"}[a.rhs])
     opt = rt.solver_defaults(npdt)
     ni = nj = a.size
     # rows are dealt cyclically (rank r: rows r, r+N, …): contiguous slabs of a black-hole image are unbalanced

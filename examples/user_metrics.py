@@ -1,0 +1,41 @@
+"""User-metric sources (api.UserMetric): metrics written the way a user of the reference would write a new Julia
+metric function next to `kerr_schild` (src/RayTraceGR.jl:274-294), as C++ templates over the scalar type."""
+
+# textbook Kerr–Schild, the same function as the built-in KerrSchild(M, a, textbook=True): η + f k⊗k
+KERR_SCHILD = r'''
+template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) {
+    const S X = x[1], Y = x[2], Z = x[3];
+    const double a2 = a * a;
+    const S rho2 = X * X + Y * Y + Z * Z;
+    const S q = rho2 - a2;
+    const S r2 = 0.5 * (q + msqrt(q * q + (4.0 * a2) * (Z * Z)));
+    const S r = msqrt(r2);
+    const S f = ((2.0 * M) * (r2 * r)) / (r2 * r2 + a2 * (Z * Z));
+    const S den = r2 + a2;
+    S k[4];
+    k[0] = mconst<S>(1.0);
+    k[1] = (r * X + a * Y) / den;
+    k[2] = (r * Y - a * X) / den;
+    k[3] = Z / r;
+    for (int p = 0; p < 4; p++)
+        for (int c = 0; c < 4; c++) {
+            g[p][c] = f * k[p] * k[c];
+            if (p == c) g[p][c] = g[p][c] + (p == 0 ? -1.0 : 1.0);
+        }
+}
+'''
+
+# Schwarzschild in isotropic coordinates — NOT of Kerr–Schild form, so no built-in covers it:
+#   ds² = −((1−m)/(1+m))² dt² + (1+m)⁴ (dx²+dy²+dz²),  m = M / (2ρ)
+SCHWARZSCHILD_ISOTROPIC = r'''
+template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) {
+    const S rho = msqrt(x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    const S m = (0.5 * M) / rho;
+    const S lapse = (1.0 - m) / (1.0 + m);
+    const S psi2 = (1.0 + m) * (1.0 + m);
+    for (int p = 0; p < 4; p++)
+        for (int c = 0; c < 4; c++) g[p][c] = mconst<S>(0.0);
+    g[0][0] = -(lapse * lapse);
+    g[1][1] = g[2][2] = g[3][3] = psi2 * psi2;
+}
+'''

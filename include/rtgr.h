@@ -52,8 +52,10 @@ enum rtgr_metric {
     RTGR_MINKOWSKI = 0, /* minkowski(x)                                           src/RayTraceGR.jl:262-264   */
     RTGR_KS_REF = 1,    /* kerr_schild(x) exactly AS WRITTEN, r = sqrt(rho^2-a^2)/2 + sqrt(a^2 z^2+((rho^2-a^2)/2)^2)
                            (src/RayTraceGR.jl:284); the reference hard-wires M=1, a=0 (:275-276)               */
-    RTGR_KS_TRUE = 2    /* textbook Kerr–Schild radius r^2 = (q + sqrt(q^2 + 4 a^2 z^2))/2, q = rho^2 - a^2
+    RTGR_KS_TRUE = 2,   /* textbook Kerr–Schild radius r^2 = (q + sqrt(q^2 + 4 a^2 z^2))/2, q = rho^2 - a^2
                            (no reference counterpart; needed for a != 0 configs)                               */
+    RTGR_USER = 3       /* the metric function loaded with rtgr_user_metric_load(); always traced with the
+                           generic dual-number RHS (RTGR_METRIC_GENERIC is implied), Float64 only              */
 };
 
 /* OR-ed into rtgr_scene.metric: evaluate the geodesic RHS the way the reference does for ANY metric callable — 4-wide
@@ -227,6 +229,22 @@ int rtgr_eval_metric_f64(const rtgr_scene* scene, const double* x /* n x 4 */, u
  * path = 0: production path (Kerr–Schild-form closed contraction), 1: generic dual-number path. */
 int rtgr_eval_geodesic_f64(const rtgr_scene* scene, const double* s /* n x 8 */, uint64_t n, int path,
                            double* ds /* n x 8 */);
+
+/* ---- user metrics: "metric is ANY callable x -> g" (src/RayTraceGR.jl:302-309, :358-370, :457-511) ------------
+ * The reference accepts any Julia function as the metric and differentiates it with forward duals.  The native
+ * counterpart: the caller writes the metric once as a C++ function template over the scalar type
+ *     template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]);
+ * (S = double for make_canvas' normalisation, S = 4-wide forward dual for dmetric), pastes it into
+ * raytracegr.jl_amd/csrc/rtgr_user_unit.hip.in, compiles that unit with
+ *     hipcc --genco --no-gpu-bundle-output --offload-arch=gfx950 -O3 -std=c++17 -I<csrc> unit.hip -o metric.hsaco
+ * and hands the code object to the library.  From then on rtgr_scene.metric = RTGR_USER selects it in every entry
+ * point that takes a scene (trace, make_canvas, eval_metric, eval_geodesic path 1); M and a of the scene are passed
+ * through to the function.  One user metric is resident at a time; loading another replaces it (the library
+ * synchronises the device first).  The Python mirror automates the three steps (api.UserMetric). */
+int rtgr_user_metric_load(const char* code_object_path);
+int rtgr_user_metric_unload(void);
+/* 1 if a user metric is resident, else 0 */
+int rtgr_user_metric_loaded(void);
 
 /* ---- image output: N0f8 quantisation + transposed PNG layout of `save(file, colorview(...))` (:566-575) ---- */
 /* rgb planes (n = ni*nj, device pointer) -> 8-bit interleaved image[j][i][c] (device pointer, 3*n bytes). */

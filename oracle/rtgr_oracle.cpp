@@ -180,10 +180,33 @@ inline void kerr_schild(const S xx[D], T M, T a, int variant, S g[D][D]) {
         for (int q = 0; q < D; q++) g[p][q] = e[p][q] + f * k[p] * k[q];            // g = η + f k k         :291
 }
 
+// Stand-in for "a metric function the user wrote" (the reference takes any callable, :302-309): Schwarzschild in
+// isotropic coordinates, ds² = −((1−m)/(1+m))² dt² + (1+m)⁴ dx², m = M/(2ρ).  Not of Kerr–Schild form, so it can only go
+// through the generic dmetric → christoffel → geodesic chain.  No reference counterpart; the oracle evaluates it for
+// metric kind RTGR_USER so that the product's run-time compiled metrics (examples/user_metrics.py) have a checker.
+template <class T, class S>
+inline S cst(T v) {
+    if constexpr (std::is_same<S, T>::value) return v; else return mk<T>(v);
+}
+template <class T, class S>
+inline void schwarzschild_isotropic(const S xx[D], T M, S g[D][D]) {
+    S rho = sqrt(pow2(xx[1]) + pow2(xx[2]) + pow2(xx[3]));
+    S m = cst<T, S>(T(0.5) * M) / rho;
+    S one = cst<T, S>(T(1));
+    S lapse = (one - m) / (one + m);
+    S psi2 = pow2(one + m);
+    for (int p = 0; p < D; p++)
+        for (int q = 0; q < D; q++) g[p][q] = cst<T, S>(T(0));
+    g[0][0] = cst<T, S>(T(0)) - pow2(lapse);
+    g[1][1] = g[2][2] = g[3][3] = pow2(psi2);
+}
+
 template <class T, class S>
 inline void metric_eval(const rtgr_scene& sc, const S x[D], S g[D][D]) {
-    if (sc.metric == RTGR_MINKOWSKI) minkowski<T, S>(x, g);
-    else kerr_schild<T, S>(x, T(sc.M), T(sc.a), (int)sc.metric, g);
+    const uint32_t kind = sc.metric & ~RTGR_METRIC_GENERIC;  // the flag picks a product code path, not a metric
+    if (kind == RTGR_MINKOWSKI) minkowski<T, S>(x, g);
+    else if (kind == RTGR_USER) schwarzschild_isotropic<T, S>(x, T(sc.M), g);
+    else kerr_schild<T, S>(x, T(sc.M), T(sc.a), (int)kind, g);
 }
 
 // dmetric(metric, x): seed 4 duals with unit eps, one metric call, split        src/RayTraceGR.jl:302-313

@@ -11,7 +11,7 @@ RTGR_MAX_OBJECTS = 16
 RTGR_ABI_VERSION = 1
 
 # enum rtgr_metric
-MINKOWSKI, KS_REF, KS_TRUE = 0, 1, 2
+MINKOWSKI, KS_REF, KS_TRUE, USER = 0, 1, 2, 3
 METRIC_GENERIC = 0x100  # RTGR_METRIC_GENERIC flag
 # enum rtgr_object_kind
 PLANE, SPHERE, DISK = 1, 2, 3
@@ -61,6 +61,7 @@ EXPORTS = [
     "rtgr_device_info", "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read", "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_rows_device_f64", "rtgr_trace_rows_device_f32", "rtgr_trace_f64", "rtgr_trace_f32",
     "rtgr_trace_pixels_f64", "rtgr_trace_one_f64", "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64",
     "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", "rtgr_quantize_device_f64",
+    "rtgr_user_metric_load", "rtgr_user_metric_unload", "rtgr_user_metric_loaded",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -104,6 +105,9 @@ def _declare(lib):
     lib.rtgr_eval_metric_f64.argtypes = [P(rtgr_scene), vp, u64, vp, vp, vp]
     lib.rtgr_eval_geodesic_f64.argtypes = [P(rtgr_scene), vp, u64, i32, vp]
     lib.rtgr_quantize_device_f64.argtypes = [vp, u64, u64, vp, vp]
+    lib.rtgr_user_metric_load.argtypes = [C.c_char_p]
+    lib.rtgr_user_metric_unload.argtypes = []
+    lib.rtgr_user_metric_loaded.argtypes = []
     for name in EXPORTS:
         if name != "rtgr_last_error":
             getattr(lib, name).restype = i32

@@ -24,6 +24,7 @@ import numpy as np
 
 from . import _abi
 from ._abi import rtgr_camera, rtgr_counters, rtgr_ray_outputs, rtgr_scene, rtgr_solver
+from .user_metric import UserMetric
 
 D = 4  # src/RayTraceGR.jl:253-254
 
@@ -101,10 +102,12 @@ class Disk(Object):
 
 def make_scene(metric, objs):
     """(metric, objs::Vector{Object}) -> rtgr_scene (order of objs preserved: it matters, :518-530)."""
-    if not isinstance(metric, Metric):
+    if isinstance(metric, UserMetric):
+        metric.activate()  # the code object of THIS metric must be the resident one when the scene is used
+    elif not isinstance(metric, Metric):
         raise TypeError(
-            "only the built-in metrics (minkowski, kerr_schild, KerrSchild(M,a)) cross the C ABI; an arbitrary "
-            "metric callable has to stay on the reference's CPU path (SURVEY §8b)")
+            "a metric is one of the built-ins (minkowski, kerr_schild, KerrSchild(M,a)) or a UserMetric(source) "
+            "compiled for the device; a Python callable cannot cross the C ABI (SURVEY §8b)")
     objs = list(objs)
     if len(objs) > _abi.RTGR_MAX_OBJECTS:
         raise ValueError(f"at most {_abi.RTGR_MAX_OBJECTS} objects")
@@ -323,7 +326,7 @@ def example2(ni=200, nj=200, save=True):
     return _run_example(example2_scene(), ni, nj, "sphere2.png", save)
 
 
-__all__ = ["D", "Metric", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
+__all__ = ["D", "Metric", "UserMetric", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
            "make_scene", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
            "trace_rays", "trace_ray", "dmetric", "christoffel", "geodesic", "example1", "example2",
            "example1_scene", "example2_scene"]

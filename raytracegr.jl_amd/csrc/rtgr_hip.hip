@@ -180,10 +180,31 @@ __global__ __launch_bounds__(256) void pixels_out_kernel(const double* px_in, co
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
+// run-time loaded metric (rtgr_user_metric_load): the metric-dependent kernels of the pipeline, from a code object
+// built out of rtgr_user_unit.hip.in
+struct UserModule {
+    hipModule_t module = nullptr;
+    hipFunction_t far = nullptr, near = nullptr, full10 = nullptr, fulln = nullptr, canvas = nullptr,
+                  eval_metric = nullptr, eval_geodesic = nullptr;
+};
+static UserModule g_user;
+constexpr int RTGR_UM = RTGR_GENERIC_BASE + RTGR_USER;
+
+// hipModuleLaunchKernel with the arguments given as C++ values
+template <class... Args>
+static hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned block, hipStream_t st, Args... args) {
+    void* params[] = {(void*)&args...};
+    return hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, st, params, nullptr);
+}
+
 template <class R>
 static int convert_scene(const rtgr_scene* s, DevScene<R>& d) {
     if (!s) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
-    if ((s->metric & ~RTGR_METRIC_GENERIC) > RTGR_KS_TRUE) return fail(RTGR_ERR_BAD_ARG, "unknown metric enum");
+    if ((s->metric & ~RTGR_METRIC_GENERIC) > RTGR_USER) return fail(RTGR_ERR_BAD_ARG, "unknown metric enum");
+    if ((s->metric & ~RTGR_METRIC_GENERIC) == RTGR_USER) {
+        if (!g_user.module) return fail(RTGR_ERR_BAD_ARG, "RTGR_USER: no user metric loaded (rtgr_user_metric_load)");
+        if (sizeof(R) != 8) return fail(RTGR_ERR_BAD_ARG, "RTGR_USER metrics are compiled for Float64 only");
+    }
     if (s->nobj > RTGR_MAX_OBJECTS) return fail(RTGR_ERR_BAD_ARG, "too many objects");
     std::memset(&d, 0, sizeof d);
     d.metric = s->metric & ~RTGR_METRIC_GENERIC;
@@ -226,6 +247,8 @@ static void convert_camera(const rtgr_camera* c, DevCamera<R>& d) {
 
 static int bind_device(int dev);
 static int ensure_device() {
+    (void)hipGetLastError();  // every entry point starts here: drop a stale error left by an earlier (or foreign) call,
+                              // so that the hipGetLastError() after our launches reports our launches only
     if (g_device >= 0) return RTGR_OK;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -320,16 +343,19 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
             P.pick_flag = r == 0 ? 0u : META_HANDBACK;
             if (r > 0) P.order = nullptr;
             { KernelTimer tm(st, 1);
-              hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
-                                 grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, P); }
+              if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.far, grid(0).x, 64, st, P));
+              else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
+                                      grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, P); }
             P.pick_flag = META_HANDED;
             P.allow_handback = (r + 1 < rounds) ? 1u : 0u;
             { KernelTimer tm(st, 3);
-              hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, P); }
+              if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.near, grid(0).x, 64, st, P));
+              else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, P); }
         }
     } else {
         KernelTimer tm(st, 1);
-        if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
+        if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(npts10 ? g_user.full10 : g_user.fulln, grid(0).x, 64, st, IA));
+        else if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
         else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, false, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
     }
     return RTGR_OK;
@@ -372,8 +398,12 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         const R* s0 = A.state0 ? A.state0 + off * 8 : gen;
         if (with_canvas) {
             KernelTimer tm(st, 0);
-            hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
-                               A.nj, A.j0, A.jstride, off, m, gen);
+            if constexpr (METRIC == RTGR_UM)
+                HIP_TRY(launch_module(g_user.canvas, (unsigned)((m + 255) / 256), 256, st, A.sc, A.cam, A.ni, A.nj, A.j0,
+                                      A.jstride, off, m, gen));
+            else
+                hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
+                                   A.nj, A.j0, A.jstride, off, m, gen);
         }
         const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 &&
                                (order_mode != 0);
@@ -394,7 +424,8 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
             qc = qc < 8 ? 8 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
             IA.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK", (int)qc);
         }
-        launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
+        rc = launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
+        if (rc) return rc;
         ResolveArgs<R> RA;
         RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = off;
         RA.n_slab = n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
@@ -412,6 +443,9 @@ static int bind_device(int dev) {
     HIP_TRY(hipGetDeviceProperties(&p, dev));
     if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
         return fail(RTGR_ERR_NO_DEVICE, std::string("librtgr_hip is built for gfx950 only; device is ") + p.gcnArchName);
+    if (g_user.module && g_device != dev) {  // a code object is loaded into one device's context
+        (void)hipModuleUnload(g_user.module); g_user = UserModule{};
+    }
     if (g_queue_pool && g_device != dev) {
         (void)hipFree(g_queue_pool); g_queue_pool = nullptr;
         if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
@@ -427,6 +461,7 @@ static int bind_device(int dev) {
 
 // generic dual-number RHS (RTGR_METRIC_GENERIC): Float64, metric kind as a template value 100 + kind
 static int launch_generic(const TraceArgs<double>& A, hipStream_t st) {
+    if (A.sc.metric == RTGR_USER) return launch_trace<double, RTGR_UM, true>(A, st);
     if (A.sc.metric == RTGR_KS_REF) return launch_trace<double, RTGR_GENERIC_BASE + RTGR_KS_REF, true>(A, st);
     return launch_trace<double, RTGR_GENERIC_BASE + RTGR_KS_TRUE, true>(A, st);
 }
@@ -469,7 +504,7 @@ static int trace_device(const rtgr_scene* scene, const rtgr_solver* opt, const R
     A.counters = (unsigned long long*)d_counters;
     hipStream_t st = (hipStream_t)stream;
     const bool spin = scene->a != 0.0;
-    const bool generic = (scene->metric & RTGR_METRIC_GENERIC) != 0 && A.sc.metric != RTGR_MINKOWSKI;
+    const bool generic = ((scene->metric & RTGR_METRIC_GENERIC) != 0 && A.sc.metric != RTGR_MINKOWSKI) || A.sc.metric == RTGR_USER;
     if (generic) {
         if (sizeof(R) != 8) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC is compiled for Float64 only");
         if (use_tile_kernel()) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC needs the persistent pipeline");
@@ -571,6 +606,7 @@ int rtgr_init(int device) {
     return bind_device(dev);
 }
 int rtgr_shutdown(void) {
+    if (g_user.module) { (void)hipDeviceSynchronize(); (void)hipModuleUnload(g_user.module); g_user = UserModule{}; }
     if (g_queue_pool) { (void)hipFree(g_queue_pool); g_queue_pool = nullptr; }
     if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
     g_device = -1;
@@ -719,8 +755,12 @@ int rtgr_make_canvas_device_f64(const rtgr_scene* scene, const rtgr_camera* cam,
     DevCamera<double> c;
     convert_camera<double>(cam, c);
     const uint64_t n = ni * (j1 - j0);
-    hipLaunchKernelGGL(canvas_kernel<double>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, sc, c, ni, nj, j0,
-                       (uint64_t)1, (uint64_t)0, n, d_state0);
+    if (sc.metric == RTGR_USER)
+        HIP_TRY(launch_module(g_user.canvas, nblk(n), 256, (hipStream_t)stream, sc, c, ni, nj, j0, (uint64_t)1, (uint64_t)0,
+                              n, d_state0));
+    else
+        hipLaunchKernelGGL(canvas_kernel<double>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, sc, c, ni, nj, j0,
+                           (uint64_t)1, (uint64_t)0, n, d_state0);
     HIP_TRY(hipGetLastError());
     return RTGR_OK;
 }
@@ -754,8 +794,12 @@ int rtgr_eval_metric_f64(const rtgr_scene* scene, const double* x, uint64_t n, d
     if (g && (rc = bg.alloc(n * 128))) return rc;
     if (dg && (rc = bd.alloc(n * 512))) return rc;
     if (Gam && (rc = bG.alloc(n * 512))) return rc;
-    hipLaunchKernelGGL(eval_metric_kernel, dim3(nblk(n)), dim3(256), 0, nullptr, sc, (const double*)bx.p, n,
-                       (double*)bg.p, (double*)bd.p, (double*)bG.p);
+    if (sc.metric == RTGR_USER)
+        HIP_TRY(launch_module(g_user.eval_metric, nblk(n), 256, (hipStream_t) nullptr, sc, (const double*)bx.p, n,
+                              (double*)bg.p, (double*)bd.p, (double*)bG.p));
+    else
+        hipLaunchKernelGGL(eval_metric_kernel, dim3(nblk(n)), dim3(256), 0, nullptr, sc, (const double*)bx.p, n,
+                           (double*)bg.p, (double*)bd.p, (double*)bG.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (g) HIP_TRY(hipMemcpy(g, bg.p, n * 128, hipMemcpyDeviceToHost));
@@ -778,13 +822,61 @@ int rtgr_eval_geodesic_f64(const rtgr_scene* scene, const double* s, uint64_t n,
     if ((rc = bi.alloc(n * 64))) return rc;
     if ((rc = bo.alloc(n * 64))) return rc;
     HIP_TRY(hipMemcpy(bi.p, s, n * 64, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(eval_geodesic_kernel, dim3(nblk(n)), dim3(256), 0, nullptr, sc, (const double*)bi.p, n, path,
-                       (double*)bo.p);
+    if (sc.metric == RTGR_USER)  // a user metric has the generic path only
+        HIP_TRY(launch_module(g_user.eval_geodesic, nblk(n), 256, (hipStream_t) nullptr, sc, (const double*)bi.p, n,
+                              (double*)bo.p));
+    else
+        hipLaunchKernelGGL(eval_geodesic_kernel, dim3(nblk(n)), dim3(256), 0, nullptr, sc, (const double*)bi.p, n, path,
+                           (double*)bo.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(ds, bo.p, n * 64, hipMemcpyDeviceToHost));
     return RTGR_OK;
 }
+
+int rtgr_user_metric_unload(void) {
+    if (!g_user.module) return RTGR_OK;
+    HIP_TRY(hipDeviceSynchronize());  // kernels of the module may still be in flight
+    hipModule_t m = g_user.module;
+    g_user = UserModule{};
+    HIP_TRY(hipModuleUnload(m));
+    return RTGR_OK;
+}
+
+int rtgr_user_metric_load(const char* code_object_path) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
+    UserModule u;
+    hipError_t e = hipModuleLoad(&u.module, code_object_path);
+    if (e != hipSuccess)
+        return fail(RTGR_ERR_HIP, std::string("hipModuleLoad(") + code_object_path + "): " + hipGetErrorString(e));
+    auto bail = [&](const std::string& why) {
+        (void)hipModuleUnload(u.module);
+        return fail(RTGR_ERR_BAD_ARG, std::string(code_object_path) + ": " + why);
+    };
+    {   // the unit must have been built against this library's headers
+        hipDeviceptr_t dptr = nullptr;
+        size_t bytes = 0;
+        unsigned ver = 0;
+        if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_abi_version") != hipSuccess || bytes != sizeof ver)
+            return bail("not a user-metric code object (no rtgr_user_abi_version)");
+        if (hipMemcpyDtoH(&ver, dptr, sizeof ver) != hipSuccess) return bail("cannot read rtgr_user_abi_version");
+        if (ver != RTGR_ABI_VERSION) return bail("built against another ABI version");
+    }
+    struct { hipFunction_t* f; const char* name; } want[] = {
+        {&u.far, "rtgr_user_integrate_far"},       {&u.near, "rtgr_user_integrate_near"},
+        {&u.full10, "rtgr_user_integrate_full10"}, {&u.fulln, "rtgr_user_integrate_fulln"},
+        {&u.canvas, "rtgr_user_canvas"},           {&u.eval_metric, "rtgr_user_eval_metric"},
+        {&u.eval_geodesic, "rtgr_user_eval_geodesic"}};
+    for (auto& w : want)
+        if (hipModuleGetFunction(w.f, u.module, w.name) != hipSuccess) return bail(std::string("missing kernel ") + w.name);
+    if ((rc = rtgr_user_metric_unload())) { (void)hipModuleUnload(u.module); return rc; }
+    g_user = u;
+    return RTGR_OK;
+}
+
+int rtgr_user_metric_loaded(void) { return g_user.module ? 1 : 0; }
 
 int rtgr_quantize_device_f64(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, void* stream) {
     int rc = ensure_device();

@@ -327,6 +327,11 @@ RTGR_DEV void make_pixel(const DevScene<R>& sc, const DevCamera<R>& cam, uint64_
         n[c] = cam.normal[c] + dx * cam.widthx[c] + dy * cam.widthy[c];               // :468
     }
     R g[4][4];
+#ifdef RTGR_USER_METRIC
+    if (sc.metric == (uint32_t)RTGR_USER) {
+        if constexpr (sizeof(R) == 8) rtgr_user_metric<double>(x, sc.M, sc.a, g);   // metric(x) with plain scalars (:469)
+    } else
+#endif
     {   // metric(x) with plain scalars (:469); built-ins are η + f k k
         R f = R(0), kk[4] = {R(1), R(0), R(0), R(0)};
         if (sc.metric != RTGR_MINKOWSKI) {

@@ -157,10 +157,10 @@ RTGR_DEV void fold_distances(const DevObject<R>& o, const R (&pos)[P][4], R (&dm
 // ---------------------------------------------------------------------------------------------------------------------
 // integrate kernel
 // ---------------------------------------------------------------------------------------------------------------------
+// The kernel body is a device function so that run-time generated units (user metrics, rtgr_user_template.hip) can
+// wrap it in extern "C" kernels of their own.
 template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE>
-__global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? RTGR_WAVES_PER_SIMD_GENERIC
-                                 : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4) : RTGR_WAVES_PER_SIMD))
-void integrate_kernel(const IntegrateArgs<R> A) {
+RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     using N = Tsit5N<R>;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t total = A.n;  // NEAR visits every ray id too and picks up the ones flagged META_HANDED
@@ -646,6 +646,13 @@ void integrate_kernel(const IntegrateArgs<R> A) {
             if (lane == 0) atomicMax(&A.counters[7], mx);
         }
     }
+}
+
+template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE>
+__global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? RTGR_WAVES_PER_SIMD_GENERIC
+                                 : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4) : RTGR_WAVES_PER_SIMD))
+void integrate_kernel(const IntegrateArgs<R> A) {
+    integrate_body<R, METRIC, SPIN, NPTS10, MODE>(A);
 }
 
 // Per-launch reset of the queue heads and of the ordering histogram.  A kernel rather than hipMemsetAsync: memset nodes

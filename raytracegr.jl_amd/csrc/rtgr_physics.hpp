@@ -383,9 +383,48 @@ template <class R> RTGR_DEV DDual<R> operator/(const DDual<R>& x, const DDual<R>
 template <class R> RTGR_DEV DDual<R> dsqrt(const DDual<R>& x) {
     DDual<R> r; r.v = rsqrt_(x.v); const R c = R(0.5) / r.v; for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
 
+// ---- user metrics (RTGR_USER): "the metric is any callable" of the reference (src/RayTraceGR.jl:302-309) -------------
+// A translation unit that defines RTGR_USER_METRIC supplies
+//     template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]);
+// written with + - * / and the m* helpers below, so that it runs on plain scalars AND on forward duals — exactly the
+// contract the reference puts on a metric function.  Such units are generated, compiled with hipcc --genco and loaded
+// at run time (rtgr_user_metric_load, api.UserMetric); see rtgr_user_template.hip.
+template <class R> RTGR_DEV DDual<R> msqrt(const DDual<R>& x) { return dsqrt(x); }
+RTGR_DEV double msqrt(double x) { return __builtin_sqrt(x); }
+template <class R> RTGR_DEV DDual<R> mexp(const DDual<R>& x) {
+    DDual<R> r; r.v = exp(x.v); for (int i = 0; i < 4; i++) r.e[i] = r.v * x.e[i]; return r; }
+RTGR_DEV double mexp(double x) { return exp(x); }
+template <class R> RTGR_DEV DDual<R> mlog(const DDual<R>& x) {
+    DDual<R> r; r.v = log(x.v); const R c = R(1) / x.v; for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+RTGR_DEV double mlog(double x) { return log(x); }
+template <class R> RTGR_DEV DDual<R> msin(const DDual<R>& x) {
+    DDual<R> r; r.v = sin(x.v); const R c = cos(x.v); for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+RTGR_DEV double msin(double x) { return sin(x); }
+template <class R> RTGR_DEV DDual<R> mcos(const DDual<R>& x) {
+    DDual<R> r; r.v = cos(x.v); const R c = -sin(x.v); for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+RTGR_DEV double mcos(double x) { return cos(x); }
+template <class S> RTGR_DEV S mconst(double c);                       // a constant of the scalar type S
+template <> RTGR_DEV double mconst<double>(double c) { return c; }
+template <> RTGR_DEV DDual<double> mconst<DDual<double>>(double c) { return dconst<double>(c); }
+template <class R> RTGR_DEV DDual<R> operator-(const DDual<R>& x) {
+    DDual<R> r; r.v = -x.v; for (int i = 0; i < 4; i++) r.e[i] = -x.e[i]; return r; }
+template <class R> RTGR_DEV DDual<R> operator+(R a, const DDual<R>& x) { return x + a; }
+template <class R> RTGR_DEV DDual<R> operator-(R a, const DDual<R>& x) { return (-x) + a; }
+template <class R> RTGR_DEV DDual<R> operator/(const DDual<R>& x, R a) { return (R(1) / a) * x; }
+template <class R> RTGR_DEV DDual<R> operator/(R a, const DDual<R>& x) { return dconst<R>(a) / x; }
+#ifdef RTGR_USER_METRIC
+template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]);
+#endif
+
 // metric(x::SVector{4,Dual}) for the built-ins; symmetric result gd[a][b], a<=b filled for all (a,b)
 template <class R>
 RTGR_DEV void metric_dual(uint32_t metric, R M, R a, const DDual<R> xx[4], DDual<R> g[4][4]) {
+#ifdef RTGR_USER_METRIC
+    if (metric == (uint32_t)RTGR_USER) {
+        if constexpr (sizeof(R) == 8) rtgr_user_metric<DDual<double>>(xx, M, a, g);
+        return;
+    }
+#endif
     for (int p = 0; p < 4; p++)
         for (int q = 0; q < 4; q++) g[p][q] = dconst<R>(p == q ? (p == 0 ? R(-1) : R(1)) : R(0));   // η  :263,:282
     if (metric == RTGR_MINKOWSKI) return;
@@ -444,7 +483,10 @@ RTGR_DEV void inv4sym(const R m[4][4], R o[4][4]) {  // cofactor inverse (Static
 }
 
 // dmetric (src/RayTraceGR.jl:302-313): g[a][b], dg[a][b][c] = ∂_c g_ab
-template <class R>
+// UPPER: read only the upper triangle of what the metric function returned (a metric is symmetric; the reference
+// asserts it, :307).  The integrate kernels use it so that a user function that fills all 16 entries pays for 10;
+// rtgr_eval_metric_f64 reports the function's output as is, which is where an asymmetric user metric shows.
+template <class R, bool UPPER = false>
 RTGR_DEV void dmetric_dev(uint32_t metric, R M, R a, const R x[4], R g[4][4], R dg[4][4][4]) {
     DDual<R> xdx[4], gd[4][4];
     for (int p = 0; p < 4; p++) {
@@ -454,8 +496,9 @@ RTGR_DEV void dmetric_dev(uint32_t metric, R M, R a, const R x[4], R g[4][4], R 
     metric_dual<R>(metric, M, a, xdx, gd);
     for (int p = 0; p < 4; p++)
         for (int q = 0; q < 4; q++) {
-            g[p][q] = gd[p][q].v;
-            for (int c = 0; c < 4; c++) dg[p][q][c] = gd[p][q].e[c];
+            const DDual<R>& e = (UPPER && q < p) ? gd[q][p] : gd[p][q];
+            g[p][q] = e.v;
+            for (int c = 0; c < 4; c++) dg[p][q][c] = e.e[c];
         }
 }
 
@@ -463,7 +506,7 @@ RTGR_DEV void dmetric_dev(uint32_t metric, R M, R a, const R x[4], R g[4][4], R 
 template <class R>
 RTGR_DEV void generic_rhs(uint32_t metric, R M, R a, const R s[8], R ds[8]) {
     R g[4][4], dg[4][4][4], gu[4][4];
-    dmetric_dev<R>(metric, M, a, s, g, dg);
+    dmetric_dev<R, true>(metric, M, a, s, g, dg);
     inv4sym<R>(g, gu);
     const R* u = s + 4;
     R L[4];

@@ -1,0 +1,105 @@
+"""Run-time compiled metrics: the host side of rtgr_user_metric_load (include/rtgr.h).
+
+The reference takes the metric as ANY Julia callable `x -> SMatrix{4,4}` and lets the compiler specialise dmetric /
+geodesic / solve on it (src/RayTraceGR.jl:302-309, :358-370, :457-511).  The MI355X counterpart keeps that freedom
+without a tracing compiler: the metric is written once as a C++ function template over the scalar type, pasted into
+csrc/rtgr_user_unit.hip.in, compiled for gfx950 with `hipcc --genco`, and the code object — canvas, FAR / NEAR / FULL
+integrate passes and the evaluation hooks specialised on that metric — is loaded into the running library.
+
+    m = UserMetric('''
+        template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) {
+            ...fill all 16 entries of the symmetric g...
+        }''', M=1.0)
+    trace_rays(m, objs, canvas)        # every entry point that takes a metric accepts it
+
+Code objects are cached by content hash (source + the headers they were built from) under
+raytracegr.jl_amd/build/user/ (override: RTGR_USER_CACHE), so a metric is compiled once.
+"""
+import hashlib
+import os
+import subprocess
+
+from . import _abi
+from . import build as _build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+TEMPLATE = os.path.join(CSRC, "rtgr_user_unit.hip.in")
+_HEADERS = [os.path.join(CSRC, f) for f in ("rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp",
+                                            "rtgr_tsit5_tables.hpp")] + [os.path.join(HERE, "..", "include", "rtgr.h")]
+FLAGS = ["--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function"]
+_loaded_path = None  # code object currently resident in the library
+
+
+def cache_dir():
+    d = os.environ.get("RTGR_USER_CACHE") or os.path.join(HERE, "build", "user")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _digest(source):
+    h = hashlib.sha256()
+    h.update(source.encode())
+    for f in [TEMPLATE] + _HEADERS:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:20]
+
+
+def compile_user_metric(source, verbose=False):
+    """Build (or fetch from the cache) the code object of a user metric; returns its path.  Needs hipcc, no GPU."""
+    if "rtgr_user_metric" not in source:
+        raise ValueError("the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
+                         "double M, double a, S g[4][4])`")
+    d = cache_dir()
+    tag = _digest(source)
+    out = os.path.join(d, f"metric_{tag}.hsaco")
+    if os.path.exists(out):
+        return out
+    with open(TEMPLATE) as fh:
+        unit = fh.read().replace("@RTGR_USER_SOURCE@", source)
+    src = os.path.join(d, f"metric_{tag}.hip")
+    with open(src, "w") as fh:
+        fh.write(unit)
+    tmp = out + f".tmp{os.getpid()}"
+    cmd = [_build.HIPCC] + FLAGS + ["-I", CSRC, "-o", tmp, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise RuntimeError(f"hipcc failed on the user metric ({src}):\n{r.stderr[-4000:]}")
+    os.replace(tmp, out)  # atomic: concurrent ranks may compile the same metric
+    return out
+
+
+def activate(path):
+    """Make `path` the resident user metric of the library (no-op when it already is)."""
+    global _loaded_path
+    lib = _abi.load()
+    if _loaded_path == path and lib.rtgr_user_metric_loaded():
+        return
+    _abi.check(lib, lib.rtgr_user_metric_load(path.encode()))
+    _loaded_path = path
+
+
+class UserMetric:
+    """A metric given as source text; duck-types api.Metric (kind / M / a / generic) so make_scene accepts it."""
+    kind = _abi.USER
+    generic = True
+
+    def __init__(self, source, M=1.0, a=0.0, name="user_metric", verbose=False):
+        self.source, self.M, self.a, self.name = source, float(M), float(a), name
+        self.code_object = compile_user_metric(source, verbose=verbose)
+
+    def activate(self):
+        activate(self.code_object)
+
+    def __call__(self, x):
+        from . import api
+        return api._eval_metric(self, x, want=(True, False, False))[0]
+
+    def __repr__(self):
+        return f"UserMetric({self.name}, M={self.M}, a={self.a}, {os.path.basename(self.code_object)})"

@@ -1,0 +1,143 @@
+"""Run-time compiled metrics (rtgr_user_metric_load / api.UserMetric): the reference accepts ANY metric callable
+(src/RayTraceGR.jl:302-309, :358-370, :457-511); the product compiles the user's function for gfx950 and loads it.
+
+CPU part: the code object builds without a GPU and carries every kernel the loader asks for.
+GPU part: (1) textbook Kerr–Schild re-typed as user source must agree with the built-in generic path (same
+mathematics, different instruction order: rounding-level agreement); (2) isotropic Schwarzschild — a metric no
+built-in covers — against the oracle's copy of the same function, to the same bars as the built-in metrics."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT
+from scenes import rt, wrap_aware_rgb_err
+
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+import user_metrics  # noqa: E402
+
+abi = rt._abi
+um = sys.modules[rt.__name__ + ".user_metric"]
+KERNELS = ["rtgr_user_integrate_far", "rtgr_user_integrate_near", "rtgr_user_integrate_full10",
+           "rtgr_user_integrate_fulln", "rtgr_user_canvas", "rtgr_user_eval_metric", "rtgr_user_eval_geodesic"]
+
+
+def test_code_object_builds_on_cpu_and_has_every_kernel():
+    path = um.compile_user_metric(user_metrics.SCHWARZSCHILD_ISOTROPIC)
+    assert path.endswith(".hsaco") and os.path.getsize(path) > 10000
+    syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--dyn-syms", "-W", path], capture_output=True,
+                          text=True, check=True).stdout
+    names = {line.split()[-1] for line in syms.splitlines() if line.strip()}
+    for k in KERNELS + ["rtgr_user_abi_version"]:
+        assert k in names, k
+    assert um.compile_user_metric(user_metrics.SCHWARZSCHILD_ISOTROPIC) == path  # cached by content
+
+
+def test_bad_user_source_is_reported_not_swallowed():
+    with pytest.raises(ValueError):
+        um.compile_user_metric("int nothing_here;")
+    bad = user_metrics.SCHWARZSCHILD_ISOTROPIC.replace("msqrt", "no_such_function")
+    with pytest.raises(RuntimeError, match="no_such_function"):
+        um.compile_user_metric(bad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def lib():
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(-1))
+    return lib
+
+
+def _points(n, seed, rmin=1.7):
+    rng = np.random.default_rng(seed)
+    x = np.zeros((n, 4))
+    x[:, 0] = rng.normal(size=n) * 5
+    d = rng.normal(size=(n, 3))
+    x[:, 1:] = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(rmin, 12, size=(n, 1))
+    return x, rng
+
+
+@pytest.mark.gpu
+def test_user_metric_needs_a_loaded_module(lib):
+    abi.check(lib, lib.rtgr_user_metric_unload())
+    sc = abi.rtgr_scene()
+    sc.metric, sc.M = abi.USER, 1.0
+    x = np.array([[0.0, 3.0, 0.0, 0.0]])
+    g = np.zeros((1, 4, 4))
+    rc = lib.rtgr_eval_metric_f64(C.byref(sc), x.ctypes.data, 1, g.ctypes.data, None, None)
+    assert rc == abi.ERR_BAD_ARG and b"no user metric loaded" in lib.rtgr_last_error()
+    assert lib.rtgr_user_metric_load(b"/nonexistent.hsaco") == abi.ERR_HIP
+    assert lib.rtgr_user_metric_load(os.path.join(ROOT, "include", "rtgr.h").encode()) != 0  # not a code object
+    assert lib.rtgr_user_metric_loaded() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a", [0.0, 0.8])
+def test_user_kerr_schild_equals_builtin_generic_path(lib, a):
+    user = rt.UserMetric(user_metrics.KERR_SCHILD, M=1.1, a=a)
+    builtin = rt.KerrSchild(1.1, a, textbook=True, generic=True)
+    x, rng = _points(2048, 5)
+    pairs = list(zip(rt.dmetric(user, x), rt.dmetric(builtin, x))) + [(rt.christoffel(user, x), rt.christoffel(builtin, x))]
+    for got, ref in pairs:
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    s = np.concatenate([x, rng.normal(size=(len(x), 4))], axis=1)
+    got, ref = rt.geodesic(s, user, path=1), rt.geodesic(s, builtin, path=1)
+    scale = np.abs(ref[:, 4:]).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(got[:, 4:] - ref[:, 4:]) / scale).max() < 5e-12
+    # whole pipeline: canvas (normalisation with the user's metric) + trace
+    _, objs, cam = rt.example2_scene()
+    opt = rt.solver_defaults()
+    from test_gpu_parity import hip_trace
+    g1 = hip_trace(lib, rt.make_scene(user, objs), opt, 48, 48, cam=rt.make_camera(**cam))
+    g2 = hip_trace(lib, rt.make_scene(builtin, objs), opt, 48, 48, cam=rt.make_camera(**cam))
+    same = g1["hit"] == g2["hit"]
+    assert (~same).sum() <= 1
+    assert wrap_aware_rgb_err(g1["rgb"][:, same], g2["rgb"][:, same], g1["hit"][same], 3) <= 1e-6
+    assert g1["counters"]["rhs_evals"] > 0
+
+
+@pytest.mark.gpu
+def test_user_isotropic_schwarzschild_matches_the_oracle(lib):
+    user = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0)
+    sc = rt.make_scene(user, [])
+    x, rng = _points(2048, 6, rmin=0.8)
+    g, dg = rt.dmetric(user, x)
+    Gam = rt.christoffel(user, x)
+    rg, rdg, rGam = O.eval_metric(sc, x)
+    for got, ref in ((g, rg), (dg, rdg), (Gam, rGam)):
+        assert np.abs(got - ref).max() <= 2e-13 * max(1.0, np.abs(ref).max())
+    assert np.abs(user(x) - O.metric_plain(sc, x)).max() <= 1e-14  # metric(x) on plain scalars (:469)
+    s = np.concatenate([x, rng.normal(size=(len(x), 4))], axis=1)
+    got, ref = rt.geodesic(s, user, path=1), O.geodesic(sc, s)
+    scale = np.abs(ref[:, 4:]).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(got[:, 4:] - ref[:, 4:]) / scale).max() < 5e-12
+    # make_canvas + trace_rays against the oracle, example2's objects
+    _, objs, cam = rt.example2_scene()
+    scn, camera, opt = rt.make_scene(user, objs), rt.make_camera(**cam), rt.solver_defaults()
+    from test_gpu_parity import compare, hip_trace
+    c_gpu = np.zeros((40 * 40, 8))
+    abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(scn), C.byref(camera), 40, 40, 0, 40, c_gpu.ctypes.data))
+    c_ref = O.make_canvas(scn, camera, 40, 40)
+    assert np.abs(c_gpu - c_ref.reshape(c_gpu.shape)).max() < 1e-14
+    gpu = hip_trace(lib, scn, opt, 64, 64, cam=camera)
+    ref = O.trace(scn, opt, 64, 64, cam=camera)
+    compare(gpu, ref, max_class_flips=2, max_step_diff=2)
+    # the FULL-scan kernels of the module (interp_points != 10)
+    opt7 = rt.solver_defaults(interp_points=7)
+    compare(hip_trace(lib, scn, opt7, 32, 32, cam=camera), O.trace(scn, opt7, 32, 32, cam=camera),
+            max_class_flips=2, max_step_diff=2)
+
+
+@pytest.mark.gpu
+def test_switching_between_user_metrics_reloads_the_right_module(lib):
+    iso = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0)
+    ks = rt.UserMetric(user_metrics.KERR_SCHILD, M=1.0, a=0.0)
+    x = np.array([[0.0, 3.0, 1.0, -2.0]])
+    g_iso, g_ks = iso(x), ks(x)
+    assert g_iso.shape == (4, 4) and abs(g_iso[0, 1]) == 0.0 and abs(g_ks[0, 1]) > 1e-3  # diagonal vs Kerr–Schild
+    assert np.array_equal(iso(x), g_iso) and np.array_equal(ks(x), g_ks)
