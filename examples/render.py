@@ -3,6 +3,8 @@
 
     python examples/render.py 2 [ni nj]     # writes scenes/sphere2.png (example2: black hole), default 200 x 200
     python examples/render.py 1             # writes scenes/sphere.png  (example1: flat space)
+    python examples/render.py 3             # writes scenes/sphere3.png (example2's scene around a Schwarzschild hole
+                                            #   in isotropic coordinates: a metric compiled at run time, UserMetric)
 
 The code below is what a user of RayTraceGR.jl writes, with `RayTraceGR.` replaced by the host mirror `rt.`.
 """
@@ -20,6 +22,10 @@ def main():
     ni = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     nj = int(sys.argv[3]) if len(sys.argv) > 3 else ni
     metric = rt.minkowski if which == 1 else rt.kerr_schild
+    if which == 3:  # a metric function of the user's own (the reference: any Julia callable, src/RayTraceGR.jl:302-309)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import user_metrics
+        metric = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0, name="schwarzschild_isotropic")
     caelum = rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10)                       # background sky, inside-out
     frustum = rt.Plane(-20)                                                    # cut-off plane in the past
     sphere = rt.Sphere((0, 0 if which == 1 else 4, 0, 0), (1, 0, 0, 0), 0.5)   # the visible sphere
@@ -29,7 +35,7 @@ def main():
     canvas, info = rt.trace_rays(metric, objs, canvas, return_info=True)
     from raytracegr_jl_amd.png import write_png
     os.makedirs(rt.api.outdir, exist_ok=True)
-    file = os.path.join(rt.api.outdir, "sphere.png" if which == 1 else "sphere2.png")
+    file = os.path.join(rt.api.outdir, {1: "sphere.png", 2: "sphere2.png", 3: "sphere3.png"}[which])
     write_png(file, canvas.image_u8())
     print(f'Output file is "{file}"  ({info["rays"]} rays, {info["accepted"] + info["rejected"]} RK step attempts)')
 

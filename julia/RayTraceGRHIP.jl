@@ -40,15 +40,37 @@ struct RtgrCounters
     events::UInt64; events_interior::UInt64; not_finished::UInt64; reserved::UInt64
 end
 
-const RTGR_MINKOWSKI, RTGR_KS_REF, RTGR_KS_TRUE = UInt32(0), UInt32(1), UInt32(2)
+const RTGR_MINKOWSKI, RTGR_KS_REF, RTGR_KS_TRUE, RTGR_USER = UInt32(0), UInt32(1), UInt32(2), UInt32(3)
 const RTGR_PLANE, RTGR_SPHERE = UInt32(1), UInt32(2)
 
 pack(pl::RayTraceGR.Plane{Float64}) = RtgrObject(RTGR_PLANE, 0, (pl.time, 0, 0, 0, 0, 0, 0, 0, 0))
 pack(s::RayTraceGR.Sphere{Float64}) = RtgrObject(RTGR_SPHERE, 0, (s.pos..., s.vel..., s.radius))
 const NOOBJ = RtgrObject(0, 0, ntuple(_ -> 0.0, 9))
 
+"""
+    DeviceMetric(code_object; M = 1.0, a = 0.0)
+
+A metric function of the user's own, given as a gfx950 code object built from `rtgr_user_unit.hip.in`
+(INTEGRATION.md "A new metric") — the native stand-in for passing a new Julia function as `metric` (:302-309).
+"""
+struct DeviceMetric
+    code_object::String
+    M::Float64
+    a::Float64
+end
+DeviceMetric(path; M = 1.0, a = 0.0) = DeviceMetric(path, M, a)
+const resident_metric = Ref("")
+function activate(m::DeviceMetric)
+    resident_metric[] == m.code_object && return
+    check(ccall((:rtgr_user_metric_load, librtgr), Cint, (Cstring,), m.code_object))
+    resident_metric[] = m.code_object
+end
+
+metric_enum(m::DeviceMetric) = (activate(m); RTGR_USER)
 metric_enum(m) = m === RayTraceGR.minkowski ? RTGR_MINKOWSKI :
                  m === RayTraceGR.kerr_schild ? RTGR_KS_REF : nothing   # as written: M = 1, a = 0 (:275-276)
+metric_params(m::DeviceMetric) = (m.M, m.a)
+metric_params(m) = (1.0, 0.0)
 
 function check(rc)
     rc < 0 && error("librtgr_hip: ", unsafe_string(ccall((:rtgr_last_error, librtgr), Cstring, ())))
@@ -67,7 +89,7 @@ function trace_rays(metric, objs::Vector{RayTraceGR.Object{Float64}}, c::RayTrac
         return RayTraceGR.trace_rays(metric, objs, c)        # arbitrary metric callable: reference CPU path
     end
     packed = ntuple(i -> i <= length(objs) ? pack(objs[i]) : NOOBJ, RTGR_MAX_OBJECTS)
-    scene = Ref(RtgrScene(me, length(objs), 1.0, 0.0, packed))
+    scene = Ref(RtgrScene(me, length(objs), metric_params(metric)..., packed))
     opt = Ref{RtgrSolver}()
     check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, 0))
     ni, nj = size(c.pixels)
@@ -91,7 +113,7 @@ function trace_ray(metric, objs::Vector{RayTraceGR.Object{Float64}}, cb, p::RayT
     me = metric_enum(metric)
     me === nothing && error("only minkowski / kerr_schild cross the C ABI")
     packed = ntuple(i -> i <= length(objs) ? pack(objs[i]) : NOOBJ, RTGR_MAX_OBJECTS)
-    scene = Ref(RtgrScene(me, length(objs), 1.0, 0.0, packed))
+    scene = Ref(RtgrScene(me, length(objs), metric_params(metric)..., packed))
     opt = Ref{RtgrSolver}()
     check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, 0))
     pos, nrm = Ref(p.pos), Ref(p.normal)
