@@ -512,3 +512,31 @@ def test_example_script_writes_the_golden_png(lib, tmp_path, monkeypatch):
     from raytracegr_jl_amd.png import read_png
     img = read_png(str(tmp_path / "scenes" / "sphere2.png"))
     assert int((img != _golden("sphere2.png")).any(axis=2).sum()) == 0
+
+
+@pytest.mark.parametrize("name,size", [("ks_true08", 1024), ("ks_true0998", 512), ("ks_ref0", 512)])
+def test_constants_of_motion_along_device_rays(lib, name, size):
+    """Oracle-independent physics check at BASELINE sizes: a stationary, axisymmetric metric conserves E = −g_tμ u^μ and
+    L_z = x p_y − y p_x (p = g u) along every geodesic, and a null ray stays null.  Evaluated from the device's own
+    start and end states (make_canvas → sol[end]) with the oracle used only as a metric evaluator.  The integration
+    tolerance is 2⁻³⁹ per step over ~200-250 steps; the bars are 10⁴ × that."""
+    sc, cam = scene_variant(name)
+    opt = rt.solver_defaults()
+    n = size * size
+    s0 = np.zeros((n, 8))
+    abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(sc), C.byref(cam), size, size, 0, size, s0.ctypes.data))
+    out = hip_trace(lib, sc, opt, size, size, cam=cam)
+    se = out["state_end"]
+    assert (out["status"] == abi.RAY_EVENT).all()
+
+    def constants(s):
+        g = O.metric_plain(sc, s[:, :4])
+        p = np.einsum("nab,nb->na", g, s[:, 4:])
+        return -p[:, 0], s[:, 1] * p[:, 2] - s[:, 2] * p[:, 1], np.einsum("na,na->n", p, s[:, 4:])
+
+    E0, L0, N0 = constants(s0)
+    E1, L1, N1 = constants(se)
+    assert np.abs(N0).max() < 1e-14                                   # make_canvas normalised the rays (:469-473)
+    assert np.abs(E1 - E0).max() < 2e-8 * np.abs(E0).max()
+    assert np.abs(L1 - L0).max() < 2e-8 * max(1.0, np.abs(L0).max())
+    assert np.abs(N1).max() < 2e-8 * (np.abs(se[:, 4:]) ** 2).sum(axis=1).max()

@@ -141,3 +141,30 @@ def test_switching_between_user_metrics_reloads_the_right_module(lib):
     g_iso, g_ks = iso(x), ks(x)
     assert g_iso.shape == (4, 4) and abs(g_iso[0, 1]) == 0.0 and abs(g_ks[0, 1]) > 1e-3  # diagonal vs Kerr–Schild
     assert np.array_equal(iso(x), g_iso) and np.array_equal(ks(x), g_ks)
+
+
+@pytest.mark.gpu
+def test_user_metric_conserves_energy_and_angular_momentum(lib):
+    """Oracle-independent: isotropic Schwarzschild is static and spherically symmetric, so E = −g_tt u^t and all three
+    components of L = x × p are constant along the traced rays, and null rays stay null (metric evaluated by the
+    user's own function on the device)."""
+    user = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0)
+    _, objs, cam = rt.example2_scene()
+    scn, camera, opt = rt.make_scene(user, objs), rt.make_camera(**cam), rt.solver_defaults()
+    from test_gpu_parity import hip_trace
+    size = 256
+    s0 = np.zeros((size * size, 8))
+    abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(scn), C.byref(camera), size, size, 0, size, s0.ctypes.data))
+    out = hip_trace(lib, scn, opt, size, size, cam=camera)
+    se = out["state_end"]
+
+    def constants(s):
+        p = np.einsum("nab,nb->na", user(s[:, :4]), s[:, 4:])
+        L = np.cross(s[:, 1:4], p[:, 1:4])
+        return -p[:, 0], L, np.einsum("na,na->n", p, s[:, 4:])
+
+    (E0, L0, N0), (E1, L1, N1) = constants(s0), constants(se)
+    assert np.abs(N0).max() < 1e-14
+    assert np.abs(E1 - E0).max() < 2e-8 * np.abs(E0).max()
+    assert np.abs(L1 - L0).max() < 2e-8 * max(1.0, np.abs(L0).max())
+    assert np.abs(N1).max() < 2e-8 * (np.abs(se[:, 4:]) ** 2).sum(axis=1).max()
