@@ -256,8 +256,13 @@ RTGR_DEV void accel_radial(const R xs[3], const R u[4], R M, R ud[4]) {
     const R alpha = rfma(-fi * K, D, P);
     const R beta = fi * K * rfma(R(0.5), K, Ku);
     const R lam = rfma(invr, alpha, rq2 * beta);                         // L_i = x_i λ
-    const R kk = rho2 * invr * invr;
-    const R S = f * rcp_<FAST>(rfma(f, kk - R(1), R(1)));
+    R S;
+    if constexpr (METRIC == RTGR_KS_REF) {
+        const R kk = rho2 * invr * invr;                                 // r ≠ ρ as written: |k|² ≠ 1
+        S = f * rcp_<FAST>(rfma(f, kk - R(1), R(1)));
+    } else {
+        S = f;                                                           // |k|² = 1
+    }
     const R kL = rfma(invr * lam, rho2, -P);                             // k♯^d L_d
     const R SkL = S * kL;
     ud[0] = P - SkL;
@@ -274,7 +279,13 @@ RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
     const R a2 = a * a;
     const R rho2 = rfma(x, x, rfma(y, y, z * z));
     const R q = rho2 - a2;
+    // With the TEXTBOOK radius r is a root of r⁴ − q r² − a²z² = 0 and k is the principal null congruence, which buys
+    // (checked to 40 digits): r⁴ + a²z² = r²·sqrt(q²+4a²z²);  |k|² = 1;  k^j ∂_j k_i = 0;  k^i ∂_d k_i = 0;  k·∇r = 1.
+    // Hence 1/den needs no reciprocal of its own, S = f/(1 + f(|k|²−1)) = f, and k♯^d L_d = −½K²(f_r + f_z k_z).
+    // The as-written radius (:284) is not that root for a ≠ 0, so KS_REF keeps the general expressions.
     R r, ir, rq2, rz;  // r, 1/r, ∇r = rq2 (x,y,z) + rz ẑ
+    R iden, rid;       // 1/(r⁴ + a² z²), r³/(r⁴ + a² z²)
+    const R a2z = a2 * z;
     if constexpr (METRIC == RTGR_KS_REF) {
         R s1, is1, s2, is2;                                   // r = sqrt(q)/2 + sqrt(a² z² + (q/2)²)            :284
         sqrt_inv<FAST>(q, s1, is1);
@@ -284,6 +295,9 @@ RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
         ir = rcp_<FAST>(r);
         rq2 = R(0.5) * rfma(q, is2, is1);
         rz = a2 * z * is2;
+        const R r2 = r * r;
+        iden = rcp_<FAST>(rfma(r2, r2, a2z * z));
+        rid = r2 * r * iden;
     } else {
         R sq, is;                                             // r² = (q + sqrt(q² + 4a²z²))/2
         sqrt_inv<FAST>(rfma(q, q, R(4) * a2 * z * z), sq, is);
@@ -291,13 +305,13 @@ RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
         const R hir = R(0.5) * ir;
         rq2 = rfma(q * is, hir, hir);
         rz = a2 * z * is * ir;
+        iden = ir * ir * is;                                  // den = r² sqrt(q²+4a²z²)
+        rid = r * is;
     }
     const R dr0 = rq2 * x, dr1 = rq2 * y, dr2 = rfma(rq2, z, rz);
-    const R r2 = r * r, a2z = a2 * z;
-    const R iden = rcp_<FAST>(rfma(r2, r2, a2z * z));          // 1/(r⁴ + a² z²)
-    const R r3 = r2 * r;
-    const R f = (R(2) * M) * r3 * iden;                         // f = 2M r³/(r⁴+a²z²)                             :285
-    const R f_r = f * rfma(R(-4) * r3, iden, R(3) * ir);        // ∂f/∂r = f (3/r − 4r³/den)
+    const R r2 = r * r;
+    const R f = (R(2) * M) * rid;                               // f = 2M r³/(r⁴+a²z²)                             :285
+    const R f_r = f * rfma(R(-4), rid, R(3) * ir);              // ∂f/∂r = f (3/r − 4r³/den)
     const R f_z = R(-2) * f * a2z * iden;                       // ∂f/∂z at fixed r
     const R w = rcp_<FAST>(r2 + a2);
     const R k0 = rfma(r, x, a * y) * w, k1 = rfma(r, y, -a * x) * w, k2 = z * ir;            // :286-289
@@ -319,10 +333,15 @@ RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
     const R L0 = rfma(k0, P, rfma(fK, Dk0 - W0, g2 * dr0));
     const R L1 = rfma(k1, P, rfma(fK, Dk1 - W1, g2 * dr1));
     const R L2 = rfma(k2, P, rfma(fK, Dk2 - W2, rfma(g2, dr2, g3)));
-    const R kk = rfma(k0, k0, rfma(k1, k1, k2 * k2));
-    const R S = f * rcp_<FAST>(rfma(f, kk - R(1), R(1)));
-    const R kL = rfma(k0, L0, rfma(k1, L1, rfma(k2, L2, -P)));
-    const R SkL = S * kL;
+    R SkL;
+    if constexpr (METRIC == RTGR_KS_REF) {
+        const R kk = rfma(k0, k0, rfma(k1, k1, k2 * k2));
+        const R S = f * rcp_<FAST>(rfma(f, kk - R(1), R(1)));
+        const R kL = rfma(k0, L0, rfma(k1, L1, rfma(k2, L2, -P)));
+        SkL = S * kL;
+    } else {
+        SkL = f * rfma(g3, k2, g2);                             // S = f,  k♯^d L_d = −½K²(f_r + f_z k_z)
+    }
     ud[0] = P - SkL;
     ud[1] = rfma(k0, SkL, -L0);
     ud[2] = rfma(k1, SkL, -L1);
