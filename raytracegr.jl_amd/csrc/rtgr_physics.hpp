@@ -317,22 +317,25 @@ RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
     const R k0 = rfma(r, x, a * y) * w, k1 = rfma(r, y, -a * x) * w, k2 = z * ir;            // :286-289
     const R m2r = R(-2) * r;
     const R kr0 = w * rfma(m2r, k0, x), kr1 = w * rfma(m2r, k1, y), kr2 = -k2 * ir;          // ∂k_i/∂r
-    const R rw = r * w, aw = a * w;
+    const R rw = r * w, aw2 = (R(2) * a) * w;
     const R ut = u[0], ux = u[1], uy = u[2], uz = u[3];
     const R D = rfma(dr0, ux, rfma(dr1, uy, dr2 * uz));        // u·∇r
     const R Df = rfma(f_r, D, f_z * uz);                        // u·∇f
     const R Ku = rfma(k0, ux, rfma(k1, uy, k2 * uz));
     const R K = ut + Ku;                                        // k_a u^a
     const R kru = rfma(kr0, ux, rfma(kr1, uy, kr2 * uz));
-    const R p0 = rw * ux, p1 = aw * uy, p2 = aw * ux, p3 = rw * uy, e2 = ir * uz;
-    const R Dk0 = rfma(kr0, D, p0 + p1), Dk1 = rfma(kr1, D, p3 - p2), Dk2 = rfma(kr2, D, e2);   // u^j ∂_j k_i
-    const R W0 = rfma(kru, dr0, p0 - p1), W1 = rfma(kru, dr1, p2 + p3), W2 = rfma(kru, dr2, e2); // u^i ∂_d k_i
-    const R A = rfma(ux, Dk0, rfma(uy, Dk1, uz * Dk2));
+    // Dk_i = u^j ∂_j k_i = kr_i D + (E u)_i and W_d = u^i ∂_d k_i = kru ∂_d r + (Eᵀu)_d are needed only as
+    //   A   = u·Dk      = kru D + uᵀE u          with uᵀE u = r w (ux² + uy²) + uz²/r   (the ±a w parts cancel)
+    //   V_i = Dk_i − W_i = kr_i D − kru ∂_i r + ((E − Eᵀ) u)_i,   (E − Eᵀ) u = 2 a w (uy, −ux, 0)
+    const R A = rfma(kru, D, rfma(rw, rfma(ux, ux, uy * uy), ir * uz * uz));
+    const R V0 = rfma(kr0, D, rfma(-kru, dr0, aw2 * uy));
+    const R V1 = rfma(kr1, D, rfma(-kru, dr1, -aw2 * ux));
+    const R V2 = rfma(kr2, D, -kru * dr2);
     const R P = rfma(K, Df, f * A);                             // L_t
     const R fK = f * K, g2 = R(-0.5) * K * K * f_r, g3 = R(-0.5) * K * K * f_z;
-    const R L0 = rfma(k0, P, rfma(fK, Dk0 - W0, g2 * dr0));
-    const R L1 = rfma(k1, P, rfma(fK, Dk1 - W1, g2 * dr1));
-    const R L2 = rfma(k2, P, rfma(fK, Dk2 - W2, rfma(g2, dr2, g3)));
+    const R L0 = rfma(k0, P, rfma(fK, V0, g2 * dr0));
+    const R L1 = rfma(k1, P, rfma(fK, V1, g2 * dr1));
+    const R L2 = rfma(k2, P, rfma(fK, V2, rfma(g2, dr2, g3)));
     R SkL;
     if constexpr (METRIC == RTGR_KS_REF) {
         const R kk = rfma(k0, k0, rfma(k1, k1, k2 * k2));
