@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void pixels_out_kernel(const double* px_in, co
 struct UserModule {
     hipModule_t module = nullptr;
     hipFunction_t far = nullptr, near = nullptr, full10 = nullptr, fulln = nullptr, canvas = nullptr,
-                  eval_metric = nullptr, eval_geodesic = nullptr;
+                  prepare = nullptr, eval_metric = nullptr, eval_geodesic = nullptr;
 };
 static UserModule g_user;
 constexpr int RTGR_UM = RTGR_GENERIC_BASE + RTGR_USER;
@@ -423,6 +423,11 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
             uint64_t qc = per_wave / 16;
             qc = qc < 8 ? 8 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
             IA.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK", (int)qc);
+        }
+        {   // ray set-up: u̇(y0), initial dt, event sign -> start records
+            KernelTimer tm(st, 0);
+            if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.prepare, (unsigned)((m + 255) / 256), 256, st, IA));
+            else hipLaunchKernelGGL((prepare_kernel<R, METRIC, SPIN>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, IA);
         }
         rc = launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
         if (rc) return rc;
@@ -868,7 +873,7 @@ int rtgr_user_metric_load(const char* code_object_path) {
         {&u.far, "rtgr_user_integrate_far"},       {&u.near, "rtgr_user_integrate_near"},
         {&u.full10, "rtgr_user_integrate_full10"}, {&u.fulln, "rtgr_user_integrate_fulln"},
         {&u.canvas, "rtgr_user_canvas"},           {&u.eval_metric, "rtgr_user_eval_metric"},
-        {&u.eval_geodesic, "rtgr_user_eval_geodesic"}};
+        {&u.eval_geodesic, "rtgr_user_eval_geodesic"}, {&u.prepare, "rtgr_user_prepare"}};
     for (auto& w : want)
         if (hipModuleGetFunction(w.f, u.module, w.name) != hipSuccess) return bail(std::string("missing kernel ") + w.name);
     if ((rc = rtgr_user_metric_unload())) { (void)hipModuleUnload(u.module); return rc; }

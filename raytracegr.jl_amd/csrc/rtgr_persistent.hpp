@@ -18,8 +18,10 @@
 // Step body (per lane, registers only):
 //   * Nyström form: since ẋ = u (src/RayTraceGR.jl:360) stage positions are x + h c_s u + h² Σ A2[s][l] k_l — only the
 //     seven acceleration 4-vectors k_l are stored (28 scalars), not the 7 x 8 stage derivatives;
-//   * the two RHS evaluations of the Hairer initial step of a fresh ray ride in the k2/k3 slots of its neighbours'
-//     regular step ("init pseudo-step");
+//   * a fresh ray's u̇(y0) and Hairer initial dt (2 RHS evaluations) are computed by prepare_kernel, one thread per
+//     ray, into the same 16-scalar record the FAR pass uses to hand a ray over — the integrate loop has ONE way to
+//     start a ray and no per-ray set-up code of its own (an in-loop "init pseudo-step" ran its ~200 extra
+//     instructions for the whole wave in the ~26 % of iterations in which some lane had just been refilled);
 //   * error norm, PI controller and initial-dt formula run in f32 on the (otherwise idle) f32 VALU/transcendental
 //     path; they only steer the step size — the state arithmetic is all R (f64);
 //   * ContinuousCallback (NEAR / FULL): the position interpolant is put in polynomial form once per accepted step and
@@ -44,7 +46,7 @@
 
 namespace rtgr {
 
-enum LaneState : int { L_FREE = 0, L_INIT = 1, L_RUN = 2, L_EXIT = 3 };
+enum LaneState : int { L_FREE = 0, L_RUN = 2, L_EXIT = 3 };
 
 // event record layout (scalars of type R per ray)
 constexpr int REC_X = 0;      // x[4]   position at the start of the last step
@@ -219,26 +221,22 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             const uint32_t rank = mask_rank(m_need, lane);
             if (state == L_FREE && rank < avail) {
                 const uint64_t w = q_next + rank;
-                if (MODE == MODE_NEAR || A.pick_flag != 0u) {
-                    // a resuming pass visits every ray id and picks up the rays flagged for it
-                    if (A.meta[w * 3 + 2] == A.pick_flag) {
-                        idx = w;
-                        const R* hd = A.hand + w * HAND_W;
+                // Every ray starts from a 16-scalar record {x, u, u̇, t, dt, sign(min_distance), log2 q_old}: written by
+                // prepare_kernel for a fresh ray (u̇(y0) and the Hairer initial dt), by the FAR pass for a ray it hands
+                // over.  A resuming pass (NEAR, hand-back rounds) visits every ray id and picks up the rays flagged for it.
+                const bool resume = (MODE == MODE_NEAR || A.pick_flag != 0u);
+                const uint64_t id = resume ? w : (A.order ? (uint64_t)A.order[w] : w);
+                if (!resume || A.meta[id * 3 + 2] == A.pick_flag) {
+                    idx = id;
+                    const R* hd = A.hand + id * HAND_W;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) { x[q] = hd[q]; u[q] = hd[4 + q]; k[0][q] = hd[8 + q]; }
-                        t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
-                        nacc = A.meta[w * 3]; nrej = A.meta[w * 3 + 1];
-                        nacc0 = nacc;
-                        safe_streak = 0;
-                        state = L_RUN;
-                    }
-                } else {
-                    idx = A.order ? (uint64_t)A.order[w] : w;
-                    const R* s0 = A.state0 + idx * 8;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { x[q] = s0[q]; u[q] = s0[4 + q]; k[0][q] = R(0); }
-                    t = t0; nacc = 0; nrej = 0;
-                    state = L_INIT;
+                    for (int q = 0; q < 4; q++) { x[q] = hd[q]; u[q] = hd[4 + q]; k[0][q] = hd[8 + q]; }
+                    t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
+                    nacc = resume ? A.meta[id * 3] : 0u;
+                    nrej = resume ? A.meta[id * 3 + 1] : 0u;
+                    nacc0 = nacc;
+                    safe_streak = 0;
+                    state = L_RUN;
                 }
             }
             const uint32_t cnt = (uint32_t)__builtin_popcountll(m_need);
@@ -246,17 +244,15 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             m_need = __ballot(state == L_FREE);
         }
         if (exhausted && q_next == q_end && state == L_FREE) state = L_EXIT;
-        if (__ballot(state == L_INIT || state == L_RUN) == 0ull) {
+        if (__ballot(state == L_RUN) == 0ull) {
             if (exhausted && q_next == q_end) break;
             continue;
         }
 
-        // ================= one Tsit5 attempt (or the init pseudo-step) per runnable lane ==========================
-        const bool init = (MODE != MODE_NEAR) && (state == L_INIT);
-        const unsigned long long m_init = (MODE != MODE_NEAR) ? __ballot(init) : 0ull;
-        if (state == L_RUN || state == L_INIT) {
-            if (!init) dt = rmin(dt, t1 - t);
-            const R h = init ? R(0) : dt;
+        // ================= one Tsit5 attempt per runnable lane ====================================================
+        if (state == L_RUN) {
+            dt = rmin(dt, t1 - t);
+            const R h = dt;
             const R h2 = h * h;
             R X[3], U[4];
             // ---- stage 2 -------------------------------------------------------------------------------------
@@ -267,58 +263,16 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(hc, u[1 + q], x[1 + q]);
             }
-            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[1]);   // init lanes (h = 0): k[1] = u̇(y0), f0 = (u, k[1])
-            R dt0 = R(0);
-            float d1f = 0.0f;
-            if (m_init != 0ull) {
-                if (init) {  // Hairer initial step, first half; norms in f32
-                    float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float iskx = __builtin_amdgcn_rcpf((float)rfma(rabs(x[q]), reltol, abstol));
-                        const float isku = __builtin_amdgcn_rcpf((float)rfma(rabs(u[q]), reltol, abstol));
-                        const float a0 = (float)x[q] * iskx, b0 = (float)u[q] * isku;
-                        const float a1 = (float)u[q] * iskx, b1 = (float)k[1][q] * isku;
-                        acc0 = __builtin_fmaf(a0, a0, __builtin_fmaf(b0, b0, acc0));
-                        acc1 = __builtin_fmaf(a1, a1, __builtin_fmaf(b1, b1, acc1));
-                    }
-                    const float d0f = __builtin_sqrtf(acc0 * 0.125f);
-                    d1f = __builtin_sqrtf(acc1 * 0.125f);
-                    const float dt0f = (d0f < 1e-5f || d1f < 1e-5f) ? 1e-6f : (d0f / d1f) * 0.01f;
-                    dt0 = rmin((R)dt0f, dtmax);
-                }
-            }
-            // ---- stage 3 (init lanes: y0 + dt0 f0 — k[0] = 0 there, so only the scalar multipliers differ) ---------
+            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[1]);
+            // ---- stage 3 -------------------------------------------------------------------------------------
             {
-                const R w1 = init ? dt0 : h * N::a[2][1];
-                const R w0 = h * N::a[2][0];
-                const R hc = init ? dt0 : h * N::c[2];
-                const R h2a = h2 * N::A2[2][0];
+                const R w1 = h * N::a[2][1], w0 = h * N::a[2][0], hc = h * N::c[2], h2a = h2 * N::A2[2][0];
 #pragma unroll
                 for (int q = 0; q < 4; q++) U[q] = rfma(w1, k[1][q], rfma(w0, k[0][q], u[q]));
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(h2a, k[0][1 + q], rfma(hc, u[1 + q], x[1 + q]));
             }
-            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[2]);   // init lanes: k[2] = u̇(y0 + dt0 f0)
-            R dt_init = R(0);
-            if (m_init != 0ull) {
-                if (init) {  // second half: f1 − f0 = (dt0·k[1], k[2] − k[1])
-                    float acc2 = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float iskx = __builtin_amdgcn_rcpf((float)rfma(rabs(x[q]), reltol, abstol));
-                        const float isku = __builtin_amdgcn_rcpf((float)rfma(rabs(u[q]), reltol, abstol));
-                        const float a2 = (float)(dt0 * k[1][q]) * iskx, b2 = (float)(k[2][q] - k[1][q]) * isku;
-                        acc2 = __builtin_fmaf(a2, a2, __builtin_fmaf(b2, b2, acc2));
-                    }
-                    const float d2f = __builtin_sqrtf(acc2 * 0.125f) / (float)dt0;
-                    const float md = fmaxf(d1f, d2f);
-                    // dt1 = 10^(-(2 + log10 md)/5) = 2^(-(2 log2 10 + log2 md)/5)
-                    const float dt1f = (md <= 1e-15f) ? fmaxf(1e-6f, (float)dt0 * 1e-3f)
-                                                      : fexp2(-0.2f * (6.643856189774724f + flog2(md)));
-                    dt_init = rmin(rmin(R(100) * dt0, (R)dt1f), dtmax);
-                }
-            }
+            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[2]);
             // ---- stages 4, 5, 6 ----------------------------------------------------------------------------------
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -357,15 +311,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             }
             accel<R, METRIC, SPIN, true>(xn + 1, un, M, aspin, k[6]);
 
-            if (init) {
-                // the fresh ray is ready: FSAL slot <- u̇(y0), controller state reset        
-#pragma unroll
-                for (int q = 0; q < 4; q++) k[0][q] = k[1][q];
-                dt = dt_init;
-                lq = lq_init;
-                ps = rsign(min_distance<R>(A.sc, x));
-                state = L_RUN;
-            } else {
+            {
                 // ---- embedded error, residual norm in f32 ----------------------------------------
                 float acc = 0.0f;
 #pragma unroll
@@ -653,6 +599,66 @@ __global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? RTGR_WAVES_PER_SI
                                  : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4) : RTGR_WAVES_PER_SIMD))
 void integrate_kernel(const IntegrateArgs<R> A) {
     integrate_body<R, METRIC, SPIN, NPTS10, MODE>(A);
+}
+
+// Ray set-up, one thread per ray: u̇(y0), the Hairer initial step (d0, d1, one Euler probe, d2; the
+// norms in f32 like the controller's), sign(min_distance(y0)) for the ContinuousCallback (App. B.4) and the controller's
+// q_old = 1e-4 (App. B.2) -> the ray's 16-scalar start record.  2 RHS evaluations per ray (counted by the integrate
+// kernel's counters).  A body function for the same reason as integrate_body.
+template <class R, int METRIC, bool SPIN>
+RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= A.n) return;
+    const R M = A.sc.M, aspin = A.sc.a;
+    const R reltol = A.opt.reltol, abstol = A.opt.abstol, dtmax = A.opt.lambda1 - A.opt.lambda0;
+    R x[4], u[4], k1[4], k2[4];
+    const R* s0 = A.state0 + w * 8;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { x[q] = s0[q]; u[q] = s0[4 + q]; }
+    accel<R, METRIC, SPIN, true>(x + 1, u, M, aspin, k1);      // f0 = (u, k1)
+    float acc0 = 0.0f, acc1 = 0.0f;
+    float iskx[4], isku[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        iskx[q] = __builtin_amdgcn_rcpf((float)rfma(rabs(x[q]), reltol, abstol));
+        isku[q] = __builtin_amdgcn_rcpf((float)rfma(rabs(u[q]), reltol, abstol));
+        const float a0 = (float)x[q] * iskx[q], b0 = (float)u[q] * isku[q];
+        const float a1 = (float)u[q] * iskx[q], b1 = (float)k1[q] * isku[q];
+        acc0 = __builtin_fmaf(a0, a0, __builtin_fmaf(b0, b0, acc0));
+        acc1 = __builtin_fmaf(a1, a1, __builtin_fmaf(b1, b1, acc1));
+    }
+    const float d0f = __builtin_sqrtf(acc0 * 0.125f), d1f = __builtin_sqrtf(acc1 * 0.125f);
+    const float dt0f = (d0f < 1e-5f || d1f < 1e-5f) ? 1e-6f : (d0f / d1f) * 0.01f;
+    const R dt0 = rmin((R)dt0f, dtmax);
+    R X[3], U[4];                                              // y0 + dt0 f0
+#pragma unroll
+    for (int q = 0; q < 4; q++) U[q] = rfma(dt0, k1[q], u[q]);
+#pragma unroll
+    for (int q = 0; q < 3; q++) X[q] = rfma(dt0, u[1 + q], x[1 + q]);
+    accel<R, METRIC, SPIN, true>(X, U, M, aspin, k2);          // f1 − f0 = (dt0·k1, k2 − k1)
+    float acc2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float a2 = (float)(dt0 * k1[q]) * iskx[q], b2 = (float)(k2[q] - k1[q]) * isku[q];
+        acc2 = __builtin_fmaf(a2, a2, __builtin_fmaf(b2, b2, acc2));
+    }
+    const float d2f = __builtin_sqrtf(acc2 * 0.125f) / (float)dt0;
+    const float md = fmaxf(d1f, d2f);
+    // dt1 = 10^(-(2 + log10 md)/5) = 2^(-(2 log2 10 + log2 md)/5)
+    const float dt1f = (md <= 1e-15f) ? fmaxf(1e-6f, (float)dt0 * 1e-3f) : fexp2(-0.2f * (6.643856189774724f + flog2(md)));
+    const R dt_init = rmin(rmin(R(100) * dt0, (R)dt1f), dtmax);
+    R* hd = A.hand + w * HAND_W;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k1[q]; }
+    hd[12] = A.opt.lambda0;
+    hd[13] = dt_init;
+    hd[14] = rsign(min_distance<R>(A.sc, x));
+    hd[15] = R(-13.287712379549449);                           // log2(qoldinit = 1e-4)
+}
+
+template <class R, int METRIC, bool SPIN>
+__global__ __launch_bounds__(256) void prepare_kernel(const IntegrateArgs<R> A) {
+    prepare_body<R, METRIC, SPIN>(A);
 }
 
 // Per-launch reset of the queue heads and of the ordering histogram.  A kernel rather than hipMemsetAsync: memset nodes

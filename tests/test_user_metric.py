@@ -23,7 +23,7 @@ import user_metrics  # noqa: E402
 abi = rt._abi
 um = sys.modules[rt.__name__ + ".user_metric"]
 KERNELS = ["rtgr_user_integrate_far", "rtgr_user_integrate_near", "rtgr_user_integrate_full10",
-           "rtgr_user_integrate_fulln", "rtgr_user_canvas", "rtgr_user_eval_metric", "rtgr_user_eval_geodesic"]
+           "rtgr_user_integrate_fulln", "rtgr_user_canvas", "rtgr_user_prepare", "rtgr_user_eval_metric", "rtgr_user_eval_geodesic"]
 
 
 def test_code_object_builds_on_cpu_and_has_every_kernel():
