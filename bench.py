@@ -220,7 +220,7 @@ def main():
                               f"and profiles/ for the hardware-counted f64 flops and VALU utilisation)",
                 "other_kernels_ms_avg": {"canvas": float(kms[0]) / max(int(kln[0]), 1),
                                          "resolve": float(kms[2]) / max(int(kln[2]), 1)},
-                "hbm_algorithmic_GBps": (my_rays * (64 + 2 * 140 + 204 + 25)) / k_avg_s / 1e9}
+                "hbm_algorithmic_GBps": (my_rays * (132 + 2 * 140 + 204 + 25)) / k_avg_s / 1e9}
         roof["traffic"] = load_traffic(a)
         name = C_name(lib)
         cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and ws == 1) else None  # N=1 only
