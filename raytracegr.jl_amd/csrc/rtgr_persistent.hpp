@@ -46,7 +46,7 @@
 
 namespace rtgr {
 
-enum LaneState : int { L_FREE = 0, L_RUN = 2, L_EXIT = 3 };
+enum LaneState : int { L_FREE = 0, L_TAKEN = 1, L_RUN = 2, L_EXIT = 3 };
 
 // event record layout (scalars of type R per ray)
 constexpr int REC_X = 0;      // x[4]   position at the start of the last step
@@ -178,18 +178,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 
     int state = L_FREE;
     bool exhausted = false;
-    R x[4], u[4], k[7][4];  // k[l] = acceleration at stage l+1 (k[0] is the FSAL slot)
+    R x[4], u[4], k0[4];  // loop-carried ray state: position, velocity, FSAL acceleration u̇(x, u)
     R t = t0, dt = R(0), ps = R(0);
     float lq = lq_init;
     uint64_t idx = 0;
     uint32_t nacc = 0, nrej = 0, nacc0 = 0, c_maxnear = 0, safe_streak = 0;
     uint32_t c_rays = 0, c_acc = 0, c_rej = 0, c_ev = 0, c_int = 0, c_nf = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        x[q] = R(1); u[q] = R(0);
-#pragma unroll
-        for (int s = 0; s < 7; s++) k[s][q] = R(0);
-    }
+    for (int q = 0; q < 4; q++) { x[q] = R(1); u[q] = R(0); k0[q] = R(0); }
 
     // wave-local slice of the global ray queue: ids [q_next, q_end) were popped with ONE atomic and are dealt to lanes as
     // they free up.  (One device-scope atomic per ray on a single word saturates at ~90 M/s chip-wide — measured: it
@@ -200,6 +196,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     const unsigned long long qchunk = A.queue_chunk;
     for (;;) {
         // ================= refill: free lanes take ray ids from the wave's slice of the queue ====================
+        const bool resume = (MODE == MODE_NEAR || A.pick_flag != 0u);
         unsigned long long m_need = __ballot(state == L_FREE);
         while (m_need != 0ull) {
             if (q_next == q_end) {
@@ -211,7 +208,12 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 first_pop = false;
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(queue, amount);
-                base = __shfl(base, 0, 64);
+                // wave-uniform BY CONSTRUCTION and, through readfirstlane, also for the compiler: q_next / q_end /
+                // exhausted then live in SGPRs and the loop's exits are scalar branches.  (With a __shfl the compiler
+                // had to treat the loop exit as divergent and copied all 12 loop-carried f64 state registers to
+                // shadow registers and back at the latch: 41 v_mov per iteration, 4.7 % of the kernel's instructions.)
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                       (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
                 q_next = base < total ? base : total;
                 q_end = (base + amount) < total ? (base + amount) : total;
                 if (base + amount >= total) exhausted = true;
@@ -221,38 +223,50 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             const uint32_t rank = mask_rank(m_need, lane);
             if (state == L_FREE && rank < avail) {
                 const uint64_t w = q_next + rank;
-                // Every ray starts from a 16-scalar record {x, u, u̇, t, dt, sign(min_distance), log2 q_old}: written by
-                // prepare_kernel for a fresh ray (u̇(y0) and the Hairer initial dt), by the FAR pass for a ray it hands
-                // over.  A resuming pass (NEAR, hand-back rounds) visits every ray id and picks up the rays flagged for it.
-                const bool resume = (MODE == MODE_NEAR || A.pick_flag != 0u);
+                // A resuming pass (NEAR, hand-back rounds) visits every ray id and picks up the rays flagged for it.
                 const uint64_t id = resume ? w : (A.order ? (uint64_t)A.order[w] : w);
                 if (!resume || A.meta[id * 3 + 2] == A.pick_flag) {
                     idx = id;
-                    const R* hd = A.hand + id * HAND_W;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { x[q] = hd[q]; u[q] = hd[4 + q]; k[0][q] = hd[8 + q]; }
-                    t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
-                    nacc = resume ? A.meta[id * 3] : 0u;
-                    nrej = resume ? A.meta[id * 3 + 1] : 0u;
-                    nacc0 = nacc;
-                    safe_streak = 0;
-                    state = L_RUN;
+                    state = L_TAKEN;
                 }
             }
             const uint32_t cnt = (uint32_t)__builtin_popcountll(m_need);
             q_next += (cnt < avail) ? cnt : avail;
             m_need = __ballot(state == L_FREE);
         }
-        if (exhausted && q_next == q_end && state == L_FREE) state = L_EXIT;
-        if (__ballot(state == L_RUN) == 0ull) {
-            if (exhausted && q_next == q_end) break;
-            continue;
+        // Every ray starts from a 16-scalar record {x, u, u̇, t, dt, sign(min_distance), log2 q_old}: written by
+        // prepare_kernel for a fresh ray (u̇(y0) and the Hairer initial dt), by the FAR pass for a ray it hands over.
+        // (The loads, like the commit at the end of the step, are a plain conditional assignment at the top level of the
+        // loop body: assigned inside nested divergent regions, the 12 f64 state registers were shadow-copied at every
+        // region entry, at the loop latch and at the loop header — 85 v_mov per iteration.)
+        if (state == L_TAKEN) {
+            const R* hd = A.hand + idx * HAND_W;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { x[q] = hd[q]; u[q] = hd[4 + q]; k0[q] = hd[8 + q]; }
+            t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
+            nacc = resume ? A.meta[idx * 3] : 0u;
+            nrej = resume ? A.meta[idx * 3 + 1] : 0u;
+            nacc0 = nacc;
+            safe_streak = 0;
+            state = L_RUN;
         }
+        if (exhausted && q_next == q_end && state == L_FREE) state = L_EXIT;
+        // The refill loop above only gives up when the queue is exhausted, so a wave without a running lane is done.
+        // (One exit and one back-edge: a `continue` here was a second latch path and cost a round trip of phi copies.)
+        if (__ballot(state == L_RUN) == 0ull) break;
 
         // ================= one Tsit5 attempt per runnable lane ====================================================
-        if (state == L_RUN) {
-            dt = rmin(dt, t1 - t);
-            const R h = dt;
+        // The seven stages run in UNIFORM control flow: a lane without a ray computes along with h = 0 on whatever
+        // state it holds (a VALU instruction costs the same with 1 or 64 lanes active) and nothing it computes is
+        // used.  Only the decisions and side effects below are per-lane.
+        const bool run = (state == L_RUN);
+        bool commit = false;
+        R xn[4], un[4], k[7][4];  // k[l] = acceleration at stage l+1 (k[0] is the FSAL slot, k[6] the next one)
+#pragma unroll
+        for (int q = 0; q < 4; q++) k[0][q] = k0[q];
+        {
+            if (run) dt = rmin(dt, t1 - t);
+            const R h = run ? dt : R(0);
             const R h2 = h * h;
             R X[3], U[4];
             // ---- stage 2 -------------------------------------------------------------------------------------
@@ -301,7 +315,6 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             N::A2[5][0] * k[0][1 + q]))), rfma(h * N::c[5], u[1 + q], x[1 + q]));
             accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[5]);
             // ---- stage 7 = the step result (FSAL) ----------------------------------------------------------------
-            R xn[4], un[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 un[q] = rfma(h, rfma(N::a[6][5], k[5][q], rfma(N::a[6][4], k[4][q], rfma(N::a[6][3], k[3][q],
@@ -311,7 +324,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             }
             accel<R, METRIC, SPIN, true>(xn + 1, un, M, aspin, k[6]);
 
-            {
+            if (run) {
                 // ---- embedded error, residual norm in f32 ----------------------------------------
                 float acc = 0.0f;
 #pragma unroll
@@ -327,7 +340,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 }
                 const float EEst = __builtin_sqrtf(acc * 0.125f);
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
-                bool is_event = false, is_interior = false, commit = false, handed = false, hand_back = false;
+                bool is_event = false, is_interior = false, handed = false, hand_back = false;
                 R top = R(0);
                 R cc[4][4];  // position polynomial of this step (set when the step is accepted; read only on events)
                 if (EEst != EEst) {
@@ -524,23 +537,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         }
                     }
                 }
-                // ---- commit the accepted step.  Event lanes are done with their state (re-filled next iteration), so only a
-                // REJECTED (or NaN) lane must keep its old state: rare (no rejection in the reference scenes), hence a
-                // wave-uniform fast path of 12 plain register moves instead of 24 selects.
-                if (__ballot(!commit && !is_event && !handed) == 0ull) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k[0][q] = k[6][q]; }
-                } else if (commit) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k[0][q] = k[6][q]; }
-                }
+                // (the accepted step is committed AFTER this region, at the top level of the loop body)
                 if (handed) state = L_FREE;
                 if (hand_back) {
                     // NEAR -> next round's FAR pass: the ray has been out of every object's reach for two steps; its
                     // committed state goes back into the hand-over record and the cheaper pass carries it on
                     R* hd = A.hand + idx * HAND_W;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k[0][q]; }
+                    for (int q = 0; q < 4; q++) { hd[q] = xn[q]; hd[4 + q] = un[q]; hd[8 + q] = k[6][q]; }
                     hd[12] = t; hd[13] = dt; hd[14] = ps; hd[15] = (R)lq;
                     A.meta[idx * 3] = nacc; A.meta[idx * 3 + 1] = nrej; A.meta[idx * 3 + 2] = META_HANDBACK;
                     if (MODE == MODE_NEAR) c_maxnear = c_maxnear > (nacc - nacc0) ? c_maxnear : (nacc - nacc0);
@@ -551,14 +555,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         // ended without an event (λ1, step cap, dt underflow, NaN): the state as it stands, θ = 0
                         R* rec = A.rec + idx * (uint64_t)A.recw;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) rec[REC_X + q] = x[q];
+                        for (int q = 0; q < 4; q++) rec[REC_X + q] = commit ? xn[q] : x[q];
                         rec[REC_PS] = R(0);
                         rec[REC_TOP] = R(0);
                         rec[REC_T] = t;
                         rec[REC_H] = R(0);
                         if (want_state) {
 #pragma unroll
-                            for (int q = 0; q < 4; q++) rec[REC_U + q] = u[q];
+                            for (int q = 0; q < 4; q++) rec[REC_U + q] = commit ? un[q] : u[q];
                         }
                     }
                     uint32_t* mt = A.meta + idx * 3;
@@ -571,6 +575,11 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                     state = L_FREE;
                 }
             }
+        }
+        // ---- commit the accepted step: the only place (besides the refill) where the ray state is assigned ------------
+        if (commit) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k0[q] = k[6][q]; }
         }
     }
     if (A.counters) {
