@@ -265,6 +265,7 @@ static int ensure_device() {
 //   RTGR_CHUNK         rays per pipeline chunk (default 2^24); bounds the library-owned workspace
 //   RTGR_SPLIT=0       one FULL integrate pass instead of the FAR + NEAR pair
 //   RTGR_ORDER=0       keep the natural ray order (default: longest-expected-first, see rtgr_persistent.hpp)
+//   RTGR_FAR4=0/1      force the 3- / 4-waves-per-SIMD instantiation of the a = 0 FAR pass (default: by launch size)
 static int g_num_cu = 0;
 static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per launch in flight
 static unsigned g_queue_next = 0;
@@ -344,8 +345,17 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
             if (r > 0) P.order = nullptr;
             { KernelTimer tm(st, 1);
               if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.far, grid(0).x, 64, st, P));
-              else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
-                                      grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, P); }
+              else {
+                  bool four = false;
+                  if constexpr (sizeof(R) == 8 && !SPIN && METRIC < RTGR_GENERIC_BASE && METRIC != RTGR_MINKOWSKI) {
+                      // >= ~48 rays per lane of a 4-waves/SIMD grid: see integrate_far4_kernel  (RTGR_FAR4=0/1 forces)
+                      const int force = env_int("RTGR_FAR4", -1);
+                      four = force >= 0 ? force != 0 : P.n >= (uint64_t)g_num_cu * 16 * 64 * 48;
+                      if (four) hipLaunchKernelGGL((integrate_far4_kernel<R, METRIC>), grid(4), dim3(64), 0, st, P);
+                  }
+                  if (!four) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
+                                                grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4), dim3(64), 0, st, P);
+              } }
             P.pick_flag = META_HANDED;
             P.allow_handback = (r + 1 < rounds) ? 1u : 0u;
             { KernelTimer tm(st, 3);

@@ -570,8 +570,20 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                     mt[1] = nrej;
                     mt[2] = done | (is_interior ? 0x100u : 0u);
                     if (MODE == MODE_NEAR) c_maxnear = c_maxnear > (nacc - nacc0) ? c_maxnear : (nacc - nacc0);
-                    c_rays += 1; c_acc += nacc; c_rej += nrej;
-                    c_ev += is_event; c_int += is_interior; c_nf += (done >= RTGR_RAY_MAXSTEPS);
+                    if constexpr (MODE == MODE_FAR) {
+                        // a ray ENDING in the FAR pass is rare (λ1, step cap, NaN — never an event): count it with
+                        // atomics of its own and keep the four accumulator registers out of the 3-waves/SIMD kernel
+                        if (A.counters) {
+                            atomicAdd(&A.counters[0], 1ull);
+                            atomicAdd(&A.counters[1], (unsigned long long)nacc);
+                            atomicAdd(&A.counters[2], (unsigned long long)nrej);
+                            atomicAdd(&A.counters[3], 6ull * (nacc + nrej) + 2ull);
+                            if (done >= RTGR_RAY_MAXSTEPS) atomicAdd(&A.counters[6], 1ull);
+                        }
+                    } else {
+                        c_rays += 1; c_acc += nacc; c_rej += nrej;
+                        c_ev += is_event; c_int += is_interior; c_nf += (done >= RTGR_RAY_MAXSTEPS);
+                    }
                     state = L_FREE;
                 }
             }
@@ -582,7 +594,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k0[q] = k[6][q]; }
         }
     }
-    if (A.counters) {
+    if (MODE != MODE_FAR && A.counters) {
         const unsigned long long s0 = wave_sum(c_rays), s1 = wave_sum(c_acc), s2 = wave_sum(c_rej),
                                  s4 = wave_sum(c_ev), s5 = wave_sum(c_int), s6 = wave_sum(c_nf);
         if (lane == 0) {
@@ -608,6 +620,14 @@ __global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? RTGR_WAVES_PER_SI
                                  : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4) : RTGR_WAVES_PER_SIMD))
 void integrate_kernel(const IntegrateArgs<R> A) {
     integrate_body<R, METRIC, SPIN, NPTS10, MODE>(A);
+}
+
+// The a = 0 FAR pass once more at FOUR waves per SIMD (128 registers: 28 B/lane of scratch for KS_REF, none for KS_TRUE).
+// Pays on big launches only — measured 84.5 vs 85.6 ms at 16.8 M rays, but 8.5 vs 7.3 ms at 1 M rays, where 4096
+// persistent waves leave 4 rays per lane and the tail dominates; with spin (92 B/lane of scratch) it loses everywhere.
+template <class R, int METRIC>
+__global__ __launch_bounds__(64, 4) void integrate_far4_kernel(const IntegrateArgs<R> A) {
+    integrate_body<R, METRIC, false, true, MODE_FAR>(A);
 }
 
 // Ray set-up, one thread per ray: u̇(y0), the Hairer initial step (d0, d1, one Euler probe, d2; the

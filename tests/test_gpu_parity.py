@@ -334,6 +334,24 @@ def test_far_near_split_is_bit_identical_to_full_scan(lib):
         assert wrap_aware_rgb_err(a["rgb"][:, same], c["rgb"][:, same], a["hit"][same]) <= RGB_TOL
 
 
+def test_four_waves_per_simd_far_variant_is_bit_identical(lib):
+    """Launches of >= 12.6 M rays run the a = 0 FAR pass from a second instantiation at 4 waves/SIMD (128 registers,
+    some scratch).  Same body, same results: forced on (RTGR_FAR4=1) and off at a size the tests can afford."""
+    for name in ("ks_ref0", "ks_true0"):
+        sc, cam = scene_variant(name)
+        opt = rt.solver_defaults()
+        res = {}
+        for force in ("0", "1"):
+            os.environ["RTGR_FAR4"] = force
+            try:
+                res[force] = hip_trace(lib, sc, opt, 200, 160, cam=cam)
+            finally:
+                del os.environ["RTGR_FAR4"]
+        for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            assert np.array_equal(res["0"][k], res["1"][k]), (name, k)
+        assert res["0"]["counters"] == res["1"]["counters"]
+
+
 def test_interp_points_other_than_10_use_the_generic_scan(lib):
     """interp_points != 10 takes the runtime-θ scan (FULL pass only); compare with the oracle at 4 and 25 points."""
     sc, cam = example(2)
