@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in sorted(glob.glob(d + "/pmc_*/*/*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0][-60:]
-        if "integrate_kernel" in k or "resolve_kernel" in k or "trace_kernel" in k or "canvas_kernel" in k:
+        if "integrate_kernel" in k or "integrate_far4_kernel" in k or "prepare_kernel" in k or "resolve_kernel" in k or "trace_kernel" in k or "canvas_kernel" in k:
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             agg[k]["_vgpr"] = float(row.get("VGPR_Count") or 0)
             agg[k]["_scratch"] = float(row.get("Scratch_Size") or 0)
