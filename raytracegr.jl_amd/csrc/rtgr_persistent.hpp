@@ -1,5 +1,5 @@
 // rtgr_persistent.hpp — the production trace pipeline:
-//     canvas -> [order] -> integrate<FAR> -> integrate<NEAR> -> resolve          (rtgr_hip.hip: launch_trace)
+//     canvas -> [order] -> prepare -> integrate<FAR> -> integrate<NEAR> -> resolve   (rtgr_hip.hip: launch_trace)
 //
 // Why a pipeline instead of one loop per ray (the simple tile kernel in rtgr_hip.hip keeps that shape):
 //   * rays need 27…991 Tsit5 step attempts inside one image; a wave that owns 64 fixed rays idles until
