@@ -341,6 +341,7 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
         IntegrateArgs<R> P = IA;
         for (int r = 0; r < rounds; r++) {
             P.ctrl = IA.ctrl + 2 * r;
+            P.queue_chunk = IA.queue_chunk;
             P.pick_flag = r == 0 ? 0u : META_HANDBACK;
             if (r > 0) P.order = nullptr;
             { KernelTimer tm(st, 1);
@@ -358,6 +359,15 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
               } }
             P.pick_flag = META_HANDED;
             P.allow_handback = (r + 1 < rounds) ? 1u : 0u;
+            {   // The NEAR pass visits EVERY ray id, and its rays last ~6 steps: all its waves pop at the same time and
+                // keep popping, so the device-scope atomic on the queue head (~90 M/s on one word) is what bounds it when
+                // the chunks are small — measured 0.8 ms for 2.1 M rays at 42 ids per pop (50 k atomics), also for a
+                // hand-back pass that picks up almost nothing.  So: 1/8 of a wave's share per pop, within [64, 256]
+                // (sweep at 2.1 / 4.2 / 16.8 M rays: best at 64-128 / 128-256 / 256; 1024 parks stragglers: +30 %).
+                const uint64_t share = P.n / ((uint64_t)grid(RTGR_WAVES_PER_SIMD).x * 8 + 1);
+                const uint64_t nc = share < 64 ? 64 : (share > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : share);
+                P.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK_NEAR", (int)nc);
+            }
             { KernelTimer tm(st, 3);
               if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.near, grid(0).x, 64, st, P));
               else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, P); }
