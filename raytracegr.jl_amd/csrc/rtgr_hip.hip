@@ -349,9 +349,11 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
               else {
                   bool four = false;
                   if constexpr (sizeof(R) == 8 && !SPIN && METRIC < RTGR_GENERIC_BASE && METRIC != RTGR_MINKOWSKI) {
-                      // >= ~48 rays per lane of a 4-waves/SIMD grid: see integrate_far4_kernel  (RTGR_FAR4=0/1 forces)
+                      // >= 24 rays per lane of a 4-waves/SIMD grid (6.3 M rays): see integrate_far4_kernel.  Measured
+                      // 3 vs 4 waves: 4.2 M rays 22.3 / 22.5 ms, 8.4 M 44.1 / 43.3, 12.2 M 63.4 / 62.6, 16.8 M 85.6 / 84.5.
+                      // (RTGR_FAR4=0/1 forces)
                       const int force = env_int("RTGR_FAR4", -1);
-                      four = force >= 0 ? force != 0 : P.n >= (uint64_t)g_num_cu * 16 * 64 * 48;
+                      four = force >= 0 ? force != 0 : P.n >= (uint64_t)g_num_cu * 16 * 64 * 24;
                       if (four) hipLaunchKernelGGL((integrate_far4_kernel<R, METRIC>), grid(4), dim3(64), 0, st, P);
                   }
                   if (!four) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),

@@ -335,7 +335,7 @@ def test_far_near_split_is_bit_identical_to_full_scan(lib):
 
 
 def test_four_waves_per_simd_far_variant_is_bit_identical(lib):
-    """Launches of >= 12.6 M rays run the a = 0 FAR pass from a second instantiation at 4 waves/SIMD (128 registers,
+    """Launches of >= 6.3 M rays run the a = 0 FAR pass from a second instantiation at 4 waves/SIMD (128 registers,
     some scratch).  Same body, same results: forced on (RTGR_FAR4=1) and off at a size the tests can afford."""
     for name in ("ks_ref0", "ks_true0"):
         sc, cam = scene_variant(name)
