@@ -259,7 +259,7 @@ static int ensure_device() {
 }
 
 // ---- launch policy ---------------------------------------------------------------------------------------------
-// Default: canvas -> integrate (persistent waves) -> resolve.  RTGR_KERNEL=tile selects the simple tile-per-wave
+// Default: prepare -> integrate FAR / NEAR (persistent waves) -> resolve.  RTGR_KERNEL=tile selects the simple tile-per-wave
 // kernel (kept as an independent formulation for A/B and cross-checks).  Tunables (experiments only):
 //   RTGR_WAVES_PER_CU  resident waves per CU of the integrate kernel (default 8 = 2 per SIMD)
 //   RTGR_CHUNK         rays per pipeline chunk (default 2^24); bounds the library-owned workspace
@@ -316,11 +316,10 @@ static int ensure_workspace(size_t bytes) {
     return RTGR_OK;
 }
 template <class R>
-static size_t workspace_bytes(uint64_t rays, bool with_state, bool with_canvas) {
+static size_t workspace_bytes(uint64_t rays, bool with_state) {
     const int recw = with_state ? REC_W_STATE : REC_W;
     return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
-           align256(rays * HAND_W * sizeof(R)) + align256(rays * sizeof(uint32_t)) + align256(rays) + 4096 +
-           (with_canvas ? align256(rays * 8 * sizeof(R)) : 0);
+           align256(rays * HAND_W * sizeof(R)) + align256(rays * sizeof(uint32_t)) + align256(rays) + 4096;
 }
 
 template <class R, int METRIC, bool SPIN>
@@ -394,8 +393,8 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     }
     const uint64_t n = A.ni * A.nrows;
     const uint64_t chunk = n < chunk_rays() ? n : chunk_rays();
-    const bool with_state = A.state_end != nullptr, with_canvas = A.state0 == nullptr;
-    int rc = ensure_workspace(workspace_bytes<R>(chunk, with_state, with_canvas));
+    const bool with_state = A.state_end != nullptr;
+    int rc = ensure_workspace(workspace_bytes<R>(chunk, with_state));
     if (rc) return rc;
     const int recw = with_state ? REC_W_STATE : REC_W;
     char* base = (char*)g_ws;
@@ -411,45 +410,35 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     cur += align256(chunk);
     uint32_t* hist = (uint32_t*)cur;  // 256 bins + 256 running offsets
     cur += 4096;
-    R* gen = (R*)cur;
     // longest-expected-first queue order: pays off when a lane gets few rays (see rtgr_persistent.hpp); RTGR_ORDER=0/1 forces
     const int order_mode = env_int("RTGR_ORDER", -1);
     const bool split = env_int("RTGR_SPLIT", sizeof(R) == 8 ? 1 : 0) != 0;  // Float32 rays last ~20 steps: one FULL pass wins (measured 5-6 %)
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
-        const R* s0 = A.state0 ? A.state0 + off * 8 : gen;
-        if (with_canvas) {
-            KernelTimer tm(st, 0);
-            if constexpr (METRIC == RTGR_UM)
-                HIP_TRY(launch_module(g_user.canvas, (unsigned)((m + 255) / 256), 256, st, A.sc, A.cam, A.ni, A.nj, A.j0,
-                                      A.jstride, off, m, gen));
-            else
-                hipLaunchKernelGGL(canvas_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, A.sc, A.cam, A.ni,
-                                   A.nj, A.j0, A.jstride, off, m, gen);
-        }
+        const R* s0 = A.state0 ? A.state0 + off * 8 : nullptr;  // null: prepare_kernel generates the camera rays
         const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 &&
                                (order_mode != 0);
         unsigned long long* q = g_queue_pool + 8 * (g_queue_next++ % RTGR_QUEUE_SLOTS);
         hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, st, q, use_order ? hist : (uint32_t*)nullptr);
-        if (use_order) {
-            KernelTimer tm(st, 0);
-            hipLaunchKernelGGL(order_key_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, s0, m, keys, hist);
-            hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, st, hist, hist + 256);
-            hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys, m, hist + 256, order);
-        }
         IntegrateArgs<R> IA;
         IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.order = use_order ? order : nullptr; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
         IA.hand = hand; IA.ctrl = q; IA.counters = A.counters; IA.pick_flag = 0; IA.allow_handback = 0;
+        IA.cam = A.cam; IA.ni = A.ni; IA.nj = A.nj; IA.j0 = A.j0; IA.jstride = A.jstride; IA.first = off;
+        IA.keys = use_order ? keys : nullptr; IA.hist = hist;
         {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [8, RTGR_QUEUE_CHUNK]
             const uint64_t per_wave = m / ((uint64_t)g_num_cu * 12 + 1);
             uint64_t qc = per_wave / 16;
             qc = qc < 8 ? 8 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
             IA.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK", (int)qc);
         }
-        {   // ray set-up: u̇(y0), initial dt, event sign -> start records
+        {   // ray set-up: camera ray (or the caller's state), ordering key, u̇(y0), initial dt, event sign -> start records
             KernelTimer tm(st, 0);
             if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.prepare, (unsigned)((m + 255) / 256), 256, st, IA));
             else hipLaunchKernelGGL((prepare_kernel<R, METRIC, SPIN>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, IA);
+            if (use_order) {
+                hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, st, hist, hist + 256);
+                hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys, m, hist + 256, order);
+            }
         }
         rc = launch_integrate<R, METRIC, SPIN>(IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
         if (rc) return rc;
@@ -690,8 +679,8 @@ int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32) {
     int rc = ensure_device();
     if (rc) return rc;
     const uint64_t chunk = n_rays < chunk_rays() ? n_rays : chunk_rays();
-    return ensure_workspace(is_f32 ? workspace_bytes<float>(chunk, with_state_end != 0, true)
-                                   : workspace_bytes<double>(chunk, with_state_end != 0, true));
+    return ensure_workspace(is_f32 ? workspace_bytes<float>(chunk, with_state_end != 0)
+                                   : workspace_bytes<double>(chunk, with_state_end != 0));
 }
 
 int rtgr_trace_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* d_state0,

@@ -1,5 +1,6 @@
 // rtgr_persistent.hpp — the production trace pipeline:
-//     canvas -> [order] -> prepare -> integrate<FAR> -> integrate<NEAR> -> resolve   (rtgr_hip.hip: launch_trace)
+//     prepare (camera ray, queue key, u̇(y0), initial dt) -> [order scan/scatter] -> integrate<FAR> -> integrate<NEAR>
+//     -> resolve                                                                   (rtgr_hip.hip: launch_trace)
 //
 // Why a pipeline instead of one loop per ray (the simple tile kernel in rtgr_hip.hip keeps that shape):
 //   * rays need 27…991 Tsit5 step attempts inside one image; a wave that owns 64 fixed rays idles until
@@ -94,6 +95,11 @@ struct IntegrateArgs {
     uint32_t allow_handback;  // NEAR: hand a ray back to the next round's FAR pass once it has left every object's reach
     uint32_t queue_chunk;   // ray ids popped per atomic: <= RTGR_QUEUE_CHUNK, smaller when a wave gets few rays in total
     unsigned long long* counters;
+    // prepare_kernel only: where the rays come from (state0 == null: the camera) and the ordering key outputs
+    DevCamera<R> cam;
+    uint64_t ni, nj, j0, jstride, first;  // ray w of the chunk is pixel idx = first + w: i = idx % ni, j = j0 + (idx / ni) * jstride
+    uint8_t* keys;          // n ordering keys (or null: natural order)
+    uint32_t* hist;         // 256-bin histogram of the keys
 };
 
 // Integrate passes.  FULL: every accepted step runs the ContinuousCallback scan (8 interior samples + end point).
@@ -630,20 +636,36 @@ __global__ __launch_bounds__(64, 4) void integrate_far4_kernel(const IntegrateAr
     integrate_body<R, METRIC, false, true, MODE_FAR>(A);
 }
 
-// Ray set-up, one thread per ray: u̇(y0), the Hairer initial step (d0, d1, one Euler probe, d2; the
+// Ray set-up, one thread per ray: the camera ray itself when the caller gave a camera instead of states (make_canvas,
+// :457-478 — the state never goes through HBM), its key for the longest-first queue (see "ray ordering" below), u̇(y0), the Hairer initial step (d0, d1, one Euler probe, d2; the
 // norms in f32 like the controller's), sign(min_distance(y0)) for the ContinuousCallback (App. B.4) and the controller's
 // q_old = 1e-4 (App. B.2) -> the ray's 16-scalar start record.  2 RHS evaluations per ray (counted by the integrate
 // kernel's counters).  A body function for the same reason as integrate_body.
+template <class R>
+RTGR_DEV void order_key(const R x4[4], const R u4[4], bool valid, uint64_t w, uint8_t* keys, uint32_t* hist);
+
 template <class R, int METRIC, bool SPIN>
 RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= A.n) return;
+    const bool valid = w < A.n;
     const R M = A.sc.M, aspin = A.sc.a;
     const R reltol = A.opt.reltol, abstol = A.opt.abstol, dtmax = A.opt.lambda1 - A.opt.lambda0;
-    R x[4], u[4], k1[4], k2[4];
-    const R* s0 = A.state0 + w * 8;
+    R x[4] = {R(0), R(1), R(0), R(0)}, u[4] = {R(-1), R(0), R(1), R(0)}, k1[4], k2[4];
+    if (valid) {
+        if (A.state0) {
+            const R* s0 = A.state0 + w * 8;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { x[q] = s0[q]; u[q] = s0[4 + q]; }
+            for (int q = 0; q < 4; q++) { x[q] = s0[q]; u[q] = s0[4 + q]; }
+        } else {  // make_canvas (src/RayTraceGR.jl:457-478) for this pixel, straight into registers
+            R s[8];
+            const uint64_t idx = A.first + w;
+            make_pixel<R>(A.sc, A.cam, A.ni, A.nj, idx % A.ni, A.j0 + (idx / A.ni) * A.jstride, s);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { x[q] = s[q]; u[q] = s[4 + q]; }
+        }
+    }
+    if (A.keys) order_key<R>(x, u, valid, w, A.keys, A.hist);  // block-wide (LDS histogram): before any early exit
+    if (!valid) return;
     accel<R, METRIC, SPIN, true>(x + 1, u, M, aspin, k1);      // f0 = (u, k1)
     float acc0 = 0.0f, acc1 = 0.0f;
     float iskx[4], isku[4];
@@ -709,15 +731,13 @@ __global__ __launch_bounds__(256) void reset_kernel(unsigned long long* ctrl, ui
 // makespan over ideal with that order: 1.02-1.03.  The order only changes WHEN a ray is integrated, never its result.
 // ---------------------------------------------------------------------------------------------------------------------
 template <class R>
-__global__ __launch_bounds__(256) void order_key_kernel(const R* state0, uint64_t n, uint8_t* keys, uint32_t* hist) {
-    __shared__ uint32_t lh[256];
+RTGR_DEV void order_key(const R x4[4], const R u4[4], bool valid, uint64_t w, uint8_t* keys, uint32_t* hist) {
+    __shared__ uint32_t lh[256];  // called by every thread of a 256-thread block (prepare_kernel)
     lh[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t b = 0xffffffffu;
-    if (w < n) {
-        const R* s = state0 + w * 8;
-        const R x = s[1], y = s[2], z = s[3], ux = s[5], uy = s[6], uz = s[7];
+    if (valid) {
+        const R x = x4[1], y = x4[2], z = x4[3], ux = u4[1], uy = u4[2], uz = u4[3];
         const R xx = x * x + y * y + z * z, uu = ux * ux + uy * uy + uz * uz, xu = x * ux + y * uy + z * uz;
         float sin2 = 1.0f;
         if (xu < R(0) && xx > R(0) && uu > R(0)) sin2 = fmaxf(0.0f, 1.0f - (float)(xu * xu / (xx * uu)));
@@ -725,11 +745,11 @@ __global__ __launch_bounds__(256) void order_key_kernel(const R* state0, uint64_
         keys[w] = (uint8_t)b;
     }
     // neighbouring rays share a handful of buckets: one LDS atomic per distinct bucket per wave, not one per ray
-    unsigned long long todo = __ballot(w < n);
+    unsigned long long todo = __ballot(valid);
     while (todo != 0ull) {
         const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
         const uint32_t b0 = __shfl(b, (int)leader, 64);
-        const unsigned long long m = __ballot(w < n && b == b0);
+        const unsigned long long m = __ballot(valid && b == b0);
         if ((threadIdx.x & 63) == leader) atomicAdd(&lh[b0], (uint32_t)__builtin_popcountll(m));
         todo &= ~m;
     }
