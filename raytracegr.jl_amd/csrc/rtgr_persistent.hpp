@@ -813,8 +813,9 @@ RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th
 // the result is a point with g >= 0 within ~32 ulp of it — the reference's prevfloat(find_zero(...))
 // up to a few ulp (a 512-ulp window, 1e-13 in θ, for the rays whose distance is too noisy for that).  If the probes fail
 // (estimate was off) the loop simply continues on the tightened bracket; the bisection point `mid` guarantees progress.
-// What is left of the tail (0.3 % of the rays need 13-50 iterations) are brackets that contain a KINK of the min over
-// objects right next to the root — e.g. the plane's and the sky sphere's distances crossing over.
+// A tail is left: 0.3 % of the rays (ordinary sky-sphere and sphere hits) still need 13-50 iterations.  It is NOT the
+// kinks of the min over objects — finding each object's own root (smooth functions) left the tail as it was and cost
+// more per evaluation (measured, reverted).
 // -DRTGR_ROOT_STATS builds report the iteration count through lambda_end (tools/debug_root_iters.py).
 template <class R>
 RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R ps, R top, int* iters = nullptr) {
