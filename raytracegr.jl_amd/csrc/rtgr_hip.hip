@@ -894,6 +894,16 @@ int rtgr_user_metric_load(const char* code_object_path) {
 
 int rtgr_user_metric_loaded(void) { return g_user.module ? 1 : 0; }
 
+#ifdef RTGR_ROOT_STATS
+// debug builds only (tools/debug_root_iters.py): copy the head of the library workspace (the event records) to the host
+int rtgr_debug_workspace(void* dst, uint64_t bytes) {
+    if (!g_ws || bytes > g_ws_bytes) return fail(RTGR_ERR_BAD_ARG, "no workspace / too many bytes");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst, g_ws, bytes, hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+#endif
+
 int rtgr_quantize_device_f64(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, void* stream) {
     int rc = ensure_device();
     if (rc) return rc;

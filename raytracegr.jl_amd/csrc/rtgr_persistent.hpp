@@ -813,9 +813,7 @@ RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th
 // the result is a point with g >= 0 within ~32 ulp of it — the reference's prevfloat(find_zero(...))
 // up to a few ulp (a 512-ulp window, 1e-13 in θ, for the rays whose distance is too noisy for that).  If the probes fail
 // (estimate was off) the loop simply continues on the tightened bracket; the bisection point `mid` guarantees progress.
-// A tail is left: 0.3 % of the rays (ordinary sky-sphere and sphere hits) still need 13-50 iterations.  It is NOT the
-// kinks of the min over objects — finding each object's own root (smooth functions) left the tail as it was and cost
-// more per evaluation (measured, reverted).
+// (tools/debug_root_dump.py replays the finder on the host, with exact FMA emulation, from a dumped event record.)
 // -DRTGR_ROOT_STATS builds report the iteration count through lambda_end (tools/debug_root_iters.py).
 template <class R>
 RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R ps, R top, int* iters = nullptr) {
@@ -837,8 +835,14 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
         } else {
             const R fm = cond_poly<R>(sc, x0, c, mid) * ps;
             const R rad = rfma(fm, fm, -flo * fhi);  // > 0 since flo > 0 > fhi
-            R x4 = rfma((mid - lo) * fm, frsq<R>(rad), mid);
-            if (!(x4 > lo && x4 < hi)) x4 = mid;
+            // Ridders' estimate.  When one end of the bracket already sits on the root (|g(lo)| ~ 1e-17 after a lucky
+            // iterate) the formula returns that end itself: the point to EVALUATE is then the midpoint (progress), but the
+            // ESTIMATE is the end — without this distinction such rays never "settled" and bisected 45 more times
+            // (0.3 % of the rays, 13-50 iterations; their waves waited: 4 iterations per ray, 10.5 per wave).
+            const R xr = rfma((mid - lo) * fm, frsq<R>(rad), mid);
+            const bool inside = xr > lo && xr < hi;
+            const R x4 = inside ? xr : mid;
+            const R est = inside ? xr : (xr <= lo ? lo : (xr >= hi ? hi : mid));
             const R f4 = (x4 == mid) ? fm : cond_poly<R>(sc, x0, c, x4) * ps;
             // An exact zero is common (a plane at a representable time makes g vanish on a whole ulp-interval of θ):
             // "directly at zero" is an accepted result, so stop there.
@@ -855,9 +859,9 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
             // two successive estimates within 256 ulp: converged down to the rounding noise of the distance itself
             // (ulp of max(θ, top/16): the noise is absolute in θ — λ = t + hθ is what matters — so a root near θ = 0
             //  must not be chased to ITS ulp)
-            const R scale = rmax(x4, R(0.0625) * top);
-            const bool settled = RTGR_ROOT_SHORTCUT && (rabs(x4 - est_prev) <= R(256) * eps * scale);
-            est_prev = x4;
+            const R scale = rmax(est, R(0.0625) * top);
+            const bool settled = RTGR_ROOT_SHORTCUT && (rabs(est - est_prev) <= R(256) * eps * scale);
+            est_prev = est;
             if (settled && !done) {
                 // Verify the settled estimate two-sidedly: 16 ulp before and after; if the sign change is not in there
                 // (the distance is evaluated with a rounding noise of ~10 ulp of θ, which makes the estimates jitter and
@@ -867,7 +871,7 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
 #pragma unroll 1
                 for (int pass = 0; pass < 2 && !done; pass++) {
                     const R wd = (pass == 0 ? R(16) : R(512)) * eps;
-                    const R pm = rmax(rfma(-wd, scale, x4), lo), pp = rmin(rfma(wd, scale, x4), hi);
+                    const R pm = rmax(rfma(-wd, scale, est), lo), pp = rmin(rfma(wd, scale, est), hi);
                     const R fpm = (pm > lo) ? cond_poly<R>(sc, x0, c, pm) * ps : flo;
                     const R fpp = (pp < hi) ? cond_poly<R>(sc, x0, c, pp) * ps : fhi;
                     if (!(fpm < R(0)) && !(fpp > R(0))) {
