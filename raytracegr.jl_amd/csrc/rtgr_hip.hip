@@ -270,6 +270,9 @@ static int g_num_cu = 0;
 static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per launch in flight
 static unsigned g_queue_next = 0;
 constexpr unsigned RTGR_QUEUE_SLOTS = 256;
+#ifdef RTGR_ROOT_STATS
+static unsigned long long* g_dbg = nullptr;
+#endif
 static void* g_ws = nullptr;  // library-owned workspace (event records, per-ray meta, generated ray states)
 static size_t g_ws_bytes = 0;
 
@@ -319,7 +322,7 @@ template <class R>
 static size_t workspace_bytes(uint64_t rays, bool with_state) {
     const int recw = with_state ? REC_W_STATE : REC_W;
     return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
-           align256(rays * HAND_W * sizeof(R)) + align256(rays * sizeof(uint32_t)) + align256(rays) + 4096;
+           align256(rays * HAND_W * sizeof(R)) + 2 * align256(rays * sizeof(uint32_t)) + align256(rays) + 4096;
 }
 
 template <class R, int METRIC, bool SPIN>
@@ -336,11 +339,12 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
         // extra passes' own start-up and tails cost more than the NEAR tail they remove.  Each pass has its own queue
         // head (ctrl[0..7]).
         int rounds = env_int("RTGR_ROUNDS", 1);
-        rounds = rounds < 1 ? 1 : (rounds > 4 ? 4 : rounds);  // 2 queue heads per round, 8 per launch
+        rounds = rounds < 1 ? 1 : (rounds > 3 ? 3 : rounds);  // 2 queue heads per round; slot 6 is the early-list cursor
         IntegrateArgs<R> P = IA;
         for (int r = 0; r < rounds; r++) {
             P.ctrl = IA.ctrl + 2 * r;
             P.queue_chunk = IA.queue_chunk;
+            if (r > 0) P.early = nullptr;  // the early list is round 0's
             P.pick_flag = r == 0 ? 0u : META_HANDBACK;
             if (r > 0) P.order = nullptr;
             { KernelTimer tm(st, 1);
@@ -406,6 +410,8 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
     cur += align256(chunk * HAND_W * sizeof(R));
     uint32_t* order = (uint32_t*)cur;
     cur += align256(chunk * sizeof(uint32_t));
+    uint32_t* early = (uint32_t*)cur;
+    cur += align256(chunk * sizeof(uint32_t));
     uint8_t* keys = (uint8_t*)cur;
     cur += align256(chunk);
     uint32_t* hist = (uint32_t*)cur;  // 256 bins + 256 running offsets
@@ -425,6 +431,11 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         IA.hand = hand; IA.ctrl = q; IA.counters = A.counters; IA.pick_flag = 0; IA.allow_handback = 0;
         IA.cam = A.cam; IA.ni = A.ni; IA.nj = A.nj; IA.j0 = A.j0; IA.jstride = A.jstride; IA.first = off;
         IA.keys = use_order ? keys : nullptr; IA.hist = hist;
+        IA.early = early; IA.near_early = (uint32_t)env_int("RTGR_NEAR_EARLY", 64);  // 0: no early list
+        if (IA.near_early == 0u) IA.early = nullptr;
+#ifdef RTGR_ROOT_STATS
+        IA.dbg = g_dbg;
+#endif
         {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [8, RTGR_QUEUE_CHUNK]
             const uint64_t per_wave = m / ((uint64_t)g_num_cu * 12 + 1);
             uint64_t qc = per_wave / 16;
@@ -895,6 +906,9 @@ int rtgr_user_metric_load(const char* code_object_path) {
 int rtgr_user_metric_loaded(void) { return g_user.module ? 1 : 0; }
 
 #ifdef RTGR_ROOT_STATS
+// debug builds only: a device buffer the NEAR pass writes per-wave {start, end, iterations, rays} and per-ray stays into
+// (tools/debug_near_waves.py)
+int rtgr_debug_set_buffer(void* d_buf) { g_dbg = (unsigned long long*)d_buf; return RTGR_OK; }
 // debug builds only (tools/debug_root_iters.py): copy the head of the library workspace (the event records) to the host
 int rtgr_debug_workspace(void* dst, uint64_t bytes) {
     if (!g_ws || bytes > g_ws_bytes) return fail(RTGR_ERR_BAD_ARG, "no workspace / too many bytes");
