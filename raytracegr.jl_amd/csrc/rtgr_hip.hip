@@ -265,6 +265,8 @@ static int ensure_device() {
 //   RTGR_CHUNK         rays per pipeline chunk (default 2^24); bounds the library-owned workspace
 //   RTGR_SPLIT=0       one FULL integrate pass instead of the FAR + NEAR pair
 //   RTGR_ORDER=0       keep the natural ray order (default: longest-expected-first, see rtgr_persistent.hpp)
+//   RTGR_FAIR=s        time slice 2^s clocks of the priority rotation (0 = off; default 13 for 0.8-1.8 M rays, else off)
+//   RTGR_NEAR_EARLY=n  accepted steps at hand-over below which a ray is put on the NEAR pass's early list (default 64)
 //   RTGR_FAR4=0/1      force the 3- / 4-waves-per-SIMD instantiation of the a = 0 FAR pass (default: by launch size)
 static int g_num_cu = 0;
 static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per launch in flight
@@ -347,6 +349,9 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
             if (r > 0) P.early = nullptr;  // the early list is round 0's
             P.pick_flag = r == 0 ? 0u : META_HANDBACK;
             if (r > 0) P.order = nullptr;
+#ifdef RTGR_ROOT_STATS
+            { const char* dp = std::getenv("RTGR_DBG_PASS"); P.dbg = (dp && std::strcmp(dp, "far") == 0) ? g_dbg : nullptr; }
+#endif
             { KernelTimer tm(st, 1);
               if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.far, grid(0).x, 64, st, P));
               else {
@@ -373,6 +378,9 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
                 const uint64_t nc = share < 64 ? 64 : (share > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : share);
                 P.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK_NEAR", (int)nc);
             }
+#ifdef RTGR_ROOT_STATS
+            { const char* dp = std::getenv("RTGR_DBG_PASS"); P.dbg = (dp && std::strcmp(dp, "far") == 0) ? nullptr : g_dbg; }
+#endif
             { KernelTimer tm(st, 3);
               if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.near, grid(0).x, 64, st, P));
               else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, P); }
@@ -433,8 +441,13 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         IA.keys = use_order ? keys : nullptr; IA.hist = hist;
         IA.early = early; IA.near_early = (uint32_t)env_int("RTGR_NEAR_EARLY", 64);  // 0: no early list
         if (IA.near_early == 0u) IA.early = nullptr;
+        // priority rotation among the waves of a SIMD: pays when a lane gets only a few rays (see rtgr_persistent.hpp)
+        // measured FAR pass, off / on: 0.26 M rays 2.70 / 3.17 ms, 0.52 M 3.83 / 4.35, 1.05 M 7.05 / 6.29, 1.44 M 8.83 / 8.30,
+        // 2.1 M 11.59 / 11.59, 16.8 M 83.8 / 84.8 -> on for 4..9 rays per lane of the 3-waves/SIMD grid
+        const uint64_t lanes3 = (uint64_t)g_num_cu * 12 * 64;
+        IA.fair_shift = (uint32_t)env_int("RTGR_FAIR", (m >= 4 * lanes3 && m < 9 * lanes3) ? 13 : 0);
 #ifdef RTGR_ROOT_STATS
-        IA.dbg = g_dbg;
+        IA.dbg = nullptr;  // set per pass in launch_integrate (RTGR_DBG_PASS = far | near, default near)
 #endif
         {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [8, RTGR_QUEUE_CHUNK]
             const uint64_t per_wave = m / ((uint64_t)g_num_cu * 12 + 1);

@@ -104,6 +104,7 @@ struct IntegrateArgs {
     // cursor); the NEAR pass starts with those
     uint32_t* early;
     uint32_t near_early;
+    uint32_t fair_shift;    // != 0: the waves of a SIMD take turns at the top priority, slices of 2^fair_shift clocks
 #ifdef RTGR_ROOT_STATS
     unsigned long long* dbg;  // debug builds: per-wave {start, end, iterations, rays} of the NEAR pass, then per-ray stays
 #endif
@@ -234,7 +235,31 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     unsigned long long dbg_iters = 0, dbg_rays = 0;
 #endif
     const unsigned long long qchunk = A.queue_chunk;
+    // Wave ages.  A SIMD's arbiter issues from its OLDEST ready wave first, and a persistent grid never renews its
+    // waves: measured (tools/debug_near_waves.py, RTGR_DBG_PASS=far) 2.9 us per iteration for the first-launched
+    // third of the FAR pass's workgroups, 5-7 us for the second, 14 us for the youngest (40 us on the 4-wave grid).
+    // Throughput does not care, the tail of a small launch does: a young wave that holds rays of 950 steps needs
+    // the whole pass for them.  So (a) the head of the longest-first queue goes to the low workgroup indices (first
+    // pop by index), and (b) in small launches (fair_shift != 0) the waves of a SIMD take turns at the top priority
+    // (s_setprio, time slices of 2^fair_shift clocks): per-iteration times 4.1-7.3 us instead of 2.9-14.5, FAR pass
+    // 7.08 -> 6.31 ms at 1 M rays; no effect at 2-4 M rays, 1 % SLOWER at 16.8 M (where there is no tail to win and the
+    // rotation only disturbs the arbiter) and 15 % slower at <= 0.5 M (one or two rays per lane: the old waves should
+    // race through the longest ones), hence by launch size.  Serving the queue from both ends — old
+    // waves from the head, young ones from the tail — was worse at every size: the tail-servers then run
+    // shortest-first, the worst order inside a wave.
+    const uint32_t n_cls = (gridDim.x + 1023u) / 1024u;               // waves per SIMD of this launch (256 CUs x 4)
+    const uint32_t my_cls = blockIdx.x / 1024u;
+    const bool fair = A.fair_shift != 0u && n_cls > 1u;
     for (;;) {
+        if (fair) {
+            const uint32_t turn = (my_cls + (uint32_t)(__builtin_readcyclecounter() >> A.fair_shift)) % n_cls;
+            switch (turn) {  // s_setprio takes an immediate
+                case 0: __builtin_amdgcn_s_setprio(3); break;
+                case 1: __builtin_amdgcn_s_setprio(2); break;
+                case 2: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+            }
+        }
         // ================= refill: free lanes take ray ids from the wave's slice of the queue ====================
         const bool resume = (MODE == MODE_NEAR || A.pick_flag != 0u);
         unsigned long long m_need = __ballot(state == L_FREE);
@@ -244,10 +269,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 // The FIRST pop takes exactly the ids the wave can start right away: in longest-first order the head of
                 // the queue holds the long rays, and ids parked in a wave's slice would only start when one of its
                 // (equally long) first rays ends — simulated makespan 1978 vs 1213 steps at 5 rays per lane.
-                const unsigned long long amount = first_pop ? (unsigned long long)__builtin_popcountll(m_need) : qchunk;
-                first_pop = false;
+                // ... and it takes them by WAVE INDEX, not by atomic order: queue positions [64 b, 64 b + 64) go to
+                // workgroup b, the atomic head serves positions from 64 * gridDim.x on (see the note on wave ages below).
+                const unsigned long long first_span = 64ull * gridDim.x;
+                const unsigned long long amount = first_pop ? 64ull : qchunk;
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(queue, amount);
+                if (first_pop) base = 64ull * blockIdx.x;
+                else if (lane == 0) base = atomicAdd(queue, amount) + first_span;
+                first_pop = false;
                 // wave-uniform BY CONSTRUCTION and, through readfirstlane, also for the compiler: q_next / q_end /
                 // exhausted then live in SGPRs and the loop's exits are scalar branches.  (With a __shfl the compiler
                 // had to treat the loop exit as divergent and copied all 12 loop-carried f64 state registers to
@@ -672,7 +701,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         if (e_cnt != 0u) flush_early(A, early_buf, e_cnt, lane);
     }
 #ifdef RTGR_ROOT_STATS
-    if (MODE == MODE_NEAR && A.dbg && lane == 0) {
+    if (A.dbg && lane == 0) {
         unsigned long long* d = A.dbg + 4ull * blockIdx.x;
         d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = dbg_iters; d[3] = dbg_rays;
     }

@@ -1,4 +1,4 @@
-"""Per-wave timeline of the NEAR pass (needs RTGR_LIB=raytracegr.jl_amd/build/librtgr_hip_stats.so, -DRTGR_ROOT_STATS)."""
+"""Per-wave timeline of the NEAR pass (RTGR_DBG_PASS=far: of the FAR pass) (needs RTGR_LIB=raytracegr.jl_amd/build/librtgr_hip_stats.so, -DRTGR_ROOT_STATS)."""
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,8 +26,15 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
           f"wave end: p10 {np.percentile(en,10):.0f} median {np.median(en):.0f} p90 {np.percentile(en,90):.0f} p99 {np.percentile(en,99):.0f} max {en.max():.0f} us")
     print(f"   alive fraction {((en-st).sum()/len(d))/en.max():.2f}; iterations per wave: median {np.median(d[:,2]):.0f} max {d[:,2].max()}; rays per wave: median {np.median(d[:,3]):.0f} min {d[:,3].min()} max {d[:,3].max()}")
     print(f"   us per iteration (median wave): {np.median((en-st)/np.maximum(d[:,2],1)):.2f}")
+    upi = (en - st) / np.maximum(d[:, 2], 1)
+    nw = len(d)
+    print("   us/iteration by wave-id octile:", " ".join(f"{upi[k*nw//8:(k+1)*nw//8].mean():.2f}" for k in range(8)))
+    print("   iterations by wave-id octile:  ", " ".join(f"{d[k*nw//8:(k+1)*nw//8, 2].mean():.0f}" for k in range(8)))
+    print("   us/iteration percentiles: p1 %.2f p10 %.2f p50 %.2f p90 %.2f p99 %.2f" % tuple(np.percentile(upi, [1, 10, 50, 90, 99])))
     late = np.argsort(-en)[:5]
     for w in late: print(f"   late wave {w}: start {st[w]:.0f} end {en[w]:.0f} iters {d[w,2]} rays {d[w,3]}")
+    if os.environ.get("RTGR_DBG_PASS") == "far":
+        continue
     pr = buf[4 * 8192:4 * 8192 + n * n].cpu().numpy().view(np.uint32).reshape(-1, 2)
     n0, stay = pr[:, 0].astype(int), pr[:, 1].astype(int)
     print(f"   NEAR stay: mean {stay.mean():.2f} p50 {np.percentile(stay,50):.0f} p90 {np.percentile(stay,90):.0f} p99 {np.percentile(stay,99):.0f} p99.9 {np.percentile(stay,99.9):.0f} max {stay.max()}")
