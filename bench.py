@@ -209,8 +209,10 @@ def main():
         k_avg_s = (float(kms[1]) + float(kms[3])) / n_launch * 1e-3
         flop_launch = my_attempts * F_STEP + 2 * my_rays * F_RHS
         achieved = flop_launch / k_avg_s / 1e12
-        roof = {"bound": "valu_f64", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+        # fp32 runs (--dtype f32) are priced against the packed-f32 vector peak (v_pk_fma_f32: two FMAs per lane)
+        peak = FP64_VALU_PEAK_TFLOPS if a.dtype == "f64" else 2 * FP64_VALU_PEAK_TFLOPS
+        roof = {"bound": "valu_f64" if a.dtype == "f64" else "valu_f32", "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                 "kernel": "rtgr::integrate_kernel (FAR pass + NEAR pass)", "kernel_ms_avg": k_avg_s * 1e3,
                 "launches": n_launch, "far_pass_ms_avg": float(kms[1]) / n_launch,
                 "near_pass_ms_avg": float(kms[3]) / max(int(kln[3]), 1),
