@@ -228,6 +228,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     // hundred rays per wave, or the last chunks would unbalance the waves.)
     uint64_t q_next = 0, q_end = 0;
     bool first_pop = true;
+    bool first_early = true, early_done = false;  // NEAR: the early list's own cursor (ctrl[7])
     __shared__ uint32_t early_buf[RTGR_EARLY_BUF];  // one wave per workgroup: private to the wave (used by the FAR pass)
     uint32_t e_cnt = 0;                             // entries in early_buf (wave-uniform)
 #ifdef RTGR_ROOT_STATS
@@ -270,8 +271,23 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 // the queue holds the long rays, and ids parked in a wave's slice would only start when one of its
                 // (equally long) first rays ends — simulated makespan 1978 vs 1213 steps at 5 rays per lane.
                 // ... and it takes them by WAVE INDEX, not by atomic order: queue positions [64 b, 64 b + 64) go to
-                // workgroup b, the atomic head serves positions from 64 * gridDim.x on (see the note on wave ages below).
+                // workgroup b, the atomic head serves positions from 64 * gridDim.x on (see the note on wave ages above).
                 const unsigned long long first_span = 64ull * gridDim.x;
+                if (MODE == MODE_NEAR && !early_done) {
+                    // the early list has a head of its own and goes out 64 entries at a time: they are long-stayers, and
+                    // a 256-entry chunk would be four rounds of them one after the other in the same wave (measured:
+                    // the late waves of the pass were the ones that had popped such a chunk)
+                    unsigned long long eb = 0;
+                    if (first_early) eb = 64ull * blockIdx.x;
+                    else if (lane == 0) eb = atomicAdd(A.ctrl + 7, 64ull) + first_span;
+                    first_early = false;
+                    eb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(eb >> 32)) << 32) |
+                         (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)eb);
+                    if (eb >= n_early) { early_done = true; continue; }
+                    q_next = eb;
+                    q_end = (eb + 64ull) < n_early ? (eb + 64ull) : n_early;
+                    continue;
+                }
                 const unsigned long long amount = first_pop ? 64ull : qchunk;
                 unsigned long long base = 0;
                 if (first_pop) base = 64ull * blockIdx.x;
@@ -283,6 +299,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 // shadow registers and back at the latch: 41 v_mov per iteration, 4.7 % of the kernel's instructions.)
                 base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
                        (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
+                base += n_early;  // positions [0, n_early) are the early list's
                 q_next = base < total ? base : total;
                 q_end = (base + amount) < total ? (base + amount) : total;
                 if (base + amount >= total) exhausted = true;
