@@ -7,8 +7,10 @@ from __graft_entry__ import load_package
 rt = load_package()
 from raytracegr_jl_amd import sharded
 lib = rt._abi.load(); rt._abi.check(lib, lib.rtgr_init(-1))
-metric, objs, cam = rt.example2_scene()
-sc, opt, camera = rt.make_scene(metric, objs), rt.solver_defaults(), rt.make_camera(**cam)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from scenes import scene_variant
+sc, camera = scene_variant(os.environ.get("RTGR_VARIANT", "ks_ref0"))   # BASELINE scene variants, tests/scenes.py
+opt = rt.solver_defaults()
 NMAX = 4096 * 4096
 buf = torch.zeros(4 * 8192 + NMAX, dtype=torch.int64, device="cuda")   # per-wave records, then 2 x u32 per ray
 lib.rtgr_debug_set_buffer.argtypes = [C.c_void_p]
