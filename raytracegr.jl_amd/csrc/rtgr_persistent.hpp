@@ -477,7 +477,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
                                     const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
                                                      rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
-                                    const R mag = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, Rr * Rr)));
+                                    const R mag = rabs(D0) + R(2) * Rr * Rr;  // >= |X|² + R²: the operands' magnitude, for the floor
                                     safe = safe && (rabs(D0) > rfma(guard, B, R(256) * eps * mag));
                                 } else {
                                     R px = x[1], py = x[2];
