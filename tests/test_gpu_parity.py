@@ -352,6 +352,26 @@ def test_four_waves_per_simd_far_variant_is_bit_identical(lib):
         assert res["0"]["counters"] == res["1"]["counters"]
 
 
+def test_scheduling_knobs_do_not_change_results(lib):
+    """Queue order, chunk sizes, the NEAR pass's early list and the priority rotation decide WHEN and WHERE a ray is
+    integrated, never its result: every setting must reproduce the default's outputs bit for bit."""
+    sc, cam = scene_variant("ks_true0998_disk")   # long NEAR stays, early hand-overs, rejected steps near the disk
+    opt = rt.solver_defaults()
+    ref = hip_trace(lib, sc, opt, 256, 192, cam=cam)
+    for knobs in ({"RTGR_NEAR_EARLY": "0"}, {"RTGR_NEAR_EARLY": "8"}, {"RTGR_NEAR_EARLY": "100000"},
+                  {"RTGR_FAIR": "11"}, {"RTGR_FAIR": "0", "RTGR_ORDER": "0"}, {"RTGR_QCHUNK": "8", "RTGR_QCHUNK_NEAR": "64"},
+                  {"RTGR_WAVES_PER_CU": "4"}, {"RTGR_FAR4": "1", "RTGR_FAIR": "13"}):
+        os.environ.update(knobs)
+        try:
+            got = hip_trace(lib, sc, opt, 256, 192, cam=cam)
+        finally:
+            for k in knobs:
+                del os.environ[k]
+        for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            assert np.array_equal(ref[k], got[k]), (knobs, k)
+        assert ref["counters"] == got["counters"], knobs
+
+
 def test_interp_points_other_than_10_use_the_generic_scan(lib):
     """interp_points != 10 takes the runtime-θ scan (FULL pass only); compare with the oracle at 4 and 25 points."""
     sc, cam = example(2)
