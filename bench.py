@@ -224,6 +224,7 @@ def main():
                                          "resolve": float(kms[2]) / max(int(kln[2]), 1)},
                 "hbm_algorithmic_GBps": (my_rays * (132 + 2 * 140 + 204 + 25)) / k_avg_s / 1e9}
         roof["traffic"] = load_traffic(a)
+        roof["hardware_counted"] = load_traffic(a, key="hardware_counted")  # ALU-side truth next to the algorithmic figure
         name = C_name(lib)
         cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and ws == 1) else None  # N=1 only
         line = {
@@ -246,9 +247,10 @@ def main():
         dist.destroy_process_group()
 
 
-def load_traffic(a):
-    """HBM bytes per launch of the dominant kernel from the latest committed PMC profile of the SAME configuration
-    (profiles/rNN/traffic.json; PMC counters cannot be collected from inside the bench), else None."""
+def load_traffic(a, key="traffic_bytes_per_launch"):
+    """HBM bytes per launch of the dominant kernel (or another recorded PMC-derived entry) from the latest committed
+    profile of the SAME configuration (profiles/rNN/traffic.json; PMC counters cannot be collected from inside the
+    bench), else None."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
@@ -258,7 +260,7 @@ def load_traffic(a):
         c = t.get("config", {})
         if (c.get("size"), c.get("variant"), c.get("dtype")) == (a.size, a.variant, a.dtype) and a.gpus == 1 \
                 and a.rhs == "closed":
-            return t["traffic_bytes_per_launch"]
+            return t.get(key)
     return None
 
 
