@@ -149,14 +149,14 @@ int rtgr_solver_defaults(rtgr_solver* s, int is_f32);
 /* Name / CU count / clock of the active device, for bench reports. */
 int rtgr_device_info(char* name, uint64_t name_len, int* n_cu, int* clock_mhz, int* wavefront);
 
-/* The device entry points are asynchronous and never allocate once the library-owned workspace (event records handed
- * from the integrate kernel to the resolve kernel: <= 440 B per ray, bounded by a 2^24-ray pipeline chunk) is large
- * enough.  Call this once up front (e.g. before hipGraph capture) to size it for slabs of n_rays rays. */
+/* The device entry points are asynchronous and never allocate once the library-owned workspace (start / hand-over /
+ * event records, per-ray meta, queue order: <= 501 B per ray, bounded by a pipeline chunk of 2^26 rays — fewer when
+ * that would not fit a quarter of the free device memory; RTGR_CHUNK overrides) is large enough.  Call this once up front (e.g. before hipGraph capture) to size it for slabs of n_rays rays. */
 int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32);
 
 /* Optional per-kernel timing for benchmarks: when enabled the library brackets every kernel it launches with HIP
  * events on the caller's stream.  rtgr_timing_read waits for them and returns, since the previous read, the summed
- * milliseconds and launch counts of [0] the camera kernel, [1] the integrate kernel's main pass (FAR, or FULL when the
+ * milliseconds and launch counts of [0] the ray set-up and queue-order kernels, [1] the integrate kernel's main pass (FAR, or FULL when the
  * far/near split is off — the hot kernel), [2] the resolve kernel, [3] the integrate kernel's NEAR pass.
  * Not for use during hipGraph capture. */
 int rtgr_timing_enable(int on);

@@ -262,7 +262,7 @@ static int ensure_device() {
 // Default: prepare -> integrate FAR / NEAR (persistent waves) -> resolve.  RTGR_KERNEL=tile selects the simple tile-per-wave
 // kernel (kept as an independent formulation for A/B and cross-checks).  Tunables (experiments only):
 //   RTGR_WAVES_PER_CU  resident waves per CU of the integrate kernel (default 8 = 2 per SIMD)
-//   RTGR_CHUNK         rays per pipeline chunk (default 2^24); bounds the library-owned workspace
+//   RTGR_CHUNK         rays per pipeline chunk (default 2^26, less if memory is short); bounds the library-owned workspace
 //   RTGR_SPLIT=0       one FULL integrate pass instead of the FAR + NEAR pair
 //   RTGR_ORDER=0       keep the natural ray order (default: longest-expected-first, see rtgr_persistent.hpp)
 //   RTGR_FAIR=s        time slice 2^s clocks of the priority rotation (0 = off; default 13 for 0.8-1.8 M rays, else off)
@@ -307,9 +307,12 @@ static bool use_tile_kernel() {
     const char* v = std::getenv("RTGR_KERNEL");
     return v && std::strcmp(v, "tile") == 0;
 }
+// Rays per pipeline chunk.  Every chunk pays the tails of its passes once, so bigger is better (8192² in one chunk instead
+// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (33.7 GB of workspace at 501 B/ray), halved
+// until the workspace fits into a quarter of the memory that is free when it has to be (re)allocated.
 static uint64_t chunk_rays() {
     const char* v = std::getenv("RTGR_CHUNK");
-    uint64_t c = (v && *v) ? std::strtoull(v, nullptr, 10) : (1ull << 24);
+    uint64_t c = (v && *v) ? std::strtoull(v, nullptr, 10) : (1ull << 26);
     return c < 64 ? 64 : c;
 }
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -319,6 +322,20 @@ static int ensure_workspace(size_t bytes) {
     HIP_TRY(hipMalloc(&g_ws, bytes));
     g_ws_bytes = bytes;
     return RTGR_OK;
+}
+template <class R>
+static size_t workspace_bytes(uint64_t rays, bool with_state);
+// the chunk size for a job of n rays: all of it if the workspace for that is there or fits, else the largest power-of-two
+// fraction of chunk_rays() that does
+template <class R>
+static uint64_t pick_chunk(uint64_t n, bool with_state) {
+    uint64_t chunk = n < chunk_rays() ? n : chunk_rays();
+    if (workspace_bytes<R>(chunk, with_state) <= g_ws_bytes) return chunk;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return chunk;
+    const size_t budget = (free_b + g_ws_bytes) / 4;  // the old workspace is released before the new one is taken
+    while (chunk > (1ull << 20) && workspace_bytes<R>(chunk, with_state) > budget) chunk = (chunk + 1) / 2;
+    return chunk;
 }
 template <class R>
 static size_t workspace_bytes(uint64_t rays, bool with_state) {
@@ -404,8 +421,8 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         return RTGR_OK;
     }
     const uint64_t n = A.ni * A.nrows;
-    const uint64_t chunk = n < chunk_rays() ? n : chunk_rays();
     const bool with_state = A.state_end != nullptr;
+    const uint64_t chunk = pick_chunk<R>(n, with_state);
     int rc = ensure_workspace(workspace_bytes<R>(chunk, with_state));
     if (rc) return rc;
     const int recw = with_state ? REC_W_STATE : REC_W;
@@ -702,9 +719,8 @@ int rtgr_timing_read(double ms[4], uint64_t launches[4]) {
 int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32) {
     int rc = ensure_device();
     if (rc) return rc;
-    const uint64_t chunk = n_rays < chunk_rays() ? n_rays : chunk_rays();
-    return ensure_workspace(is_f32 ? workspace_bytes<float>(chunk, with_state_end != 0)
-                                   : workspace_bytes<double>(chunk, with_state_end != 0));
+    if (is_f32) return ensure_workspace(workspace_bytes<float>(pick_chunk<float>(n_rays, with_state_end != 0), with_state_end != 0));
+    return ensure_workspace(workspace_bytes<double>(pick_chunk<double>(n_rays, with_state_end != 0), with_state_end != 0));
 }
 
 int rtgr_trace_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* d_state0,
