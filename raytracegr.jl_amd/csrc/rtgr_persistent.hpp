@@ -120,6 +120,7 @@ enum IntegrateMode : int { MODE_FULL = 0, MODE_FAR = 1, MODE_NEAR = 2 };
 constexpr int HAND_W = 16;  // x[4] u[4] k0[4] t dt ps lq
 constexpr uint32_t META_HANDED = 0xffff0000u;    // meta[3*idx+2] of a ray waiting for a NEAR pass
 constexpr uint32_t META_HANDBACK = 0xffff0001u;  // … of a ray a NEAR pass handed back to the next round's FAR pass
+constexpr uint32_t META_HANDED_EARLY = 0xffff0002u;  // … of a ray waiting for the NEAR pass ON ITS EARLY LIST
 #ifndef RTGR_QUEUE_CHUNK
 #define RTGR_QUEUE_CHUNK 256ull
 #endif
@@ -315,8 +316,10 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 if (resume) {
                     const bool listed = MODE == MODE_NEAR && w < n_early;
                     if (MODE == MODE_NEAR) id = listed ? (uint64_t)A.early[w] : w - n_early;
-                    take = A.meta[id * 3 + 2] == A.pick_flag;
-                    if (MODE == MODE_NEAR && A.early) take = take && ((A.meta[id * 3] < A.near_early) == listed);
+                    // ONE word decides: which sweep a ray belongs to is part of its flag.  (Deciding it from the step count
+                    // in meta[0] raced with the wave that finishes the ray and overwrites meta[0..2] word by word: 3 rays in
+                    // 4 M were traced twice — found by tools/stress_determinism.py.)
+                    take = A.meta[id * 3 + 2] == (listed ? META_HANDED_EARLY : A.pick_flag);
                 }
                 if (take) {
                     idx = id;
@@ -503,12 +506,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #pragma unroll
                         for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k[0][q]; }
                         hd[12] = t; hd[13] = dt; hd[14] = ps; hd[15] = (R)lq;
-                        A.meta[idx * 3] = nacc; A.meta[idx * 3 + 1] = nrej; A.meta[idx * 3 + 2] = META_HANDED;
+                        const bool early_ray = MODE == MODE_FAR && A.early && nacc < A.near_early;
+                        A.meta[idx * 3] = nacc; A.meta[idx * 3 + 1] = nrej;
+                        A.meta[idx * 3 + 2] = early_ray ? META_HANDED_EARLY : META_HANDED;
                         // A ray handed over EARLY in its life is passing an object it may well miss, and then it stays in
                         // the NEAR pass for the rest of its path: in example2, 1.2 % of the rays, all handed over at
                         // steps 30-34, hold 55 % of the NEAR pass's steps.  They are listed so that the NEAR pass can
                         // start with them, packed together (collected per wave in LDS, see the end of the loop body).
-                        if (MODE == MODE_FAR && A.early && nacc < A.near_early) list_it = true;
+                        if (early_ray) list_it = true;
                         handed = true;
                     } else if (EEst <= 1.0f) {
                         nacc++;

@@ -352,6 +352,32 @@ def test_four_waves_per_simd_far_variant_is_bit_identical(lib):
         assert res["0"]["counters"] == res["1"]["counters"]
 
 
+def test_repeated_passes_are_bit_identical(lib):
+    """Race guard.  The schedule of the persistent passes differs from run to run (atomic queue heads, the early list's
+    order); the results must not, and every ray is traced exactly once (a flag/step-count race once traced 3 rays in
+    4 M twice — tools/stress_determinism.py is the long version of this test)."""
+    import torch
+    from raytracegr_jl_amd import sharded
+    for name, n in (("ks_ref0", 1024), ("ks_true0998_disk", 768)):
+        sc, cam = scene_variant(name)
+        opt = rt.solver_defaults()
+        ref = None
+        for rep in range(8):
+            ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+            out = sharded.trace_slab_torch(sc, opt, cam, n, n, 0, n, details=True, counters=ctr)
+            torch.cuda.synchronize()
+            assert int(ctr[0]) == n * n and int(ctr[4]) + int(ctr[6]) <= n * n
+            cur = {k: v.clone() for k, v in out.items()}
+            cur["ctr"] = ctr[:7].clone()
+            if ref is None:
+                ref = cur
+                continue
+            for k in ref:
+                a, b = ref[k], cur[k]
+                same = torch.equal(a, b) if not a.is_floating_point() else bool(((a == b) | (a.isnan() & b.isnan())).all())
+                assert same, (name, rep, k)
+
+
 def test_scheduling_knobs_do_not_change_results(lib):
     """Queue order, chunk sizes, the NEAR pass's early list and the priority rotation decide WHEN and WHERE a ray is
     integrated, never its result: every setting must reproduce the default's outputs bit for bit."""
