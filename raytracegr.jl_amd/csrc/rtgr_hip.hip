@@ -267,6 +267,7 @@ static int ensure_device() {
 //   RTGR_ORDER=0       keep the natural ray order (default: longest-expected-first, see rtgr_persistent.hpp)
 //   RTGR_FAIR=s        time slice 2^s clocks of the priority rotation (0 = off; default 13 for 0.8-1.8 M rays, else off)
 //   RTGR_NEAR_EARLY=n  accepted steps at hand-over below which a ray is put on the NEAR pass's early list (default 64)
+//   RTGR_WAVES_PER_CU_NEAR=n  resident waves per CU of the NEAR pass (default 4 below 1.6 M rays, else 8)
 //   RTGR_FAR4=0/1      force the 3- / 4-waves-per-SIMD instantiation of the a = 0 FAR pass (default: by launch size)
 static int g_num_cu = 0;
 static unsigned long long* g_queue_pool = nullptr;  // RTGR_QUEUE_SLOTS work-queue heads, one per launch in flight
@@ -400,7 +401,16 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
 #endif
             { KernelTimer tm(st, 3);
               if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(g_user.near, grid(0).x, 64, st, P));
-              else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, P); }
+              else {
+                  // A small launch's NEAR pass ends on its longest-staying rays (one lane each, up to 370 steps in the
+                  // a = 0.8 scene), and such a wave steps faster alone on its SIMD than next to a second wave: ONE wave per
+                  // SIMD below 1.6 M rays (1024²: a = 0.8 NEAR 2.17 -> 1.43 ms, a = 0 0.87 -> 0.64 ms; from 2 M rays on
+                  // the second wave's throughput is worth more).  RTGR_WAVES_PER_CU_NEAR overrides.
+                  dim3 gn = grid(RTGR_WAVES_PER_SIMD);
+                  const int wn = env_int("RTGR_WAVES_PER_CU_NEAR", P.n < (uint64_t)g_num_cu * 12 * 64 * 8 ? 4 : 0);
+                  if (wn > 0 && (uint64_t)g_num_cu * wn < gn.x) gn.x = (unsigned)((uint64_t)g_num_cu * wn);
+                  hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), gn, dim3(64), 0, st, P);
+              } }
         }
     } else {
         KernelTimer tm(st, 1);
