@@ -392,7 +392,7 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
                 // the chunks are small — measured 0.8 ms for 2.1 M rays at 42 ids per pop (50 k atomics), also for a
                 // hand-back pass that picks up almost nothing.  So: 1/8 of a wave's share per pop, within [64, 256]
                 // (sweep at 2.1 / 4.2 / 16.8 M rays: best at 64-128 / 128-256 / 256; 1024 parks stragglers: +30 %).
-                const uint64_t share = P.n / ((uint64_t)grid(RTGR_WAVES_PER_SIMD).x * 8 + 1);
+                const uint64_t share = P.n / ((uint64_t)grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32).x * 8 + 1);
                 const uint64_t nc = share < 64 ? 64 : (share > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : share);
                 P.queue_chunk = (uint32_t)env_int("RTGR_QCHUNK_NEAR", (int)nc);
             }
@@ -406,17 +406,21 @@ static int launch_integrate(const IntegrateArgs<R>& IA, bool npts10, bool split,
                   // a = 0.8 scene), and such a wave steps faster alone on its SIMD than next to a second wave: ONE wave per
                   // SIMD below 1.6 M rays (1024²: a = 0.8 NEAR 2.17 -> 1.43 ms, a = 0 0.87 -> 0.64 ms; from 2 M rays on
                   // the second wave's throughput is worth more).  RTGR_WAVES_PER_CU_NEAR overrides.
-                  dim3 gn = grid(RTGR_WAVES_PER_SIMD);
+                  dim3 gn = grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32);
                   const int wn = env_int("RTGR_WAVES_PER_CU_NEAR", P.n < (uint64_t)g_num_cu * 12 * 64 * 8 ? 4 : 0);
                   if (wn > 0 && (uint64_t)g_num_cu * wn < gn.x) gn.x = (unsigned)((uint64_t)g_num_cu * wn);
                   hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), gn, dim3(64), 0, st, P);
               } }
         }
     } else {
+#ifdef RTGR_ROOT_STATS
+        IntegrateArgs<R> IAd = IA; IAd.dbg = g_dbg;   // debug builds: the FULL pass reports its wave timeline too
+        const IntegrateArgs<R>& IA = IAd;
+#endif
         KernelTimer tm(st, 1);
         if constexpr (METRIC == RTGR_UM) HIP_TRY(launch_module(npts10 ? g_user.full10 : g_user.fulln, grid(0).x, 64, st, IA));
-        else if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
-        else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, false, MODE_FULL>), grid(RTGR_WAVES_PER_SIMD), dim3(64), 0, st, IA);
+        else if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FULL>), grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32), dim3(64), 0, st, IA);
+        else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, false, MODE_FULL>), grid(sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32), dim3(64), 0, st, IA);
     }
     return RTGR_OK;
 }

@@ -41,6 +41,9 @@
 #ifndef RTGR_WAVES_PER_SIMD_FAR
 #define RTGR_WAVES_PER_SIMD_FAR 3  // the FAR pass has no sample-point arrays: <=168 registers, three waves per SIMD
 #endif
+#ifndef RTGR_WAVES_PER_SIMD_F32
+#define RTGR_WAVES_PER_SIMD_F32 3  // Float32 NEAR / FULL passes: 146-158 registers, three waves fit (2048²: 4.02 -> 3.50 ms; four: 3.82)
+#endif
 #ifndef RTGR_WAVES_PER_SIMD
 #define RTGR_WAVES_PER_SIMD 2  // 2 -> <=256 VGPR+AGPR per lane; 1 -> the whole 512-entry file
 #endif
@@ -751,7 +754,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 
 template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE>
 __global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? RTGR_WAVES_PER_SIMD_GENERIC
-                                 : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4) : RTGR_WAVES_PER_SIMD))
+                                 : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4)
+                                                     : (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32)))
 void integrate_kernel(const IntegrateArgs<R> A) {
     integrate_body<R, METRIC, SPIN, NPTS10, MODE>(A);
 }

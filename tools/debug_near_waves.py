@@ -10,7 +10,8 @@ lib = rt._abi.load(); rt._abi.check(lib, lib.rtgr_init(-1))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from scenes import scene_variant
 sc, camera = scene_variant(os.environ.get("RTGR_VARIANT", "ks_ref0"))   # BASELINE scene variants, tests/scenes.py
-opt = rt.solver_defaults()
+DT = np.float32 if os.environ.get("RTGR_DTYPE") == "f32" else np.float64
+opt = rt.solver_defaults(DT)
 NMAX = 4096 * 4096
 buf = torch.zeros(4 * 8192 + NMAX, dtype=torch.int64, device="cuda")   # per-wave records, then 2 x u32 per ray
 lib.rtgr_debug_set_buffer.argtypes = [C.c_void_p]
@@ -18,7 +19,7 @@ lib.rtgr_debug_set_buffer(buf.data_ptr())
 for n in [int(a) for a in sys.argv[1:]] or [4096]:
     for rep in range(2):
         buf.zero_()
-        sharded.trace_slab_torch(sc, opt, camera, n, n, 0, n)
+        sharded.trace_slab_torch(sc, opt, camera, n, n, 0, n, dtype=DT)
         torch.cuda.synchronize()
     d = buf[:4 * 8192].cpu().numpy().reshape(-1, 4)
     d = d[d[:, 1] > 0]
@@ -35,7 +36,7 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
     print("   us/iteration percentiles: p1 %.2f p10 %.2f p50 %.2f p90 %.2f p99 %.2f" % tuple(np.percentile(upi, [1, 10, 50, 90, 99])))
     late = np.argsort(-en)[:5]
     for w in late: print(f"   late wave {w}: start {st[w]:.0f} end {en[w]:.0f} iters {d[w,2]} rays {d[w,3]}")
-    if os.environ.get("RTGR_DBG_PASS") == "far":
+    if os.environ.get("RTGR_DBG_PASS") == "far" or DT == np.float32:
         continue
     pr = buf[4 * 8192:4 * 8192 + n * n].cpu().numpy().view(np.uint32).reshape(-1, 2)
     n0, stay = pr[:, 0].astype(int), pr[:, 1].astype(int)
