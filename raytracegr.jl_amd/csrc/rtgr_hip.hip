@@ -475,6 +475,7 @@ static int launch_trace(const TraceArgs<R>& A, hipStream_t st) {
         // priority rotation among the waves of a SIMD: pays when a lane gets only a few rays (see rtgr_persistent.hpp)
         // measured FAR pass, off / on: 0.26 M rays 2.70 / 3.17 ms, 0.52 M 3.83 / 4.35, 1.05 M 7.05 / 6.29, 1.44 M 8.83 / 8.30,
         // 2.1 M 11.59 / 11.59, 16.8 M 83.8 / 84.8 -> on for 4..9 rays per lane of the 3-waves/SIMD grid
+        IA.n_simd = (uint32_t)g_num_cu * 4u;
         const uint64_t lanes3 = (uint64_t)g_num_cu * 12 * 64;
         IA.fair_shift = (uint32_t)env_int("RTGR_FAIR", (m >= 4 * lanes3 && m < 9 * lanes3) ? 13 : 0);
 #ifdef RTGR_ROOT_STATS

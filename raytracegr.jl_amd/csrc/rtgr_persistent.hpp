@@ -107,6 +107,7 @@ struct IntegrateArgs {
     // cursor); the NEAR pass starts with those
     uint32_t* early;
     uint32_t near_early;
+    uint32_t n_simd;        // SIMDs of the device (4 per CU): workgroup b is the (b / n_simd)-th oldest wave of its SIMD
     uint32_t fair_shift;    // != 0: the waves of a SIMD take turns at the top priority, slices of 2^fair_shift clocks
 #ifdef RTGR_ROOT_STATS
     unsigned long long* dbg;  // debug builds: per-wave {start, end, iterations, rays} of the NEAR pass, then per-ray stays
@@ -252,8 +253,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     // race through the longest ones), hence by launch size.  Serving the queue from both ends — old
     // waves from the head, young ones from the tail — was worse at every size: the tail-servers then run
     // shortest-first, the worst order inside a wave.
-    const uint32_t n_cls = (gridDim.x + 1023u) / 1024u;               // waves per SIMD of this launch (256 CUs x 4)
-    const uint32_t my_cls = blockIdx.x / 1024u;
+    const uint32_t n_simd = A.n_simd ? A.n_simd : 1024u;              // SIMDs of the device (MI355X: 256 CUs x 4)
+    const uint32_t n_cls = (gridDim.x + n_simd - 1u) / n_simd;        // waves per SIMD of this launch
+    const uint32_t my_cls = blockIdx.x / n_simd;
     const bool fair = A.fair_shift != 0u && n_cls > 1u;
     for (;;) {
         if (fair) {
