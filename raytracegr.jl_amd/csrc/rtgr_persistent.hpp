@@ -439,28 +439,30 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                      rfma(N::bt[3], k[3][q], rfma(N::bt[2], k[2][q], rfma(N::bt[1], k[1][q], N::bt[0] * k[0][q]))))));
                     const R ex = h * rfma(h, rfma(N::BT2[5], k[5][q], rfma(N::BT2[4], k[4][q], rfma(N::BT2[3], k[3][q],
                                      rfma(N::BT2[2], k[2][q], rfma(N::BT2[1], k[1][q], N::BT2[0] * k[0][q]))))), N::sbt * u[q]);
-                    const float isku = __builtin_amdgcn_rcpf((float)rfma(rmax(rabs(u[q]), rabs(un[q])), reltol, abstol));
-                    const float iskx = __builtin_amdgcn_rcpf((float)rfma(rmax(rabs(x[q]), rabs(xn[q])), reltol, abstol));
+                    const float isku = __builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(u[q], un[q]), reltol, abstol));
+                    const float iskx = __builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(x[q], xn[q]), reltol, abstol));
                     const float ru = (float)eu * isku, rx = (float)ex * iskx;
                     acc = __builtin_fmaf(ru, ru, __builtin_fmaf(rx, rx, acc));
                 }
-                const float EEst = __builtin_sqrtf(acc * 0.125f);
+                // EEst² — the square root is never taken: the tests are EEst <= 1 <=> EEst² <= 1, and the controller works with
+                // log2 EEst = ½ log2 EEst² (sqrtf's IEEE expansion was ~15 instructions per step)
+                const float EEst2 = acc * 0.125f;
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
                 bool is_event = false, is_interior = false, handed = false, hand_back = false;
                 R top = R(0);
                 R cc[4][4];  // position polynomial of this step (set when the step is accepted; read only on events)
-                if (EEst != EEst) {
+                if (EEst2 != EEst2) {
                     done = RTGR_RAY_NAN;
                 } else {
                     // ---- PI controller in log2 space: q = EEst^β1 / qold^β2 / γ ----------------------
-                    const float le = flog2(fmaxf(EEst, 1e-30f));
+                    const float le = 0.5f * flog2(fmaxf(EEst2, 1e-37f));  // log2 of the error estimate itself (floor 3e-19)
                     const float q11 = fexp2(beta1 * le);
                     float qf = fexp2(__builtin_fmaf(beta1, le, -beta2 * lq)) * igamma;
-                    qf = (EEst == 0.0f) ? qmax_inv : fmaxf(qmax_inv, fminf(qmin_inv, qf));
+                    qf = (EEst2 == 0.0f) ? qmax_inv : fmaxf(qmax_inv, fminf(qmin_inv, qf));
                     bool hand_over = false;
                     bool need_scan = true;  // NEAR: false when no lane of the wave can see a sign change in this step
                     if constexpr (MODE == MODE_FAR || MODE == MODE_NEAR) {
-                        if (EEst <= 1.0f) {
+                        if (EEst2 <= 1.0f) {
                             // ---- can ANY object's distance change sign anywhere in this step?  |x_q(θ) − x_q| <= δ_q for all
                             // θ in [0,1] (Nyström form of the dense output, beta[l] = max|B2_l(θ)|); a plane's distance then
                             // moves by <= δ_t, a sphere's by <= Σ_q δ_q (2|X_q| + δ_q), a disk's by <= δ_x + δ_y + δ_z.
@@ -503,7 +505,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         // NEAR pass: a ray stays here until it ends, also after it has left every object's reach; its
                         // wave then runs with few lanes (the longest stays are 150-370 steps), so the scan is skipped
                         // whenever NO active lane needs it — a wave-uniform decision, same results by the same bound.
-                        if constexpr (MODE == MODE_NEAR) need_scan = __ballot((EEst <= 1.0f) && need_scan) != 0ull;
+                        if constexpr (MODE == MODE_NEAR) need_scan = __ballot((EEst2 <= 1.0f) && need_scan) != 0ull;
                     }
                     if (hand_over) {
                         // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
@@ -520,12 +522,12 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         // start with them, packed together (collected per wave in LDS, see the end of the loop body).
                         if (early_ray) list_it = true;
                         handed = true;
-                    } else if (EEst <= 1.0f) {
+                    } else if (EEst2 <= 1.0f) {
                         nacc++;
                         lq = fmaxf(le, lq_init);  // log2(max(EEst, qoldinit))
                         const R dtnew = dt * (R)__builtin_amdgcn_rcpf(qf);
                         R tnew = t + dt;
-                        if (rabs(tnew - t1) < R(10) * eps * rmax(rabs(tnew), rabs(t1))) tnew = t1;
+                        if (rabs(tnew - t1) < R(10) * eps * rmaxabs<R>(tnew, t1)) tnew = t1;
                         // ---- ContinuousCallback ----------------------------------------------------
                         // x(θ) = x + θ c1 + θ² c2 + θ³ c3 + θ⁴ c4 ;  c1 = h u,  c_m = h² Σ_l R2[l][m] k_l
                         // (FAR pass: proven above that no object's distance changes sign in this step — nothing to scan)
