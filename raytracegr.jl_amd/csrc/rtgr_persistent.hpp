@@ -130,6 +130,10 @@ constexpr uint32_t META_HANDED_EARLY = 0xffff0002u;  // … of a ray waiting for
 #endif
 
 // fast f32 helpers for the step-size machinery
+// one-instruction f32 max / min / clamp (fmaxf / fminf spend a second v_max x, x on canonicalising each computed operand)
+RTGR_DEV float fmax1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTGR_DEV float fmin1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTGR_DEV float fclamp1(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }  // v_med3_f32
 RTGR_DEV float flog2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 RTGR_DEV float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 
@@ -455,10 +459,10 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                     done = RTGR_RAY_NAN;
                 } else {
                     // ---- PI controller in log2 space: q = EEst^β1 / qold^β2 / γ ----------------------
-                    const float le = 0.5f * flog2(fmaxf(EEst2, 1e-37f));  // log2 of the error estimate itself (floor 3e-19)
+                    const float le = 0.5f * flog2(fmax1(EEst2, 1e-37f));  // log2 of the error estimate itself (floor 3e-19)
                     const float q11 = fexp2(beta1 * le);
                     float qf = fexp2(__builtin_fmaf(beta1, le, -beta2 * lq)) * igamma;
-                    qf = (EEst2 == 0.0f) ? qmax_inv : fmaxf(qmax_inv, fminf(qmin_inv, qf));
+                    qf = (EEst2 == 0.0f) ? qmax_inv : fclamp1(qf, qmax_inv, qmin_inv);
                     bool hand_over = false;
                     bool need_scan = true;  // NEAR: false when no lane of the wave can see a sign change in this step
                     if constexpr (MODE == MODE_FAR || MODE == MODE_NEAR) {
@@ -524,7 +528,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         handed = true;
                     } else if (EEst2 <= 1.0f) {
                         nacc++;
-                        lq = fmaxf(le, lq_init);  // log2(max(EEst, qoldinit))
+                        lq = fmax1(le, lq_init);  // log2(max(EEst, qoldinit))
                         const R dtnew = dt * (R)__builtin_amdgcn_rcpf(qf);
                         R tnew = t + dt;
                         if (rabs(tnew - t1) < R(10) * eps * rmaxabs<R>(tnew, t1)) tnew = t1;
@@ -620,7 +624,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         }
                     } else {
                         nrej++;
-                        dt = dt * (R)__builtin_amdgcn_rcpf(fminf(qmin_inv, q11 * igamma));
+                        dt = dt * (R)__builtin_amdgcn_rcpf(fmin1(qmin_inv, q11 * igamma));
                         if (nacc + nrej >= A.opt.max_steps) done = RTGR_RAY_MAXSTEPS;
                         else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
                     }
