@@ -130,6 +130,17 @@ constexpr uint32_t META_HANDED_EARLY = 0xffff0002u;  // … of a ray waiting for
 #endif
 
 // fast f32 helpers for the step-size machinery
+// A wave-uniform value computed with vector instructions (there is no scalar f64 ALU) lives in a VGPR — and, in a kernel
+// squeezed to 127 registers, gets spilled to scratch and reloaded in the loop.  Through readfirstlane it lives in SGPRs.
+RTGR_DEV double uniform_(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned long long u = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                                 (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    return __builtin_bit_cast(double, u);
+}
+RTGR_DEV float uniform_(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v)));
+}
 // one-instruction f32 max / min / clamp (fmaxf / fminf spend a second v_max x, x on canonicalising each computed operand)
 RTGR_DEV float fmax1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RTGR_DEV float fmin1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -213,7 +224,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     unsigned long long* const queue = (MODE == MODE_NEAR) ? A.ctrl + 1 : A.ctrl;
     const R M = A.sc.M, aspin = A.sc.a;
     const R reltol = A.opt.reltol, abstol = A.opt.abstol;
-    const R t0 = A.opt.lambda0, t1 = A.opt.lambda1, dtmax = A.opt.lambda1 - A.opt.lambda0;
+    const R t0 = A.opt.lambda0, t1 = A.opt.lambda1, dtmax = uniform_(A.opt.lambda1 - A.opt.lambda0);
     const float igamma = 1.0f / 0.9f, qmin_inv = 5.0f, qmax_inv = 0.1f;
     const float lq_init = -13.287712379549449f;  // log2(qoldinit = 1e-4)
     const float beta1 = 0.14f, beta2 = 0.08f;
