@@ -166,7 +166,7 @@ def main():
         one_pass()
     torch.cuda.synchronize()
     ctr.zero_()
-    rt._abi.check(lib, lib.rtgr_timing_enable(1))
+    rt._abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     if ws > 1:
         dist.barrier()
@@ -196,7 +196,7 @@ def main():
     import ctypes
     kms = (ctypes.c_double * 4)()
     kln = (ctypes.c_uint64 * 4)()
-    rt._abi.check(lib, lib.rtgr_timing_read(ctypes.byref(kms), ctypes.byref(kln)))
+    rt._abi.check(lib, lib.rtgr_timing_read(None, 0, ctypes.byref(kms), ctypes.byref(kln)))
     if rank == 0:
         # roofline of the dominant kernel — integrate_kernel's main (FAR) pass, ~93 % of device time — over this rank's
         # launches: algorithmic flop per launch / average launch duration (HIP events around the kernel itself).
@@ -268,7 +268,7 @@ def C_name(lib):
     import ctypes
     buf = ctypes.create_string_buffer(128)
     cu, mhz, wf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    lib.rtgr_device_info(buf, 128, ctypes.byref(cu), ctypes.byref(mhz), ctypes.byref(wf))
+    lib.rtgr_device_info(None, 0, buf, 128, ctypes.byref(cu), ctypes.byref(mhz), ctypes.byref(wf))
     return f"{buf.value.decode()} {cu.value} CU @ {mhz.value} MHz"
 
 

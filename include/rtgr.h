@@ -24,6 +24,22 @@
  *  - All functions return 0 on success and a negative rtgr_status on failure; they never throw or abort.
  *    The message of the last failure on the calling thread is rtgr_last_error().
  *  - The library never keeps a caller pointer after a call returns.
+ *
+ * Contexts, ownership, threading
+ *  - All device state — workspaces, work-queue heads, run-time loaded metric modules, staging buffers, streams,
+ *    timing events, launch-policy options — lives in an opaque rtgr_context created for a list of devices
+ *    (rtgr_create).  Every entry point takes the context first; NULL means the process's DEFAULT context, which is
+ *    created on first use on the calling thread's current HIP device (or by rtgr_init).  There is no other global state.
+ *  - The reference's caller is ONE thread and the parallelism is inside the call (src/RayTraceGR.jl:510-511).  The
+ *    same holds here, and more: one host thread can drive every device of a context (rtgr_trace_sharded_f64 deals the
+ *    image rows to all of them and collects the frame on device 0 — one call, no MPI / torch / second process), and
+ *    several host threads may use one context concurrently.
+ *  - Device entry points are asynchronous on the caller's stream.  Two calls on the SAME stream are ordered by the
+ *    stream and share that stream's workspace; calls on DIFFERENT streams (or devices) use different workspaces and
+ *    may run concurrently.  Results are bit-identical to serial execution either way (tests: two streams, two threads).
+ *  - A workspace only grows.  The superseded allocation stays alive until rtgr_trim / rtgr_destroy, so a hipGraph
+ *    captured earlier never dangles; growth DURING stream capture is refused with RTGR_ERR_BAD_ARG (hipMalloc cannot be
+ *    captured): call rtgr_reserve_workspace before capturing.
  */
 #ifndef RTGR_H
 #define RTGR_H
@@ -34,8 +50,9 @@
 extern "C" {
 #endif
 
-#define RTGR_ABI_VERSION 1
+#define RTGR_ABI_VERSION 2
 #define RTGR_MAX_OBJECTS 16
+#define RTGR_MAX_DEVICES 16
 
 /* ---- return codes -------------------------------------------------------------------------------------- */
 enum rtgr_status {
@@ -54,21 +71,23 @@ enum rtgr_metric {
                            (src/RayTraceGR.jl:284); the reference hard-wires M=1, a=0 (:275-276)               */
     RTGR_KS_TRUE = 2,   /* textbook Kerr–Schild radius r^2 = (q + sqrt(q^2 + 4 a^2 z^2))/2, q = rho^2 - a^2
                            (no reference counterpart; needed for a != 0 configs)                               */
-    RTGR_USER = 3       /* the metric function loaded with rtgr_user_metric_load(); always traced with the
-                           generic dual-number RHS (RTGR_METRIC_GENERIC is implied), Float64 only              */
+    RTGR_USER = 3       /* the metric function rtgr_scene.user_metric names (rtgr_user_metric_load); always traced
+                           with the generic dual-number RHS (RTGR_METRIC_GENERIC is implied)                   */
 };
 
 /* OR-ed into rtgr_scene.metric: evaluate the geodesic RHS the way the reference does for ANY metric callable — 4-wide
  * forward duals through the metric, symmetric g / dg, 4x4 inverse, Christoffel contraction (the "generic" path of
  * DESIGN.md §4.2) — instead of the closed Kerr–Schild contraction.  Same results to rounding; ~5x the flops.  It is the
  * path a new (non-Kerr–Schild-form) metric functor would take, and the one whose executed flops equal the algorithmic
- * count of SURVEY §8(d). */
+ * count of SURVEY §8(d).  Float64 and Float32 (the reference's own test runs T = Float32 through it, test/runtests.jl:37). */
 #define RTGR_METRIC_GENERIC 0x100u
 
 /* ---- objects: replaces Vector{Object{T}} (src/RayTraceGR.jl:374-428); ORDER MATTERS (:518-530) ---------- */
 enum rtgr_object_kind {
     RTGR_PLANE = 1,  /* Plane{T}(time)            p[0] = time                     src/RayTraceGR.jl:394-404  */
-    RTGR_SPHERE = 2, /* Sphere{T}(pos, vel, radius)  p[0..3]=pos  p[4..7]=vel (unused, :411)  p[8]=radius     */
+    RTGR_SPHERE = 2, /* Sphere{T}(pos, vel, radius)  p[0..3]=pos  p[4..7]=vel  p[8]=radius   (:409-413)
+                        vel is dead data in the reference (:411, "TODO: Use metric?" :416); here it is the emitter's
+                        coordinate 4-velocity for the optional redshift output (rtgr_ray_outputs.redshift)       */
     RTGR_DISK = 3    /* thin disk (no reference counterpart): p[0]=half thickness h, p[1]=r_in, p[2]=r_out;
                         distance = max(|z|-h, r_in-rho_cyl, rho_cyl-r_out) obeying the contract at :377-383    */
 };
@@ -80,10 +99,12 @@ typedef struct rtgr_object {
 } rtgr_object;
 
 typedef struct rtgr_scene {
-    uint32_t metric; /* rtgr_metric */
+    uint32_t metric; /* rtgr_metric (| RTGR_METRIC_GENERIC) */
     uint32_t nobj;   /* 0..RTGR_MAX_OBJECTS */
     double M;        /* mass  (reference: 1, :275) */
     double a;        /* spin  (reference: 0, :276) */
+    uint64_t user_metric; /* RTGR_USER: id of the loaded metric module this scene is written for (rtgr_user_metric_load);
+                             a scene can never run with another module's kernels.  0 otherwise. */
     rtgr_object obj[RTGR_MAX_OBJECTS];
 } rtgr_scene;
 
@@ -136,45 +157,73 @@ typedef struct rtgr_ray_outputs {
     uint8_t* hit;         /* n: omin of the colouring rule (0 = miss, else 1-based object index, :518-526)  */
     uint32_t* n_accept;   /* n: accepted steps per ray                                                      */
     uint32_t* n_reject;   /* n: rejected attempts per ray                                                   */
+    void* redshift;       /* n scalars: g = (k.u_obs)/(k.u_emit), the frequency ratio observed/emitted of the light that
+                             reaches the pixel (k = the ray's tangent, . = the metric's inner product).  u_obs = the
+                             camera's static observer (make_canvas' normalised g^-1 e_t, :471-472) at the pixel;
+                             u_emit = the hit Sphere's `vel` (:411) normalised at the end point, or the static observer
+                             there for planes / disks; NaN where the ray hits nothing or u_emit is not timelike.
+                             No reference counterpart (`vel` is stored and never used, :411, :416).  Float64 entry
+                             points of the built-in metrics only. */
 } rtgr_ray_outputs;
 
 /* ---- lifecycle --------------------------------------------------------------------------------------------- */
-/* Select the HIP device this process drives (one process per GPU). device < 0 means "current device". */
+typedef struct rtgr_context rtgr_context;
+
+/* A context over n_devices HIP devices (device_ids[k] = HIP ordinal; the same ordinal may appear more than once: each
+ * entry gets streams and workspaces of its own).  device_ids == NULL: the calling thread's current device. */
+int rtgr_create(const int* device_ids, int n_devices, rtgr_context** ctx_out);
+int rtgr_destroy(rtgr_context* ctx);
+/* number of devices of the context (negative rtgr_status on error) */
+int rtgr_context_devices(rtgr_context* ctx);
+/* Synchronise the context's devices and free retired workspaces (and staging buffers). */
+int rtgr_trim(rtgr_context* ctx);
+/* (Re)create the process's default context on HIP device `device` (< 0: the current device).  Optional: the default
+ * context is otherwise created on first use. */
 int rtgr_init(int device);
+/* Destroy the default context. */
 int rtgr_shutdown(void);
 const char* rtgr_last_error(void);
 int rtgr_abi_version(void);
 /* Fill `s` with the reference's constants for T = Float64 (is_f32 = 0) or Float32 (is_f32 = 1). */
 int rtgr_solver_defaults(rtgr_solver* s, int is_f32);
-/* Name / CU count / clock of the active device, for bench reports. */
-int rtgr_device_info(char* name, uint64_t name_len, int* n_cu, int* clock_mhz, int* wavefront);
+/* Name / CU count / clock of device `index` of the context, for bench reports. */
+int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len, int* n_cu, int* clock_mhz, int* wavefront);
 
-/* The device entry points are asynchronous and never allocate once the library-owned workspace (start / hand-over /
- * event records, per-ray meta, queue order: <= 501 B per ray, bounded by a pipeline chunk of 2^26 rays — fewer when
- * that would not fit a quarter of the free device memory; RTGR_CHUNK overrides) is large enough.  Call this once up front (e.g. before hipGraph capture) to size it for slabs of n_rays rays. */
-int rtgr_reserve_workspace(uint64_t n_rays, int with_state_end, int is_f32);
+/* Launch-policy options (experiments and schedule-invariance tests; none changes a result bit).  Names: "waves_per_cu",
+ * "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early", "far4", "rounds", "qchunk", "qchunk_near",
+ * "tile", "lds_stages", "host_chunk".  value -1 = automatic.  Initial values come from the environment variables
+ * RTGR_<NAME> read ONCE when the context is created. */
+int rtgr_set_option(rtgr_context* ctx, const char* name, long value);
+int rtgr_get_option(rtgr_context* ctx, const char* name, long* value);
 
-/* Optional per-kernel timing for benchmarks: when enabled the library brackets every kernel it launches with HIP
- * events on the caller's stream.  rtgr_timing_read waits for them and returns, since the previous read, the summed
- * milliseconds and launch counts of [0] the ray set-up and queue-order kernels, [1] the integrate kernel's main pass (FAR, or FULL when the
- * far/near split is off — the hot kernel), [2] the resolve kernel, [3] the integrate kernel's NEAR pass.
- * Not for use during hipGraph capture. */
-int rtgr_timing_enable(int on);
-int rtgr_timing_read(double ms[4], uint64_t launches[4]);
+/* The device entry points never allocate once the stream's workspace (start / hand-over / event records, per-ray meta,
+ * queue order: <= 501 B per ray, bounded by a pipeline chunk of 2^26 rays — fewer when that would not fit a quarter of
+ * the free device memory) is large enough.  Call this once up front (e.g. before hipGraph capture) to size the workspace
+ * of `stream` on the device that owns `d_any` (any device pointer of the later call; NULL: device 0 of the context). */
+int rtgr_reserve_workspace(rtgr_context* ctx, const void* d_any, void* stream, uint64_t n_rays, int with_state_end, int is_f32);
+
+/* Optional per-kernel timing for benchmarks: when enabled the library brackets every kernel it launches on device
+ * `index` with HIP events on the launch stream.  rtgr_timing_read waits for them and returns, since the previous read,
+ * the summed milliseconds and launch counts of [0] the ray set-up and queue-order kernels, [1] the integrate kernel's main
+ * pass (FAR, or FULL when the far/near split is off — the hot kernel), [2] the resolve kernel, [3] the integrate kernel's
+ * NEAR pass.  Not for use during hipGraph capture. */
+int rtgr_timing_enable(rtgr_context* ctx, int index, int on);
+int rtgr_timing_read(rtgr_context* ctx, int index, double ms[4], uint64_t launches[4]);
 
 /* ---- the hot path, device-resident buffers ------------------------------------------------------------------
  * Replaces the body of trace_rays (src/RayTraceGR.jl:482-536) for rows j in [j0, j1) of an ni x nj canvas.
  *   d_state0 : n x 8 initial ray states on the DEVICE (n = ni*(j1-j0)), as `input_func(i)` yields (:492-496),
  *              or NULL — then rays are generated on the device from `cam` exactly as make_canvas does (:464-476).
- *   d_rgb    : 3*n scalars on the device, plane-major (required).
+ *   d_rgb    : 3*n scalars on the device, plane-major (required).  The device of the context that owns this
+ *              pointer runs the call.
  *   out      : optional per-ray device outputs.
  *   d_counters : optional device pointer to one rtgr_counters; the call ADDS to it (caller zeroes it).
  *   stream   : hipStream_t to enqueue on (NULL = default stream).  The call is asynchronous: it only enqueues.
  */
-int rtgr_trace_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* d_state0,
+int rtgr_trace_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* d_state0,
                           const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1,
                           double* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
-int rtgr_trace_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const float* d_state0,
+int rtgr_trace_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* d_state0,
                           const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1,
                           float* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
 
@@ -182,73 +231,98 @@ int rtgr_trace_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const
  * on the device); local row k of the output planes (n = ni*nrows) is image row j0 + k*jstride.  jstride = 1 is a
  * contiguous slab; jstride = N, j0 = rank is the CYCLIC row split used for multi-GPU runs — contiguous slabs of a
  * black-hole image are unbalanced (rows through the hole cost ~1.8x the edge rows), cyclic rows are not. */
-int rtgr_trace_rows_device_f64(const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
-                               uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, double* d_rgb,
+int rtgr_trace_rows_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                               uint64_t ni, uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, double* d_rgb,
                                const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
-int rtgr_trace_rows_device_f32(const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
-                               uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, float* d_rgb,
+int rtgr_trace_rows_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                               uint64_t ni, uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, float* d_rgb,
                                const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
 
-/* ---- the hot path, host buffers (what a Julia ccall would pass) ---------------------------------------------
- * Same semantics with HOST pointers; the library stages through its own device buffers and blocks until done.
+/* ---- the hot path, host buffers (what a Julia ccall passes) ---------------------------------------------------
+ * Same semantics with HOST pointers; the library stages through pinned buffers of the context (device 0), pipelines
+ * H2D copy / integration / D2H copy of successive pieces on three streams, and blocks until done.
  *   state0 may be NULL (device-side make_canvas from `cam`).  `ctr` (host, optional) is overwritten.
  */
-int rtgr_trace_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* state0, const rtgr_camera* cam,
-                   uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, double* rgb, const rtgr_ray_outputs* out,
-                   rtgr_counters* ctr);
-int rtgr_trace_f32(const rtgr_scene* scene, const rtgr_solver* opt, const float* state0, const rtgr_camera* cam,
-                   uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, float* rgb, const rtgr_ray_outputs* out,
-                   rtgr_counters* ctr);
+int rtgr_trace_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* state0,
+                   const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, double* rgb,
+                   const rtgr_ray_outputs* out, rtgr_counters* ctr);
+int rtgr_trace_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* state0,
+                   const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, float* rgb,
+                   const rtgr_ray_outputs* out, rtgr_counters* ctr);
 
 /* Accepts the reference's own pixel array: `pointer(c.pixels)` of an Array{Pixel{Float64},2} — 11 doubles per
  * pixel (pos 4, normal 4, rgb 3; src/RayTraceGR.jl:446-450), column-major ni x nj.  Traces every pixel and
  * writes rgb back into the same AoS layout of `pixels_out` (may alias pixels_in), as trace_rays does (:532). */
-int rtgr_trace_pixels_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in, uint64_t ni,
-                          uint64_t nj, double* pixels_out, rtgr_counters* ctr);
+int rtgr_trace_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in,
+                          uint64_t ni, uint64_t nj, double* pixels_out, rtgr_counters* ctr);
 
 /* Legacy single-ray shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:76): one pixel in, rgb out. */
-int rtgr_trace_one_f64(const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
+int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
                        const double normal[4], double rgb[3], double state_end[8], uint8_t* status);
+
+/* ---- the hot path over ALL devices of the context -------------------------------------------------
+ * One blocking call from one host thread: image rows are dealt cyclically to the context's N devices (device k traces
+ * rows k, k+N, …), every device runs the pipeline on a stream of its own, and the rows — RGB planes and, when asked
+ * for, status / hit / step counts / end states / lambda_end / redshift — are copied peer-to-peer (hipMemcpyPeerAsync: one
+ * xGMI link per peer, no reduction, no halo) to device 0, put back in place there, and (host variant) downloaded.
+ * Counters of all devices are summed into `ctr` (host).  The `_device` variant leaves the full frame in device-0
+ * memory: d_rgb (3 planes of ni*nj) and the members of `out` are device-0 pointers. */
+int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                           uint64_t ni, uint64_t nj, double* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr);
+int rtgr_trace_sharded_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt,
+                                  const rtgr_camera* cam, uint64_t ni, uint64_t nj, double* d_rgb,
+                                  const rtgr_ray_outputs* out, rtgr_counters* ctr);
 
 /* ---- camera: make_canvas (src/RayTraceGR.jl:457-478) on the device ------------------------------------------
  * Writes n x 8 ray states (pos, null past-directed 4-velocity) for rows [j0, j1).  Device / host variants. */
-int rtgr_make_canvas_device_f64(const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
-                                uint64_t j0, uint64_t j1, double* d_state0, void* stream);
-int rtgr_make_canvas_f64(const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0,
-                         uint64_t j1, double* state0);
+int rtgr_make_canvas_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni,
+                                uint64_t nj, uint64_t j0, uint64_t j1, double* d_state0, void* stream);
+int rtgr_make_canvas_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
+                         uint64_t j0, uint64_t j1, double* state0);
 
 /* ---- physics kernels exposed for parity tests (test/runtests.jl:12-61 exercises exactly these) -------------
  * Evaluated ON THE DEVICE for n points (host pointers in/out):
  *   g   : n x 16  metric g_ab            (minkowski / kerr_schild, :262-294)
  *   dg  : n x 64  dg[a][b][c] = d_c g_ab (dmetric, :302-313)
  *   Gam : n x 64  Gamma^a_bc             (christoffel, :321-331)
- * Any output may be NULL. */
-int rtgr_eval_metric_f64(const rtgr_scene* scene, const double* x /* n x 4 */, uint64_t n, double* g, double* dg,
-                         double* Gam);
+ * Any output may be NULL.  _f32: T = Float32, as the reference's Kerr-Schild testset runs it (test/runtests.jl:37). */
+int rtgr_eval_metric_f64(rtgr_context* ctx, const rtgr_scene* scene, const double* x /* n x 4 */, uint64_t n, double* g,
+                         double* dg, double* Gam);
+int rtgr_eval_metric_f32(rtgr_context* ctx, const rtgr_scene* scene, const float* x /* n x 4 */, uint64_t n, float* g,
+                         float* dg, float* Gam);
 /* geodesic RHS (src/RayTraceGR.jl:358-370): n x 8 states -> n x 8 derivatives, on the device.
- * path = 0: production path (Kerr–Schild-form closed contraction), 1: generic dual-number path. */
-int rtgr_eval_geodesic_f64(const rtgr_scene* scene, const double* s /* n x 8 */, uint64_t n, int path,
+ * path = 0: Kerr–Schild-form closed contraction with IEEE division (the tile kernel's RHS);
+ * path = 1: generic dual-number path (RTGR_METRIC_GENERIC, user metrics);
+ * path = 2: EXACTLY the function the production integrate loop calls (closed contraction with the fast reciprocal /
+ *           reciprocal-square-root sequences, null-congruence shortcuts of the textbook metric). */
+int rtgr_eval_geodesic_f64(rtgr_context* ctx, const rtgr_scene* scene, const double* s /* n x 8 */, uint64_t n, int path,
                            double* ds /* n x 8 */);
+int rtgr_eval_geodesic_f32(rtgr_context* ctx, const rtgr_scene* scene, const float* s /* n x 8 */, uint64_t n, int path,
+                           float* ds /* n x 8 */);
+/* the hot loop's reciprocal and reciprocal-square-root sequences (hardware seed + one third-order correction) on n
+ * operands; either output may be NULL */
+int rtgr_eval_fastmath_f64(rtgr_context* ctx, const double* x, uint64_t n, double* rcp, double* rsq);
 
 /* ---- user metrics: "metric is ANY callable x -> g" (src/RayTraceGR.jl:302-309, :358-370, :457-511) ------------
  * The reference accepts any Julia function as the metric and differentiates it with forward duals.  The native
  * counterpart: the caller writes the metric once as a C++ function template over the scalar type
  *     template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]);
- * (S = double for make_canvas' normalisation, S = 4-wide forward dual for dmetric), pastes it into
+ * (S = double / float for make_canvas' normalisation, S = 4-wide forward dual of either for dmetric), pastes it into
  * raytracegr.jl_amd/csrc/rtgr_user_unit.hip.in, compiles that unit with
  *     hipcc --genco --no-gpu-bundle-output --offload-arch=gfx950 -O3 -std=c++17 -I<csrc> unit.hip -o metric.hsaco
- * and hands the code object to the library.  From then on rtgr_scene.metric = RTGR_USER selects it in every entry
- * point that takes a scene (trace, make_canvas, eval_metric, eval_geodesic path 1); M and a of the scene are passed
- * through to the function.  One user metric is resident at a time; loading another replaces it (the library
- * synchronises the device first).  The Python mirror automates the three steps (api.UserMetric). */
-int rtgr_user_metric_load(const char* code_object_path);
-int rtgr_user_metric_unload(void);
-/* 1 if a user metric is resident, else 0 */
-int rtgr_user_metric_loaded(void);
+ * and hands the code object to the library, which loads it on every device of the context and returns its id (a hash
+ * of the code object: loading the same file twice yields the same id and one resident copy).  A scene selects it with
+ * metric = RTGR_USER and user_metric = id, in every entry point that takes a scene (trace, make_canvas, eval_metric,
+ * eval_geodesic path 1); M and a of the scene are passed through to the function.  Several metrics may be resident at
+ * once.  The Python mirror automates the steps (api.UserMetric). */
+int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out);
+int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
+/* 1 if module `id` is resident (id 0: any module), else 0 */
+int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id);
 
 /* ---- image output: N0f8 quantisation + transposed PNG layout of `save(file, colorview(...))` (:566-575) ---- */
 /* rgb planes (n = ni*nj, device pointer) -> 8-bit interleaved image[j][i][c] (device pointer, 3*n bytes). */
-int rtgr_quantize_device_f64(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, void* stream);
+int rtgr_quantize_device_f64(rtgr_context* ctx, const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 RTGR_MAX_OBJECTS = 16
-RTGR_ABI_VERSION = 1
+RTGR_ABI_VERSION = 2
+RTGR_MAX_DEVICES = 16
 
 # enum rtgr_metric
 MINKOWSKI, KS_REF, KS_TRUE, USER = 0, 1, 2, 3
@@ -27,7 +28,7 @@ class rtgr_object(C.Structure):
 
 class rtgr_scene(C.Structure):
     _fields_ = [("metric", C.c_uint32), ("nobj", C.c_uint32), ("M", C.c_double), ("a", C.c_double),
-                ("obj", rtgr_object * RTGR_MAX_OBJECTS)]
+                ("user_metric", C.c_uint64), ("obj", rtgr_object * RTGR_MAX_OBJECTS)]
 
 
 class rtgr_solver(C.Structure):
@@ -52,15 +53,20 @@ class rtgr_counters(C.Structure):
 
 class rtgr_ray_outputs(C.Structure):
     _fields_ = [("state_end", C.c_void_p), ("lambda_end", C.c_void_p), ("status", C.c_void_p),
-                ("hit", C.c_void_p), ("n_accept", C.c_void_p), ("n_reject", C.c_void_p)]
+                ("hit", C.c_void_p), ("n_accept", C.c_void_p), ("n_reject", C.c_void_p), ("redshift", C.c_void_p)]
 
 
 # Every symbol include/rtgr.h declares (tests check the .so exports exactly this list).
 EXPORTS = [
-    "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version", "rtgr_solver_defaults",
-    "rtgr_device_info", "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read", "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_rows_device_f64", "rtgr_trace_rows_device_f32", "rtgr_trace_f64", "rtgr_trace_f32",
-    "rtgr_trace_pixels_f64", "rtgr_trace_one_f64", "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64",
-    "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", "rtgr_quantize_device_f64",
+    "rtgr_create", "rtgr_destroy", "rtgr_context_devices", "rtgr_trim", "rtgr_init", "rtgr_shutdown", "rtgr_last_error",
+    "rtgr_abi_version", "rtgr_solver_defaults", "rtgr_device_info", "rtgr_set_option", "rtgr_get_option",
+    "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read",
+    "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_rows_device_f64", "rtgr_trace_rows_device_f32",
+    "rtgr_trace_f64", "rtgr_trace_f32", "rtgr_trace_pixels_f64", "rtgr_trace_one_f64",
+    "rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64",
+    "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64",
+    "rtgr_eval_metric_f64", "rtgr_eval_metric_f32", "rtgr_eval_geodesic_f64", "rtgr_eval_geodesic_f32",
+    "rtgr_eval_fastmath_f64", "rtgr_quantize_device_f64",
     "rtgr_user_metric_load", "rtgr_user_metric_unload", "rtgr_user_metric_loaded",
 ]
 
@@ -78,36 +84,49 @@ class RtgrError(RuntimeError):
 
 
 def _declare(lib):
-    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    """argtypes of every entry point.  The first argument of every compute entry point is the rtgr_context* (None = the
+    process's default context)."""
+    vp, u64, i32, clong = C.c_void_p, C.c_uint64, C.c_int, C.c_long
     P = C.POINTER
+    ctx = vp
+    lib.rtgr_create.argtypes = [P(i32), i32, P(vp)]
+    lib.rtgr_destroy.argtypes = [ctx]
+    lib.rtgr_context_devices.argtypes = [ctx]
+    lib.rtgr_trim.argtypes = [ctx]
     lib.rtgr_init.argtypes = [i32]
     lib.rtgr_shutdown.argtypes = []
     lib.rtgr_last_error.argtypes = []
     lib.rtgr_last_error.restype = C.c_char_p
     lib.rtgr_abi_version.argtypes = []
     lib.rtgr_solver_defaults.argtypes = [P(rtgr_solver), i32]
-    lib.rtgr_device_info.argtypes = [C.c_char_p, u64, P(i32), P(i32), P(i32)]
-    lib.rtgr_reserve_workspace.argtypes = [u64, i32, i32]
-    lib.rtgr_timing_enable.argtypes = [i32]
-    lib.rtgr_timing_read.argtypes = [P(C.c_double * 4), P(C.c_uint64 * 4)]
+    lib.rtgr_device_info.argtypes = [ctx, i32, C.c_char_p, u64, P(i32), P(i32), P(i32)]
+    lib.rtgr_set_option.argtypes = [ctx, C.c_char_p, clong]
+    lib.rtgr_get_option.argtypes = [ctx, C.c_char_p, P(clong)]
+    lib.rtgr_reserve_workspace.argtypes = [ctx, vp, vp, u64, i32, i32]
+    lib.rtgr_timing_enable.argtypes = [ctx, i32, i32]
+    lib.rtgr_timing_read.argtypes = [ctx, i32, P(C.c_double * 4), P(C.c_uint64 * 4)]
     for suf in ("f64", "f32"):
         getattr(lib, f"rtgr_trace_device_{suf}").argtypes = [
-            P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]
+            ctx, P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]
         getattr(lib, f"rtgr_trace_rows_device_{suf}").argtypes = [
-            P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]
+            ctx, P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]
         getattr(lib, f"rtgr_trace_{suf}").argtypes = [
-            P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs),
+            ctx, P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs),
             P(rtgr_counters)]
-    lib.rtgr_trace_pixels_f64.argtypes = [P(rtgr_scene), P(rtgr_solver), vp, u64, u64, vp, P(rtgr_counters)]
-    lib.rtgr_trace_one_f64.argtypes = [P(rtgr_scene), P(rtgr_solver), vp, vp, vp, vp, vp]
-    lib.rtgr_make_canvas_device_f64.argtypes = [P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp, vp]
-    lib.rtgr_make_canvas_f64.argtypes = [P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp]
-    lib.rtgr_eval_metric_f64.argtypes = [P(rtgr_scene), vp, u64, vp, vp, vp]
-    lib.rtgr_eval_geodesic_f64.argtypes = [P(rtgr_scene), vp, u64, i32, vp]
-    lib.rtgr_quantize_device_f64.argtypes = [vp, u64, u64, vp, vp]
-    lib.rtgr_user_metric_load.argtypes = [C.c_char_p]
-    lib.rtgr_user_metric_unload.argtypes = []
-    lib.rtgr_user_metric_loaded.argtypes = []
+        getattr(lib, f"rtgr_eval_metric_{suf}").argtypes = [ctx, P(rtgr_scene), vp, u64, vp, vp, vp]
+        getattr(lib, f"rtgr_eval_geodesic_{suf}").argtypes = [ctx, P(rtgr_scene), vp, u64, i32, vp]
+    lib.rtgr_trace_pixels_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, u64, u64, vp, P(rtgr_counters)]
+    lib.rtgr_trace_one_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, vp, vp, vp, vp]
+    for name in ("rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64"):
+        getattr(lib, name).argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, vp,
+                                       P(rtgr_ray_outputs), P(rtgr_counters)]
+    lib.rtgr_make_canvas_device_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp, vp]
+    lib.rtgr_make_canvas_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp]
+    lib.rtgr_eval_fastmath_f64.argtypes = [ctx, vp, u64, vp, vp]
+    lib.rtgr_quantize_device_f64.argtypes = [ctx, vp, u64, u64, vp, vp]
+    lib.rtgr_user_metric_load.argtypes = [ctx, C.c_char_p, P(u64)]
+    lib.rtgr_user_metric_unload.argtypes = [ctx, u64]
+    lib.rtgr_user_metric_loaded.argtypes = [ctx, u64]
     for name in EXPORTS:
         if name != "rtgr_last_error":
             getattr(lib, name).restype = i32
@@ -159,3 +178,32 @@ def check(lib, code):
         msg = lib.rtgr_last_error()
         raise RtgrError(code, msg.decode() if msg else "?")
     return code
+
+
+class options:
+    """`with options(lib, split=0, near_early=8): ...` — set launch-policy options of a context (default: the
+    process's default context) for the duration of the block (rtgr_set_option; they never change a result bit)."""
+
+    def __init__(self, lib, ctx=None, **kw):
+        self.lib, self.ctx, self.kw, self.old = lib, ctx, kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            cur = C.c_long(0)
+            check(self.lib, self.lib.rtgr_get_option(self.ctx, k.encode(), C.byref(cur)))
+            self.old[k] = cur.value
+            check(self.lib, self.lib.rtgr_set_option(self.ctx, k.encode(), int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            check(self.lib, self.lib.rtgr_set_option(self.ctx, k.encode(), v))
+        return False
+
+
+def create_context(lib, device_ids):
+    """rtgr_create over a list of HIP device ordinals -> opaque context handle (pass it as the first argument)."""
+    ids = (C.c_int * len(device_ids))(*device_ids)
+    h = C.c_void_p(None)
+    check(lib, lib.rtgr_create(ids, len(device_ids), C.byref(h)))
+    return h

@@ -100,10 +100,13 @@ class Disk(Object):
         return [self.h, self.r_in, self.r_out] + [0.0] * 6
 
 
-def make_scene(metric, objs):
-    """(metric, objs::Vector{Object}) -> rtgr_scene (order of objs preserved: it matters, :518-530)."""
+def make_scene(metric, objs, ctx=None):
+    """(metric, objs::Vector{Object}) -> rtgr_scene (order of objs preserved: it matters, :518-530).  A scene of a
+    UserMetric carries the id of that metric's module in `ctx` (loaded on first use), so it can only ever run with its
+    own kernels — whichever other metrics are resident."""
+    user_id = 0
     if isinstance(metric, UserMetric):
-        metric.activate()  # the code object of THIS metric must be the resident one when the scene is used
+        user_id = metric.module_id(ctx)
     elif not isinstance(metric, Metric):
         raise TypeError(
             "a metric is one of the built-ins (minkowski, kerr_schild, KerrSchild(M,a)) or a UserMetric(source) "
@@ -114,6 +117,7 @@ def make_scene(metric, objs):
     sc = rtgr_scene()
     sc.metric = metric.kind | (_abi.METRIC_GENERIC if metric.generic else 0)
     sc.nobj, sc.M, sc.a = len(objs), metric.M, metric.a
+    sc.user_metric = user_id
     for o, obj in enumerate(objs):
         sc.obj[o].kind = obj.kind
         p = obj._pack()
@@ -195,7 +199,7 @@ def make_canvas(metric, pos, widthx, widthy, normal, ni, nj):
     sc = make_scene(metric, [])
     cam = make_camera(pos, widthx, widthy, normal)
     st = np.empty((ni * nj, 8), dtype=np.float64)
-    _abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
+    _abi.check(lib, lib.rtgr_make_canvas_f64(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
     px = np.zeros((ni, nj), dtype=pixel_dtype(), order="F")
     flat = px.reshape(-1, order="F")
     flat["pos"] = st[:, :4]
@@ -217,7 +221,7 @@ def trace_rays(metric, objs, c, opt=None, return_info=False):
         raise TypeError("Canvas{Float64} expected")
     pout = np.empty_like(pin, order="F")
     ctr = rtgr_counters()
-    _abi.check(lib, lib.rtgr_trace_pixels_f64(C.byref(sc), C.byref(opt), pin.ctypes.data, ni, nj,
+    _abi.check(lib, lib.rtgr_trace_pixels_f64(None, C.byref(sc), C.byref(opt), pin.ctypes.data, ni, nj,
                                               pout.ctypes.data, C.byref(ctr)))
     out = Canvas(pout)
     return (out, ctr.as_dict()) if return_info else out
@@ -235,7 +239,7 @@ def trace_ray(metric, objs, cb, p, opt=None):
     rgb = np.zeros(3)
     se = np.zeros(8)
     st = C.c_uint8(0)
-    _abi.check(lib, lib.rtgr_trace_one_f64(C.byref(sc), C.byref(opt), pos.ctypes.data, nrm.ctypes.data,
+    _abi.check(lib, lib.rtgr_trace_one_f64(None, C.byref(sc), C.byref(opt), pos.ctypes.data, nrm.ctypes.data,
                                            rgb.ctypes.data, se.ctypes.data, C.addressof(st)))
     return Pixel(pos, nrm, rgb)
 
@@ -249,7 +253,7 @@ def _eval_metric(metric, x, want=(True, True, True)):
     g = np.empty((n, 4, 4)) if want[0] else None
     dg = np.empty((n, 4, 4, 4)) if want[1] else None
     G = np.empty((n, 4, 4, 4)) if want[2] else None
-    _abi.check(lib, lib.rtgr_eval_metric_f64(C.byref(sc), x.ctypes.data, n, g.ctypes.data if want[0] else None,
+    _abi.check(lib, lib.rtgr_eval_metric_f64(None, C.byref(sc), x.ctypes.data, n, g.ctypes.data if want[0] else None,
                                              dg.ctypes.data if want[1] else None,
                                              G.ctypes.data if want[2] else None))
     sq = (lambda v: v[0] if (v is not None and n == 1) else v)
@@ -273,7 +277,7 @@ def geodesic(s, metric, lam=0.0, path=0):
     sc = make_scene(metric, [])
     s = np.ascontiguousarray(s, dtype=np.float64).reshape(-1, 8)
     ds = np.empty_like(s)
-    _abi.check(lib, lib.rtgr_eval_geodesic_f64(C.byref(sc), s.ctypes.data, s.shape[0], path, ds.ctypes.data))
+    _abi.check(lib, lib.rtgr_eval_geodesic_f64(None, C.byref(sc), s.ctypes.data, s.shape[0], path, ds.ctypes.data))
     return ds[0] if ds.shape[0] == 1 else ds
 
 

@@ -1,0 +1,1349 @@
+// rtgr_api.hip — the C ABI of include/rtgr.h over the HIP pipeline (gfx950 only; no CPU fallback, no compatibility paths).
+//
+// This file holds NO kernel: contexts and their per-device / per-stream state (rtgr_host.hpp), argument checking and
+// conversion, dispatch to the translation unit that owns the metric variant's kernels (tu_*.hip), the host-pointer
+// entry points (pinned staging + a three-stream H2D / compute / D2H pipeline), the single-process multi-device path
+// (cyclic rows, peer copies to device 0) and run-time loaded metric modules.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+#include "rtgr_host.hpp"
+
+namespace rtgr {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// knobs
+// ---------------------------------------------------------------------------------------------------------------------
+static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
+                                         "far4", "rounds", "qchunk", "qchunk_near", "tile", "lds_stages", "host_chunk",
+                                         "dbg_pass_far", nullptr};
+const char* const* knob_names() { return KNOB_NAMES; }
+long* knob_slot(Knobs& k, const char* name) {
+    if (!name) return nullptr;
+    long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
+                     &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.lds_stages, &k.host_chunk, &k.dbg_pass_far};
+    for (int i = 0; KNOB_NAMES[i]; i++)
+        if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
+    return nullptr;
+}
+static Knobs knobs_from_env() {  // once per context
+    Knobs k;
+    for (int i = 0; KNOB_NAMES[i]; i++) {
+        std::string env = "RTGR_";
+        for (const char* c = KNOB_NAMES[i]; *c; c++) env += (char)std::toupper((unsigned char)*c);
+        const char* v = std::getenv(env.c_str());
+        if (v && *v) *knob_slot(k, KNOB_NAMES[i]) = std::atol(v);
+    }
+    const char* kn = std::getenv("RTGR_KERNEL");  // historical spelling of tile = 1
+    if (kn && std::strcmp(kn, "tile") == 0) k.tile = 1;
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// workspaces
+// ---------------------------------------------------------------------------------------------------------------------
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+template <class R>
+size_t workspace_bytes(uint64_t rays, bool with_state) {
+    const int recw = with_state ? REC_W_STATE : REC_W;
+    return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
+           align256(rays * HAND_W * sizeof(R)) + 2 * align256(rays * sizeof(uint32_t)) + align256(rays) + 4096;
+}
+template size_t workspace_bytes<double>(uint64_t, bool);
+template size_t workspace_bytes<float>(uint64_t, bool);
+
+// Rays per pipeline chunk.  Every chunk pays the tails of its passes once, so bigger is better (8192² in one chunk instead
+// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (33.7 GB of workspace at 501 B/ray), halved
+// until the workspace fits into a quarter of the memory that is free when it has to be (re)allocated.
+template <class R>
+uint64_t pick_chunk(const DeviceCtx& d, const StreamState& ss, uint64_t n, bool with_state) {
+    const uint64_t cap = d.knobs.chunk > 0 ? (uint64_t)(d.knobs.chunk < 64 ? 64 : d.knobs.chunk) : (1ull << 26);
+    uint64_t chunk = n < cap ? n : cap;
+    if (workspace_bytes<R>(chunk, with_state) <= ss.ws_bytes) return chunk;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return chunk;
+    const size_t budget = free_b / 4;
+    while (chunk > (1ull << 20) && workspace_bytes<R>(chunk, with_state) > budget) chunk = (chunk + 1) / 2;
+    return chunk;
+}
+template uint64_t pick_chunk<double>(const DeviceCtx&, const StreamState&, uint64_t, bool);
+template uint64_t pick_chunk<float>(const DeviceCtx&, const StreamState&, uint64_t, bool);
+
+int ensure_workspace(DeviceCtx& d, StreamState& ss, size_t bytes, hipStream_t st) {
+    if (bytes <= ss.ws_bytes) return RTGR_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(RTGR_ERR_BAD_ARG, "the stream's workspace must grow but the stream is being captured: call "
+                                      "rtgr_reserve_workspace for this stream before hipStreamBeginCapture");
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    // the old buffer may be referenced by kernels still in flight on this stream or by a graph captured earlier: retire it
+    if (ss.ws) ss.retired.push_back(ss.ws);
+    ss.ws = p;
+    ss.ws_bytes = bytes;
+    return RTGR_OK;
+}
+
+static int stream_state(DeviceCtx& d, hipStream_t st, StreamState** out) {
+    auto it = d.streams.find(st);
+    if (it == d.streams.end()) {
+        StreamState ss;
+        HIP_TRY(hipMalloc((void**)&ss.queue, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ss.queue, 0, 8 * sizeof(unsigned long long)));
+        it = d.streams.emplace(st, ss).first;
+    }
+    *out = &it->second;
+    return RTGR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// contexts
+// ---------------------------------------------------------------------------------------------------------------------
+struct PinnedBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int need(size_t b) {
+        if (b <= bytes) return RTGR_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        HIP_TRY(hipHostMalloc(&p, b, hipHostMallocDefault));
+        bytes = b;
+        return RTGR_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+struct DevBufG {  // grow-only device buffer
+    void* p = nullptr; size_t bytes = 0;
+    int need(size_t b) {
+        if (b <= bytes) return RTGR_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }  // only called with the owning streams idle
+        HIP_TRY(hipMalloc(&p, b));
+        bytes = b;
+        return RTGR_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// staging of the host-pointer entry points and of the multi-device path (one per DeviceCtx, created on first use)
+struct Staging {
+    hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
+    static constexpr int IN_SLOTS = 3, OUT_SLOTS = 2;
+    PinnedBuf pin_in[IN_SLOTS], pin_out[OUT_SLOTS], pin_small;
+    hipEvent_t ev_in[IN_SLOTS] = {nullptr, nullptr, nullptr};
+    DevBufG d_in, d_out, d_small;  // device-side inputs (ray states), outputs (all requested arrays), counters + flags
+    DevBufG d_recv;                // device 0 of a multi-device context: rows received from the peers
+    std::mutex mu;                 // one host-pointer call at a time per device (they share the staging buffers)
+};
+static void staging_delete(Staging* s) {
+    if (!s) return;
+    for (auto& b : s->pin_in) b.release();
+    for (auto& b : s->pin_out) b.release();
+    s->pin_small.release();
+    s->d_in.release(); s->d_out.release(); s->d_small.release(); s->d_recv.release();
+    for (auto& e : s->ev_in) if (e) (void)hipEventDestroy(e);
+    if (s->s_up) (void)hipStreamDestroy(s->s_up);
+    if (s->s_comp) (void)hipStreamDestroy(s->s_comp);
+    if (s->s_down) (void)hipStreamDestroy(s->s_down);
+    delete s;
+}
+
+}  // namespace rtgr
+
+using namespace rtgr;
+
+struct rtgr_context {
+    std::vector<std::unique_ptr<DeviceCtx>> devs;
+};
+
+namespace {
+
+struct DeviceGuard {  // the calling thread's current device is restored on scope exit
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+std::mutex g_default_mu;
+rtgr_context* g_default = nullptr;
+
+int staging_of(DeviceCtx& d, Staging** out) {
+    if (!d.staging) {
+        std::unique_ptr<Staging, void (*)(Staging*)> s(new Staging, staging_delete);
+        HIP_TRY(hipStreamCreateWithFlags(&s->s_up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&s->s_down, hipStreamNonBlocking));
+        for (auto& e : s->ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d.staging = std::move(s);
+    }
+    *out = d.staging.get();
+    return RTGR_OK;
+}
+
+void free_device_state(DeviceCtx& d, bool all) {
+    DeviceGuard g(d.dev);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : d.streams) {
+        for (void* p : kv.second.retired) (void)hipFree(p);
+        kv.second.retired.clear();
+        if (all) {
+            if (kv.second.ws) (void)hipFree(kv.second.ws);
+            if (kv.second.queue) (void)hipFree(kv.second.queue);
+        }
+    }
+    d.staging.reset();
+    if (all) {
+        d.streams.clear();
+        for (auto& m : d.modules) if (m.module) (void)hipModuleUnload(m.module);
+        d.modules.clear();
+        for (auto& t : d.timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        d.timed.clear();
+        for (auto e : d.event_pool) (void)hipEventDestroy(e);
+        d.event_pool.clear();
+    }
+}
+
+int create_context(const int* ids, int n, rtgr_context** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RTGR_ERR_NO_DEVICE, "no HIP device visible; librtgr_hip has no CPU fallback");
+    int cur = 0;
+    if (!ids) { HIP_TRY(hipGetDevice(&cur)); ids = &cur; n = 1; }
+    if (n <= 0 || n > RTGR_MAX_DEVICES) return fail(RTGR_ERR_BAD_ARG, "need 1..RTGR_MAX_DEVICES devices");
+    std::unique_ptr<rtgr_context> c(new rtgr_context);
+    const Knobs k = knobs_from_env();
+    for (int i = 0; i < n; i++) {
+        if (ids[i] < 0 || ids[i] >= ndev) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
+        hipDeviceProp_t p;
+        HIP_TRY(hipGetDeviceProperties(&p, ids[i]));
+        if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            return fail(RTGR_ERR_NO_DEVICE, std::string("librtgr_hip is built for gfx950 only; device is ") + p.gcnArchName);
+        std::unique_ptr<DeviceCtx> d(new DeviceCtx);
+        d->dev = ids[i];
+        d->num_cu = p.multiProcessorCount;
+        d->name = std::string(p.name) + " (" + p.gcnArchName + ")";
+        d->knobs = k;
+        c->devs.push_back(std::move(d));
+    }
+    // peer access device 0 <-> every other physical device (the multi-device gather); failures are not fatal —
+    // hipMemcpyPeerAsync then stages through the host
+    for (int i = 1; i < n; i++) {
+        const int a = c->devs[0]->dev, b = c->devs[i]->dev;
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+            { DeviceGuard g(a); (void)hipDeviceEnablePeerAccess(b, 0); }
+            { DeviceGuard g(b); (void)hipDeviceEnablePeerAccess(a, 0); }
+            (void)hipGetLastError();  // "already enabled" is fine
+        }
+    }
+    *out = c.release();
+    return RTGR_OK;
+}
+
+void destroy_context(rtgr_context* c) {
+    if (!c) return;
+    for (auto& d : c->devs) free_device_state(*d, true);
+    delete c;
+}
+
+// ctx == NULL: the process's default context (created on the calling thread's current device on first use)
+int resolve_ctx(rtgr_context* in, rtgr_context** out) {
+    (void)hipGetLastError();  // every entry point starts here: drop a stale error left by an earlier (or foreign) call
+    if (in) { *out = in; return RTGR_OK; }
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        int rc = create_context(nullptr, 0, &g_default);
+        if (rc) return rc;
+    }
+    *out = g_default;
+    return RTGR_OK;
+}
+
+// the DeviceCtx that owns a device pointer (first entry of the context with that ordinal); NULL pointer: device 0
+int device_of(rtgr_context* c, const void* d_ptr, DeviceCtx** out) {
+    if (!d_ptr) { *out = c->devs[0].get(); return RTGR_OK; }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, d_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RTGR_ERR_BAD_ARG, "not a device pointer (hipPointerGetAttributes failed)");
+    }
+    for (auto& d : c->devs)
+        if (d->dev == at.device) { *out = d.get(); return RTGR_OK; }
+    return fail(RTGR_ERR_BAD_ARG, "the device that owns this pointer is not part of the context");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// argument conversion
+// ---------------------------------------------------------------------------------------------------------------------
+template <class R>
+int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserModule** user) {
+    if (!s) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
+    if ((s->metric & ~RTGR_METRIC_GENERIC) > RTGR_USER) return fail(RTGR_ERR_BAD_ARG, "unknown metric enum");
+    *user = nullptr;
+    if ((s->metric & ~RTGR_METRIC_GENERIC) == RTGR_USER) {
+        if (D.modules.empty()) return fail(RTGR_ERR_BAD_ARG, "RTGR_USER: no user metric loaded (rtgr_user_metric_load)");
+        *user = D.find_module(s->user_metric);
+        if (!*user)
+            return fail(RTGR_ERR_BAD_ARG, "RTGR_USER: rtgr_scene.user_metric names a module that is not loaded in this "
+                                          "context (a scene only ever runs with the kernels of its own metric)");
+        if (sizeof(R) != 8 && !(*user)->full10_f32)
+            return fail(RTGR_ERR_BAD_ARG, "this user-metric code object carries no Float32 kernels");
+    }
+    if (s->nobj > RTGR_MAX_OBJECTS) return fail(RTGR_ERR_BAD_ARG, "too many objects");
+    std::memset(&d, 0, sizeof d);
+    d.metric = s->metric & ~RTGR_METRIC_GENERIC;
+    d.nobj = s->nobj;
+    d.M = (R)s->M;
+    d.a = (R)s->a;
+    for (uint32_t o = 0; o < s->nobj; o++) {
+        if (s->obj[o].kind < RTGR_PLANE || s->obj[o].kind > RTGR_DISK)
+            return fail(RTGR_ERR_BAD_ARG, "unknown object kind (abstract Object has no distance)");
+        d.obj[o].kind = s->obj[o].kind;
+        for (int q = 0; q < 9; q++) d.obj[o].p[q] = (R)s->obj[o].p[q];
+    }
+    return RTGR_OK;
+}
+template <class R>
+int convert_solver(const rtgr_solver* s, DevSolver<R>& d) {
+    if (!s) return fail(RTGR_ERR_BAD_ARG, "solver is NULL");
+    if (!(s->reltol > 0) || !(s->abstol > 0)) return fail(RTGR_ERR_BAD_ARG, "tolerances must be positive");
+    if (!(s->lambda1 > s->lambda0)) return fail(RTGR_ERR_BAD_ARG, "lambda1 must exceed lambda0");
+    if (s->max_steps == 0) return fail(RTGR_ERR_BAD_ARG, "max_steps must be positive");
+    d.reltol = (R)s->reltol;
+    d.abstol = (R)s->abstol;
+    d.lambda0 = (R)s->lambda0;
+    d.lambda1 = (R)s->lambda1;
+    d.hit_threshold = (R)s->hit_threshold;
+    for (int c = 0; c < 3; c++) d.miss_rgb[c] = (R)s->miss_rgb[c];
+    d.max_steps = s->max_steps;
+    d.interp_points = s->interp_points;
+    return RTGR_OK;
+}
+template <class R>
+void convert_camera(const rtgr_camera* c, DevCamera<R>& d) {
+    for (int a = 0; a < 4; a++) {
+        d.pos[a] = (R)c->pos[a];
+        d.widthx[a] = (R)c->widthx[a];
+        d.widthy[a] = (R)c->widthy[a];
+        d.normal[a] = (R)c->normal[a];
+    }
+}
+
+int dispatch(LaunchEnv& E, const TraceArgs<double>& A, bool generic, bool spin, hipStream_t st) {
+    if (generic) return launch_f64_generic(E, A, st);
+    switch (A.sc.metric) {
+        case RTGR_MINKOWSKI: return launch_f64_mink(E, A, st);
+        case RTGR_KS_REF: return launch_f64_ksref(E, A, spin, st);
+        default: return launch_f64_kstrue(E, A, spin, st);
+    }
+}
+int dispatch(LaunchEnv& E, const TraceArgs<float>& A, bool generic, bool spin, hipStream_t st) {
+    if (generic) return launch_f32_generic(E, A, st);
+    return launch_f32_closed(E, A, spin, st);
+}
+
+// window of a larger output: see TraceArgs::plane_stride / out_offset
+struct Window { uint64_t plane_stride = 0, out_offset = 0; uint32_t* nan_flag = nullptr; };
+
+// Enqueue the pipeline for rows of a canvas on device D, stream st.  The caller holds no lock; this takes D.mu for the
+// duration of the enqueue.
+template <class R>
+int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const R* d_state0, const rtgr_camera* cam,
+                 uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* d_rgb, const rtgr_ray_outputs* out,
+                 rtgr_counters* d_counters, hipStream_t st, uint64_t jstride = 1, uint64_t nrows_strided = 0,
+                 const Window* win = nullptr) {
+    DeviceGuard guard(D.dev);
+    if (!guard.ok) return fail(RTGR_ERR_HIP, "hipSetDevice failed");
+    std::lock_guard<std::mutex> lk(D.mu);
+    TraceArgs<R> A;
+    std::memset(&A, 0, sizeof A);
+    const UserModule* user = nullptr;
+    int rc;
+    if ((rc = convert_scene<R>(D, scene, A.sc, &user))) return rc;
+    if ((rc = convert_solver<R>(opt, A.opt))) return rc;
+    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    uint64_t nrows = j1 - j0;
+    if (jstride != 1 || nrows_strided != 0) {  // rows j0, j0+jstride, … (nrows_strided of them)
+        if (jstride == 0 || nrows_strided == 0 || j0 >= nj || j0 + (nrows_strided - 1) * jstride >= nj)
+            return fail(RTGR_ERR_BAD_ARG, "bad strided row range: need j0 + (nrows-1)*jstride < nj");
+        nrows = nrows_strided;
+    } else if (j1 <= j0 || j1 > nj) {
+        return fail(RTGR_ERR_BAD_ARG, "bad canvas range: need 0 <= j0 < j1 <= nj, ni > 0");
+    }
+    if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "bad canvas range: need 0 <= j0 < j1 <= nj, ni > 0");
+    if (!d_state0 && !cam) return fail(RTGR_ERR_BAD_ARG, "need state0 or a camera");
+    if (ni * nrows > (1ull << 40)) return fail(RTGR_ERR_BAD_ARG, "canvas too large");
+    if (cam) convert_camera<R>(cam, A.cam);
+    A.state0 = d_state0;
+    A.ni = ni; A.nj = nj; A.j0 = j0; A.nrows = nrows; A.jstride = jstride;
+    A.rgb = d_rgb;
+    if (out) {
+        A.state_end = (R*)out->state_end;
+        A.lambda_end = (R*)out->lambda_end;
+        A.status = out->status;
+        A.hit = out->hit;
+        A.n_accept = out->n_accept;
+        A.n_reject = out->n_reject;
+        if (out->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
+    }
+    if (win) { A.plane_stride = win->plane_stride; A.out_offset = win->out_offset; A.nan_flag = win->nan_flag; }
+    A.counters = (unsigned long long*)d_counters;
+    const bool spin = scene->a != 0.0;
+    const bool generic = ((scene->metric & RTGR_METRIC_GENERIC) != 0 && A.sc.metric != RTGR_MINKOWSKI) || A.sc.metric == RTGR_USER;
+    if (D.knobs.tile) {
+        if (generic) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC needs the persistent pipeline (option tile = 0)");
+        if (win && (win->plane_stride || win->out_offset)) return fail(RTGR_ERR_BAD_ARG, "the tile kernel writes whole slabs only");
+    }
+    StreamState* ss = nullptr;
+    if ((rc = stream_state(D, st, &ss))) return rc;
+    LaunchEnv E{D, *ss, user};
+    rc = dispatch(E, A, generic, spin, st);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return RTGR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host <-> pinned copies with a few threads (a single core moves ~8 GB/s; PCIe Gen5 x16 wants ~55)
+// ---------------------------------------------------------------------------------------------------------------------
+template <class F>
+void parallel_rows(uint64_t n, size_t bytes_per_item, F&& body) {  // body(first, count)
+    const size_t total = (size_t)n * bytes_per_item;
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = total < (4u << 20) ? 1u : (hw >= 16 ? 8u : (hw >= 4 ? hw / 2 : 1u));
+    if (nt <= 1) { body((uint64_t)0, n); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t a = (uint64_t)t * per, b = a + per < n ? a + per : n;
+        if (a >= b) break;
+        th.emplace_back([&, a, b] { body(a, b - a); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// One output array of a host-pointer call: `planes` planes (rgb: 3, else 1) of `elem` bytes per ray.
+struct OutArray { void* host; size_t elem; int planes; size_t dev_off; };
+
+// The host-pointer hot path (rtgr_trace_f64 / _f32 / _pixels_f64 / _one_f64).  Rays [0, n) are rows [j0, j1) of the
+// canvas; the job is cut into compute chunks of whole rows (~2^22 rays: big enough that the persistent kernels lose
+// nothing, SURVEY §6 / DESIGN §4.2) and each chunk's input into transfer pieces (~2^20 rays).  Three streams:
+//     s_up:   H2D of the pieces from pinned staging (the host packs them there with a few threads)
+//     s_comp: the trace pipeline of chunk c once its last piece has landed
+//     s_down: D2H of chunk c's outputs into pinned staging; a helper thread unpacks them into the caller's arrays
+// so that upload, integration and download of successive chunks overlap, and PCIe carries 64 B/ray in (ray states; nothing
+// when the camera generates them on the device) and 24 B/ray out (+ what `out` asks for) — never the 88-byte pixels.
+// `px_in` != NULL: the input is the reference's Pixel{Float64} array (11 doubles per pixel, pos + normal are packed
+// out of it on the way up) and `px_out` receives Pixel(p.pos, p.normal, rgb) (:532).
+template <class R>
+int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const R* state0, const double* px_in,
+                         double* px_out, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* rgb,
+                         const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    DeviceGuard guard(D.dev);
+    if (!guard.ok) return fail(RTGR_ERR_HIP, "hipSetDevice failed");
+    Staging* S = nullptr;
+    int rc;
+    { std::lock_guard<std::mutex> lk(D.mu); if ((rc = staging_of(D, &S))) return rc; }
+    std::lock_guard<std::mutex> call_lock(S->mu);
+    const uint64_t nrows = j1 - j0, n = ni * nrows;
+    const bool have_in = state0 != nullptr || px_in != nullptr;
+
+    // ---- output arrays ---------------------------------------------------------------------------------------------
+    std::vector<OutArray> outs;
+    size_t dev_bytes = 0;
+    auto add = [&](void* host, size_t elem, int planes) {
+        outs.push_back({host, elem, planes, dev_bytes});
+        dev_bytes += align256((size_t)n * elem * planes);
+    };
+    add(px_in ? nullptr : (void*)rgb, sizeof(R), 3);  // [0] = rgb, always (pixels: unpacked into px_out)
+    rtgr_ray_outputs dout;
+    std::memset(&dout, 0, sizeof dout);
+    if (out) {
+        if (out->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
+        if (out->state_end) add(out->state_end, 8 * sizeof(R), 1);
+        if (out->lambda_end) add(out->lambda_end, sizeof(R), 1);
+        if (out->status) add(out->status, 1, 1);
+        if (out->hit) add(out->hit, 1, 1);
+        if (out->n_accept) add(out->n_accept, 4, 1);
+        if (out->n_reject) add(out->n_reject, 4, 1);
+    }
+    size_t out_bytes_per_ray = 0;
+    for (auto& o : outs) out_bytes_per_ray += o.elem * o.planes;
+
+    // ---- chunking ----------------------------------------------------------------------------------------------------
+    const uint64_t piece_target = D.knobs.host_chunk > 0 ? (uint64_t)D.knobs.host_chunk : (1ull << 20);
+    uint64_t rows_per_chunk = nrows;
+    if (!D.knobs.tile) {
+        const uint64_t chunk_target = 4 * piece_target;
+        rows_per_chunk = chunk_target / ni;
+        if (rows_per_chunk == 0) rows_per_chunk = 1;
+        if (rows_per_chunk > nrows) rows_per_chunk = nrows;
+    }
+    const uint64_t nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk;
+    const uint64_t chunk_rays_max = rows_per_chunk * ni;
+    const uint64_t piece = chunk_rays_max < piece_target ? chunk_rays_max : piece_target;
+
+    // ---- buffers (grow-only; device streams of the staging are idle here: every call ends synchronised) ----------------
+    if (have_in) {
+        if ((rc = S->d_in.need((size_t)n * 8 * sizeof(R)))) return rc;
+        for (auto& b : S->pin_in) if ((rc = b.need((size_t)piece * 8 * sizeof(R)))) return rc;
+    }
+    if ((rc = S->d_out.need(dev_bytes))) return rc;
+    for (auto& b : S->pin_out) if ((rc = b.need((size_t)chunk_rays_max * out_bytes_per_ray + 256 * outs.size() * 3))) return rc;
+    if ((rc = S->d_small.need(256))) return rc;
+    if ((rc = S->pin_small.need(256))) return rc;
+    char* dsmall = (char*)S->d_small.p;
+    rtgr_counters* d_ctr = (rtgr_counters*)dsmall;
+    uint32_t* d_nan = (uint32_t*)(dsmall + 128);
+    HIP_TRY(hipMemsetAsync(dsmall, 0, 256, S->s_comp));
+    char* dob = (char*)S->d_out.p;
+    R* d_rgb = (R*)(dob + outs[0].dev_off);
+    {
+        size_t k = 1;
+        if (out) {
+            if (out->state_end) dout.state_end = dob + outs[k++].dev_off;
+            if (out->lambda_end) dout.lambda_end = dob + outs[k++].dev_off;
+            if (out->status) dout.status = (uint8_t*)(dob + outs[k++].dev_off);
+            if (out->hit) dout.hit = (uint8_t*)(dob + outs[k++].dev_off);
+            if (out->n_accept) dout.n_accept = (uint32_t*)(dob + outs[k++].dev_off);
+            if (out->n_reject) dout.n_reject = (uint32_t*)(dob + outs[k++].dev_off);
+        }
+    }
+    R* d_in = (R*)S->d_in.p;
+
+    std::vector<hipEvent_t> ev_comp(nchunks), ev_down(nchunks);
+    for (auto& e : ev_comp) { e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    for (auto& e : ev_down) { e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    struct EvFree { std::vector<hipEvent_t>&a, &b; ~EvFree() { for (auto e : a) if (e) (void)hipEventDestroy(e); for (auto e : b) if (e) (void)hipEventDestroy(e); } } evfree{ev_comp, ev_down};
+    hipEvent_t ev_up_last = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev_up_last, hipEventDisableTiming));
+    struct OneEv { hipEvent_t e; ~OneEv() { if (e) (void)hipEventDestroy(e); } } onefree{ev_up_last};
+
+    // ---- download side: a helper thread waits for each chunk's D2H and unpacks it into the caller's arrays --------------
+    std::atomic<int> down_rc{RTGR_OK};
+    std::atomic<uint64_t> chunks_enqueued{0};
+    std::atomic<bool> abort_flag{false};
+    std::vector<std::atomic<int>> slot_busy(Staging::OUT_SLOTS);
+    for (auto& b : slot_busy) b.store(0);
+    auto chunk_range = [&](uint64_t c, uint64_t& r0, uint64_t& m) {
+        const uint64_t row0 = c * rows_per_chunk;
+        const uint64_t rows = (nrows - row0) < rows_per_chunk ? (nrows - row0) : rows_per_chunk;
+        r0 = row0 * ni; m = rows * ni;
+    };
+    const int dev_ordinal = D.dev;
+    std::thread downloader([&] {
+        (void)hipSetDevice(dev_ordinal);
+        for (uint64_t c = 0; c < nchunks; c++) {
+            while (chunks_enqueued.load(std::memory_order_acquire) <= c) {
+                if (abort_flag.load()) return;
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            if (hipEventSynchronize(ev_down[c]) != hipSuccess) { down_rc.store(RTGR_ERR_HIP); return; }
+            uint64_t r0, m;
+            chunk_range(c, r0, m);
+            const char* src = (const char*)S->pin_out[c % Staging::OUT_SLOTS].p;
+            size_t off = 0;
+            for (size_t k = 0; k < outs.size(); k++) {
+                const OutArray& o = outs[k];
+                if (k == 0 && px_in) {  // Pixel(p.pos, p.normal, col)  (:532)
+                    const double* pr = (const double*)(src + off);
+                    parallel_rows(m, 88, [&](uint64_t a, uint64_t cnt) {
+                        for (uint64_t w = a; w < a + cnt; w++) {
+                            double* po = px_out + (r0 + w) * 11;
+                            const double* pi = px_in + (r0 + w) * 11;
+                            if (po != pi) for (int q = 0; q < 8; q++) po[q] = pi[q];
+                            po[8] = pr[w]; po[9] = pr[m + w]; po[10] = pr[2 * m + w];
+                        }
+                    });
+                } else {
+                    for (int pl = 0; pl < o.planes; pl++) {
+                        char* dst = (char*)o.host + ((size_t)pl * n + r0) * o.elem;
+                        const char* s2 = src + off + (size_t)pl * m * o.elem;
+                        parallel_rows(m, o.elem, [&](uint64_t a, uint64_t cnt) { std::memcpy(dst + a * o.elem, s2 + a * o.elem, cnt * o.elem); });
+                    }
+                }
+                off += align256((size_t)m * o.elem * o.planes);
+            }
+            slot_busy[c % Staging::OUT_SLOTS].store(0, std::memory_order_release);
+        }
+    });
+    struct Joiner { std::thread& t; std::atomic<bool>& ab; ~Joiner() { ab.store(true); if (t.joinable()) t.join(); } } joiner{downloader, abort_flag};
+
+    // ---- upload + compute, chunk by chunk ---------------------------------------------------------------------------------
+    uint64_t piece_no = 0;
+    for (uint64_t c = 0; c < nchunks; c++) {
+        uint64_t r0, m;
+        chunk_range(c, r0, m);
+        if (have_in) {
+            for (uint64_t p0 = 0; p0 < m; p0 += piece, piece_no++) {
+                const uint64_t pm = (m - p0) < piece ? (m - p0) : piece;
+                const int slot = (int)(piece_no % Staging::IN_SLOTS);
+                if (piece_no >= (uint64_t)Staging::IN_SLOTS) HIP_TRY(hipEventSynchronize(S->ev_in[slot]));  // slot's last H2D done
+                R* pin = (R*)S->pin_in[slot].p;
+                const uint64_t g0 = r0 + p0;
+                if (px_in) {
+                    parallel_rows(pm, 64, [&](uint64_t a, uint64_t cnt) {
+                        for (uint64_t w = a; w < a + cnt; w++) {
+                            const double* pi = px_in + (g0 + w) * 11;
+                            double* d = (double*)pin + w * 8;
+                            for (int q = 0; q < 8; q++) d[q] = pi[q];
+                        }
+                    });
+                } else {
+                    const R* src = state0 + g0 * 8;
+                    parallel_rows(pm, 8 * sizeof(R), [&](uint64_t a, uint64_t cnt) { std::memcpy(pin + a * 8, src + a * 8, cnt * 8 * sizeof(R)); });
+                }
+                HIP_TRY(hipMemcpyAsync(d_in + g0 * 8, pin, (size_t)pm * 8 * sizeof(R), hipMemcpyHostToDevice, S->s_up));
+                HIP_TRY(hipEventRecord(S->ev_in[slot], S->s_up));
+            }
+            HIP_TRY(hipEventRecord(ev_up_last, S->s_up));
+            HIP_TRY(hipStreamWaitEvent(S->s_comp, ev_up_last, 0));
+        }
+        Window win;
+        win.plane_stride = n; win.out_offset = r0; win.nan_flag = have_in ? d_nan : nullptr;
+        const uint64_t row0 = c * rows_per_chunk;
+        const uint64_t rows = m / ni;
+        if (D.knobs.tile) { win.plane_stride = 0; win.out_offset = 0; }
+        rc = trace_device<R>(D, scene, opt, have_in ? d_in + r0 * 8 : nullptr, cam, ni, nj, j0 + row0, j0 + row0 + rows, d_rgb,
+                             &dout, d_ctr, S->s_comp, 1, 0, &win);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev_comp[c], S->s_comp));
+        // D2H of this chunk's outputs (the slot must have been unpacked: two chunks ago)
+        const int oslot = (int)(c % Staging::OUT_SLOTS);
+        while (slot_busy[oslot].load(std::memory_order_acquire)) {
+            if (down_rc.load() != RTGR_OK) return fail(RTGR_ERR_HIP, "download thread failed");
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        slot_busy[oslot].store(1);
+        HIP_TRY(hipStreamWaitEvent(S->s_down, ev_comp[c], 0));
+        char* dst = (char*)S->pin_out[oslot].p;
+        size_t off = 0;
+        for (auto& o : outs) {
+            for (int pl = 0; pl < o.planes; pl++)
+                HIP_TRY(hipMemcpyAsync(dst + off + (size_t)pl * m * o.elem, dob + o.dev_off + ((size_t)pl * n + r0) * o.elem,
+                                       (size_t)m * o.elem, hipMemcpyDeviceToHost, S->s_down));
+            off += align256((size_t)m * o.elem * o.planes);
+        }
+        HIP_TRY(hipEventRecord(ev_down[c], S->s_down));
+        chunks_enqueued.store(c + 1, std::memory_order_release);
+    }
+    // counters + NaN flag ride the compute stream
+    HIP_TRY(hipMemcpyAsync(S->pin_small.p, dsmall, 256, hipMemcpyDeviceToHost, S->s_comp));
+    HIP_TRY(hipStreamSynchronize(S->s_comp));
+    downloader.join();
+    HIP_TRY(hipStreamSynchronize(S->s_down));
+    HIP_TRY(hipStreamSynchronize(S->s_up));
+    if (down_rc.load() != RTGR_OK) return fail(RTGR_ERR_HIP, "download thread failed");
+    if (*(const uint32_t*)((const char*)S->pin_small.p + 128) != 0u)
+        return fail(RTGR_ERR_NAN_INPUT, "NaN in an input ray (AssertionError in the reference, :279)");
+    if (ctr) std::memcpy(ctr, S->pin_small.p, sizeof(rtgr_counters));
+    return RTGR_OK;
+}
+
+template <class R>
+int trace_host(rtgr_context* ctx_in, const rtgr_scene* scene, const rtgr_solver* opt, const R* state0, const rtgr_camera* cam,
+               uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx_in, &c);
+    if (rc) return rc;
+    if (!rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    if (ni == 0 || nj == 0 || j1 <= j0 || j1 > nj) return fail(RTGR_ERR_BAD_ARG, "bad canvas range: need 0 <= j0 < j1 <= nj, ni > 0");
+    if (!state0 && !cam) return fail(RTGR_ERR_BAD_ARG, "need state0 or a camera");
+    if (!scene) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
+    return trace_host_pipelined<R>(*c->devs[0], scene, opt, state0, nullptr, nullptr, cam, ni, nj, j0, j1, rgb, out, ctr);
+}
+
+// scratch device buffers of the small host-pointer hooks (eval_*, make_canvas): RAII, synchronous
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (bytes == 0) return RTGR_OK;
+        HIP_TRY(hipMalloc(&p, bytes));
+        return RTGR_OK;
+    }
+};
+
+template <class R>
+int host_has_nan(const R* v, uint64_t count) {
+    for (uint64_t q = 0; q < count; q++)
+        if (v[q] != v[q]) return 1;
+    return 0;
+}
+
+uint64_t fnv1a(const std::vector<char>& b) {
+    uint64_t h = 1469598103934665603ull;
+    for (char ch : b) { h ^= (unsigned char)ch; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int rtgr_abi_version(void) { return RTGR_ABI_VERSION; }
+const char* rtgr_last_error(void) { return g_err.c_str(); }
+
+int rtgr_create(const int* device_ids, int n_devices, rtgr_context** ctx_out) {
+    if (!ctx_out) return fail(RTGR_ERR_BAD_ARG, "ctx_out is NULL");
+    *ctx_out = nullptr;
+    (void)hipGetLastError();
+    return create_context(device_ids, n_devices, ctx_out);
+}
+int rtgr_destroy(rtgr_context* ctx) {
+    if (!ctx) return RTGR_OK;
+    { std::lock_guard<std::mutex> lk(g_default_mu); if (ctx == g_default) g_default = nullptr; }
+    destroy_context(ctx);
+    return RTGR_OK;
+}
+int rtgr_context_devices(rtgr_context* ctx) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    return rc ? rc : (int)c->devs.size();
+}
+int rtgr_trim(rtgr_context* ctx) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    for (auto& d : c->devs) { std::lock_guard<std::mutex> lk(d->mu); free_device_state(*d, false); }
+    return RTGR_OK;
+}
+int rtgr_init(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(RTGR_ERR_NO_DEVICE, "no HIP device visible; librtgr_hip has no CPU fallback");
+    if (device >= n) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
+    int dev = device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    else HIP_TRY(hipSetDevice(dev));
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g_default && g_default->devs.size() == 1 && g_default->devs[0]->dev == dev) return RTGR_OK;
+    if (g_default) { destroy_context(g_default); g_default = nullptr; }
+    return create_context(&dev, 1, &g_default);
+}
+int rtgr_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g_default) { destroy_context(g_default); g_default = nullptr; }
+    return RTGR_OK;
+}
+int rtgr_solver_defaults(rtgr_solver* s, int is_f32) {
+    if (!s) return fail(RTGR_ERR_BAD_ARG, "solver is NULL");
+    const double eps = is_f32 ? 1.1920928955078125e-07 : 2.220446049250313e-16;
+    s->reltol = s->abstol = std::pow(eps, 0.75);  // eps(T)^(3/4)   src/RayTraceGR.jl:485
+    s->lambda0 = 0.0;                             // :497
+    s->lambda1 = 100.0;
+    s->hit_threshold = 0.01;                      // :519
+    s->miss_rgb[0] = 1.0;                         // :528
+    s->miss_rgb[1] = s->miss_rgb[2] = 0.0;
+    s->max_steps = 100000;
+    s->interp_points = 10;
+    return RTGR_OK;
+}
+int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len, int* n_cu, int* clock_mhz, int* wavefront) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (index < 0 || index >= (int)c->devs.size()) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, c->devs[index]->dev));
+    if (name && name_len) std::snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = p.clockRate / 1000;
+    if (wavefront) *wavefront = p.warpSize;
+    return RTGR_OK;
+}
+
+int rtgr_set_option(rtgr_context* ctx, const char* name, long value) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    for (auto& d : c->devs) {
+        std::lock_guard<std::mutex> lk(d->mu);
+        long* s = knob_slot(d->knobs, name);
+        if (!s) return fail(RTGR_ERR_BAD_ARG, std::string("unknown option ") + (name ? name : "(null)"));
+        *s = value;
+    }
+    return RTGR_OK;
+}
+int rtgr_get_option(rtgr_context* ctx, const char* name, long* value) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!value) return fail(RTGR_ERR_BAD_ARG, "value is NULL");
+    long* s = knob_slot(c->devs[0]->knobs, name);
+    if (!s) return fail(RTGR_ERR_BAD_ARG, std::string("unknown option ") + (name ? name : "(null)"));
+    *value = *s;
+    return RTGR_OK;
+}
+
+int rtgr_timing_enable(rtgr_context* ctx, int index, int on) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (index < 0 || index >= (int)c->devs.size()) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
+    std::lock_guard<std::mutex> lk(c->devs[index]->mu);
+    c->devs[index]->timing = on != 0;
+    return RTGR_OK;
+}
+int rtgr_timing_read(rtgr_context* ctx, int index, double ms[4], uint64_t launches[4]) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!ms || !launches) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    if (index < 0 || index >= (int)c->devs.size()) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
+    DeviceCtx& d = *c->devs[index];
+    std::lock_guard<std::mutex> lk(d.mu);
+    for (int w = 0; w < 4; w++) { ms[w] = 0.0; launches[w] = 0; }
+    for (auto& t : d.timed) {
+        HIP_TRY(hipEventSynchronize(t.b));
+        float e = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, t.a, t.b));
+        ms[t.which] += e;
+        launches[t.which] += 1;
+        d.event_pool.push_back(t.a);
+        d.event_pool.push_back(t.b);
+    }
+    d.timed.clear();
+    return RTGR_OK;
+}
+
+int rtgr_reserve_workspace(rtgr_context* ctx, const void* d_any, void* stream, uint64_t n_rays, int with_state_end, int is_f32) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    DeviceCtx* D = nullptr;
+    if ((rc = device_of(c, d_any, &D))) return rc;
+    DeviceGuard guard(D->dev);
+    std::lock_guard<std::mutex> lk(D->mu);
+    StreamState* ss = nullptr;
+    if ((rc = stream_state(*D, (hipStream_t)stream, &ss))) return rc;
+    const bool ws = with_state_end != 0;
+    const size_t bytes = is_f32 ? workspace_bytes<float>(pick_chunk<float>(*D, *ss, n_rays, ws), ws)
+                                : workspace_bytes<double>(pick_chunk<double>(*D, *ss, n_rays, ws), ws);
+    return ensure_workspace(*D, *ss, bytes, (hipStream_t)stream);
+}
+
+#define RESOLVE_DEVICE(ptr)                          \
+    rtgr_context* c = nullptr;                       \
+    int rc = resolve_ctx(ctx, &c);                   \
+    if (rc) return rc;                               \
+    DeviceCtx* D = nullptr;                          \
+    if ((rc = device_of(c, (ptr), &D))) return rc
+
+int rtgr_trace_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* d_state0,
+                          const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, double* d_rgb,
+                          const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream) {
+    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    RESOLVE_DEVICE(d_rgb);
+    return trace_device<double>(*D, scene, opt, d_state0, cam, ni, nj, j0, j1, d_rgb, out, d_counters, (hipStream_t)stream);
+}
+int rtgr_trace_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* d_state0,
+                          const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, float* d_rgb,
+                          const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream) {
+    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    RESOLVE_DEVICE(d_rgb);
+    return trace_device<float>(*D, scene, opt, d_state0, cam, ni, nj, j0, j1, d_rgb, out, d_counters, (hipStream_t)stream);
+}
+int rtgr_trace_rows_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                               uint64_t ni, uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, double* d_rgb,
+                               const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream) {
+    if (!cam) return fail(RTGR_ERR_BAD_ARG, "camera is NULL");
+    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    RESOLVE_DEVICE(d_rgb);
+    return trace_device<double>(*D, scene, opt, nullptr, cam, ni, nj, j0, j0 + 1, d_rgb, out, d_counters, (hipStream_t)stream, jstride, nrows);
+}
+int rtgr_trace_rows_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                               uint64_t ni, uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t nrows, float* d_rgb,
+                               const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream) {
+    if (!cam) return fail(RTGR_ERR_BAD_ARG, "camera is NULL");
+    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    RESOLVE_DEVICE(d_rgb);
+    return trace_device<float>(*D, scene, opt, nullptr, cam, ni, nj, j0, j0 + 1, d_rgb, out, d_counters, (hipStream_t)stream, jstride, nrows);
+}
+int rtgr_trace_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* state0,
+                   const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, double* rgb,
+                   const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    return trace_host<double>(ctx, scene, opt, state0, cam, ni, nj, j0, j1, rgb, out, ctr);
+}
+int rtgr_trace_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* state0,
+                   const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, float* rgb,
+                   const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    return trace_host<float>(ctx, scene, opt, state0, cam, ni, nj, j0, j1, rgb, out, ctr);
+}
+
+int rtgr_trace_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in,
+                          uint64_t ni, uint64_t nj, double* pixels_out, rtgr_counters* ctr) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!pixels_in || !pixels_out) return fail(RTGR_ERR_BAD_ARG, "pixels is NULL");
+    if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
+    if (!scene) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
+    return trace_host_pipelined<double>(*c->devs[0], scene, opt, nullptr, pixels_in, pixels_out, nullptr, ni, nj, 0, nj, nullptr,
+                                        nullptr, ctr);
+}
+
+int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
+                       const double normal[4], double rgb[3], double state_end[8], uint8_t* status) {
+    if (!pos || !normal || !rgb) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    double s0[8];
+    for (int q = 0; q < 4; q++) { s0[q] = pos[q]; s0[4 + q] = normal[q]; }
+    rtgr_ray_outputs out;
+    std::memset(&out, 0, sizeof out);
+    out.state_end = state_end;
+    out.status = status;
+    return trace_host<double>(ctx, scene, opt, s0, nullptr, 1, 1, 0, 1, rgb, &out, nullptr);
+}
+
+// ---- all devices of the context ------------------------------------------------------------------------------------------
+// per-device scratch of the sharded path lives in the device's Staging: d_out = this rank's rows (all requested arrays),
+// d_small = counters; device 0 additionally d_recv = the peers' rows as they arrive.
+static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
+                         uint64_t nj, double* d_rgb0, const rtgr_ray_outputs* out0, rtgr_counters* ctr) {
+    const uint64_t N = c->devs.size();
+    if (!scene || !opt || !cam) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
+    if (c->devs[0]->knobs.tile) return fail(RTGR_ERR_BAD_ARG, "the multi-device path needs the persistent pipeline (option tile = 0)");
+    if (out0 && out0->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
+    struct Arr { size_t elem; int planes; void* full; size_t off; };  // one per requested array
+    std::vector<Arr> arrs;
+    arrs.push_back({8, 3, d_rgb0, 0});
+    if (out0) {
+        if (out0->state_end) arrs.push_back({64, 1, out0->state_end, 0});
+        if (out0->lambda_end) arrs.push_back({8, 1, out0->lambda_end, 0});
+        if (out0->status) arrs.push_back({1, 1, out0->status, 0});
+        if (out0->hit) arrs.push_back({1, 1, out0->hit, 0});
+        if (out0->n_accept) arrs.push_back({4, 1, out0->n_accept, 0});
+        if (out0->n_reject) arrs.push_back({4, 1, out0->n_reject, 0});
+    }
+    const uint64_t nrows_max = (nj + N - 1) / N, nmax = ni * nrows_max;
+    size_t part_bytes = 0;
+    for (auto& a : arrs) { a.off = part_bytes; part_bytes += align256((size_t)nmax * a.elem * a.planes); }
+    std::vector<Staging*> S(N, nullptr);
+    std::vector<uint64_t> nrows(N, 0);
+    std::vector<hipEvent_t> ev(N, nullptr);
+    struct EvFree { std::vector<hipEvent_t>& e; ~EvFree() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } evfree{ev};
+    int rc;
+    // the part / counter / receive buffers are shared by consecutive sharded calls: one such call at a time per context
+    // (lock order: device 0's staging mutex first)
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (uint64_t k = 0; k < N; k++) {
+        DeviceCtx& D = *c->devs[k];
+        DeviceGuard g(D.dev);
+        { std::lock_guard<std::mutex> lk(D.mu); if ((rc = staging_of(D, &S[k]))) return rc; }
+        locks.emplace_back(S[k]->mu);
+        nrows[k] = nj > k ? (nj - k + N - 1) / N : 0;
+        if ((rc = S[k]->d_out.need(part_bytes))) return rc;
+        if ((rc = S[k]->d_small.need(256))) return rc;
+        if ((rc = S[k]->pin_small.need(256))) return rc;
+        if (k == 0 && N > 1 && (rc = S[0]->d_recv.need(part_bytes * (N - 1)))) return rc;
+        HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    }
+    // 1. every device traces its rows on its own stream
+    for (uint64_t k = 0; k < N; k++) {
+        if (nrows[k] == 0) continue;
+        DeviceCtx& D = *c->devs[k];
+        DeviceGuard g(D.dev);
+        char* pb = (char*)S[k]->d_out.p;
+        HIP_TRY(hipMemsetAsync(S[k]->d_small.p, 0, 256, S[k]->s_comp));
+        rtgr_ray_outputs po;
+        std::memset(&po, 0, sizeof po);
+        size_t q = 1;
+        if (out0) {
+            if (out0->state_end) po.state_end = pb + arrs[q++].off;
+            if (out0->lambda_end) po.lambda_end = pb + arrs[q++].off;
+            if (out0->status) po.status = (uint8_t*)(pb + arrs[q++].off);
+            if (out0->hit) po.hit = (uint8_t*)(pb + arrs[q++].off);
+            if (out0->n_accept) po.n_accept = (uint32_t*)(pb + arrs[q++].off);
+            if (out0->n_reject) po.n_reject = (uint32_t*)(pb + arrs[q++].off);
+        }
+        rc = trace_device<double>(D, scene, opt, nullptr, cam, ni, nj, k, k + 1, (double*)pb, &po, (rtgr_counters*)S[k]->d_small.p,
+                                  S[k]->s_comp, N, nrows[k]);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(S[k]->pin_small.p, S[k]->d_small.p, sizeof(rtgr_counters), hipMemcpyDeviceToHost, S[k]->s_comp));
+        // 2. its rows travel to device 0 (ordered behind the trace on the SOURCE device's stream; one xGMI link per peer)
+        if (k > 0) {
+            char* rb = (char*)S[0]->d_recv.p + (k - 1) * part_bytes;
+            const size_t used = part_bytes;  // padded arrays: a single copy per peer
+            if (c->devs[0]->dev == D.dev) HIP_TRY(hipMemcpyAsync(rb, pb, used, hipMemcpyDeviceToDevice, S[k]->s_comp));
+            else HIP_TRY(hipMemcpyPeerAsync(rb, c->devs[0]->dev, pb, D.dev, used, S[k]->s_comp));
+        }
+        HIP_TRY(hipEventRecord(ev[k], S[k]->s_comp));
+    }
+    // 3. device 0 puts every rank's rows back in place
+    {
+        DeviceCtx& D0 = *c->devs[0];
+        DeviceGuard g(D0.dev);
+        hipStream_t s0 = S[0]->s_down;
+        for (uint64_t k = 0; k < N; k++) {
+            if (nrows[k] == 0) continue;
+            HIP_TRY(hipStreamWaitEvent(s0, ev[k], 0));
+            const char* src = k == 0 ? (const char*)S[0]->d_out.p : (const char*)S[0]->d_recv.p + (k - 1) * part_bytes;
+            for (auto& a : arrs) {
+                if (a.planes == 3) {  // rgb: the part's planes are ni*nrows[k] apart
+                    if ((rc = misc_place_rows_f64((const double*)(src + a.off), ni, nj, k, N, 3, (double*)a.full, s0))) return rc;
+                } else if ((rc = misc_place_rows_u8((const uint8_t*)(src + a.off), ni, nj, k, N, a.elem, (uint8_t*)a.full, s0))) return rc;
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(s0));
+    }
+    rtgr_counters sum;
+    std::memset(&sum, 0, sizeof sum);
+    for (uint64_t k = 0; k < N; k++) {
+        if (nrows[k] == 0) continue;
+        DeviceGuard g(c->devs[k]->dev);
+        HIP_TRY(hipStreamSynchronize(S[k]->s_comp));
+        const uint64_t* p = (const uint64_t*)S[k]->pin_small.p;
+        uint64_t* q = (uint64_t*)&sum;
+        for (int w = 0; w < 8; w++) q[w] += p[w];
+    }
+    if (ctr) *ctr = sum;
+    return RTGR_OK;
+}
+
+int rtgr_trace_sharded_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                                  uint64_t ni, uint64_t nj, double* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    return trace_sharded(c, scene, opt, cam, ni, nj, d_rgb, out, ctr);
+}
+
+int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                           uint64_t ni, uint64_t nj, double* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
+    const uint64_t n = ni * nj;
+    DeviceCtx& D0 = *c->devs[0];
+    DeviceGuard g(D0.dev);
+    // the full frame on device 0, then one download per array
+    struct Item { void* host; size_t bytes; void* dev; };
+    std::vector<Item> items;
+    items.push_back({rgb, (size_t)n * 24, nullptr});
+    rtgr_ray_outputs dout;
+    std::memset(&dout, 0, sizeof dout);
+    if (out) {
+        if (out->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
+        if (out->state_end) items.push_back({out->state_end, (size_t)n * 64, nullptr});
+        if (out->lambda_end) items.push_back({out->lambda_end, (size_t)n * 8, nullptr});
+        if (out->status) items.push_back({out->status, (size_t)n, nullptr});
+        if (out->hit) items.push_back({out->hit, (size_t)n, nullptr});
+        if (out->n_accept) items.push_back({out->n_accept, (size_t)n * 4, nullptr});
+        if (out->n_reject) items.push_back({out->n_reject, (size_t)n * 4, nullptr});
+    }
+    size_t total = 0;
+    for (auto& it : items) total += align256(it.bytes);
+    DevBuf full;
+    if ((rc = full.alloc(total))) return rc;
+    {
+        size_t off = 0;
+        for (auto& it : items) { it.dev = (char*)full.p + off; off += align256(it.bytes); }
+        size_t k = 1;
+        if (out) {
+            if (out->state_end) dout.state_end = items[k++].dev;
+            if (out->lambda_end) dout.lambda_end = items[k++].dev;
+            if (out->status) dout.status = (uint8_t*)items[k++].dev;
+            if (out->hit) dout.hit = (uint8_t*)items[k++].dev;
+            if (out->n_accept) dout.n_accept = (uint32_t*)items[k++].dev;
+            if (out->n_reject) dout.n_reject = (uint32_t*)items[k++].dev;
+        }
+    }
+    if ((rc = trace_sharded(c, scene, opt, cam, ni, nj, (double*)items[0].dev, &dout, ctr))) return rc;
+    for (auto& it : items) HIP_TRY(hipMemcpy(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+
+// ---- camera / hooks ------------------------------------------------------------------------------------------------------
+int rtgr_make_canvas_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
+                                uint64_t j0, uint64_t j1, double* d_state0, void* stream) {
+    if (!cam || !d_state0) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    RESOLVE_DEVICE(d_state0);
+    if (ni == 0 || nj == 0 || j1 <= j0 || j1 > nj) return fail(RTGR_ERR_BAD_ARG, "bad canvas range");
+    DeviceGuard guard(D->dev);
+    std::lock_guard<std::mutex> lk(D->mu);
+    DevScene<double> sc;
+    const UserModule* user = nullptr;
+    if ((rc = convert_scene<double>(*D, scene, sc, &user))) return rc;
+    DevCamera<double> cm;
+    convert_camera<double>(cam, cm);
+    const uint64_t n = ni * (j1 - j0);
+    if (sc.metric == RTGR_USER) {
+        HIP_TRY(launch_module(user->canvas, (unsigned)((n + 255) / 256), 256, (hipStream_t)stream, sc, cm, ni, nj, j0, (uint64_t)1,
+                              (uint64_t)0, n, d_state0));
+        return RTGR_OK;
+    }
+    return misc_canvas_f64(sc, cm, ni, nj, j0, n, d_state0, (hipStream_t)stream);
+}
+int rtgr_make_canvas_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                         uint64_t j1, double* state0) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!state0) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    if (ni == 0 || nj == 0 || j1 <= j0 || j1 > nj) return fail(RTGR_ERR_BAD_ARG, "bad canvas range");
+    const uint64_t n = ni * (j1 - j0);
+    DeviceGuard guard(c->devs[0]->dev);
+    DevBuf b;
+    if ((rc = b.alloc(n * 64))) return rc;
+    if ((rc = rtgr_make_canvas_device_f64(c, scene, cam, ni, nj, j0, j1, (double*)b.p, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(state0, b.p, n * 64, hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+
+}  // extern "C"
+template <class R>
+static int eval_metric_host(rtgr_context* ctx, const rtgr_scene* scene, const R* x, uint64_t n, R* g, R* dg, R* Gam) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!x) return fail(RTGR_ERR_BAD_ARG, "x is NULL");
+    if (n == 0) return RTGR_OK;
+    if (host_has_nan(x, 4 * n)) return fail(RTGR_ERR_NAN_INPUT, "NaN coordinate (AssertionError in the reference, :279)");
+    DeviceCtx& D = *c->devs[0];
+    DeviceGuard guard(D.dev);
+    std::lock_guard<std::mutex> lk(D.mu);
+    DevScene<R> sc;
+    const UserModule* user = nullptr;
+    if ((rc = convert_scene<R>(D, scene, sc, &user))) return rc;
+    DevBuf bx, bg, bd, bG;
+    if ((rc = bx.alloc(n * 4 * sizeof(R)))) return rc;
+    HIP_TRY(hipMemcpy(bx.p, x, n * 4 * sizeof(R), hipMemcpyHostToDevice));
+    if (g && (rc = bg.alloc(n * 16 * sizeof(R)))) return rc;
+    if (dg && (rc = bd.alloc(n * 64 * sizeof(R)))) return rc;
+    if (Gam && (rc = bG.alloc(n * 64 * sizeof(R)))) return rc;
+    if (sc.metric == RTGR_USER) {
+        if (sizeof(R) != 8) return fail(RTGR_ERR_BAD_ARG, "user metrics are evaluated in Float64");
+        HIP_TRY(launch_module(user->eval_metric, (unsigned)((n + 255) / 256), 256, (hipStream_t) nullptr, sc, (const R*)bx.p, n,
+                              (R*)bg.p, (R*)bd.p, (R*)bG.p));
+    } else if constexpr (sizeof(R) == 8) {
+        if ((rc = misc_eval_metric_f64(sc, (const double*)bx.p, n, (double*)bg.p, (double*)bd.p, (double*)bG.p, nullptr))) return rc;
+    } else {
+        if ((rc = misc_eval_metric_f32(sc, (const float*)bx.p, n, (float*)bg.p, (float*)bd.p, (float*)bG.p, nullptr))) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (g) HIP_TRY(hipMemcpy(g, bg.p, n * 16 * sizeof(R), hipMemcpyDeviceToHost));
+    if (dg) HIP_TRY(hipMemcpy(dg, bd.p, n * 64 * sizeof(R), hipMemcpyDeviceToHost));
+    if (Gam) HIP_TRY(hipMemcpy(Gam, bG.p, n * 64 * sizeof(R), hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+extern "C" {
+int rtgr_eval_metric_f64(rtgr_context* ctx, const rtgr_scene* scene, const double* x, uint64_t n, double* g, double* dg, double* Gam) {
+    return eval_metric_host<double>(ctx, scene, x, n, g, dg, Gam);
+}
+int rtgr_eval_metric_f32(rtgr_context* ctx, const rtgr_scene* scene, const float* x, uint64_t n, float* g, float* dg, float* Gam) {
+    return eval_metric_host<float>(ctx, scene, x, n, g, dg, Gam);
+}
+
+}  // extern "C"
+template <class R>
+static int eval_geodesic_host(rtgr_context* ctx, const rtgr_scene* scene, const R* s, uint64_t n, int path, R* ds) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!s || !ds) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    if (path < 0 || path > 2)
+        return fail(RTGR_ERR_BAD_ARG, "path must be 0 (closed contraction, IEEE division), 1 (generic duals) or 2 (the integrate loop's own RHS)");
+    if (n == 0) return RTGR_OK;
+    if (host_has_nan(s, 8 * n)) return fail(RTGR_ERR_NAN_INPUT, "NaN state (AssertionError in the reference, :279)");
+    DeviceCtx& D = *c->devs[0];
+    DeviceGuard guard(D.dev);
+    std::lock_guard<std::mutex> lk(D.mu);
+    DevScene<R> sc;
+    const UserModule* user = nullptr;
+    if ((rc = convert_scene<R>(D, scene, sc, &user))) return rc;
+    DevBuf bi, bo;
+    if ((rc = bi.alloc(n * 8 * sizeof(R)))) return rc;
+    if ((rc = bo.alloc(n * 8 * sizeof(R)))) return rc;
+    HIP_TRY(hipMemcpy(bi.p, s, n * 8 * sizeof(R), hipMemcpyHostToDevice));
+    if (sc.metric == RTGR_USER) {  // a user metric has the generic path only
+        if (sizeof(R) != 8) return fail(RTGR_ERR_BAD_ARG, "user metrics are evaluated in Float64");
+        HIP_TRY(launch_module(user->eval_geodesic, (unsigned)((n + 255) / 256), 256, (hipStream_t) nullptr, sc, (const R*)bi.p, n, (R*)bo.p));
+    } else if constexpr (sizeof(R) == 8) {
+        if ((rc = misc_eval_geodesic_f64(sc, (const double*)bi.p, n, path, (double*)bo.p, nullptr))) return rc;
+    } else {
+        if ((rc = misc_eval_geodesic_f32(sc, (const float*)bi.p, n, path, (float*)bo.p, nullptr))) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ds, bo.p, n * 8 * sizeof(R), hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+extern "C" {
+int rtgr_eval_geodesic_f64(rtgr_context* ctx, const rtgr_scene* scene, const double* s, uint64_t n, int path, double* ds) {
+    return eval_geodesic_host<double>(ctx, scene, s, n, path, ds);
+}
+int rtgr_eval_geodesic_f32(rtgr_context* ctx, const rtgr_scene* scene, const float* s, uint64_t n, int path, float* ds) {
+    return eval_geodesic_host<float>(ctx, scene, s, n, path, ds);
+}
+int rtgr_eval_fastmath_f64(rtgr_context* ctx, const double* x, uint64_t n, double* rcp, double* rsq) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!x) return fail(RTGR_ERR_BAD_ARG, "x is NULL");
+    if (n == 0) return RTGR_OK;
+    DeviceGuard guard(c->devs[0]->dev);
+    DevBuf bx, b1, b2;
+    if ((rc = bx.alloc(n * 8))) return rc;
+    if (rcp && (rc = b1.alloc(n * 8))) return rc;
+    if (rsq && (rc = b2.alloc(n * 8))) return rc;
+    HIP_TRY(hipMemcpy(bx.p, x, n * 8, hipMemcpyHostToDevice));
+    if ((rc = misc_eval_fastmath_f64((const double*)bx.p, n, (double*)b1.p, (double*)b2.p, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (rcp) HIP_TRY(hipMemcpy(rcp, b1.p, n * 8, hipMemcpyDeviceToHost));
+    if (rsq) HIP_TRY(hipMemcpy(rsq, b2.p, n * 8, hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+
+// ---- run-time loaded metrics -------------------------------------------------------------------------------------------
+int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    for (auto& d : c->devs) {
+        DeviceGuard guard(d->dev);
+        std::lock_guard<std::mutex> lk(d->mu);
+        bool any = false;
+        for (auto& m : d->modules) any = any || id == 0 || m.id == id;
+        if (!any) continue;
+        HIP_TRY(hipDeviceSynchronize());  // kernels of the module may still be in flight
+        for (size_t k = 0; k < d->modules.size();) {
+            if (id == 0 || d->modules[k].id == id) {
+                (void)hipModuleUnload(d->modules[k].module);
+                d->modules.erase(d->modules.begin() + (long)k);
+            } else k++;
+        }
+    }
+    return RTGR_OK;
+}
+
+int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
+    std::vector<char> image;
+    {
+        FILE* f = std::fopen(code_object_path, "rb");
+        if (!f) return fail(RTGR_ERR_BAD_ARG, std::string("cannot open ") + code_object_path);
+        std::fseek(f, 0, SEEK_END);
+        const long sz = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        if (sz <= 0) { std::fclose(f); return fail(RTGR_ERR_BAD_ARG, std::string(code_object_path) + ": empty file"); }
+        image.resize((size_t)sz);
+        const size_t got = std::fread(image.data(), 1, (size_t)sz, f);
+        std::fclose(f);
+        if (got != (size_t)sz) return fail(RTGR_ERR_BAD_ARG, std::string("short read on ") + code_object_path);
+    }
+    const uint64_t id = fnv1a(image);
+    for (auto& d : c->devs) {
+        DeviceGuard guard(d->dev);
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (d->find_module(id)) continue;
+        bool same_phys = false;  // a logical duplicate of a device shares the module of its twin
+        for (auto& o : c->devs)
+            if (o.get() != d.get() && o->dev == d->dev)
+                if (const UserModule* m = o->find_module(id)) { d->modules.push_back(*m); same_phys = true; break; }
+        if (same_phys) continue;
+        UserModule u;
+        u.id = id;
+        hipError_t e = hipModuleLoadData(&u.module, image.data());
+        if (e != hipSuccess)
+            return fail(RTGR_ERR_HIP, std::string("hipModuleLoadData(") + code_object_path + "): " + hipGetErrorString(e));
+        auto bail = [&](const std::string& why) {
+            (void)hipModuleUnload(u.module);
+            return fail(RTGR_ERR_BAD_ARG, std::string(code_object_path) + ": " + why);
+        };
+        {   // the unit must have been built against this library's headers
+            hipDeviceptr_t dptr = nullptr;
+            size_t bytes = 0;
+            unsigned ver = 0;
+            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_abi_version") != hipSuccess || bytes != sizeof ver)
+                return bail("not a user-metric code object (no rtgr_user_abi_version)");
+            if (hipMemcpyDtoH(&ver, dptr, sizeof ver) != hipSuccess) return bail("cannot read rtgr_user_abi_version");
+            if (ver != RTGR_ABI_VERSION) return bail("built against another ABI version");
+        }
+        struct { hipFunction_t* f; const char* name; bool required; } want[] = {
+            {&u.far, "rtgr_user_integrate_far", true},       {&u.near, "rtgr_user_integrate_near", true},
+            {&u.full10, "rtgr_user_integrate_full10", true}, {&u.fulln, "rtgr_user_integrate_fulln", true},
+            {&u.canvas, "rtgr_user_canvas", true},           {&u.eval_metric, "rtgr_user_eval_metric", true},
+            {&u.eval_geodesic, "rtgr_user_eval_geodesic", true}, {&u.prepare, "rtgr_user_prepare", true},
+            {&u.full10_f32, "rtgr_user_integrate_full10_f32", false}, {&u.fulln_f32, "rtgr_user_integrate_fulln_f32", false},
+            {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false}};
+        for (auto& w : want)
+            if (hipModuleGetFunction(w.f, u.module, w.name) != hipSuccess) {
+                (void)hipGetLastError();
+                if (w.required) return bail(std::string("missing kernel ") + w.name);
+                *w.f = nullptr;
+            }
+        if (!u.prepare_f32 || !u.fulln_f32) u.full10_f32 = nullptr;  // all or nothing
+        d->modules.push_back(u);
+    }
+    if (id_out) *id_out = id;
+    return RTGR_OK;
+}
+
+int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    DeviceCtx& d = *c->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (id == 0) return d.modules.empty() ? 0 : 1;
+    return d.find_module(id) ? 1 : 0;
+}
+
+#ifdef RTGR_ROOT_STATS
+// debug builds only: a device buffer the NEAR pass writes per-wave {start, end, iterations, rays} and per-ray stays into
+// (tools/debug_near_waves.py)
+int rtgr_debug_set_buffer(void* d_buf) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(nullptr, &c);
+    if (rc) return rc;
+    c->devs[0]->dbg = (unsigned long long*)d_buf;
+    return RTGR_OK;
+}
+// debug builds only (tools/debug_root_iters.py): copy the head of the default stream's workspace (the event records) to the host
+int rtgr_debug_workspace(void* stream, void* dst, uint64_t bytes) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(nullptr, &c);
+    if (rc) return rc;
+    DeviceCtx& d = *c->devs[0];
+    auto it = d.streams.find((hipStream_t)stream);
+    if (it == d.streams.end() || bytes > it->second.ws_bytes) return fail(RTGR_ERR_BAD_ARG, "no workspace / too many bytes");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst, it->second.ws, bytes, hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+#endif
+
+int rtgr_quantize_device_f64(rtgr_context* ctx, const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, void* stream) {
+    if (!d_rgb || !d_img || ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "bad argument");
+    RESOLVE_DEVICE(d_rgb);
+    DeviceGuard guard(D->dev);
+    return misc_quantize(d_rgb, ni, nj, d_img, (hipStream_t)stream);
+}
+
+}  // extern "C"

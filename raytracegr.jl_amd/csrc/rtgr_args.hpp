@@ -1,0 +1,142 @@
+// rtgr_args.hpp — plain-old-data shared by host and device code: device-side scene / solver / camera, the argument
+// blocks of the pipeline's kernels and the layout of the per-ray records in the workspace.  No device code here, so the
+// host-only translation units (rtgr_api.hip) can include it without instantiating kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rtgr.h"
+
+namespace rtgr {
+
+template <class R>
+struct DevObject {
+    uint32_t kind;
+    uint32_t pad;
+    R p[9];
+};
+
+template <class R>
+struct DevScene {
+    uint32_t metric;
+    uint32_t nobj;
+    R M, a;
+    DevObject<R> obj[RTGR_MAX_OBJECTS];
+};
+
+template <class R>
+struct DevSolver {
+    R reltol, abstol, lambda0, lambda1, hit_threshold;
+    R miss_rgb[3];
+    uint32_t max_steps, interp_points;
+};
+
+template <class R>
+struct DevCamera {
+    R pos[4], widthx[4], widthy[4], normal[4];
+};
+
+enum LaneState : int { L_FREE = 0, L_TAKEN = 1, L_RUN = 2, L_EXIT = 3 };
+
+// event record layout (scalars of type R per ray)
+constexpr int REC_X = 0;      // x[4]   position at the start of the last step
+constexpr int REC_C = 4;      // c[m][q], m = 0..3 (θ¹..θ⁴), q = 0..3
+constexpr int REC_PS = 20;    // sign of the callback condition at the step start (0: no event, use θ = top = 0)
+constexpr int REC_TOP = 21;   // bracket top θ
+constexpr int REC_T = 22;     // λ at the step start
+constexpr int REC_H = 23;     // step size
+constexpr int REC_U = 24;     // u[4] and cu[m][q] (only when the caller wants state_end)
+constexpr int REC_CU = 28;
+constexpr int REC_W = 24;
+constexpr int REC_W_STATE = 44;
+
+template <class R>
+struct TraceArgs {
+    DevScene<R> sc;
+    DevSolver<R> opt;
+    DevCamera<R> cam;
+    const R* state0;  // n x 8 or null (camera)
+    uint64_t ni, nj, j0, nrows;
+    uint64_t jstride; // local row k is image row j0 + k*jstride (1 = contiguous slab; N = cyclic rows of an N-way split)
+    R* rgb;           // 3 planes of n
+    R* state_end;     // optional
+    R* lambda_end;
+    uint8_t* status;
+    uint8_t* hit;
+    uint32_t* n_accept;
+    uint32_t* n_reject;
+    unsigned long long* counters;  // rtgr_counters or null
+    // the outputs may be a window of larger arrays (host entry points pipeline a job piece by piece, the multi-device path
+    // writes a rank's rows): ray w of this call goes to element out_offset + w, rgb planes are plane_stride apart
+    uint64_t plane_stride;  // 0: ni * nrows
+    uint64_t out_offset;
+    uint32_t* nan_flag;     // optional: set to 1 when a caller-supplied state0 holds a NaN (the reference asserts, :279)
+};
+
+template <class R>
+struct IntegrateArgs {
+    DevScene<R> sc;
+    DevSolver<R> opt;
+    const R* state0;        // n x 8
+    const uint32_t* order;  // queue position -> ray index (longest-expected-first), or null = natural order
+    uint64_t n;             // rays in this chunk
+    R* rec;                 // n x recw
+    uint32_t* meta;         // n x 3: accepted, rejected, status | interior << 8
+    int recw;               // REC_W or REC_W_STATE
+    R* hand;                // n x HAND_W: rays handed from the FAR pass to the NEAR pass
+    unsigned long long* ctrl;  // [0] ray queue head of the FULL / FAR pass, [1] queue head of the NEAR pass (per round)
+    uint32_t pick_flag;     // passes that resume rays (NEAR, FAR of round >= 1): meta flag of the rays to pick up; 0 = camera rays
+    uint32_t allow_handback;  // NEAR: hand a ray back to the next round's FAR pass once it has left every object's reach
+    uint32_t queue_chunk;   // ray ids popped per atomic: <= RTGR_QUEUE_CHUNK, smaller when a wave gets few rays in total
+    unsigned long long* counters;
+    // prepare_kernel only: where the rays come from (state0 == null: the camera) and the ordering key outputs
+    DevCamera<R> cam;
+    uint64_t ni, nj, j0, jstride, first;  // ray w of the chunk is pixel idx = first + w: i = idx % ni, j = j0 + (idx / ni) * jstride
+    uint8_t* keys;          // n ordering keys (or null: natural order)
+    uint32_t* hist;         // 256-bin histogram of the keys
+    // FAR -> NEAR: ids of the rays handed over with fewer than near_early accepted steps (appended with ctrl[6] as the
+    // cursor); the NEAR pass starts with those
+    uint32_t* early;
+    uint32_t near_early;
+    uint32_t n_simd;        // SIMDs of the device (4 per CU): workgroup b is the (b / n_simd)-th oldest wave of its SIMD
+    uint32_t fair_shift;    // != 0: the waves of a SIMD take turns at the top priority, slices of 2^fair_shift clocks
+    uint32_t* nan_flag;     // prepare_kernel: raised when a caller-supplied ray state holds a NaN (:279), or null
+#ifdef RTGR_ROOT_STATS
+    unsigned long long* dbg;  // debug builds: per-wave {start, end, iterations, rays} of the NEAR pass, then per-ray stays
+#endif
+};
+
+// Integrate passes.  FULL: every accepted step runs the ContinuousCallback scan (8 interior samples + end point).
+// FAR / NEAR split the same work by phase of the ray: the FAR pass replaces the scan by a rigorous per-object bound
+// ("no object's distance can change sign anywhere in this step"); a ray for which the bound fails is handed — with its
+// PRE-step state, so the step is simply redone — to the NEAR pass, which is the FULL algorithm started from a
+// hand-over record instead of a camera ray.  Results are identical to FULL by construction (the scan is skipped only
+// where it provably finds nothing); rays spend >90 % of their steps in the FAR pass, which is ~30 % cheaper per step.
+enum IntegrateMode : int { MODE_FULL = 0, MODE_FAR = 1, MODE_NEAR = 2 };
+constexpr int HAND_W = 16;  // x[4] u[4] k0[4] t dt ps lq
+constexpr uint32_t META_HANDED = 0xffff0000u;    // meta[3*idx+2] of a ray waiting for a NEAR pass
+constexpr uint32_t META_HANDBACK = 0xffff0001u;  // … of a ray a NEAR pass handed back to the next round's FAR pass
+constexpr uint32_t META_HANDED_EARLY = 0xffff0002u;  // … of a ray waiting for the NEAR pass ON ITS EARLY LIST
+#ifndef RTGR_QUEUE_CHUNK
+#define RTGR_QUEUE_CHUNK 256ull
+#endif
+
+template <class R>
+struct ResolveArgs {
+    DevScene<R> sc;
+    DevSolver<R> opt;
+    const R* rec;
+    const uint32_t* meta;
+    int recw;
+    uint64_t n;        // rays in this chunk
+    uint64_t offset;   // first ray of the chunk in the caller's slab
+    uint64_t n_slab;   // rays in the slab (plane stride of rgb)
+    R* rgb;
+    R* state_end;
+    R* lambda_end;
+    uint8_t* status;
+    uint8_t* hit;
+    uint32_t* n_accept;
+    uint32_t* n_reject;
+};
+
+}  // namespace rtgr

@@ -1,0 +1,176 @@
+// rtgr_host.hpp — host-side state of librtgr_hip.so: contexts, per-stream workspaces, launch policy knobs.
+//
+// SURVEY §8(b) "Ownership / Threading": the library owns device buffers and streams inside an OPAQUE CONTEXT
+// (rtgr_context, include/rtgr.h); calls are re-entrant per context, one host thread may drive several devices and
+// several host threads may drive one.  Layout of that state:
+//
+//   rtgr_context            the devices one host process drives (rtgr_create(device_ids, n))
+//     DeviceCtx[n]          one per entry of device_ids (the same physical GPU may be listed twice: two "logical
+//                           devices" with streams and workspaces of their own — how the multi-device path is tested on a
+//                           one-GPU box)
+//       StreamState[*]      one per hipStream_t the caller has used on that device: the pipeline workspace (start /
+//                           hand-over / event records, per-ray meta, queue order, work-queue heads).  Launches on ONE
+//                           stream are ordered by the stream and share a workspace; launches on DIFFERENT streams get
+//                           different workspaces, so they never race (round 1 had one process-global workspace)
+//       user modules        run-time compiled metrics, keyed by the 64-bit id a scene carries (rtgr_scene.user_metric)
+//       staging             pinned host buffers + device buffers + 3 streams of the host-pointer entry points
+//
+// A workspace only grows; the superseded allocation is RETIRED, not freed (a hipGraph captured earlier may still
+// reference it) until rtgr_destroy / rtgr_trim.  Growth during stream capture is refused (hipMalloc is not capturable):
+// reserve first (rtgr_reserve_workspace).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rtgr.h"
+#include "rtgr_args.hpp"
+
+namespace rtgr {
+
+int fail(int code, const std::string& msg);  // records the calling thread's last error, returns `code`
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return ::rtgr::fail(RTGR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+// ---- launch policy knobs ------------------------------------------------------------------------------------------------
+// Parsed ONCE from the environment when a context is created (RTGR_<NAME>), changeable per context with
+// rtgr_set_option(ctx, "name", value).  -1 = "auto" (the library decides from the launch size).  Experiments and
+// schedule-invariance tests only: no knob changes a result bit.
+struct Knobs {
+    long waves_per_cu = -1;       // resident waves per CU of the integrate kernels (auto: 4 x waves/SIMD of the instantiation)
+    long waves_per_cu_near = -1;  // ... of the NEAR pass (auto: 4 below 1.6 M rays)
+    long chunk = -1;              // rays per pipeline chunk (auto: 2^26, less if memory is short)
+    long split = -1;              // 0: one FULL pass instead of FAR + NEAR (auto: on for f64, off for f32)
+    long order = -1;              // 0: natural ray order (auto: longest-expected-first from 4096 rays)
+    long fair = -1;               // log2 of the priority-rotation time slice in clocks, 0 = off (auto: by launch size)
+    long near_early = 64;         // accepted steps at hand-over below which a ray goes on the NEAR pass's early list (0: no list)
+    long far4 = -1;               // 0/1: force the 3- / 4-waves-per-SIMD a = 0 FAR instantiation (auto: by launch size)
+    long rounds = 1;              // FAR/NEAR hand-back rounds (1..3)
+    long qchunk = -1;             // ray ids per queue atomic, FAR / FULL pass (auto)
+    long qchunk_near = -1;        // ... NEAR pass (auto)
+    long tile = 0;                // 1: the simple tile-per-wave kernel (RTGR_KERNEL=tile), an independent formulation
+    long lds_stages = -1;         // generic RHS: keep the stage accelerations k[1..5] in LDS (auto: on)
+    long host_chunk = -1;         // host entry points: rays per H2D/compute/D2H pipeline piece (auto: 2^20)
+    long dbg_pass_far = 0;        // debug builds: which pass reports its wave timeline
+};
+const char* const* knob_names();  // NULL-terminated
+long* knob_slot(Knobs& k, const char* name);
+
+// ---- run-time loaded metric: the metric-dependent kernels of the pipeline from a code object ------------------------------
+struct UserModule {
+    uint64_t id = 0;
+    hipModule_t module = nullptr;
+    hipFunction_t far = nullptr, near = nullptr, full10 = nullptr, fulln = nullptr, canvas = nullptr, prepare = nullptr,
+                  eval_metric = nullptr, eval_geodesic = nullptr;
+    // Float32 twins (absent in units built without them)
+    hipFunction_t full10_f32 = nullptr, fulln_f32 = nullptr, prepare_f32 = nullptr, canvas_f32 = nullptr;
+};
+
+struct TimedLaunch { hipEvent_t a, b; int which; };
+
+// pipeline workspace of one (device, stream)
+struct StreamState {
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    unsigned long long* queue = nullptr;  // 8 work-queue heads; stream order makes one slot per stream enough
+    std::vector<void*> retired;           // superseded workspaces: kept alive for graphs captured earlier
+};
+
+struct Staging;  // host entry points (rtgr_api.hip)
+
+struct DeviceCtx {
+    int dev = -1;       // HIP device ordinal
+    int num_cu = 0;
+    std::string name;
+    std::mutex mu;      // held while a call enqueues its kernels: the enqueue sequences of two host threads never interleave
+    std::unordered_map<hipStream_t, StreamState> streams;
+    std::vector<UserModule> modules;
+    Knobs knobs;
+    // optional per-kernel timing (bench.py's roofline leg): hipEvents around each kernel of the pipeline
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    std::unique_ptr<Staging, void (*)(Staging*)> staging{nullptr, nullptr};
+#ifdef RTGR_ROOT_STATS
+    unsigned long long* dbg = nullptr;
+#endif
+    hipEvent_t take_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    const UserModule* find_module(uint64_t id) const {
+        for (auto& m : modules) if (m.id == id) return &m;
+        return nullptr;
+    }
+};
+
+struct KernelTimer {  // RAII: records start now, stop at scope exit
+    DeviceCtx& d; hipStream_t st; int which; hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(DeviceCtx& dc, hipStream_t s, int w) : d(dc), st(s), which(w) {
+        if (d.timing) { a = d.take_event(); b = d.take_event(); (void)hipEventRecord(a, st); }
+    }
+    ~KernelTimer() {
+        if (a) { (void)hipEventRecord(b, st); d.timed.push_back({a, b, which}); }
+    }
+};
+
+// what one pipeline launch needs from the context
+struct LaunchEnv {
+    DeviceCtx& d;
+    StreamState& ss;
+    const UserModule* user;  // resolved from the scene's user_metric id (RTGR_USER) or null
+};
+
+size_t align256(size_t b);
+template <class R> size_t workspace_bytes(uint64_t rays, bool with_state);
+template <class R> uint64_t pick_chunk(const DeviceCtx& d, const StreamState& ss, uint64_t n, bool with_state);
+int ensure_workspace(DeviceCtx& d, StreamState& ss, size_t bytes, hipStream_t st);
+
+// hipModuleLaunchKernel with the arguments given as C++ values
+template <class... Args>
+static inline hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned block, hipStream_t st, Args... args) {
+    void* params[] = {(void*)&args...};
+    return hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, st, params, nullptr);
+}
+
+// ---- the pipeline, one function per translation unit (each TU instantiates the kernels of its metric variants) ----------
+int launch_f64_mink(LaunchEnv& E, const TraceArgs<double>& A, hipStream_t st);
+int launch_f64_ksref(LaunchEnv& E, const TraceArgs<double>& A, bool spin, hipStream_t st);
+int launch_f64_kstrue(LaunchEnv& E, const TraceArgs<double>& A, bool spin, hipStream_t st);
+int launch_f64_generic(LaunchEnv& E, const TraceArgs<double>& A, hipStream_t st);  // KS_REF / KS_TRUE / RTGR_USER
+int launch_f32_closed(LaunchEnv& E, const TraceArgs<float>& A, bool spin, hipStream_t st);  // all three built-ins
+int launch_f32_generic(LaunchEnv& E, const TraceArgs<float>& A, hipStream_t st);
+
+// ---- small kernels (rtgr_misc.hip) -------------------------------------------------------------------------------------
+int misc_canvas_f64(const DevScene<double>& sc, const DevCamera<double>& cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                    uint64_t n, double* d_state0, hipStream_t st);
+int misc_eval_metric_f64(const DevScene<double>& sc, const double* d_x, uint64_t n, double* g, double* dg, double* Gam, hipStream_t st);
+int misc_eval_metric_f32(const DevScene<float>& sc, const float* d_x, uint64_t n, float* g, float* dg, float* Gam, hipStream_t st);
+int misc_eval_geodesic_f64(const DevScene<double>& sc, const double* d_s, uint64_t n, int path, double* d_ds, hipStream_t st);
+int misc_eval_geodesic_f32(const DevScene<float>& sc, const float* d_s, uint64_t n, int path, float* d_ds, hipStream_t st);
+int misc_eval_fastmath_f64(const double* d_x, uint64_t n, double* d_rcp, double* d_rsq, hipStream_t st);
+int misc_quantize(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, hipStream_t st);
+// Pixel{Float64} AoS (11 doubles) -> ray states, with the reference's NaN assertion (:279) evaluated on the device:
+// *d_nan_flag is set to 1 when any of the 8 input scalars of any pixel is NaN
+int misc_pixels_in(const double* d_px, uint64_t n, double* d_state0, uint32_t* d_nan_flag, hipStream_t st);
+int misc_pixels_out(const double* d_px_in, const double* d_rgb, uint64_t n_slab, uint64_t first, uint64_t n, double* d_px_out, hipStream_t st);
+int misc_nan_scan(const void* d_v, uint64_t count, bool f32, uint32_t* d_nan_flag, hipStream_t st);
+// multi-device gather on device 0: rows of rank r (cyclic over nranks) back into place
+int misc_place_rows_f64(const double* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,
+                        double* d_full, hipStream_t st);
+int misc_place_rows_u8(const uint8_t* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t elem,
+                       uint8_t* d_full, hipStream_t st);
+
+}  // namespace rtgr

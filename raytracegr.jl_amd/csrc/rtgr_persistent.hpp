@@ -38,6 +38,9 @@
 #ifndef RTGR_WAVES_PER_SIMD_GENERIC
 #define RTGR_WAVES_PER_SIMD_GENERIC 2  // generic dual-number RHS: ~270 registers wanted; 2 waves with a small spill beat 1 wave (measured 6.72 vs 6.22 Gstep/s)
 #endif
+#ifndef RTGR_WAVES_PER_SIMD_GENERIC_F32
+#define RTGR_WAVES_PER_SIMD_GENERIC_F32 3  // generic dual-number RHS in Float32: half the register bytes of the f64 kernel
+#endif
 #ifndef RTGR_WAVES_PER_SIMD_FAR
 #define RTGR_WAVES_PER_SIMD_FAR 3  // the FAR pass has no sample-point arrays: <=168 registers, three waves per SIMD
 #endif
@@ -49,85 +52,6 @@
 #endif
 
 namespace rtgr {
-
-enum LaneState : int { L_FREE = 0, L_TAKEN = 1, L_RUN = 2, L_EXIT = 3 };
-
-// event record layout (scalars of type R per ray)
-constexpr int REC_X = 0;      // x[4]   position at the start of the last step
-constexpr int REC_C = 4;      // c[m][q], m = 0..3 (θ¹..θ⁴), q = 0..3
-constexpr int REC_PS = 20;    // sign of the callback condition at the step start (0: no event, use θ = top = 0)
-constexpr int REC_TOP = 21;   // bracket top θ
-constexpr int REC_T = 22;     // λ at the step start
-constexpr int REC_H = 23;     // step size
-constexpr int REC_U = 24;     // u[4] and cu[m][q] (only when the caller wants state_end)
-constexpr int REC_CU = 28;
-constexpr int REC_W = 24;
-constexpr int REC_W_STATE = 44;
-
-template <class R>
-struct TraceArgs {
-    DevScene<R> sc;
-    DevSolver<R> opt;
-    DevCamera<R> cam;
-    const R* state0;  // n x 8 or null (camera)
-    uint64_t ni, nj, j0, nrows;
-    uint64_t jstride; // local row k is image row j0 + k*jstride (1 = contiguous slab; N = cyclic rows of an N-way split)
-    R* rgb;           // 3 planes of n
-    R* state_end;     // optional
-    R* lambda_end;
-    uint8_t* status;
-    uint8_t* hit;
-    uint32_t* n_accept;
-    uint32_t* n_reject;
-    unsigned long long* counters;  // rtgr_counters or null
-};
-
-template <class R>
-struct IntegrateArgs {
-    DevScene<R> sc;
-    DevSolver<R> opt;
-    const R* state0;        // n x 8
-    const uint32_t* order;  // queue position -> ray index (longest-expected-first), or null = natural order
-    uint64_t n;             // rays in this chunk
-    R* rec;                 // n x recw
-    uint32_t* meta;         // n x 3: accepted, rejected, status | interior << 8
-    int recw;               // REC_W or REC_W_STATE
-    R* hand;                // n x HAND_W: rays handed from the FAR pass to the NEAR pass
-    unsigned long long* ctrl;  // [0] ray queue head of the FULL / FAR pass, [1] queue head of the NEAR pass (per round)
-    uint32_t pick_flag;     // passes that resume rays (NEAR, FAR of round >= 1): meta flag of the rays to pick up; 0 = camera rays
-    uint32_t allow_handback;  // NEAR: hand a ray back to the next round's FAR pass once it has left every object's reach
-    uint32_t queue_chunk;   // ray ids popped per atomic: <= RTGR_QUEUE_CHUNK, smaller when a wave gets few rays in total
-    unsigned long long* counters;
-    // prepare_kernel only: where the rays come from (state0 == null: the camera) and the ordering key outputs
-    DevCamera<R> cam;
-    uint64_t ni, nj, j0, jstride, first;  // ray w of the chunk is pixel idx = first + w: i = idx % ni, j = j0 + (idx / ni) * jstride
-    uint8_t* keys;          // n ordering keys (or null: natural order)
-    uint32_t* hist;         // 256-bin histogram of the keys
-    // FAR -> NEAR: ids of the rays handed over with fewer than near_early accepted steps (appended with ctrl[6] as the
-    // cursor); the NEAR pass starts with those
-    uint32_t* early;
-    uint32_t near_early;
-    uint32_t n_simd;        // SIMDs of the device (4 per CU): workgroup b is the (b / n_simd)-th oldest wave of its SIMD
-    uint32_t fair_shift;    // != 0: the waves of a SIMD take turns at the top priority, slices of 2^fair_shift clocks
-#ifdef RTGR_ROOT_STATS
-    unsigned long long* dbg;  // debug builds: per-wave {start, end, iterations, rays} of the NEAR pass, then per-ray stays
-#endif
-};
-
-// Integrate passes.  FULL: every accepted step runs the ContinuousCallback scan (8 interior samples + end point).
-// FAR / NEAR split the same work by phase of the ray: the FAR pass replaces the scan by a rigorous per-object bound
-// ("no object's distance can change sign anywhere in this step"); a ray for which the bound fails is handed — with its
-// PRE-step state, so the step is simply redone — to the NEAR pass, which is the FULL algorithm started from a
-// hand-over record instead of a camera ray.  Results are identical to FULL by construction (the scan is skipped only
-// where it provably finds nothing); rays spend >90 % of their steps in the FAR pass, which is ~30 % cheaper per step.
-enum IntegrateMode : int { MODE_FULL = 0, MODE_FAR = 1, MODE_NEAR = 2 };
-constexpr int HAND_W = 16;  // x[4] u[4] k0[4] t dt ps lq
-constexpr uint32_t META_HANDED = 0xffff0000u;    // meta[3*idx+2] of a ray waiting for a NEAR pass
-constexpr uint32_t META_HANDBACK = 0xffff0001u;  // … of a ray a NEAR pass handed back to the next round's FAR pass
-constexpr uint32_t META_HANDED_EARLY = 0xffff0002u;  // … of a ray waiting for the NEAR pass ON ITS EARLY LIST
-#ifndef RTGR_QUEUE_CHUNK
-#define RTGR_QUEUE_CHUNK 256ull
-#endif
 
 // fast f32 helpers for the step-size machinery
 // A wave-uniform value computed with vector instructions (there is no scalar f64 ALU) lives in a VGPR — and, in a kernel
@@ -772,7 +696,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 }
 
 template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE>
-__global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? RTGR_WAVES_PER_SIMD_GENERIC
+__global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_GENERIC : RTGR_WAVES_PER_SIMD_GENERIC_F32)
                                  : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4)
                                                      : (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32)))
 void integrate_kernel(const IntegrateArgs<R> A) {
@@ -805,8 +729,12 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     if (valid) {
         if (A.state0) {
             const R* s0 = A.state0 + w * 8;
+            bool bad = false;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { x[q] = s0[q]; u[q] = s0[4 + q]; }
+            for (int q = 0; q < 4; q++) { x[q] = s0[q]; u[q] = s0[4 + q]; bad = bad || x[q] != x[q] || u[q] != u[q]; }
+            // `@assert !any(isnan, xx)` of kerr_schild (src/RayTraceGR.jl:279): evaluated here, where every caller-supplied
+            // state is read anyway; the host entry points turn the flag into RTGR_ERR_NAN_INPUT
+            if (bad && A.nan_flag) atomicOr(A.nan_flag, 1u);
         } else {  // make_canvas (src/RayTraceGR.jl:457-478) for this pixel, straight into registers
             R s[8];
             const uint64_t idx = A.first + w;
@@ -866,7 +794,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(const IntegrateArgs<R> A) 
 // Per-launch reset of the queue heads and of the ordering histogram.  A kernel rather than hipMemsetAsync: memset nodes
 // of a captured HIP graph were observed not to re-run on later replays (ROCm 7.0 runtime bundled with PyTorch), which
 // left stale queue heads / histograms and sent the scatter out of bounds; kernel nodes replay reliably.
-__global__ __launch_bounds__(256) void reset_kernel(unsigned long long* ctrl, uint32_t* hist512) {
+static __global__ __launch_bounds__(256) void reset_kernel(unsigned long long* ctrl, uint32_t* hist512) {
     if (threadIdx.x < 8) ctrl[threadIdx.x] = 0ull;
     if (hist512) { hist512[threadIdx.x] = 0u; hist512[256 + threadIdx.x] = 0u; }
 }
@@ -908,7 +836,7 @@ RTGR_DEV void order_key(const R x4[4], const R u4[4], bool valid, uint64_t w, ui
     if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 // exclusive prefix sum of the 256-bin histogram (one block) -> running offsets used by the scatter
-__global__ __launch_bounds__(256) void order_scan_kernel(const uint32_t* hist, uint32_t* offsets) {
+static __global__ __launch_bounds__(256) void order_scan_kernel(const uint32_t* hist, uint32_t* offsets) {
     __shared__ uint32_t sh[256];
     sh[threadIdx.x] = hist[threadIdx.x];
     __syncthreads();
@@ -921,7 +849,7 @@ __global__ __launch_bounds__(256) void order_scan_kernel(const uint32_t* hist, u
 }
 // order[offset(bucket)++] = ray index.  Ranks inside a 256-ray block come from LDS atomics; each block then claims its
 // range of every non-empty bucket with ONE global atomic (neighbouring rays share a handful of buckets).
-__global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* keys, uint64_t n, uint32_t* offsets, uint32_t* order) {
+static __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* keys, uint64_t n, uint32_t* offsets, uint32_t* order) {
     __shared__ uint32_t lcount[256], gbase[256];
     lcount[threadIdx.x] = 0;
     __syncthreads();
@@ -1046,25 +974,6 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
 #else
 #define RTGR_ROOT_STATS_ARG
 #endif
-
-template <class R>
-struct ResolveArgs {
-    DevScene<R> sc;
-    DevSolver<R> opt;
-    const R* rec;
-    const uint32_t* meta;
-    int recw;
-    uint64_t n;        // rays in this chunk
-    uint64_t offset;   // first ray of the chunk in the caller's slab
-    uint64_t n_slab;   // rays in the slab (plane stride of rgb)
-    R* rgb;
-    R* state_end;
-    R* lambda_end;
-    uint8_t* status;
-    uint8_t* hit;
-    uint32_t* n_accept;
-    uint32_t* n_reject;
-};
 
 template <class R>
 __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {

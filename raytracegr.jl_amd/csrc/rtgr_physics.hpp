@@ -19,37 +19,11 @@
 #include <stdint.h>
 
 #include "../../include/rtgr.h"
+#include "rtgr_args.hpp"
 
 namespace rtgr {
 
 #define RTGR_DEV __device__ __forceinline__
-
-template <class R>
-struct DevObject {
-    uint32_t kind;
-    uint32_t pad;
-    R p[9];
-};
-
-template <class R>
-struct DevScene {
-    uint32_t metric;
-    uint32_t nobj;
-    R M, a;
-    DevObject<R> obj[RTGR_MAX_OBJECTS];
-};
-
-template <class R>
-struct DevSolver {
-    R reltol, abstol, lambda0, lambda1, hit_threshold;
-    R miss_rgb[3];
-    uint32_t max_steps, interp_points;
-};
-
-template <class R>
-struct DevCamera {
-    R pos[4], widthx[4], widthy[4], normal[4];
-};
 
 // ---- small math helpers -------------------------------------------------------------------------------------------
 template <class R> RTGR_DEV R rfma(R a, R b, R c);

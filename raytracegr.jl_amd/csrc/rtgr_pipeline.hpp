@@ -1,0 +1,256 @@
+// rtgr_pipeline.hpp — host side of the trace pipeline: launch policy and the per-chunk kernel sequence
+//     reset -> prepare (camera ray, queue key, u̇(y0), initial dt) -> [order scan/scatter] -> integrate<FAR> -> integrate<NEAR>
+//     -> resolve
+// as templates over (scalar, metric variant, spin).  Each tu_*.hip instantiates the variants of its group, so the
+// library's translation units build in parallel and the C-ABI file (rtgr_api.hip) instantiates no kernel at all.
+//
+// Launch policy (Knobs, rtgr_host.hpp; "auto" decisions by launch size are documented where they are taken):
+//   waves_per_cu       resident waves per CU of the integrate kernel (auto = 4 x the instantiation's waves/SIMD)
+//   chunk              rays per pipeline chunk (auto 2^26, less if memory is short); bounds the workspace
+//   split = 0          one FULL integrate pass instead of the FAR + NEAR pair
+//   order = 0          keep the natural ray order (auto: longest-expected-first, see rtgr_persistent.hpp)
+//   fair = s           time slice 2^s clocks of the priority rotation (0 = off; auto 13 for 0.8-1.8 M rays, else off)
+//   near_early = n     accepted steps at hand-over below which a ray is put on the NEAR pass's early list (64)
+//   waves_per_cu_near  resident waves per CU of the NEAR pass (auto 4 below 1.6 M rays, else all)
+//   far4 = 0/1         force the 3- / 4-waves-per-SIMD instantiation of the a = 0 FAR pass (auto: by launch size)
+#pragma once
+#include "rtgr_host.hpp"
+#include "rtgr_persistent.hpp"
+
+namespace rtgr {
+
+// One lane = one ray.  A wave owns an 8x8 pixel tile (lock-step efficiency 0.90 vs 0.45 for 64 consecutive
+// pixels); a 256-thread workgroup owns 4 horizontally adjacent tiles.  The simple variant (knob tile = 1):
+// whole adaptive loop + event finder + colouring inline — an independent formulation kept for A/B and cross-checks.
+template <class R, int METRIC, bool SPIN>
+__global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
+    const uint64_t tiles_i = (A.ni + 7) >> 3;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t ti = wave % tiles_i, tj = wave / tiles_i;
+    const uint64_t i = ti * 8 + (lane & 7), jl = tj * 8 + (lane >> 3);
+    const bool valid = (i < A.ni) && (jl < A.nrows);
+    const uint64_t n = A.ni * A.nrows;
+    const uint64_t idx = i + jl * A.ni;
+
+    RayStats st{0, 0, 0, 0, 0};
+    bool ev = false;
+    if (valid) {
+        R s0[8], se[8], lam, col[3];
+        if (A.state0) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) s0[c] = A.state0[idx * 8 + c];
+        } else {
+            make_pixel<R>(A.sc, A.cam, A.ni, A.nj, i, A.j0 + jl * A.jstride, s0);
+        }
+        st = integrate_ray<R, METRIC, SPIN>(A.sc, A.opt, s0, se, lam);
+        const uint8_t hit = colour_pixel<R>(A.sc, A.opt, se, col);
+        A.rgb[idx] = col[0];
+        A.rgb[n + idx] = col[1];
+        A.rgb[2 * n + idx] = col[2];
+        if (A.state_end) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) A.state_end[idx * 8 + c] = se[c];
+        }
+        if (A.lambda_end) A.lambda_end[idx] = lam;
+        if (A.status) A.status[idx] = st.status;
+        if (A.hit) A.hit[idx] = hit;
+        if (A.n_accept) A.n_accept[idx] = st.nacc;
+        if (A.n_reject) A.n_reject[idx] = st.nrej;
+        ev = (st.status == RTGR_RAY_EVENT);
+    }
+    if (A.counters) {
+        const unsigned long long c0 = wave_sum(valid ? 1ull : 0ull), c1 = wave_sum(st.nacc), c2 = wave_sum(st.nrej),
+                                 c3 = wave_sum(st.nrhs), c4 = wave_sum(ev ? 1ull : 0ull),
+                                 c5 = wave_sum(st.interior), c6 = wave_sum((valid && st.status >= RTGR_RAY_MAXSTEPS) ? 1ull : 0ull);
+        if (lane == 0) {
+            atomicAdd(&A.counters[0], c0);
+            atomicAdd(&A.counters[1], c1);
+            atomicAdd(&A.counters[2], c2);
+            atomicAdd(&A.counters[3], c3);
+            atomicAdd(&A.counters[4], c4);
+            atomicAdd(&A.counters[5], c5);
+            atomicAdd(&A.counters[6], c6);
+        }
+    }
+}
+
+template <class R, int METRIC> constexpr int waves_per_simd_of(int mode) {
+    if (METRIC >= RTGR_GENERIC_BASE) return sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_GENERIC : RTGR_WAVES_PER_SIMD_GENERIC_F32;
+    if (mode == MODE_FAR) return sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4;
+    return sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32;
+}
+
+template <class R, int METRIC, bool SPIN>
+static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts10, bool split, uint64_t waves, hipStream_t st) {
+    constexpr bool USER = (METRIC == RTGR_GENERIC_BASE + RTGR_USER);
+    DeviceCtx& D = E.d;
+    const Knobs& K = D.knobs;
+    auto grid = [&](int per_simd) {
+        const uint64_t per_cu = K.waves_per_cu > 0 ? (uint64_t)K.waves_per_cu : (uint64_t)(4 * per_simd);
+        const uint64_t resident = (uint64_t)D.num_cu * per_cu;
+        return dim3((unsigned)(waves < resident ? waves : resident));
+    };
+    if (npts10 && split) {
+        // round 0: FAR over the camera rays, NEAR over what it hands over (the NEAR pass keeps a ray to its end).
+        // rounds = 2 (experiment, measured SLOWER: 9.9 -> 11.8 ms at 1024², 99.3 -> 101.9 ms at 4096²): the NEAR pass
+        // hands rays that have left every object's reach back, and a second FAR + NEAR round carries them on — the
+        // extra passes' own start-up and tails cost more than the NEAR tail they remove.  Each pass has its own queue
+        // head (ctrl[0..7]).
+        int rounds = (int)K.rounds;
+        rounds = rounds < 1 ? 1 : (rounds > 3 ? 3 : rounds);  // 2 queue heads per round; slot 6 is the early-list cursor
+        IntegrateArgs<R> P = IA;
+        for (int r = 0; r < rounds; r++) {
+            P.ctrl = IA.ctrl + 2 * r;
+            P.queue_chunk = IA.queue_chunk;
+            if (r > 0) P.early = nullptr;  // the early list is round 0's
+            P.pick_flag = r == 0 ? 0u : META_HANDBACK;
+            if (r > 0) P.order = nullptr;
+#ifdef RTGR_ROOT_STATS
+            P.dbg = K.dbg_pass_far ? D.dbg : nullptr;
+#endif
+            { KernelTimer tm(D, st, 1);
+              if constexpr (USER) {
+                  HIP_TRY(launch_module(E.user->far, grid(waves_per_simd_of<R, METRIC>(MODE_FAR)).x, 64, st, P));
+              } else {
+                  bool four = false;
+                  if constexpr (sizeof(R) == 8 && !SPIN && METRIC < RTGR_GENERIC_BASE && METRIC != RTGR_MINKOWSKI) {
+                      // >= 24 rays per lane of a 4-waves/SIMD grid (6.3 M rays): see integrate_far4_kernel.  Measured
+                      // 3 vs 4 waves: 4.2 M rays 22.3 / 22.5 ms, 8.4 M 44.1 / 43.3, 12.2 M 63.4 / 62.6, 16.8 M 85.6 / 84.5.
+                      four = K.far4 >= 0 ? K.far4 != 0 : P.n >= (uint64_t)D.num_cu * 16 * 64 * 24;
+                      if (four) hipLaunchKernelGGL((integrate_far4_kernel<R, METRIC>), grid(4), dim3(64), 0, st, P);
+                  }
+                  if (!four) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
+                                                grid(waves_per_simd_of<R, METRIC>(MODE_FAR)), dim3(64), 0, st, P);
+              } }
+            P.pick_flag = META_HANDED;
+            P.allow_handback = (r + 1 < rounds) ? 1u : 0u;
+            {   // The NEAR pass visits EVERY ray id, and its rays last ~6 steps: all its waves pop at the same time and
+                // keep popping, so the device-scope atomic on the queue head (~90 M/s on one word) is what bounds it when
+                // the chunks are small — measured 0.8 ms for 2.1 M rays at 42 ids per pop (50 k atomics), also for a
+                // hand-back pass that picks up almost nothing.  So: 1/8 of a wave's share per pop, within [64, 256]
+                // (sweep at 2.1 / 4.2 / 16.8 M rays: best at 64-128 / 128-256 / 256; 1024 parks stragglers: +30 %).
+                const uint64_t share = P.n / ((uint64_t)grid(waves_per_simd_of<R, METRIC>(MODE_NEAR)).x * 8 + 1);
+                const uint64_t nc = share < 64 ? 64 : (share > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : share);
+                P.queue_chunk = (uint32_t)(K.qchunk_near > 0 ? K.qchunk_near : (long)nc);
+            }
+#ifdef RTGR_ROOT_STATS
+            P.dbg = K.dbg_pass_far ? nullptr : D.dbg;
+#endif
+            { KernelTimer tm(D, st, 3);
+              // A small launch's NEAR pass ends on its longest-staying rays (one lane each, up to 370 steps in the
+              // a = 0.8 scene), and such a wave steps faster alone on its SIMD than next to a second wave: ONE wave per
+              // SIMD below 1.6 M rays (1024²: a = 0.8 NEAR 2.17 -> 1.43 ms, a = 0 0.87 -> 0.64 ms; from 2 M rays on
+              // the second wave's throughput is worth more).
+              dim3 gn = grid(waves_per_simd_of<R, METRIC>(MODE_NEAR));
+              const long wn = K.waves_per_cu_near >= 0 ? K.waves_per_cu_near : (P.n < (uint64_t)D.num_cu * 12 * 64 * 8 ? 4 : 0);
+              if (wn > 0 && (uint64_t)D.num_cu * (uint64_t)wn < gn.x) gn.x = (unsigned)((uint64_t)D.num_cu * (uint64_t)wn);
+              if constexpr (USER) HIP_TRY(launch_module(E.user->near, gn.x, 64, st, P));
+              else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), gn, dim3(64), 0, st, P);
+            }
+        }
+    } else {
+        IntegrateArgs<R> P = IA;
+#ifdef RTGR_ROOT_STATS
+        P.dbg = D.dbg;   // debug builds: the FULL pass reports its wave timeline too
+#endif
+        KernelTimer tm(D, st, 1);
+        const dim3 g = grid(waves_per_simd_of<R, METRIC>(MODE_FULL));
+        if constexpr (USER) {
+            hipFunction_t f = sizeof(R) == 8 ? (npts10 ? E.user->full10 : E.user->fulln)
+                                             : (npts10 ? E.user->full10_f32 : E.user->fulln_f32);
+            HIP_TRY(launch_module(f, g.x, 64, st, P));
+        } else if (npts10) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FULL>), g, dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, false, MODE_FULL>), g, dim3(64), 0, st, P);
+    }
+    return RTGR_OK;
+}
+
+template <class R, int METRIC, bool SPIN>
+static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
+    constexpr bool USER = (METRIC == RTGR_GENERIC_BASE + RTGR_USER);
+    DeviceCtx& D = E.d;
+    const Knobs& K = D.knobs;
+    if constexpr (METRIC < RTGR_GENERIC_BASE) if (K.tile) {
+        const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
+        const uint64_t blocks = (tiles + 3) / 4;
+        KernelTimer tm(D, st, 1);
+        hipLaunchKernelGGL((trace_kernel<R, METRIC, SPIN>), dim3((unsigned)blocks), dim3(256), 0, st, A);
+        return RTGR_OK;
+    }
+    const uint64_t n = A.ni * A.nrows;
+    const bool with_state = A.state_end != nullptr;
+    const uint64_t chunk = pick_chunk<R>(D, E.ss, n, with_state);
+    int rc = ensure_workspace(D, E.ss, workspace_bytes<R>(chunk, with_state), st);
+    if (rc) return rc;
+    const int recw = with_state ? REC_W_STATE : REC_W;
+    char* base = (char*)E.ss.ws;
+    R* rec = (R*)base;
+    char* cur = base + align256(chunk * recw * sizeof(R));
+    uint32_t* meta = (uint32_t*)cur;
+    cur += align256(chunk * 3 * sizeof(uint32_t));
+    R* hand = (R*)cur;
+    cur += align256(chunk * HAND_W * sizeof(R));
+    uint32_t* order = (uint32_t*)cur;
+    cur += align256(chunk * sizeof(uint32_t));
+    uint32_t* early = (uint32_t*)cur;
+    cur += align256(chunk * sizeof(uint32_t));
+    uint8_t* keys = (uint8_t*)cur;
+    cur += align256(chunk);
+    uint32_t* hist = (uint32_t*)cur;  // 256 bins + 256 running offsets
+    cur += 4096;
+    // Float32 rays last ~20 steps: one FULL pass wins (measured 5-6 %)
+    // (a user unit carries Float32 twins of the FULL pass only)
+    const bool split = (K.split >= 0 ? K.split != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
+        const R* s0 = A.state0 ? A.state0 + off * 8 : nullptr;  // null: prepare_kernel generates the camera rays
+        // longest-expected-first queue order: pays off when a lane gets few rays (see rtgr_persistent.hpp)
+        const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 && K.order != 0;
+        unsigned long long* q = E.ss.queue;  // one slot per stream: the stream orders this chunk behind the previous one
+        hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, st, q, use_order ? hist : (uint32_t*)nullptr);
+        IntegrateArgs<R> IA;
+        std::memset(&IA, 0, sizeof IA);
+        IA.sc = A.sc; IA.opt = A.opt; IA.state0 = s0; IA.order = use_order ? order : nullptr; IA.n = m; IA.rec = rec; IA.meta = meta; IA.recw = recw;
+        IA.hand = hand; IA.ctrl = q; IA.counters = A.counters; IA.pick_flag = 0; IA.allow_handback = 0;
+        IA.cam = A.cam; IA.ni = A.ni; IA.nj = A.nj; IA.j0 = A.j0; IA.jstride = A.jstride; IA.first = off;
+        IA.keys = use_order ? keys : nullptr; IA.hist = hist; IA.nan_flag = A.nan_flag;
+        IA.early = early; IA.near_early = (uint32_t)(K.near_early < 0 ? 64 : K.near_early);  // 0: no early list
+        if (IA.near_early == 0u) IA.early = nullptr;
+        // priority rotation among the waves of a SIMD: pays when a lane gets only a few rays (see rtgr_persistent.hpp)
+        // measured FAR pass, off / on: 0.26 M rays 2.70 / 3.17 ms, 0.52 M 3.83 / 4.35, 1.05 M 7.05 / 6.29, 1.44 M 8.83 / 8.30,
+        // 2.1 M 11.59 / 11.59, 16.8 M 83.8 / 84.8 -> on for 4..9 rays per lane of the 3-waves/SIMD grid
+        IA.n_simd = (uint32_t)D.num_cu * 4u;
+        const uint64_t lanes3 = (uint64_t)D.num_cu * 12 * 64;
+        IA.fair_shift = (uint32_t)(K.fair >= 0 ? K.fair : ((m >= 4 * lanes3 && m < 9 * lanes3) ? 13 : 0));
+        {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [8, RTGR_QUEUE_CHUNK]
+            const uint64_t per_wave = m / ((uint64_t)D.num_cu * 12 + 1);
+            uint64_t qc = per_wave / 16;
+            qc = qc < 8 ? 8 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
+            IA.queue_chunk = (uint32_t)(K.qchunk > 0 ? K.qchunk : (long)qc);
+        }
+        {   // ray set-up: camera ray (or the caller's state), ordering key, u̇(y0), initial dt, event sign -> start records
+            KernelTimer tm(D, st, 0);
+            if constexpr (USER) {
+                HIP_TRY(launch_module(sizeof(R) == 8 ? E.user->prepare : E.user->prepare_f32, (unsigned)((m + 255) / 256), 256, st, IA));
+            } else hipLaunchKernelGGL((prepare_kernel<R, METRIC, SPIN>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, IA);
+            if (use_order) {
+                hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, st, hist, hist + 256);
+                hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys, m, hist + 256, order);
+            }
+        }
+        rc = launch_integrate<R, METRIC, SPIN>(E, IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
+        if (rc) return rc;
+        ResolveArgs<R> RA;
+        RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = A.out_offset + off;
+        RA.n_slab = A.plane_stride ? A.plane_stride : n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
+        RA.status = A.status; RA.hit = A.hit; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
+        {
+            KernelTimer tm(D, st, 2);
+            hipLaunchKernelGGL(resolve_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, RA);
+        }
+    }
+    return RTGR_OK;
+}
+
+}  // namespace rtgr

@@ -28,7 +28,7 @@ def _torch_dtype(dtype):
 
 
 def trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device="cuda", dtype=np.float64, details=False, counters=None,
-                     out=None, state0=None):
+                     out=None, state0=None, ctx=None):
     """Trace rows [j0, j1) on `device` into torch tensors (device-resident in and out). Asynchronous: enqueues on
     torch's current stream.  Returns dict(rgb[3, n] (+ per-ray tensors when details))."""
     import torch
@@ -57,7 +57,7 @@ def trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device="cuda", dtype=np.fl
         if state0 is not None:
             assert state0.is_cuda and state0.is_contiguous() and state0.shape == (n, 8) and state0.dtype == td
             s0 = state0.data_ptr()
-        _abi.check(lib, fn(C.byref(scene), C.byref(opt), s0, C.byref(cam) if cam is not None else None, ni, nj, j0,
+        _abi.check(lib, fn(ctx, C.byref(scene), C.byref(opt), s0, C.byref(cam) if cam is not None else None, ni, nj, j0,
                            j1, res["rgb"].data_ptr(), C.byref(o),
                            counters.data_ptr() if counters is not None else None, stream))
     return res
@@ -74,7 +74,7 @@ def row_assignment(nj, world_size, rank, layout="cyclic"):
 
 
 def trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device="cuda", dtype=np.float64, counters=None,
-                     out=None):
+                     out=None, ctx=None):
     """Trace image rows j0, j0+jstride, … (nrows of them) into a device tensor rgb[3, ni*nrows]; asynchronous."""
     import torch
     lib = _abi.load()
@@ -87,7 +87,7 @@ def trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device="cuda",
             res["rgb"] = torch.empty((3, n), dtype=td, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         fn = lib.rtgr_trace_rows_device_f64 if dtype == np.float64 else lib.rtgr_trace_rows_device_f32
-        _abi.check(lib, fn(C.byref(scene), C.byref(opt), C.byref(cam), ni, nj, j0, jstride, nrows,
+        _abi.check(lib, fn(ctx, C.byref(scene), C.byref(opt), C.byref(cam), ni, nj, j0, jstride, nrows,
                            res["rgb"].data_ptr(), None, counters.data_ptr() if counters is not None else None, stream))
     return res
 

@@ -25,10 +25,11 @@ from . import build as _build
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 TEMPLATE = os.path.join(CSRC, "rtgr_user_unit.hip.in")
-_HEADERS = [os.path.join(CSRC, f) for f in ("rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp",
-                                            "rtgr_tsit5_tables.hpp")] + [os.path.join(HERE, "..", "include", "rtgr.h")]
+_HEADERS = [os.path.join(CSRC, f) for f in ("rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp",
+                                            "rtgr_persistent.hpp", "rtgr_tsit5_tables.hpp")] + \
+           [os.path.join(HERE, "..", "include", "rtgr.h")]
 FLAGS = ["--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function"]
-_loaded_path = None  # code object currently resident in the library
+_ids = {}  # (context handle value or None, code object path) -> module id returned by rtgr_user_metric_load
 
 
 def cache_dir():
@@ -60,8 +61,10 @@ def compile_user_metric(source, verbose=False):
     with open(TEMPLATE) as fh:
         unit = fh.read().replace("@RTGR_USER_SOURCE@", source)
     src = os.path.join(d, f"metric_{tag}.hip")
-    with open(src, "w") as fh:
+    tmp_src = src + f".tmp{os.getpid()}"   # concurrent ranks may generate the same unit: never expose a partial file
+    with open(tmp_src, "w") as fh:
         fh.write(unit)
+    os.replace(tmp_src, src)
     tmp = out + f".tmp{os.getpid()}"
     cmd = [_build.HIPCC] + FLAGS + ["-I", CSRC, "-o", tmp, src]
     if verbose:
@@ -75,14 +78,20 @@ def compile_user_metric(source, verbose=False):
     return out
 
 
-def activate(path):
-    """Make `path` the resident user metric of the library (no-op when it already is)."""
-    global _loaded_path
+def load(path, ctx=None):
+    """Load the code object into the context (default: the process's default context) and return its module id — the
+    value a scene carries in rtgr_scene.user_metric.  Loading the same file again is a no-op that returns the same id;
+    several metrics may be resident at once."""
+    import ctypes as C
     lib = _abi.load()
-    if _loaded_path == path and lib.rtgr_user_metric_loaded():
-        return
-    _abi.check(lib, lib.rtgr_user_metric_load(path.encode()))
-    _loaded_path = path
+    key = (getattr(ctx, "value", ctx), path)
+    mid = _ids.get(key)
+    if mid is not None and lib.rtgr_user_metric_loaded(ctx, mid) == 1:
+        return mid
+    out = C.c_uint64(0)
+    _abi.check(lib, lib.rtgr_user_metric_load(ctx, path.encode(), C.byref(out)))
+    _ids[key] = out.value
+    return out.value
 
 
 class UserMetric:
@@ -94,8 +103,9 @@ class UserMetric:
         self.source, self.M, self.a, self.name = source, float(M), float(a), name
         self.code_object = compile_user_metric(source, verbose=verbose)
 
-    def activate(self):
-        activate(self.code_object)
+    def module_id(self, ctx=None):
+        """id of this metric's module in the context (loads the code object on first use)"""
+        return load(self.code_object, ctx)
 
     def __call__(self, x):
         from . import api

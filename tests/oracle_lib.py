@@ -17,7 +17,8 @@ def lib():
     global _lib
     if _lib is None:
         src = os.path.join(ROOT, "oracle", "rtgr_oracle.cpp")
-        if (not os.path.exists(_ORACLE)) or os.path.getmtime(_ORACLE) < os.path.getmtime(src):
+        hdr = os.path.join(ROOT, "include", "rtgr.h")  # the oracle shares the product's struct layouts
+        if (not os.path.exists(_ORACLE)) or os.path.getmtime(_ORACLE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         _lib = C.CDLL(_ORACLE)
     return _lib

@@ -38,13 +38,13 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_struct_sizes_match_the_header(lib):
-    # layouts in include/rtgr.h: object 8+72, scene 8+16+16*80, solver 8*8+8, camera 128, counters 64, outputs 48
+    # layouts in include/rtgr.h: object 8+72, scene 8+16+8+16*80, solver 8*8+8, camera 128, counters 64, outputs 56
     assert C.sizeof(abi.rtgr_object) == 80
-    assert C.sizeof(abi.rtgr_scene) == 24 + 16 * 80
+    assert C.sizeof(abi.rtgr_scene) == 32 + 16 * 80
     assert C.sizeof(abi.rtgr_solver) == 72
     assert C.sizeof(abi.rtgr_camera) == 128
     assert C.sizeof(abi.rtgr_counters) == 64
-    assert C.sizeof(abi.rtgr_ray_outputs) == 48
+    assert C.sizeof(abi.rtgr_ray_outputs) == 56
 
 
 def test_solver_defaults_are_the_reference_constants(lib):
@@ -69,7 +69,7 @@ def test_no_cpu_fallback_without_a_gpu(lib):
     opt = rt.solver_defaults()
     s0 = np.zeros((1, 8))
     rgb = np.zeros(3)
-    rc = lib.rtgr_trace_f64(C.byref(sc), C.byref(opt), s0.ctypes.data, None, 1, 1, 0, 1, rgb.ctypes.data, None, None)
+    rc = lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), s0.ctypes.data, None, 1, 1, 0, 1, rgb.ctypes.data, None, None)
     assert rc == abi.ERR_NO_DEVICE
     assert b"no CPU fallback" in lib.rtgr_last_error()
     with pytest.raises(abi.RtgrError):

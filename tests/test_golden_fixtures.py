@@ -46,7 +46,7 @@ def test_hip_path_matches_committed_fixtures(name):
     nrej = np.zeros(n, np.uint32)
     o = abi.rtgr_ray_outputs()
     o.hit, o.status, o.n_accept, o.n_reject = hit.ctypes.data, status.ctypes.data, nacc.ctypes.data, nrej.ctypes.data
-    abi.check(lib, lib.rtgr_trace_f64(C.byref(sc), C.byref(opt), None, C.byref(cam), N, N, 0, N, rgb.ctypes.data,
+    abi.check(lib, lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), N, N, 0, N, rgb.ctypes.data,
                                       C.byref(o), None))
     f = _fixture(name)
     flips = hit != f["hit"]

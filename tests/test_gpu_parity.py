@@ -39,7 +39,7 @@ def hip_trace(lib, sc, opt, ni, nj, j0=0, j1=None, cam=None, state0=None, dtype=
     if state0 is not None:
         state0 = np.ascontiguousarray(state0, dtype)
         s0 = state0.ctypes.data
-    abi.check(lib, fn(C.byref(sc), C.byref(opt), s0, C.byref(cam) if cam is not None else None, ni, nj, j0, j1,
+    abi.check(lib, fn(None, C.byref(sc), C.byref(opt), s0, C.byref(cam) if cam is not None else None, ni, nj, j0, j1,
                       rgb.ctypes.data, C.byref(o), C.byref(ctr)))
     arrs.update(rgb=rgb, counters=ctr.as_dict())
     return arrs
@@ -238,15 +238,15 @@ def test_bad_arguments_are_rejected(lib):
     opt = rt.solver_defaults()
     rgb = np.zeros(3 * 4)
     f = lib.rtgr_trace_f64
-    assert f(C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 0, 2, None, None, None) == abi.ERR_BAD_ARG
-    assert f(C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 2, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
-    assert f(C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 0, 3, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
-    assert f(C.byref(sc), C.byref(opt), None, None, 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
+    assert f(None, C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 0, 2, None, None, None) == abi.ERR_BAD_ARG
+    assert f(None, C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 2, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
+    assert f(None, C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 0, 3, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
+    assert f(None, C.byref(sc), C.byref(opt), None, None, 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
     bad = rt.make_scene(rt.kerr_schild, [])
     bad.metric = 7
-    assert f(C.byref(bad), C.byref(opt), None, C.byref(cam), 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
+    assert f(None, C.byref(bad), C.byref(opt), None, C.byref(cam), 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
     s0 = np.full((4, 8), np.nan)
-    assert f(C.byref(sc), C.byref(opt), s0.ctypes.data, None, 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_NAN_INPUT
+    assert f(None, C.byref(sc), C.byref(opt), s0.ctypes.data, None, 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_NAN_INPUT
 
 
 def test_max_steps_status(lib):
@@ -279,7 +279,7 @@ def test_quantize_and_device_pointers(lib):
     ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
     res = sharded.trace_slab_torch(sc, opt, cam, 200, 200, 0, 200, details=True, counters=ctr)
     img = torch.empty((200, 200, 3), dtype=torch.uint8, device="cuda")
-    abi.check(lib, lib.rtgr_quantize_device_f64(res["rgb"].data_ptr(), 200, 200, img.data_ptr(),
+    abi.check(lib, lib.rtgr_quantize_device_f64(None, res["rgb"].data_ptr(), 200, 200, img.data_ptr(),
                                                 torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert int((img.cpu().numpy() != _golden("sphere2.png")).any(axis=2).sum()) == 0
@@ -315,19 +315,13 @@ def test_far_near_split_is_bit_identical_to_full_scan(lib):
         sc, cam = scene_variant(name)
         opt = rt.solver_defaults()
         a = hip_trace(lib, sc, opt, 96, 80, cam=cam)
-        os.environ["RTGR_SPLIT"] = "0"
-        try:
+        with abi.options(lib, split=0):
             b = hip_trace(lib, sc, opt, 96, 80, cam=cam)
-        finally:
-            del os.environ["RTGR_SPLIT"]
         for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
             assert np.array_equal(a[k], b[k]), (name, k)
         assert a["counters"] == b["counters"]
-        os.environ["RTGR_KERNEL"] = "tile"
-        try:
+        with abi.options(lib, tile=1):
             c = hip_trace(lib, sc, opt, 96, 80, cam=cam)
-        finally:
-            del os.environ["RTGR_KERNEL"]
         flips = a["hit"] != c["hit"]
         assert int(flips.sum()) <= (40 if name == "mink" else 2)
         same = ~flips
@@ -342,11 +336,8 @@ def test_four_waves_per_simd_far_variant_is_bit_identical(lib):
         opt = rt.solver_defaults()
         res = {}
         for force in ("0", "1"):
-            os.environ["RTGR_FAR4"] = force
-            try:
+            with abi.options(lib, far4=int(force)):
                 res[force] = hip_trace(lib, sc, opt, 200, 160, cam=cam)
-            finally:
-                del os.environ["RTGR_FAR4"]
         for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
             assert np.array_equal(res["0"][k], res["1"][k]), (name, k)
         assert res["0"]["counters"] == res["1"]["counters"]
@@ -384,15 +375,11 @@ def test_scheduling_knobs_do_not_change_results(lib):
     sc, cam = scene_variant("ks_true0998_disk")   # long NEAR stays, early hand-overs, rejected steps near the disk
     opt = rt.solver_defaults()
     ref = hip_trace(lib, sc, opt, 256, 192, cam=cam)
-    for knobs in ({"RTGR_NEAR_EARLY": "0"}, {"RTGR_NEAR_EARLY": "8"}, {"RTGR_NEAR_EARLY": "100000"},
-                  {"RTGR_FAIR": "11"}, {"RTGR_FAIR": "0", "RTGR_ORDER": "0"}, {"RTGR_QCHUNK": "8", "RTGR_QCHUNK_NEAR": "64"},
-                  {"RTGR_WAVES_PER_CU": "4"}, {"RTGR_FAR4": "1", "RTGR_FAIR": "13"}):
-        os.environ.update(knobs)
-        try:
+    for knobs in ({"near_early": 0}, {"near_early": 8}, {"near_early": 100000},
+                  {"fair": 11}, {"fair": 0, "order": 0}, {"qchunk": 8, "qchunk_near": 64},
+                  {"waves_per_cu": 4}, {"far4": 1, "fair": 13}, {"host_chunk": 4096}):
+        with abi.options(lib, **knobs):
             got = hip_trace(lib, sc, opt, 256, 192, cam=cam)
-        finally:
-            for k in knobs:
-                del os.environ[k]
         for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
             assert np.array_equal(ref[k], got[k]), (knobs, k)
         assert ref["counters"] == got["counters"], knobs
@@ -414,11 +401,8 @@ def test_pipeline_chunking_is_invisible(lib):
     sc, cam = example(2)
     opt = rt.solver_defaults()
     a = hip_trace(lib, sc, opt, 100, 70, cam=cam)
-    os.environ["RTGR_CHUNK"] = "1500"
-    try:
+    with abi.options(lib, chunk=1500):
         b = hip_trace(lib, sc, opt, 100, 70, cam=cam)
-    finally:
-        del os.environ["RTGR_CHUNK"]
     for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
         assert np.array_equal(a[k], b[k]), k
     assert a["counters"] == b["counters"]
@@ -516,12 +500,13 @@ def test_pipeline_is_hipgraph_capturable(lib):
     sc, cam = example(2)
     opt = rt.solver_defaults()
     ni = nj = 192
-    abi.check(lib, lib.rtgr_reserve_workspace(ni * nj, 0, 0))
     eager = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj)["rgb"].clone()
     torch.cuda.synchronize()
     out = {"rgb": torch.zeros((3, ni * nj), dtype=torch.float64, device="cuda")}
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    side = torch.cuda.Stream()   # torch captures on a side stream: the workspace is per stream, so reserve THAT stream's
+    abi.check(lib, lib.rtgr_reserve_workspace(None, out["rgb"].data_ptr(), side.cuda_stream, ni * nj, 0, 0))
+    with torch.cuda.graph(g, stream=side):
         sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, out=out)
     for _ in range(3):
         out["rgb"].zero_()
@@ -547,7 +532,7 @@ def test_strided_rows_equal_the_rows_of_the_full_frame(lib):
             assert torch.equal(part.reshape(3, nr, ni), full.reshape(3, nj, ni)[:, j0::st, :])
             parts.append(part)
         assert torch.equal(sharded.assemble_rows(parts, ni, nj, ws, "cyclic"), full)
-    bad = lib.rtgr_trace_rows_device_f64(C.byref(sc), C.byref(opt), C.byref(cam), ni, nj, 3, 8, 7, full.data_ptr(), None, None, None)
+    bad = lib.rtgr_trace_rows_device_f64(None, C.byref(sc), C.byref(opt), C.byref(cam), ni, nj, 3, 8, 7, full.data_ptr(), None, None, None)
     assert bad == abi.ERR_BAD_ARG   # 3 + 6*8 = 51 >= nj
 
 
@@ -557,11 +542,8 @@ def test_hand_back_rounds_do_not_change_results(lib):
     sc, cam = scene_variant("ks_true08")
     opt = rt.solver_defaults()
     a = hip_trace(lib, sc, opt, 96, 80, cam=cam)
-    os.environ["RTGR_ROUNDS"] = "2"
-    try:
+    with abi.options(lib, rounds=2):
         b = hip_trace(lib, sc, opt, 96, 80, cam=cam)
-    finally:
-        del os.environ["RTGR_ROUNDS"]
     for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
         assert np.array_equal(a[k], b[k]), k
 
@@ -588,7 +570,7 @@ def test_constants_of_motion_along_device_rays(lib, name, size):
     opt = rt.solver_defaults()
     n = size * size
     s0 = np.zeros((n, 8))
-    abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(sc), C.byref(cam), size, size, 0, size, s0.ctypes.data))
+    abi.check(lib, lib.rtgr_make_canvas_f64(None, C.byref(sc), C.byref(cam), size, size, 0, size, s0.ctypes.data))
     out = hip_trace(lib, sc, opt, size, size, cam=cam)
     se = out["state_end"]
     assert (out["status"] == abi.RAY_EVENT).all()

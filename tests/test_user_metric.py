@@ -64,16 +64,16 @@ def _points(n, seed, rmin=1.7):
 
 @pytest.mark.gpu
 def test_user_metric_needs_a_loaded_module(lib):
-    abi.check(lib, lib.rtgr_user_metric_unload())
+    abi.check(lib, lib.rtgr_user_metric_unload(None, 0))
     sc = abi.rtgr_scene()
     sc.metric, sc.M = abi.USER, 1.0
     x = np.array([[0.0, 3.0, 0.0, 0.0]])
     g = np.zeros((1, 4, 4))
-    rc = lib.rtgr_eval_metric_f64(C.byref(sc), x.ctypes.data, 1, g.ctypes.data, None, None)
+    rc = lib.rtgr_eval_metric_f64(None, C.byref(sc), x.ctypes.data, 1, g.ctypes.data, None, None)
     assert rc == abi.ERR_BAD_ARG and b"no user metric loaded" in lib.rtgr_last_error()
-    assert lib.rtgr_user_metric_load(b"/nonexistent.hsaco") == abi.ERR_HIP
-    assert lib.rtgr_user_metric_load(os.path.join(ROOT, "include", "rtgr.h").encode()) != 0  # not a code object
-    assert lib.rtgr_user_metric_loaded() == 0
+    assert lib.rtgr_user_metric_load(None, b"/nonexistent.hsaco", None) == abi.ERR_BAD_ARG
+    assert lib.rtgr_user_metric_load(None, os.path.join(ROOT, "include", "rtgr.h").encode(), None) != 0  # not a code object
+    assert lib.rtgr_user_metric_loaded(None, 0) == 0
 
 
 @pytest.mark.gpu
@@ -121,7 +121,7 @@ def test_user_isotropic_schwarzschild_matches_the_oracle(lib):
     scn, camera, opt = rt.make_scene(user, objs), rt.make_camera(**cam), rt.solver_defaults()
     from test_gpu_parity import compare, hip_trace
     c_gpu = np.zeros((40 * 40, 8))
-    abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(scn), C.byref(camera), 40, 40, 0, 40, c_gpu.ctypes.data))
+    abi.check(lib, lib.rtgr_make_canvas_f64(None, C.byref(scn), C.byref(camera), 40, 40, 0, 40, c_gpu.ctypes.data))
     c_ref = O.make_canvas(scn, camera, 40, 40)
     assert np.abs(c_gpu - c_ref.reshape(c_gpu.shape)).max() < 1e-14
     gpu = hip_trace(lib, scn, opt, 64, 64, cam=camera)
@@ -134,13 +134,32 @@ def test_user_isotropic_schwarzschild_matches_the_oracle(lib):
 
 
 @pytest.mark.gpu
-def test_switching_between_user_metrics_reloads_the_right_module(lib):
+def test_scenes_of_two_resident_user_metrics_run_their_own_kernels(lib):
+    """Several metric modules are resident at once and a scene names its own (rtgr_scene.user_metric): building the
+    scene of metric B must not change what the scene of metric A computes (round 1 had ONE resident module, activated
+    when a scene was built, so the older scene silently ran the newer metric's kernels)."""
     iso = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0)
     ks = rt.UserMetric(user_metrics.KERR_SCHILD, M=1.0, a=0.0)
     x = np.array([[0.0, 3.0, 1.0, -2.0]])
     g_iso, g_ks = iso(x), ks(x)
     assert g_iso.shape == (4, 4) and abs(g_iso[0, 1]) == 0.0 and abs(g_ks[0, 1]) > 1e-3  # diagonal vs Kerr–Schild
     assert np.array_equal(iso(x), g_iso) and np.array_equal(ks(x), g_ks)
+    _, objs, cam = rt.example2_scene()
+    opt, camera = rt.solver_defaults(), rt.make_camera(**cam)
+    from test_gpu_parity import hip_trace
+    sc_iso = rt.make_scene(iso, objs)
+    first = hip_trace(lib, sc_iso, opt, 24, 24, cam=camera)
+    sc_ks = rt.make_scene(ks, objs)                  # a second metric's scene is built (and its module loaded) ...
+    other = hip_trace(lib, sc_ks, opt, 24, 24, cam=camera)
+    again = hip_trace(lib, sc_iso, opt, 24, 24, cam=camera)   # ... and the first scene still traces ITS metric
+    assert sc_iso.user_metric != sc_ks.user_metric and sc_iso.user_metric != 0
+    assert np.array_equal(first["rgb"], again["rgb"]) and not np.array_equal(first["rgb"], other["rgb"])
+    assert lib.rtgr_user_metric_loaded(None, sc_iso.user_metric) == 1 and lib.rtgr_user_metric_loaded(None, sc_ks.user_metric) == 1
+    bad = rt.make_scene(ks, objs)
+    bad.user_metric = 12345                          # a module that is not loaded: refused, never substituted
+    rgb = np.zeros(3 * 4)
+    rc = lib.rtgr_trace_f64(None, C.byref(bad), C.byref(opt), None, C.byref(camera), 2, 2, 0, 2, rgb.ctypes.data, None, None)
+    assert rc == abi.ERR_BAD_ARG and b"not loaded" in lib.rtgr_last_error()
 
 
 @pytest.mark.gpu
@@ -154,7 +173,7 @@ def test_user_metric_conserves_energy_and_angular_momentum(lib):
     from test_gpu_parity import hip_trace
     size = 256
     s0 = np.zeros((size * size, 8))
-    abi.check(lib, lib.rtgr_make_canvas_f64(C.byref(scn), C.byref(camera), size, size, 0, size, s0.ctypes.data))
+    abi.check(lib, lib.rtgr_make_canvas_f64(None, C.byref(scn), C.byref(camera), size, size, 0, size, s0.ctypes.data))
     out = hip_trace(lib, scn, opt, size, size, cam=camera)
     se = out["state_end"]
 

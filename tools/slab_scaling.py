@@ -24,12 +24,12 @@ for N in (1, 2, 4, 8):
         ts.append(dt * 1e3)
     import ctypes
     lib = rt._abi.load()
-    lib.rtgr_timing_enable(1)
+    lib.rtgr_timing_enable(None, 0, 1)
     sharded.trace_rows_torch(sc, opt, camera, ni, nj, j0, st, nr, out=out)
     torch.cuda.synchronize()
     kms = (ctypes.c_double * 4)(); kln = (ctypes.c_uint64 * 4)()
-    lib.rtgr_timing_read(ctypes.byref(kms), ctypes.byref(kln))
-    lib.rtgr_timing_enable(0)
+    lib.rtgr_timing_read(None, 0, ctypes.byref(kms), ctypes.byref(kln))
+    lib.rtgr_timing_enable(None, 0, 0)
     print("      kernels ms: canvas+order %.2f  FAR %.2f  NEAR %.2f  resolve %.2f" % (kms[0], kms[1], kms[3], kms[2]))
     j1 = j0 + nr
     t = max(ts)
