@@ -1,9 +1,23 @@
 # RayTraceGRHIP.jl — the reference-side binding a RayTraceGR.jl maintainer would add to route the hot path
-# (`trace_rays`, src/RayTraceGR.jl:482-536) through librtgr_hip.so (include/rtgr.h).
+# (`trace_rays`, src/RayTraceGR.jl:482-536) through librtgr_hip.so (include/rtgr.h, ABI version 2).
 #
-# UNTESTED IN THIS REPOSITORY'S CI: the build image has no Julia.  It is a thin `ccall` layer; host code stays Julia,
-# the metric/object/Pixel signatures of the reference are preserved, and anything that cannot cross the C ABI (an
-# arbitrary metric callable) falls back to the reference's own CPU path.
+# NOT EXECUTED IN THIS REPOSITORY: the build image has no Julia.  What stands in for running it:
+#   * tests/c/abi_layout.c — a compiled C caller that passes the same bytes this file would (structs by pointer, an
+#     88-byte Pixel array) and whose _Static_asserts pin the table below; tests/test_abi.py runs it on the CPU (layout,
+#     symbols) and on the GPU (example2() == sphere2.png through rtgr_trace_pixels_f64 + rtgr_trace_one_f64);
+#   * raytracegr.jl_amd/api.py — the same calls through Python ctypes, which every GPU test uses.
+#
+# fieldoffset table (bytes; Julia lays isbits structs out by the C rules, so `fieldoffset(T, i)` must print exactly this —
+# a maintainer can check with `[(fieldname(T,i), fieldoffset(T,i)) for i in 1:fieldcount(T)]`):
+#
+#   RtgrObject       80   kind 0, reserved 4, p 8
+#   RtgrScene     1312   metric 0, nobj 4, M 8, a 16, user_metric 24, obj 32
+#   RtgrSolver      72   reltol 0, abstol 8, lambda0 16, lambda1 24, hit_threshold 32, miss_rgb 40, max_steps 64, interp_points 68
+#   RtgrCounters    64   rays 0, accepted 8, rejected 16, rhs_evals 24, events 32, events_interior 40, not_finished 48, reserved 56
+#   Pixel{Float64}  88   pos 0, normal 32, rgb 64          (the reference's own type, src/RayTraceGR.jl:446-450)
+#
+# It is a thin `ccall` layer; host code stays Julia, the metric/object/Pixel signatures of the reference are preserved,
+# and anything that cannot cross the C ABI (an arbitrary metric callable) falls back to the reference's own CPU path.
 module RayTraceGRHIP
 
 using RayTraceGR
@@ -11,6 +25,7 @@ using StaticArrays
 
 const librtgr = get(ENV, "RTGR_LIB", "librtgr_hip.so")
 const RTGR_MAX_OBJECTS = 16
+const Ctx = Ptr{Cvoid}          # rtgr_context*; C_NULL = the process's default context
 
 # ---- PODs of include/rtgr.h ------------------------------------------------------------------------------------------
 struct RtgrObject
@@ -23,6 +38,7 @@ struct RtgrScene
     nobj::UInt32
     M::Float64
     a::Float64
+    user_metric::UInt64
     obj::NTuple{RTGR_MAX_OBJECTS,RtgrObject}
 end
 struct RtgrSolver
@@ -47,11 +63,36 @@ pack(pl::RayTraceGR.Plane{Float64}) = RtgrObject(RTGR_PLANE, 0, (pl.time, 0, 0, 
 pack(s::RayTraceGR.Sphere{Float64}) = RtgrObject(RTGR_SPHERE, 0, (s.pos..., s.vel..., s.radius))
 const NOOBJ = RtgrObject(0, 0, ntuple(_ -> 0.0, 9))
 
+function check(rc)
+    rc < 0 && error("librtgr_hip: ", unsafe_string(ccall((:rtgr_last_error, librtgr), Cstring, ())))
+    rc
+end
+
+"""
+    Context(device_ids) / close(ctx)
+
+All devices one Julia process drives (`rtgr_create`).  `trace_rays(...; ctx)` on a context with several devices deals the
+image rows to all of them and collects the frame on the first (one `ccall`, one host thread — no Distributed.jl, which
+the reference tried and abandoned, README.md:129-135).  Without a context the library's default one is used.
+"""
+mutable struct Context
+    handle::Ctx
+    function Context(device_ids::Vector{<:Integer} = Int[])
+        h = Ref{Ctx}(C_NULL)
+        ids = Cint.(device_ids)
+        check(ccall((:rtgr_create, librtgr), Cint, (Ptr{Cint}, Cint, Ptr{Ctx}), isempty(ids) ? C_NULL : ids, length(ids), h))
+        finalizer(c -> ccall((:rtgr_destroy, librtgr), Cint, (Ctx,), c.handle), new(h[]))
+    end
+end
+handle(::Nothing) = C_NULL
+handle(c::Context) = c.handle
+
 """
     DeviceMetric(code_object; M = 1.0, a = 0.0)
 
 A metric function of the user's own, given as a gfx950 code object built from `rtgr_user_unit.hip.in`
 (INTEGRATION.md "A new metric") — the native stand-in for passing a new Julia function as `metric` (:302-309).
+Several may be resident at once; a scene names its own by id.
 """
 struct DeviceMetric
     code_object::String
@@ -59,37 +100,34 @@ struct DeviceMetric
     a::Float64
 end
 DeviceMetric(path; M = 1.0, a = 0.0) = DeviceMetric(path, M, a)
-const resident_metric = Ref("")
-function activate(m::DeviceMetric)
-    resident_metric[] == m.code_object && return
-    check(ccall((:rtgr_user_metric_load, librtgr), Cint, (Cstring,), m.code_object))
-    resident_metric[] = m.code_object
+function module_id(m::DeviceMetric, ctx)
+    id = Ref{UInt64}(0)
+    check(ccall((:rtgr_user_metric_load, librtgr), Cint, (Ctx, Cstring, Ptr{UInt64}), handle(ctx), m.code_object, id))
+    id[]
 end
 
-metric_enum(m::DeviceMetric) = (activate(m); RTGR_USER)
-metric_enum(m) = m === RayTraceGR.minkowski ? RTGR_MINKOWSKI :
-                 m === RayTraceGR.kerr_schild ? RTGR_KS_REF : nothing   # as written: M = 1, a = 0 (:275-276)
-metric_params(m::DeviceMetric) = (m.M, m.a)
-metric_params(m) = (1.0, 0.0)
+# (enum, M, a, user_metric id) of a metric argument, or nothing when it cannot cross the ABI
+metric_desc(m::DeviceMetric, ctx) = (RTGR_USER, m.M, m.a, module_id(m, ctx))
+metric_desc(m, ctx) = m === RayTraceGR.minkowski ? (RTGR_MINKOWSKI, 1.0, 0.0, UInt64(0)) :
+                      m === RayTraceGR.kerr_schild ? (RTGR_KS_REF, 1.0, 0.0, UInt64(0)) :   # as written: M = 1, a = 0 (:275-276)
+                      nothing
 
-function check(rc)
-    rc < 0 && error("librtgr_hip: ", unsafe_string(ccall((:rtgr_last_error, librtgr), Cstring, ())))
-    rc
+function scene_of(metric, objs, ctx)
+    d = metric_desc(metric, ctx)
+    (d === nothing || length(objs) > RTGR_MAX_OBJECTS) && return nothing
+    packed = ntuple(i -> i <= length(objs) ? pack(objs[i]) : NOOBJ, RTGR_MAX_OBJECTS)
+    Ref(RtgrScene(d[1], length(objs), d[2], d[3], d[4], packed))
 end
 
 """
-    trace_rays(metric, objs, c::Canvas{Float64}) -> Canvas{Float64}
+    trace_rays(metric, objs, c::Canvas{Float64}; ctx = nothing) -> Canvas{Float64}
 
 Drop-in for `RayTraceGR.trace_rays` (src/RayTraceGR.jl:483-484).  Passes `pointer(c.pixels)` — the reference's own
 88-byte `Pixel{Float64}` AoS (:446-450) — across the ABI; returns a new canvas with `rgb` filled (:532).
 """
-function trace_rays(metric, objs::Vector{RayTraceGR.Object{Float64}}, c::RayTraceGR.Canvas{Float64})
-    me = metric_enum(metric)
-    if me === nothing || length(objs) > RTGR_MAX_OBJECTS
-        return RayTraceGR.trace_rays(metric, objs, c)        # arbitrary metric callable: reference CPU path
-    end
-    packed = ntuple(i -> i <= length(objs) ? pack(objs[i]) : NOOBJ, RTGR_MAX_OBJECTS)
-    scene = Ref(RtgrScene(me, length(objs), metric_params(metric)..., packed))
+function trace_rays(metric, objs::Vector{RayTraceGR.Object{Float64}}, c::RayTraceGR.Canvas{Float64}; ctx = nothing)
+    scene = scene_of(metric, objs, ctx)
+    scene === nothing && return RayTraceGR.trace_rays(metric, objs, c)        # arbitrary metric callable: reference CPU path
     opt = Ref{RtgrSolver}()
     check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, 0))
     ni, nj = size(c.pixels)
@@ -97,30 +135,28 @@ function trace_rays(metric, objs::Vector{RayTraceGR.Object{Float64}}, c::RayTrac
     ctr = Ref{RtgrCounters}()
     GC.@preserve c out begin
         check(ccall((:rtgr_trace_pixels_f64, librtgr), Cint,
-                    (Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, UInt64, UInt64, Ptr{Cvoid}, Ptr{RtgrCounters}),
-                    scene, opt, pointer(c.pixels), ni, nj, pointer(out), ctr))
+                    (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, UInt64, UInt64, Ptr{Cvoid}, Ptr{RtgrCounters}),
+                    handle(ctx), scene, opt, pointer(c.pixels), ni, nj, pointer(out), ctr))
     end
     RayTraceGR.Canvas{Float64}(out)
 end
 
 """
-    trace_ray(metric, objs, cb, p::Pixel{Float64}) -> Pixel{Float64}
+    trace_ray(metric, objs, cb, p::Pixel{Float64}; ctx = nothing) -> Pixel{Float64}
 
 Legacy single-pixel shape (test/runtests.jl:76).  `cb` is ignored: the callback is always
 `ContinuousCallback(min_distance(objs, ·), terminate!)` (src/RayTraceGR.jl:488-490).
 """
-function trace_ray(metric, objs::Vector{RayTraceGR.Object{Float64}}, cb, p::RayTraceGR.Pixel{Float64})
-    me = metric_enum(metric)
-    me === nothing && error("only minkowski / kerr_schild cross the C ABI")
-    packed = ntuple(i -> i <= length(objs) ? pack(objs[i]) : NOOBJ, RTGR_MAX_OBJECTS)
-    scene = Ref(RtgrScene(me, length(objs), metric_params(metric)..., packed))
+function trace_ray(metric, objs::Vector{RayTraceGR.Object{Float64}}, cb, p::RayTraceGR.Pixel{Float64}; ctx = nothing)
+    scene = scene_of(metric, objs, ctx)
+    scene === nothing && error("only minkowski / kerr_schild / DeviceMetric cross the C ABI")
     opt = Ref{RtgrSolver}()
     check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, 0))
     pos, nrm = Ref(p.pos), Ref(p.normal)
     rgb = Ref(zeros(SVector{3,Float64})); se = Ref(zeros(SVector{8,Float64})); st = Ref{UInt8}(0)
     check(ccall((:rtgr_trace_one_f64, librtgr), Cint,
-                (Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
-                scene, opt, pos, nrm, rgb, se, st))
+                (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
+                handle(ctx), scene, opt, pos, nrm, rgb, se, st))
     RayTraceGR.Pixel{Float64}(p.pos, p.normal, rgb[])
 end
 

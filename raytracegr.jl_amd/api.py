@@ -37,8 +37,8 @@ class Metric:
         self.kind, self.M, self.a, self.__name__ = int(kind), float(M), float(a), name
         self.generic = bool(generic)  # True: trace with the generic dual-number RHS (RTGR_METRIC_GENERIC)
 
-    def __call__(self, x):
-        g, _, _ = _eval_metric(self, x, want=(True, False, False))
+    def __call__(self, x, dtype=np.float64):
+        g, _, _ = _eval_metric(self, x, want=(True, False, False), dtype=dtype)
         return g
 
     def __repr__(self):
@@ -245,39 +245,41 @@ def trace_ray(metric, objs, cb, p, opt=None):
 
 
 # ---- physics kernels for the reference's unit tests (test/runtests.jl:12-61), evaluated on the GPU ------------
-def _eval_metric(metric, x, want=(True, True, True)):
+def _eval_metric(metric, x, want=(True, True, True), dtype=np.float64):
     lib = _lib()
     sc = make_scene(metric, [])
-    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 4)
+    x = np.ascontiguousarray(x, dtype=dtype).reshape(-1, 4)
     n = x.shape[0]
-    g = np.empty((n, 4, 4)) if want[0] else None
-    dg = np.empty((n, 4, 4, 4)) if want[1] else None
-    G = np.empty((n, 4, 4, 4)) if want[2] else None
-    _abi.check(lib, lib.rtgr_eval_metric_f64(None, C.byref(sc), x.ctypes.data, n, g.ctypes.data if want[0] else None,
-                                             dg.ctypes.data if want[1] else None,
-                                             G.ctypes.data if want[2] else None))
+    g = np.empty((n, 4, 4), dtype) if want[0] else None
+    dg = np.empty((n, 4, 4, 4), dtype) if want[1] else None
+    G = np.empty((n, 4, 4, 4), dtype) if want[2] else None
+    fn = lib.rtgr_eval_metric_f64 if dtype == np.float64 else lib.rtgr_eval_metric_f32
+    _abi.check(lib, fn(None, C.byref(sc), x.ctypes.data, n, g.ctypes.data if want[0] else None,
+                       dg.ctypes.data if want[1] else None, G.ctypes.data if want[2] else None))
     sq = (lambda v: v[0] if (v is not None and n == 1) else v)
     return sq(g), sq(dg), sq(G)
 
 
-def dmetric(metric, x):
-    """dmetric(metric, x) -> (g[a,b], dg[a,b,c] = ∂_c g_ab)  (src/RayTraceGR.jl:302-313)"""
-    g, dg, _ = _eval_metric(metric, x, (True, True, False))
+def dmetric(metric, x, dtype=np.float64):
+    """dmetric(metric, x) -> (g[a,b], dg[a,b,c] = ∂_c g_ab)  (src/RayTraceGR.jl:302-313); dtype = the reference's T"""
+    g, dg, _ = _eval_metric(metric, x, (True, True, False), dtype)
     return g, dg
 
 
-def christoffel(metric, x):
+def christoffel(metric, x, dtype=np.float64):
     """christoffel(metric, x) -> Γ[a,b,c] = Γ^a_bc  (src/RayTraceGR.jl:321-331)"""
-    return _eval_metric(metric, x, (False, False, True))[2]
+    return _eval_metric(metric, x, (False, False, True), dtype)[2]
 
 
-def geodesic(s, metric, lam=0.0, path=0):
-    """geodesic(s::SVector{8}, metric, λ) -> ṡ  (src/RayTraceGR.jl:367-370); λ is ignored as in the reference."""
+def geodesic(s, metric, lam=0.0, path=0, dtype=np.float64):
+    """geodesic(s::SVector{8}, metric, λ) -> ṡ  (src/RayTraceGR.jl:367-370); λ is ignored as in the reference.
+    path: 0 closed contraction (IEEE division), 1 generic dual numbers, 2 the integrate loop's own RHS."""
     lib = _lib()
     sc = make_scene(metric, [])
-    s = np.ascontiguousarray(s, dtype=np.float64).reshape(-1, 8)
+    s = np.ascontiguousarray(s, dtype=dtype).reshape(-1, 8)
     ds = np.empty_like(s)
-    _abi.check(lib, lib.rtgr_eval_geodesic_f64(None, C.byref(sc), s.ctypes.data, s.shape[0], path, ds.ctypes.data))
+    fn = lib.rtgr_eval_geodesic_f64 if dtype == np.float64 else lib.rtgr_eval_geodesic_f32
+    _abi.check(lib, fn(None, C.byref(sc), s.ctypes.data, s.shape[0], path, ds.ctypes.data))
     return ds[0] if ds.shape[0] == 1 else ds
 
 

@@ -101,6 +101,10 @@ int ensure_workspace(DeviceCtx& d, StreamState& ss, size_t bytes, hipStream_t st
 static int stream_state(DeviceCtx& d, hipStream_t st, StreamState** out) {
     auto it = d.streams.find(st);
     if (it == d.streams.end()) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(RTGR_ERR_BAD_ARG, "first use of this stream while it is being captured: call "
+                                          "rtgr_reserve_workspace for this stream before hipStreamBeginCapture");
         StreamState ss;
         HIP_TRY(hipMalloc((void**)&ss.queue, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(ss.queue, 0, 8 * sizeof(unsigned long long)));

@@ -28,7 +28,7 @@ def _torch_dtype(dtype):
 
 
 def trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device="cuda", dtype=np.float64, details=False, counters=None,
-                     out=None, state0=None, ctx=None):
+                     out=None, state0=None, ctx=None, hit_only=False):
     """Trace rows [j0, j1) on `device` into torch tensors (device-resident in and out). Asynchronous: enqueues on
     torch's current stream.  Returns dict(rgb[3, n] (+ per-ray tensors when details))."""
     import torch
@@ -41,6 +41,10 @@ def trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device="cuda", dtype=np.fl
         if "rgb" not in res:
             res["rgb"] = torch.empty((3, n), dtype=td, device=dev)
         o = _abi.rtgr_ray_outputs()
+        if hit_only:  # big frames: the hit map is one byte per ray, the other per-ray outputs are 85
+            if "hit" not in res:
+                res["hit"] = torch.empty(n, dtype=torch.uint8, device=dev)
+            o.hit = res["hit"].data_ptr()
         if details:
             if "state_end" not in res:
                 res["state_end"] = torch.empty((n, 8), dtype=td, device=dev)

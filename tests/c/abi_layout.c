@@ -1,0 +1,125 @@
+/* abi_layout.c — a plain C caller of include/rtgr.h, compiled with gcc by tests/test_abi.py.
+ *
+ * What it pins: the byte layout a Julia `ccall` depends on.  julia/RayTraceGRHIP.jl passes isbits structs
+ * (RtgrScene with an NTuple{16,RtgrObject}, RtgrSolver, RtgrCounters) by Ref and `pointer(c.pixels)` of an
+ * Array{Pixel{Float64},2}; Julia lays isbits structs out by the C rules, so the numbers below ARE the `fieldoffset`
+ * table of the Julia stub (mirrored there as a comment block).  Every offset is a _Static_assert: a header edit that
+ * moves a field fails this file at compile time, on a box with no GPU.
+ *
+ *   abi_layout --symbols <lib>      dlopen the library and resolve every entry point the stub binds (no GPU needed)
+ *   abi_layout --render  <lib> out  example2() at 200x200 the way the reference does it — make_canvas, pack the rays into an
+ *                                   88-byte Pixel array exactly as src/RayTraceGR.jl:446-450 lays it out, rtgr_trace_pixels_f64
+ *                                   — and write the N0f8 image[j][i][c] bytes (compared with sphere2.png by the test);
+ *                                   also rtgr_trace_one_f64 on the centre pixel (legacy trace_ray shape, test/runtests.jl:76)
+ */
+#include <dlfcn.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/rtgr.h"
+
+/* ---- the table (bytes) -------------------------------------------------------------------------------------------- */
+_Static_assert(sizeof(rtgr_object) == 80, "rtgr_object");
+_Static_assert(offsetof(rtgr_object, kind) == 0 && offsetof(rtgr_object, reserved) == 4 && offsetof(rtgr_object, p) == 8, "rtgr_object fields");
+_Static_assert(sizeof(rtgr_scene) == 1312, "rtgr_scene");
+_Static_assert(offsetof(rtgr_scene, metric) == 0 && offsetof(rtgr_scene, nobj) == 4 && offsetof(rtgr_scene, M) == 8 &&
+               offsetof(rtgr_scene, a) == 16 && offsetof(rtgr_scene, user_metric) == 24 && offsetof(rtgr_scene, obj) == 32, "rtgr_scene fields");
+_Static_assert(sizeof(rtgr_solver) == 72, "rtgr_solver");
+_Static_assert(offsetof(rtgr_solver, reltol) == 0 && offsetof(rtgr_solver, abstol) == 8 && offsetof(rtgr_solver, lambda0) == 16 &&
+               offsetof(rtgr_solver, lambda1) == 24 && offsetof(rtgr_solver, hit_threshold) == 32 &&
+               offsetof(rtgr_solver, miss_rgb) == 40 && offsetof(rtgr_solver, max_steps) == 64 &&
+               offsetof(rtgr_solver, interp_points) == 68, "rtgr_solver fields");
+_Static_assert(sizeof(rtgr_camera) == 128, "rtgr_camera");
+_Static_assert(offsetof(rtgr_camera, pos) == 0 && offsetof(rtgr_camera, widthx) == 32 && offsetof(rtgr_camera, widthy) == 64 &&
+               offsetof(rtgr_camera, normal) == 96, "rtgr_camera fields");
+_Static_assert(sizeof(rtgr_counters) == 64, "rtgr_counters");
+_Static_assert(offsetof(rtgr_counters, rays) == 0 && offsetof(rtgr_counters, accepted) == 8 && offsetof(rtgr_counters, rejected) == 16 &&
+               offsetof(rtgr_counters, rhs_evals) == 24 && offsetof(rtgr_counters, events) == 32 &&
+               offsetof(rtgr_counters, events_interior) == 40 && offsetof(rtgr_counters, not_finished) == 48, "rtgr_counters fields");
+_Static_assert(sizeof(rtgr_ray_outputs) == 56, "rtgr_ray_outputs");
+_Static_assert(offsetof(rtgr_ray_outputs, state_end) == 0 && offsetof(rtgr_ray_outputs, lambda_end) == 8 &&
+               offsetof(rtgr_ray_outputs, status) == 16 && offsetof(rtgr_ray_outputs, hit) == 24 &&
+               offsetof(rtgr_ray_outputs, n_accept) == 32 && offsetof(rtgr_ray_outputs, n_reject) == 40 &&
+               offsetof(rtgr_ray_outputs, redshift) == 48, "rtgr_ray_outputs fields");
+
+/* Pixel{Float64} of the reference (src/RayTraceGR.jl:446-450): pos::SVector{4}, normal::SVector{4}, rgb::SVector{3} */
+typedef struct { double pos[4], normal[4], rgb[3]; } pixel_f64;
+_Static_assert(sizeof(pixel_f64) == 88 && offsetof(pixel_f64, normal) == 32 && offsetof(pixel_f64, rgb) == 64, "Pixel{Float64}");
+
+static const char* const BOUND[] = {"rtgr_create", "rtgr_destroy", "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version",
+                                    "rtgr_solver_defaults", "rtgr_trace_pixels_f64", "rtgr_trace_one_f64", "rtgr_trace_f64",
+                                    "rtgr_trace_sharded_f64", "rtgr_make_canvas_f64", "rtgr_user_metric_load",
+                                    "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", NULL};
+
+typedef int (*fn_defaults)(rtgr_solver*, int);
+typedef int (*fn_canvas)(rtgr_context*, const rtgr_scene*, const rtgr_camera*, uint64_t, uint64_t, uint64_t, uint64_t, double*);
+typedef int (*fn_pixels)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const double*, uint64_t, uint64_t, double*, rtgr_counters*);
+typedef int (*fn_one)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const double*, const double*, double*, double*, uint8_t*);
+typedef const char* (*fn_err)(void);
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render <lib> [out]\n"); return 2; }
+    void* h = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
+    for (int i = 0; BOUND[i]; i++)
+        if (!dlsym(h, BOUND[i])) { fprintf(stderr, "missing symbol %s\n", BOUND[i]); return 4; }
+    if (strcmp(argv[1], "--symbols") == 0) {
+        printf("scene %zu solver %zu camera %zu counters %zu outputs %zu object %zu pixel %zu\n", sizeof(rtgr_scene),
+               sizeof(rtgr_solver), sizeof(rtgr_camera), sizeof(rtgr_counters), sizeof(rtgr_ray_outputs), sizeof(rtgr_object), sizeof(pixel_f64));
+        return 0;
+    }
+    if (argc < 4) return 2;
+    fn_defaults defaults = (fn_defaults)dlsym(h, "rtgr_solver_defaults");
+    fn_canvas canvas = (fn_canvas)dlsym(h, "rtgr_make_canvas_f64");
+    fn_pixels pixels = (fn_pixels)dlsym(h, "rtgr_trace_pixels_f64");
+    fn_one one = (fn_one)dlsym(h, "rtgr_trace_one_f64");
+    fn_err err = (fn_err)dlsym(h, "rtgr_last_error");
+    /* example2(): src/RayTraceGR.jl:581-593 */
+    rtgr_scene sc;
+    memset(&sc, 0, sizeof sc);
+    sc.metric = RTGR_KS_REF; sc.M = 1.0; sc.a = 0.0; sc.nobj = 3;
+    sc.obj[0].kind = RTGR_SPHERE; sc.obj[0].p[4] = 1.0; sc.obj[0].p[8] = -10.0;               /* caelum */
+    sc.obj[1].kind = RTGR_PLANE; sc.obj[1].p[0] = -20.0;                                       /* frustum */
+    sc.obj[2].kind = RTGR_SPHERE; sc.obj[2].p[1] = 4.0; sc.obj[2].p[4] = 1.0; sc.obj[2].p[8] = 0.5;  /* sphere */
+    rtgr_camera cam;
+    memset(&cam, 0, sizeof cam);
+    cam.pos[1] = 4.0; cam.pos[2] = -2.0; cam.widthx[1] = 1.0; cam.widthy[3] = 1.0; cam.normal[2] = 1.0;
+    rtgr_solver opt;
+    if (defaults(&opt, 0)) return 5;
+    const uint64_t ni = 200, nj = 200, n = ni * nj;
+    double* st = (double*)malloc(n * 8 * sizeof(double));
+    pixel_f64* px = (pixel_f64*)calloc(n, sizeof(pixel_f64));
+    pixel_f64* out = (pixel_f64*)calloc(n, sizeof(pixel_f64));
+    if (canvas(NULL, &sc, &cam, ni, nj, 0, nj, st)) { fprintf(stderr, "make_canvas: %s\n", err()); return 6; }
+    for (uint64_t k = 0; k < n; k++) {   /* Pixel(pos, normal, zeros)  (:475) at pixels[i,j], linear index i + j*ni */
+        memcpy(px[k].pos, st + 8 * k, 32);
+        memcpy(px[k].normal, st + 8 * k + 4, 32);
+    }
+    rtgr_counters ctr;
+    if (pixels(NULL, &sc, &opt, (const double*)px, ni, nj, (double*)out, &ctr)) { fprintf(stderr, "trace_pixels: %s\n", err()); return 7; }
+    if (ctr.rays != n || ctr.events != n) { fprintf(stderr, "counters: %llu rays %llu events\n", (unsigned long long)ctr.rays, (unsigned long long)ctr.events); return 8; }
+    FILE* f = fopen(argv[3], "wb");
+    if (!f) return 9;
+    for (uint64_t k = 0; k < n; k++) {   /* image[j][i][c]: k = i + j*ni is already row j, column i */
+        if (memcmp(out[k].pos, px[k].pos, 64) != 0) { fprintf(stderr, "pos/normal not preserved at %llu\n", (unsigned long long)k); return 10; }
+        for (int c = 0; c < 3; c++) {
+            double v = out[k].rgb[c];
+            v = v < 0 ? 0 : (v > 1 ? 1 : v);
+            fputc((int)nearbyint(v * 255.0), f);
+        }
+    }
+    fclose(f);
+    /* legacy trace_ray(metric, objs, cb, p)::Pixel on the centre pixel (i,j) = (100,100), 1-based */
+    const uint64_t kc = 99 + 99 * ni;
+    double rgb1[3], se[8];
+    uint8_t status = 255;
+    if (one(NULL, &sc, &opt, px[kc].pos, px[kc].normal, rgb1, se, &status)) { fprintf(stderr, "trace_one: %s\n", err()); return 11; }
+    for (int c = 0; c < 3; c++)
+        if (rgb1[c] != out[kc].rgb[c]) { fprintf(stderr, "trace_one differs from trace_pixels\n"); return 12; }
+    if (status != RTGR_RAY_EVENT) return 13;
+    printf("ok %llu rays\n", (unsigned long long)ctr.rays);
+    return 0;
+}

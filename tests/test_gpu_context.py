@@ -1,0 +1,281 @@
+"""Contexts, streams, threads, devices (SURVEY §8b "Ownership / Threading", §8e): the library's state lives in an
+opaque rtgr_context; calls on different streams / from different host threads / on different (logical) devices must give
+the SAME BITS as serial execution, and one host thread must be able to drive every device of a context with one call.
+`pytest -m gpu` (one GPU: a context may list the same physical device several times)."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT
+from scenes import example, rt, scene_variant
+
+pytestmark = pytest.mark.gpu
+abi = rt._abi
+OUT_KEYS = ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(-1))
+    return lib
+
+
+def _trace(sc, opt, cam, ni, nj, ctx=None, stream=None):
+    import torch
+    from raytracegr_jl_amd import sharded
+    ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+    if stream is None:
+        out = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, details=True, counters=ctr, ctx=ctx)
+    else:
+        with torch.cuda.stream(stream):
+            out = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, details=True, counters=ctr, ctx=ctx)
+    out["ctr"] = ctr
+    return out
+
+
+def _same(a, b):
+    import torch
+    for k in a:
+        x, y = a[k], b[k]
+        if x.is_floating_point():
+            assert bool(((x == y) | (x.isnan() & y.isnan())).all()), k
+        else:
+            assert torch.equal(x, y), k
+
+
+def test_explicit_context_equals_default_context(lib):
+    import torch
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+    ref = _trace(sc, opt, cam, 96, 64)
+    torch.cuda.synchronize()
+    ctx = abi.create_context(lib, [torch.cuda.current_device()])
+    try:
+        assert lib.rtgr_context_devices(ctx) == 1
+        got = _trace(sc, opt, cam, 96, 64, ctx=ctx)
+        torch.cuda.synchronize()
+        _same(ref, got)
+        # options are per context
+        abi.check(lib, lib.rtgr_set_option(ctx, b"split", 0))
+        v = C.c_long(7)
+        abi.check(lib, lib.rtgr_get_option(None, b"split", C.byref(v)))
+        assert v.value == -1
+        assert lib.rtgr_set_option(ctx, b"no_such_option", 1) == abi.ERR_BAD_ARG
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+def test_two_streams_in_flight_are_bit_identical_to_serial(lib):
+    """Round 1 had ONE process-global workspace: two traces on different streams raced on the same records.  Now every
+    (device, stream) owns its workspace and queue heads."""
+    import torch
+    jobs = [(scene_variant("ks_ref0"), 320, 256), (scene_variant("ks_true0998_disk"), 256, 320)]
+    opt = rt.solver_defaults()
+    serial = []
+    for (sc, cam), ni, nj in jobs:
+        serial.append(_trace(sc, opt, cam, ni, nj))
+        torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        outs = []
+        for ((sc, cam), ni, nj), st in zip(jobs, (s1, s2)):   # both enqueued before either is waited for
+            outs.append(_trace(sc, opt, cam, ni, nj, stream=st))
+        torch.cuda.synchronize()
+        for a, b in zip(serial, outs):
+            _same(a, b)
+
+
+def test_two_host_threads_on_one_context(lib):
+    """Re-entrancy: two host threads, each with a stream of its own, drive the same context at the same time."""
+    import torch
+    jobs = [(scene_variant("ks_ref0"), 200, 160), (scene_variant("ks_true08"), 160, 200)]
+    opt = rt.solver_defaults()
+    serial = []
+    for (sc, cam), ni, nj in jobs:
+        serial.append(_trace(sc, opt, cam, ni, nj))
+        torch.cuda.synchronize()
+    dev = torch.cuda.current_device()
+    results, errors = [None, None], []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream()
+            (sc, cam), ni, nj = jobs[k]
+            for _ in range(4):
+                results[k] = _trace(sc, opt, cam, ni, nj, stream=st)
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for a, b in zip(serial, results):
+        _same(a, b)
+
+
+def test_host_entry_points_from_two_threads(lib):
+    """The blocking host-pointer entry points (what a Julia ccall binds) from two threads at once: they share the
+    context's staging buffers and must serialise on them, not corrupt them."""
+    from test_gpu_parity import hip_trace
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+    ref = hip_trace(lib, sc, opt, 80, 60, cam=cam)
+    got, errors = [None, None], []
+
+    def worker(k):
+        try:
+            for _ in range(3):
+                got[k] = hip_trace(lib, sc, opt, 80, 60, cam=cam)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for g in got:
+        for k in OUT_KEYS:
+            assert np.array_equal(ref[k], g[k]), k
+        assert ref["counters"] == g["counters"]
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_single_process_multi_device_trace(lib, ndev):
+    """rtgr_trace_sharded_f64: ONE call from ONE host thread deals the rows cyclically to every device of the context,
+    and RGB + status + hit + step counts + end states + lambda_end + counters come back assembled on device 0.  On a
+    one-GPU box the context lists the same physical device `ndev` times (logical devices with streams, workspaces and
+    peer copies of their own); the frame must equal the single-device frame bit for bit."""
+    import torch
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_true0998_disk")
+    opt = rt.solver_defaults()
+    ni, nj = 96, 77   # 77 rows: unequal shares
+    ref = hip_trace(lib, sc, opt, ni, nj, cam=cam)
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * ndev)
+    try:
+        assert lib.rtgr_context_devices(ctx) == ndev
+        n = ni * nj
+        rgb = np.zeros((3, n))
+        o, arrs = O._outs(n, np.float64, True)
+        ctr = abi.rtgr_counters()
+        for rep in range(2):
+            abi.check(lib, lib.rtgr_trace_sharded_f64(ctx, C.byref(sc), C.byref(opt), C.byref(cam), ni, nj,
+                                                      rgb.ctypes.data, C.byref(o), C.byref(ctr)))
+            assert np.array_equal(rgb, ref["rgb"])
+            for k in OUT_KEYS[1:]:
+                assert np.array_equal(arrs[k], ref[k]), k
+            assert ctr.as_dict() == ref["counters"]
+        # device variant: the frame stays in device-0 memory
+        d_rgb = torch.zeros((3, n), dtype=torch.float64, device="cuda")
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device="cuda")
+        od = abi.rtgr_ray_outputs()
+        od.status = d_st.data_ptr()
+        abi.check(lib, lib.rtgr_trace_sharded_device_f64(ctx, C.byref(sc), C.byref(opt), C.byref(cam), ni, nj,
+                                                         d_rgb.data_ptr(), C.byref(od), None))
+        assert np.array_equal(d_rgb.cpu().numpy(), ref["rgb"]) and np.array_equal(d_st.cpu().numpy(), ref["status"])
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+def test_more_devices_than_rows(lib):
+    import torch
+    from test_gpu_parity import hip_trace
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+    ref = hip_trace(lib, sc, opt, 9, 2, cam=cam)
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 4)
+    try:
+        rgb = np.zeros((3, 18))
+        abi.check(lib, lib.rtgr_trace_sharded_f64(ctx, C.byref(sc), C.byref(opt), C.byref(cam), 9, 2, rgb.ctypes.data, None, None))
+        assert np.array_equal(rgb, ref["rgb"])
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+def test_pixels_entry_point_is_pipelined_in_pieces(lib):
+    """rtgr_trace_pixels_f64 — the entry point INTEGRATION.md tells Julia to ccall — cuts the job into transfer pieces
+    and compute chunks (H2D || integrate || D2H on three streams).  With tiny pieces (many chunks, ragged last one) the
+    returned Array{Pixel} must equal the one-chunk result bit for bit, inputs preserved, in place or not."""
+    metric, objs, cam = rt.example2_scene()
+    canvas = rt.make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], 60, 45)
+    one = rt.trace_rays(metric, objs, canvas)
+    with abi.options(lib, host_chunk=256):     # 1024-ray compute chunks = 17 rows of 60; 45 rows -> 3 chunks, pieces of 256
+        many = rt.trace_rays(metric, objs, canvas)
+        # in place: pixels_out aliases pixels_in
+        sc, opt = rt.make_scene(metric, objs), rt.solver_defaults()
+        px = np.asfortranarray(canvas.pixels.copy())
+        abi.check(lib, lib.rtgr_trace_pixels_f64(None, C.byref(sc), C.byref(opt), px.ctypes.data, 60, 45, px.ctypes.data, None))
+    for f in ("pos", "normal", "rgb"):
+        assert np.array_equal(one.pixels[f], many.pixels[f]), f
+        assert np.array_equal(one.pixels[f], px[f]), f
+    assert np.array_equal(one.pixels["pos"], canvas.pixels["pos"])
+    bad = np.asfortranarray(canvas.pixels.copy())
+    bad["normal"][7, 3, 2] = np.nan
+    out = np.empty_like(bad)
+    sc, opt = rt.make_scene(metric, objs), rt.solver_defaults()
+    rc = lib.rtgr_trace_pixels_f64(None, C.byref(sc), C.byref(opt), bad.ctypes.data, 60, 45, out.ctypes.data, None)
+    assert rc == abi.ERR_NAN_INPUT   # `@assert !any(isnan, …)` (src/RayTraceGR.jl:279), evaluated on the device
+
+
+def _hip_runtime():
+    """the HIP runtime already loaded in this process (torch's bundled libamdhip64)"""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    return C.CDLL(cand if os.path.exists(cand) else "libamdhip64.so")
+
+
+def test_workspace_growth_and_stream_capture(lib):
+    """(1) A workspace that must grow while its stream is being captured is an ERROR (hipMalloc cannot be captured), not
+    a crash.  (2) A graph captured after rtgr_reserve_workspace keeps replaying correctly after the SAME stream's
+    workspace has grown for a bigger job: the superseded buffer is retired, never freed under the graph."""
+    import torch
+    from raytracegr_jl_amd import sharded
+    hip = _hip_runtime()
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+    # (1)
+    fresh = torch.cuda.Stream()
+    rgb = torch.zeros((3, 64 * 64), dtype=torch.float64, device="cuda")
+    graph = C.c_void_p(None)
+    assert hip.hipStreamBeginCapture(C.c_void_p(fresh.cuda_stream), 2) == 0   # hipStreamCaptureModeRelaxed
+    rc = lib.rtgr_trace_device_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), 64, 64, 0, 64, rgb.data_ptr(),
+                                   None, None, fresh.cuda_stream)
+    msg = lib.rtgr_last_error()
+    assert hip.hipStreamEndCapture(C.c_void_p(fresh.cuda_stream), C.byref(graph)) == 0
+    if graph.value:
+        hip.hipGraphDestroy(graph)
+    assert rc == abi.ERR_BAD_ARG and b"rtgr_reserve_workspace" in msg
+    # (2)
+    ni = nj = 128
+    side = torch.cuda.Stream()
+    out = {"rgb": torch.zeros((3, ni * nj), dtype=torch.float64, device="cuda")}
+    abi.check(lib, lib.rtgr_reserve_workspace(None, out["rgb"].data_ptr(), side.cuda_stream, ni * nj, 0, 0))
+    eager = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj)["rgb"].clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, out=out)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["rgb"], eager)
+    with torch.cuda.stream(side):   # the same stream's workspace grows ...
+        big = sharded.trace_slab_torch(sc, opt, cam, 512, 512, 0, 512)["rgb"]
+    torch.cuda.synchronize()
+    out["rgb"].zero_()
+    g.replay()                      # ... and the graph, which references the retired buffer, still works
+    torch.cuda.synchronize()
+    assert torch.equal(out["rgb"], eager) and bool(torch.isfinite(big).all())
+    abi.check(lib, lib.rtgr_trim(None))   # frees retired buffers (graph `g` must not be replayed afterwards)
