@@ -28,12 +28,9 @@ def lib():
 def _trace(sc, opt, cam, ni, nj, ctx=None, stream=None):
     import torch
     from raytracegr_jl_amd import sharded
-    ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
-    if stream is None:
+    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+        ctr = torch.zeros(8, dtype=torch.int64, device="cuda")   # (zero-filled ON the stream the trace will add on)
         out = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, details=True, counters=ctr, ctx=ctx)
-    else:
-        with torch.cuda.stream(stream):
-            out = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, details=True, counters=ctr, ctx=ctx)
     out["ctr"] = ctr
     return out
 
