@@ -7,13 +7,25 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" of this bench is one full pass of the hot path over the whole screen (every ray integrated to its event and
-coloured, slabs gathered on rank 0).  `value` = Tsit5 step attempts (accepted + rejected, each = 6 RHS evaluations,
-SURVEY §8d) of the whole job per second; rays/s is reported beside it.  Inputs are generated on the device
-(make_canvas fused into the kernel), so nothing crosses PCIe inside the timed region.
+coloured, rows — RGB and status bytes — gathered on rank 0).  `value` = Tsit5 step attempts (accepted + rejected, each =
+6 RHS evaluations) of the whole job per second; rays/s is reported beside it.  Inputs are generated on the
+device (make_canvas fused into the set-up kernel), so nothing crosses PCIe inside the timed region (`--entry device`).
+
+`roofline` (dominant kernels: the integrate kernel's FAR + NEAR passes) is an EXECUTED-flop figure:
+    achieved = executed f64 flop per step attempt (hardware-counted: 64 x (2 FMA + MUL + ADD) wave-instructions, from the
+               rocprofv3 --pmc pass recorded in profiles/rNN/flops.json) x the step attempts THIS run counted
+               / the integrate kernels' time THIS run measured with HIP events on the launch stream
+    frac     = achieved / 78.6 TF/s  (fp64 vector peak)  — always <= 1
+and it is emitted only when flops.json was collected from the SAME kernel sources (sha256 of the device headers + flags,
+raytracegr.jl_amd/build.py:kernel_source_hash); otherwise achieved / frac / traffic are null and `stale_profile` says why.
+The reference-formulation figure of SURVEY §8d (5404 flop per attempt, what Julia's dual-number chain would execute for
+the same steps) is reported separately as `reference_equivalent_tflops` and may exceed the hardware peak: the closed
+Kerr–Schild contraction does not execute that work.
 
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -25,9 +37,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_RHS = 814           # algorithmic flop per RHS, lean generic-metric form
-F_STEP = 6 * F_RHS + 520   # = 5404 flop per Tsit5 step attempt
+F_STEP = 6 * F_RHS + 520   # = 5404 flop per Tsit5 step attempt: the REFERENCE FORMULATION's work
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (½ of the
 #                                157.3 TF fp32 vector figure in MI355X_MICROARCH.md)
+# Float32 kernels issue SCALAR v_fma_f32 (one ray per lane), which issues at the f64 rate on gfx950 (measured 0.9 of a
+# v_fma_f64 slot, tools/micro/valu_rates.hip); the 157.3 TF/s fp32 vector peak needs v_pk_fma_f32 = two rays per lane.
+F32_SCALAR_VALU_PEAK_TFLOPS = 78.6
 
 
 def parse():
@@ -43,8 +58,16 @@ def parse():
                     help="CPU baseline renders a sample x sample screen; -1 = auto (~15 s of CPU work), 0 = off")
     ap.add_argument("--rhs", default="closed", choices=["closed", "generic", "user"],
                     help="closed = Kerr-Schild-form contraction (production); generic = reference-style dual-number RHS "
-                         "(RTGR_METRIC_GENERIC): its executed flops equal the algorithmic count of the roofline model; "
+                         "(RTGR_METRIC_GENERIC): its executed flops are the reference formulation's; "
                          "user = the same metric typed as run-time compiled source (api.UserMetric; ks_true* variants)")
+    ap.add_argument("--entry", default="device", choices=["device", "host", "pixels"],
+                    help="which C-ABI entry point the timed passes go through: device = rtgr_trace_rows_device (inputs and "
+                         "outputs resident in HBM: the headline), host = rtgr_trace (camera on the device, RGB planes to "
+                         "host memory), pixels = rtgr_trace_pixels_f64 (the reference's Array{Pixel} in and out over "
+                         "PCIe — what a Julia ccall binds).  N = 1 only for host / pixels")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="1: after the timed region (rank 0, N = 1, default workload) also time the host and pixels entry "
+                         "points and the Kerr a = 0.8 variant, reported in entry_points / variants; 0: skip")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--layout", default="cyclic", choices=["cyclic", "slab"], help="row distribution over ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -98,13 +121,44 @@ def cpu_baseline(rt, scene, cam, opt, sample):
             "rays_per_s": c["rays"] / dt, "seconds": dt}
 
 
+def kernel_source_hash():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rtgr_build", os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.kernel_source_hash()
+
+
+def load_profile(a):
+    """The PMC-derived entry (executed flop per step attempt, HBM bytes per ray, instruction mix) of THIS configuration
+    from the newest profiles/rNN/flops.json whose recorded kernel-source hash equals the current sources' — or (None, why).
+    PMC counters cannot be collected from inside the bench; a profile of other sources must not be presented as this run's."""
+    cur = kernel_source_hash()
+    key = f"{a.variant}/{a.dtype}/{a.rhs}"
+    seen = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "flops.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        seen.append((os.path.relpath(f, ROOT), t.get("kernel_source_hash")))
+        if t.get("kernel_source_hash") == cur and key in t.get("entries", {}):
+            e = dict(t["entries"][key])
+            e["source"] = os.path.relpath(f, ROOT)
+            e["kernel_source_hash"] = cur
+            return e, None
+    return None, f"no profiles/r*/flops.json entry {key!r} collected from kernel sources {cur} (found: {seen})"
+
+
 def main():
     a = parse()
+    import ctypes
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
     rt = load_package()
     from raytracegr_jl_amd import sharded
+    abi = rt._abi
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -123,8 +177,9 @@ def main():
         else:
             dist.init_process_group("gloo")
     assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
-    lib = rt._abi.load()
-    rt._abi.check(lib, lib.rtgr_init(local))
+    assert a.entry == "device" or ws == 1, "--entry host/pixels: N = 1 only"
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(local))
 
     npdt = np.float64 if a.dtype == "f64" else np.float32
     scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user"}[a.rhs])
@@ -134,98 +189,126 @@ def main():
     j0, jstride, nrows = sharded.row_assignment(nj, ws, rank, a.layout)
     ctr = torch.zeros(8, dtype=torch.int64, device=dev)
     out = {}
+    host = {}
 
-    def one_pass(timed_events=None):
-        if timed_events is not None:
-            timed_events[0].record()
+    def device_pass():
         sharded.trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device=dev, dtype=npdt, counters=ctr,
-                                 out=out)
-        if timed_events is not None:
-            timed_events[1].record()
+                                 out=out, status=(ws > 1))
         if ws > 1 and not a.no_gather:
-            gather(out["rgb"])
+            gather(out["rgb"], out["status"])
+
+    def host_pass():   # rtgr_trace_f64/_f32: camera on the device, RGB planes to (pageable) host memory
+        if "rgb" not in host:
+            host["rgb"] = np.empty((3, ni * nj), npdt)
+        c = abi.rtgr_counters()
+        fn = lib.rtgr_trace_f64 if a.dtype == "f64" else lib.rtgr_trace_f32
+        abi.check(lib, fn(None, ctypes.byref(scene), ctypes.byref(opt), None, ctypes.byref(cam), ni, nj, 0, nj,
+                          host["rgb"].ctypes.data, None, ctypes.byref(c)))
+        return c
+
+    def pixels_pass():  # rtgr_trace_pixels_f64: the reference's Array{Pixel{Float64},2} in, a new one out
+        if "px" not in host:
+            st = np.empty((ni * nj, 8))
+            abi.check(lib, lib.rtgr_make_canvas_f64(None, ctypes.byref(scene), ctypes.byref(cam), ni, nj, 0, nj, st.ctypes.data))
+            px = np.zeros(ni * nj, dtype=rt.pixel_dtype())
+            px["pos"], px["normal"] = st[:, :4], st[:, 4:]
+            host["px"], host["px_out"] = px, np.empty_like(px)
+        c = abi.rtgr_counters()
+        abi.check(lib, lib.rtgr_trace_pixels_f64(None, ctypes.byref(scene), ctypes.byref(opt), host["px"].ctypes.data, ni, nj,
+                                                 host["px_out"].ctypes.data, ctypes.byref(c)))
+        return c
 
     nmax = ni * max(sharded.row_assignment(nj, ws, r, a.layout)[2] for r in range(ws))
-    parts = None
-    image = None
+    parts = {}
+    image = {}
 
-    def gather(slab):
-        nonlocal parts
-        send = slab if slab.shape[1] == nmax else torch.cat([slab, slab.new_zeros((3, nmax - slab.shape[1]))], 1)
-        send = send.contiguous().to(cdev)
+    def gather(slab, status):
+        """ONE exchange per pass: every rank's rows — RGB planes and status bytes — to rank 0 ("status bytes and
+        counters ride the same gather"; the counters are summed after the timed region)."""
+        for name, t, shape in (("rgb", slab, (3, nmax)), ("status", status, (nmax,))):
+            send = t if t.shape[-1] == nmax else torch.cat([t, t.new_zeros(shape[:-1] + (nmax - t.shape[-1],))], -1)
+            send = send.contiguous().to(cdev)
+            if rank == 0:
+                if name not in parts:
+                    parts[name] = [torch.empty(shape, dtype=t.dtype, device=cdev) for _ in range(ws)]
+                dist.gather(send, parts[name], dst=0)
+            else:
+                dist.gather(send, None, dst=0)
         if rank == 0:
-            if parts is None:
-                parts = [torch.empty((3, nmax), dtype=slab.dtype, device=cdev) for _ in range(ws)]
-            dist.gather(send, parts, dst=0)
-            nonlocal image
-            image = sharded.assemble_rows(parts, ni, nj, ws, a.layout)  # the gathered frame, rows back in place
-        else:
-            dist.gather(send, None, dst=0)
+            image["rgb"] = sharded.assemble_rows(parts["rgb"], ni, nj, ws, a.layout)  # the gathered frame, rows back in place
+            image["status"] = sharded.assemble_rows([p[None] for p in parts["status"]], ni, nj, ws, a.layout)[0]
 
+    one_pass = {"device": device_pass, "host": host_pass, "pixels": pixels_pass}[a.entry]
     for _ in range(a.warmup):
         one_pass()
     torch.cuda.synchronize()
     ctr.zero_()
-    rt._abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
     if ws > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    hc = []
     for k in range(a.steps):
-        one_pass(evs[k])
+        hc.append(one_pass())
     torch.cuda.synchronize()
     if ws > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]  # whole pipeline (3 kernels) per pass, torch events
+    if a.entry != "device":   # the host entry points return their counters by value
+        for c in hc:
+            ctr += torch.tensor([c.rays, c.accepted, c.rejected, c.rhs_evals, c.events, c.events_interior,
+                                 c.not_finished, 0], dtype=torch.int64, device=dev)
 
     tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
     totals = ctr.clone().to(cdev)
-    kmax = torch.tensor([max(kern_ms)], dtype=torch.float64, device=cdev)
     if ws > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     dt = float(tt[0])
     rays, acc, rej, nrhs = (int(totals[i]) for i in range(4))
     attempts = acc + rej
 
     # per-kernel HIP-event timing recorded by the library on the launch stream (rtgr_timing_*)
-    import ctypes
     kms = (ctypes.c_double * 4)()
     kln = (ctypes.c_uint64 * 4)()
-    rt._abi.check(lib, lib.rtgr_timing_read(None, 0, ctypes.byref(kms), ctypes.byref(kln)))
+    abi.check(lib, lib.rtgr_timing_read(None, 0, ctypes.byref(kms), ctypes.byref(kln)))
+    abi.check(lib, lib.rtgr_timing_enable(None, 0, 0))
     if rank == 0:
-        # roofline of the dominant kernel — integrate_kernel's main (FAR) pass, ~93 % of device time — over this rank's
-        # launches: algorithmic flop per launch / average launch duration (HIP events around the kernel itself).
-        # The few steps per ray that the NEAR pass redoes/finishes are attributed to the NEAR pass's own time below;
-        # charging ALL step attempts to the FAR kernel's time alone would overstate it, so the denominator is
-        # FAR + NEAR (the two launches of the same kernel template that together perform the counted attempts).
+        # roofline of the dominant kernels — integrate_kernel's FAR pass (~93 % of device time) and NEAR pass, the two
+        # launches of the same template that together perform the counted step attempts — over this rank's launches
         my = ctr.cpu().numpy()
-        n_launch = max(int(kln[1]), 1)
-        my_attempts, my_rays = int(my[1] + my[2]) / n_launch, int(my[0]) / n_launch
-        k_avg_s = (float(kms[1]) + float(kms[3])) / n_launch * 1e-3
-        flop_launch = my_attempts * F_STEP + 2 * my_rays * F_RHS
-        achieved = flop_launch / k_avg_s / 1e12
-        # fp32 runs (--dtype f32) are priced against the packed-f32 vector peak (v_pk_fma_f32: two FMAs per lane)
-        peak = FP64_VALU_PEAK_TFLOPS if a.dtype == "f64" else 2 * FP64_VALU_PEAK_TFLOPS
-        roof = {"bound": "valu_f64" if a.dtype == "f64" else "valu_f32", "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                "kernel": "rtgr::integrate_kernel (FAR pass + NEAR pass)", "kernel_ms_avg": k_avg_s * 1e3,
-                "launches": n_launch, "far_pass_ms_avg": float(kms[1]) / n_launch,
-                "near_pass_ms_avg": float(kms[3]) / max(int(kln[3]), 1),
-                "algorithmic_flop_per_launch": flop_launch,
-                "flop_model": f"{F_STEP} flop/step attempt + 2x{F_RHS} per ray (SURVEY 8d: reference-formulation "
-                              f"work; the kernel's closed Kerr-Schild contraction executes fewer — see DESIGN.md "
-                              f"and profiles/ for the hardware-counted f64 flops and VALU utilisation)",
-                "other_kernels_ms_avg": {"canvas": float(kms[0]) / max(int(kln[0]), 1),
-                                         "resolve": float(kms[2]) / max(int(kln[2]), 1)},
-                "hbm_algorithmic_GBps": (my_rays * (132 + 2 * 140 + 204 + 25)) / k_avg_s / 1e9}
-        roof["traffic"] = load_traffic(a)
-        roof["hardware_counted"] = load_traffic(a, key="hardware_counted")  # ALU-side truth next to the algorithmic figure
+        n_launch = max(int(kln[1]), 1)   # (host entry points launch once per pipeline chunk)
+        my_attempts, my_rays = int(my[1] + my[2]), int(my[0])
+        k_s = (float(kms[1]) + float(kms[3])) * 1e-3   # seconds in the integrate kernels, all launches of this rank
+        prof, why = load_profile(a)
+        peak = FP64_VALU_PEAK_TFLOPS if a.dtype == "f64" else F32_SCALAR_VALU_PEAK_TFLOPS
+        roof = {"bound": "valu_f64" if a.dtype == "f64" else "valu_f32_scalar", "achieved": None, "peak": peak,
+                "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "kernel": "rtgr::integrate_kernel (FAR pass + NEAR pass)", "kernel_ms_per_pass": k_s * 1e3 / a.steps,
+                "launches": n_launch, "far_pass_ms_per_pass": float(kms[1]) / a.steps,
+                "near_pass_ms_per_pass": float(kms[3]) / a.steps,
+                "other_kernels_ms_per_pass": {"setup_and_order": float(kms[0]) / a.steps, "resolve": float(kms[2]) / a.steps},
+                "step_attempts_this_rank": my_attempts,
+                "reference_equivalent_tflops": (my_attempts * F_STEP + 2 * my_rays * F_RHS) / k_s / 1e12,
+                "reference_equivalent_model": f"{F_STEP} flop/step attempt + 2x{F_RHS} per ray (SURVEY 8d: what the "
+                                              f"reference's dual-number formulation would execute for the same steps; NOT "
+                                              f"a utilisation — the closed Kerr-Schild contraction executes fewer)",
+                "hbm_algorithmic_GBps": (my_rays * (132 + 2 * 140 + 204 + 25)) / k_s / 1e9}
+        if prof is not None:
+            flop = prof["flop_per_step_attempt"] * my_attempts
+            roof["achieved"] = flop / k_s / 1e12
+            roof["frac"] = roof["achieved"] / peak
+            roof["executed_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
+            roof["traffic"] = prof["hbm_bytes_per_ray"] * my_rays / a.steps if prof.get("hbm_bytes_per_ray") else None
+            roof["profile"] = prof
+        else:
+            roof["stale_profile"] = why
         name = C_name(lib)
+        extras = {}
+        if a.extras and ws == 1 and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64":
+            extras = run_extras(a, rt, host_pass, pixels_pass, dt / a.steps)
         cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and ws == 1) else None  # N=1 only
         line = {
             "metric": "geodesic RK step attempts/s (Tsit5, 6 RHS each), Kerr-Schild screen, whole job",
@@ -234,34 +317,61 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"example2 scene (Kerr-Schild {a.variant}, 3 objects) {ni}x{nj} screen, "
                                    f"tol=eps^(3/4), lambda in [0,100]; rows dealt {a.layout} over {ws} GPU(s)"
-                                   f"{'' if ws == 1 or a.no_gather else ' + ' + ('RCCL' if a.backend == 'nccl' else 'gloo') + ' gather to rank 0'}",
-                       "size": a.size, "variant": a.variant, "rhs": a.rhs, "parallelism": f"rows/{ws}"},
+                                   f"{'' if ws == 1 or a.no_gather else ' + ' + ('RCCL' if a.backend == 'nccl' else 'gloo') + ' gather of RGB + status to rank 0'}",
+                       "size": a.size, "variant": a.variant, "rhs": a.rhs, "entry": a.entry, "parallelism": f"rows/{ws}"},
             "rays_per_s": rays / dt, "rays": rays // a.steps, "step_attempts_per_pass": attempts // a.steps,
             "accepted": acc // a.steps, "rejected": rej // a.steps, "rhs_evals_per_pass": nrhs // a.steps,
-            "pipeline_ms_max_over_ranks": float(kmax[0]), "device": name,
-            "roofline": roof, "cpu_baseline": cpu,
+            "device": name, "roofline": roof, "cpu_baseline": cpu,
         }
+        line.update(extras)
+        if ws > 1 and not a.no_gather:
+            line["gathered_status_not_event"] = int((image["status"] != 0).sum())
         print(json.dumps(line), flush=True)
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def load_traffic(a, key="traffic_bytes_per_launch"):
-    """HBM bytes per launch of the dominant kernel (or another recorded PMC-derived entry) from the latest committed
-    profile of the SAME configuration (profiles/rNN/traffic.json; PMC counters cannot be collected from inside the
-    bench), else None."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
-        try:
-            t = json.load(open(f))
-        except Exception:
-            continue
-        c = t.get("config", {})
-        if (c.get("size"), c.get("variant"), c.get("dtype")) == (a.size, a.variant, a.dtype) and a.gpus == 1 \
-                and a.rhs == "closed":
-            return t.get(key)
-    return None
+def run_extras(a, rt, host_pass, pixels_pass, device_s):
+    """N = 1, default workload only, OUTSIDE the timed region: (1) the same frame through the host-pointer entry points
+    (rtgr_trace_f64: RGB planes to host; rtgr_trace_pixels_f64: the reference's Array{Pixel} in and out — PCIe-inclusive,
+    never `value`); (2) the workload as BASELINE.json words it for configs 2/3 — Kerr a = 0.8 (textbook radius), which runs
+    the spin RHS — so that the headline is not only the cheapest RHS."""
+    import torch
+    from raytracegr_jl_amd import sharded
+    ex = {}
+    ep = {"device_ms": device_s * 1e3}
+    for name, fn in (("host", host_pass), ("pixels", pixels_pass)):
+        fn()  # warm (allocates the pinned staging)
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            fn()
+        ep[f"{name}_ms"] = (time.perf_counter() - t0) / reps * 1e3
+    ep["pixels_over_device"] = ep["pixels_ms"] / ep["device_ms"]
+    ep["note"] = ("host = rtgr_trace_f64 (camera on device, RGB planes -> pageable host memory); pixels = "
+                  "rtgr_trace_pixels_f64 (88-byte Pixel array in and out of pageable host memory; 64 B/ray up, 24 B/ray "
+                  "down over PCIe, H2D || integrate || D2H pipelined).  Wall time of blocking calls, PCIe-inclusive.")
+    ex["entry_points"] = ep
+    sc8, cam8 = build_scene(rt, "ks_true08")
+    opt = rt.solver_defaults()
+    ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+    o = {}
+    n = a.size
+    sharded.trace_rows_torch(sc8, opt, cam8, n, n, 0, 1, n, counters=ctr, out=o)
+    torch.cuda.synchronize()
+    ctr.zero_()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        sharded.trace_rows_torch(sc8, opt, cam8, n, n, 0, 1, n, counters=ctr, out=o)
+    torch.cuda.synchronize()
+    d8 = (time.perf_counter() - t0) / reps
+    att = (int(ctr[1]) + int(ctr[2])) / reps
+    ex["variants"] = {"ks_true08": {"workload": f"Kerr-Schild a=0.8 (textbook radius), same scene and camera, {n}x{n}",
+                                    "ms_per_pass": d8 * 1e3, "step_attempts_per_s": att / d8, "rays_per_s": n * n / d8,
+                                    "step_attempts_per_ray": att / (n * n)}}
+    return ex
 
 
 def C_name(lib):

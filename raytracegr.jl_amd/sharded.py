@@ -78,7 +78,7 @@ def row_assignment(nj, world_size, rank, layout="cyclic"):
 
 
 def trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device="cuda", dtype=np.float64, counters=None,
-                     out=None, ctx=None):
+                     out=None, ctx=None, status=False):
     """Trace image rows j0, j0+jstride, … (nrows of them) into a device tensor rgb[3, ni*nrows]; asynchronous."""
     import torch
     lib = _abi.load()
@@ -89,28 +89,39 @@ def trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device="cuda",
         res = out if out is not None else {}
         if "rgb" not in res:
             res["rgb"] = torch.empty((3, n), dtype=td, device=dev)
+        o = None
+        if status:  # per-ray status bytes (they ride the multi-GPU gather next to the RGB rows)
+            if "status" not in res:
+                res["status"] = torch.empty(n, dtype=torch.uint8, device=dev)
+            o = _abi.rtgr_ray_outputs()
+            o.status = res["status"].data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
         fn = lib.rtgr_trace_rows_device_f64 if dtype == np.float64 else lib.rtgr_trace_rows_device_f32
         _abi.check(lib, fn(ctx, C.byref(scene), C.byref(opt), C.byref(cam), ni, nj, j0, jstride, nrows,
-                           res["rgb"].data_ptr(), None, counters.data_ptr() if counters is not None else None, stream))
+                           res["rgb"].data_ptr(), C.byref(o) if o is not None else None,
+                           counters.data_ptr() if counters is not None else None, stream))
     return res
 
 
 def assemble_rows(parts, ni, nj, world_size, layout="cyclic"):
     """Rank-0 side of the gather: parts[r] = rgb[3, >= ni*nrows_r] of rank r  ->  full image rgb[3, ni*nj]."""
-    full = parts[0].new_empty((3, nj, ni))
+    planes = parts[0].shape[0]   # 3 for RGB, 1 for a per-ray array such as the status bytes
+    full = parts[0].new_empty((planes, nj, ni))
     for r in range(world_size):
         j0, st, nr = row_assignment(nj, world_size, r, layout)
-        full[:, j0:j0 + (nr - 1) * st + 1:st, :] = parts[r][:, :ni * nr].reshape(3, nr, ni)
-    return full.reshape(3, nj * ni)
+        full[:, j0:j0 + (nr - 1) * st + 1:st, :] = parts[r][:, :ni * nr].reshape(planes, nr, ni)
+    return full.reshape(planes, nj * ni)
 
 
 def trace_sharded(scene, opt, cam, ni, nj, group=None, device=None, dtype=np.float64, trace_rows=None,
-                  gather=True, counters=None, layout="cyclic"):
-    """Every rank traces its rows; rank 0 receives the whole image [3, ni*nj] (None elsewhere).
+                  gather=True, counters=None, layout="cyclic", with_status=False):
+    """Every rank traces its rows; rank 0 receives the whole image [3, ni*nj] (None elsewhere).  with_status=True: the
+    per-ray status bytes ride the same exchange and the counters are summed over the ranks — rank 0 gets
+    dict(rgb[3, n], status[n], counters[8]).
 
-    `trace_rows(scene, opt, cam, ni, nj, j0, jstride, nrows) -> tensor[3, ni*nrows]` is an injection point for the
-    world_size-2 gloo tests on CPU-only hosts; the default is the HIP path (fails loudly without a GPU).
+    `trace_rows(scene, opt, cam, ni, nj, j0, jstride, nrows) -> tensor[3, ni*nrows]` (or, with_status,
+    dict(rgb=…, status=…, counters=…)) is an injection point for the world_size-2 gloo tests on CPU-only hosts; the
+    default is the HIP path (fails loudly without a GPU).
     """
     import torch
     import torch.distributed as dist
@@ -118,19 +129,34 @@ def trace_sharded(scene, opt, cam, ni, nj, group=None, device=None, dtype=np.flo
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     j0, st, nr = row_assignment(nj, ws, rank, layout)
     if trace_rows is None:
-        mine = trace_rows_torch(scene, opt, cam, ni, nj, j0, st, nr, device=device or "cuda", dtype=dtype,
-                                counters=counters)["rgb"]
+        if with_status and counters is None:
+            counters = torch.zeros(8, dtype=torch.int64, device=device or "cuda")
+        res = trace_rows_torch(scene, opt, cam, ni, nj, j0, st, nr, device=device or "cuda", dtype=dtype,
+                               counters=counters, status=with_status)
+        mine = {"rgb": res["rgb"], "status": res.get("status"), "counters": counters}
     else:
         mine = trace_rows(scene, opt, cam, ni, nj, j0, st, nr)
+        if not isinstance(mine, dict):
+            mine = {"rgb": mine}
     if ws == 1 or not gather:
-        return mine
+        return mine if with_status else mine["rgb"]
     # gather of unequal shares: pad to the largest (row counts differ by at most one)
     nmax = ni * max(row_assignment(nj, ws, r, layout)[2] for r in range(ws))
-    send = mine if mine.shape[1] == nmax else torch.cat([mine, mine.new_zeros((3, nmax - mine.shape[1]))], dim=1)
-    send = send.contiguous()
-    if rank == 0:
-        parts = [torch.empty_like(send) for _ in range(ws)]
-        dist.gather(send, parts, dst=0, group=group)
-        return assemble_rows(parts, ni, nj, ws, layout)
-    dist.gather(send, None, dst=0, group=group)
-    return None
+    full = {}
+    for name in (("rgb", "status") if with_status else ("rgb",)):
+        t = mine[name] if name == "rgb" else mine[name][None]
+        send = t if t.shape[1] == nmax else torch.cat([t, t.new_zeros((t.shape[0], nmax - t.shape[1]))], dim=1)
+        send = send.contiguous()
+        if rank == 0:
+            parts = [torch.empty_like(send) for _ in range(ws)]
+            dist.gather(send, parts, dst=0, group=group)
+            full[name] = assemble_rows(parts, ni, nj, ws, layout)
+        else:
+            dist.gather(send, None, dst=0, group=group)
+    if with_status:
+        total = mine["counters"].clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        if rank == 0:
+            return {"rgb": full["rgb"], "status": full["status"][0], "counters": total}
+        return None
+    return full.get("rgb")

@@ -35,13 +35,20 @@ def _worker(rank, ws, port, ni, nj, out_path, layout):
     opt = rt.solver_defaults()
 
     def oracle_rows(scene, o, camera, ni_, nj_, j0, jstride, nrows):
-        rows = [O.trace(scene, o, ni_, nj_, j0=j, j1=j + 1, cam=camera, details=False, nthreads=2)["rgb"]
-                for j in range(j0, j0 + nrows * jstride, jstride)]
-        return torch.from_numpy(np.concatenate(rows, axis=1))
+        rs = [O.trace(scene, o, ni_, nj_, j0=j, j1=j + 1, cam=camera, details=True, nthreads=2)
+              for j in range(j0, j0 + nrows * jstride, jstride)]
+        ctr = np.zeros(8, np.int64)
+        for r in rs:
+            ctr[:7] += [r["counters"][k] for k in ("rays", "accepted", "rejected", "rhs_evals", "events",
+                                                   "events_interior", "not_finished")]
+        return {"rgb": torch.from_numpy(np.concatenate([r["rgb"] for r in rs], axis=1)),
+                "status": torch.from_numpy(np.concatenate([r["status"] for r in rs])),
+                "counters": torch.from_numpy(ctr)}
 
-    full = sharded.trace_sharded(sc, opt, cam, ni, nj, trace_rows=oracle_rows, layout=layout)
+    # RGB rows, status bytes and counters ride the exchange
+    full = sharded.trace_sharded(sc, opt, cam, ni, nj, trace_rows=oracle_rows, layout=layout, with_status=True)
     if rank == 0:
-        np.save(out_path, full.numpy())
+        np.savez(out_path, rgb=full["rgb"].numpy(), status=full["status"].numpy(), counters=full["counters"].numpy())
     else:
         assert full is None
     dist.barrier()
@@ -52,13 +59,17 @@ def _worker(rank, ws, port, ni, nj, out_path, layout):
 def test_sharded_gather_world_size_2(tmp_path, ni, nj, layout):
     import oracle_lib as O
     from scenes import example, rt
-    out = str(tmp_path / "img.npy")
+    out = str(tmp_path / "img.npz")
     mp.spawn(_worker, args=(2, _free_port(), ni, nj, out, layout), nprocs=2, join=True)
     got = np.load(out)
     sc, cam = example(2)
-    ref = O.trace(sc, rt.solver_defaults(), ni, nj, cam=cam, details=False)["rgb"]
-    assert got.shape == (3, ni * nj)
-    assert np.array_equal(got, ref)
+    ref = O.trace(sc, rt.solver_defaults(), ni, nj, cam=cam, details=True)
+    assert got["rgb"].shape == (3, ni * nj)
+    assert np.array_equal(got["rgb"], ref["rgb"])
+    assert np.array_equal(got["status"], ref["status"])
+    c = ref["counters"]
+    assert list(got["counters"][:7]) == [c[k] for k in ("rays", "accepted", "rejected", "rhs_evals", "events",
+                                                        "events_interior", "not_finished")]
 
 
 def test_slab_bounds_tile_the_frame():
