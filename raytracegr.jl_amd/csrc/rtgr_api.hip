@@ -106,8 +106,10 @@ static int stream_state(DeviceCtx& d, hipStream_t st, StreamState** out) {
             return fail(RTGR_ERR_BAD_ARG, "first use of this stream while it is being captured: call "
                                           "rtgr_reserve_workspace for this stream before hipStreamBeginCapture");
         StreamState ss;
+        // (not zeroed here: reset_kernel zeroes the heads on the launch stream at the start of every chunk.  A hipMemset
+        //  would run on the NULL stream, which does not order with a non-blocking caller stream: it landed in the middle
+        //  of the first pipeline of a new stream and wiped the early-list cursor — found by the two-streams test)
         HIP_TRY(hipMalloc((void**)&ss.queue, 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(ss.queue, 0, 8 * sizeof(unsigned long long)));
         it = d.streams.emplace(st, ss).first;
     }
     *out = &it->second;

@@ -329,7 +329,7 @@ RTGR_DEV void make_pixel(const DevScene<R>& sc, const DevCamera<R>& cam, uint64_
     R g[4][4];
 #ifdef RTGR_USER_METRIC
     if (sc.metric == (uint32_t)RTGR_USER) {
-        if constexpr (sizeof(R) == 8) rtgr_user_metric<double>(x, sc.M, sc.a, g);   // metric(x) with plain scalars (:469)
+        rtgr_user_metric<R>(x, (double)sc.M, (double)sc.a, g);   // metric(x) with plain scalars (:469)
     } else
 #endif
     {   // metric(x) with plain scalars (:469); built-ins are η + f k k

@@ -371,99 +371,156 @@ RTGR_DEV void rhs(const R s[8], R M, R a, R ds[8]) {
 }
 
 // ---- generic forward-mode path ----------------------------------------------------------------------------------------
-// Dual{T,SVector{4,T}} (src/RayTraceGR.jl:11-14) on the device: value + 4 partials, in registers.
-template <class R>
+// Dual{T,DT} (src/RayTraceGR.jl:11-14) on the device: value + NE partials, in registers.
+//   NE   = 4: DT = SVector{4,T}, the reference's choice (all four coordinates seeded, :303-306)
+//   NE   = 3: the spatial partials only — for a STATIONARY metric ∂_t g ≡ 0, so the t-seed carries exact zeros through
+//          every operation (a quarter of the dual arithmetic); the integrate kernels use it for the built-in metrics and
+//          for user metrics declared stationary
+//   FAST = true: the reciprocals and square roots inside `/` and `sqrt` are the 4 / 6-instruction sequences of the hot
+//          loop (frcp / frsq, <= 1.5e-16 relative) instead of the 11 / 14-instruction IEEE expansions
+template <class R, int NE = 4, bool FAST = false>
 struct DDual {
-    R v, e[4];
+    R v, e[NE];
 };
-template <class R> RTGR_DEV DDual<R> dconst(R v) { return DDual<R>{v, {R(0), R(0), R(0), R(0)}}; }
-template <class R> RTGR_DEV DDual<R> operator+(const DDual<R>& x, const DDual<R>& y) {
-    DDual<R> r; r.v = x.v + y.v; for (int i = 0; i < 4; i++) r.e[i] = x.e[i] + y.e[i]; return r; }
-template <class R> RTGR_DEV DDual<R> operator-(const DDual<R>& x, const DDual<R>& y) {
-    DDual<R> r; r.v = x.v - y.v; for (int i = 0; i < 4; i++) r.e[i] = x.e[i] - y.e[i]; return r; }
-template <class R> RTGR_DEV DDual<R> operator+(const DDual<R>& x, R a) { DDual<R> r = x; r.v = x.v + a; return r; }
-template <class R> RTGR_DEV DDual<R> operator-(const DDual<R>& x, R a) { DDual<R> r = x; r.v = x.v - a; return r; }
-template <class R> RTGR_DEV DDual<R> operator*(const DDual<R>& x, const DDual<R>& y) {
-    DDual<R> r; r.v = x.v * y.v; for (int i = 0; i < 4; i++) r.e[i] = rfma(x.e[i], y.v, x.v * y.e[i]); return r; }
-template <class R> RTGR_DEV DDual<R> operator*(R a, const DDual<R>& x) {
-    DDual<R> r; r.v = a * x.v; for (int i = 0; i < 4; i++) r.e[i] = a * x.e[i]; return r; }
-template <class R> RTGR_DEV DDual<R> operator*(const DDual<R>& x, R a) { return a * x; }
-template <class R> RTGR_DEV DDual<R> operator/(const DDual<R>& x, const DDual<R>& y) {
-    const R iy = R(1) / y.v; DDual<R> r; r.v = x.v * iy;
-    for (int i = 0; i < 4; i++) r.e[i] = rfma(-r.v, y.e[i], x.e[i]) * iy; return r; }
-template <class R> RTGR_DEV DDual<R> dsqrt(const DDual<R>& x) {
-    DDual<R> r; r.v = rsqrt_(x.v); const R c = R(0.5) / r.v; for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+#define RTGR_DT template <class R, int NE, bool FAST>
+#define RTGR_DD DDual<R, NE, FAST>
+// a plain-scalar operand of a mixed operation takes the dual's scalar type without taking part in template deduction, so
+// that `0.5 * q` works on Float32 duals too (the literal is a double)
+template <class T> struct NoDeduce { using type = T; };
+#define RTGR_SC typename NoDeduce<R>::type
+RTGR_DT RTGR_DEV RTGR_DD dconst_(R v) { RTGR_DD r; r.v = v; for (int i = 0; i < NE; i++) r.e[i] = R(0); return r; }
+template <class R> RTGR_DEV DDual<R> dconst(R v) { return dconst_<R, 4, false>(v); }
+RTGR_DT RTGR_DEV RTGR_DD operator+(const RTGR_DD& x, const RTGR_DD& y) {
+    RTGR_DD r; r.v = x.v + y.v; for (int i = 0; i < NE; i++) r.e[i] = x.e[i] + y.e[i]; return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator-(const RTGR_DD& x, const RTGR_DD& y) {
+    RTGR_DD r; r.v = x.v - y.v; for (int i = 0; i < NE; i++) r.e[i] = x.e[i] - y.e[i]; return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator+(const RTGR_DD& x, RTGR_SC a) { RTGR_DD r = x; r.v = x.v + a; return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator-(const RTGR_DD& x, RTGR_SC a) { RTGR_DD r = x; r.v = x.v - a; return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator*(const RTGR_DD& x, const RTGR_DD& y) {
+    RTGR_DD r; r.v = x.v * y.v; for (int i = 0; i < NE; i++) r.e[i] = rfma(x.e[i], y.v, x.v * y.e[i]); return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator*(RTGR_SC a, const RTGR_DD& x) {
+    RTGR_DD r; r.v = a * x.v; for (int i = 0; i < NE; i++) r.e[i] = a * x.e[i]; return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator*(const RTGR_DD& x, RTGR_SC a) { return a * x; }
+RTGR_DT RTGR_DEV RTGR_DD operator/(const RTGR_DD& x, const RTGR_DD& y) {
+    const R iy = rcp_<FAST, R>(y.v); RTGR_DD r; r.v = x.v * iy;
+    for (int i = 0; i < NE; i++) r.e[i] = rfma(-r.v, y.e[i], x.e[i]) * iy; return r; }
+RTGR_DT RTGR_DEV RTGR_DD dsqrt(const RTGR_DD& x) {
+    RTGR_DD r; R is; sqrt_inv<FAST, R>(x.v, r.v, is); const R c = R(0.5) * is;
+    for (int i = 0; i < NE; i++) r.e[i] = c * x.e[i]; return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator-(const RTGR_DD& x) {
+    RTGR_DD r; r.v = -x.v; for (int i = 0; i < NE; i++) r.e[i] = -x.e[i]; return r; }
+RTGR_DT RTGR_DEV RTGR_DD operator+(RTGR_SC a, const RTGR_DD& x) { return x + a; }
+RTGR_DT RTGR_DEV RTGR_DD operator-(RTGR_SC a, const RTGR_DD& x) { return (-x) + a; }
+RTGR_DT RTGR_DEV RTGR_DD operator/(const RTGR_DD& x, RTGR_SC a) { return rcp_<FAST, R>(a) * x; }
+RTGR_DT RTGR_DEV RTGR_DD operator/(RTGR_SC a, const RTGR_DD& x) { return dconst_<R, NE, FAST>(a) / x; }
+// f(x) with derivative f'(x): the chain rule every elementary function below is an instance of
+RTGR_DT RTGR_DEV RTGR_DD dchain(const RTGR_DD& x, R fv, R dfv) {
+    RTGR_DD r; r.v = fv; for (int i = 0; i < NE; i++) r.e[i] = dfv * x.e[i]; return r; }
 
 // ---- user metrics (RTGR_USER): "the metric is any callable" of the reference (src/RayTraceGR.jl:302-309) -------------
 // A translation unit that defines RTGR_USER_METRIC supplies
 //     template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]);
 // written with + - * / and the m* helpers below, so that it runs on plain scalars AND on forward duals — exactly the
 // contract the reference puts on a metric function.  Such units are generated, compiled with hipcc --genco and loaded
-// at run time (rtgr_user_metric_load, api.UserMetric); see rtgr_user_template.hip.
-template <class R> RTGR_DEV DDual<R> msqrt(const DDual<R>& x) { return dsqrt(x); }
+// at run time (rtgr_user_metric_load, api.UserMetric); see rtgr_user_unit.hip.in.
+// The helpers are the elementary functions the reference's Dual carries (src/RayTraceGR.jl:132-196):
+//     msqrt mexp mlog msin mcos (:171-196)   mabs (:150)   macos masin matan (:154-163)   matan2(y, x) (:165-169)
+//     mcbrt (:171)   mpow(x, p) with a real exponent (:138-148; integer powers are better written as products)
+// with the textbook derivatives.  (The reference's own atan(y,x) drops a 1/ρ² on its first term, `\` has a sign flipped
+// and `scalar - Dual` keeps +eps — SURVEY §4.3: off the reference's hot path, not reproduced here; the oracle's twins of
+// these helpers are the textbook forms too, see oracle/rtgr_oracle.cpp.)
+template <class R> RTGR_DEV R mfun_sqrt(R x) { return rsqrt_(x); }
 RTGR_DEV double msqrt(double x) { return __builtin_sqrt(x); }
-template <class R> RTGR_DEV DDual<R> mexp(const DDual<R>& x) {
-    DDual<R> r; r.v = exp(x.v); for (int i = 0; i < 4; i++) r.e[i] = r.v * x.e[i]; return r; }
+RTGR_DEV float msqrt(float x) { return __builtin_sqrtf(x); }
+RTGR_DT RTGR_DEV RTGR_DD msqrt(const RTGR_DD& x) { return dsqrt(x); }
 RTGR_DEV double mexp(double x) { return exp(x); }
-template <class R> RTGR_DEV DDual<R> mlog(const DDual<R>& x) {
-    DDual<R> r; r.v = log(x.v); const R c = R(1) / x.v; for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+RTGR_DEV float mexp(float x) { return expf(x); }
+RTGR_DT RTGR_DEV RTGR_DD mexp(const RTGR_DD& x) { const R f = mexp(x.v); return dchain(x, f, f); }
 RTGR_DEV double mlog(double x) { return log(x); }
-template <class R> RTGR_DEV DDual<R> msin(const DDual<R>& x) {
-    DDual<R> r; r.v = sin(x.v); const R c = cos(x.v); for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+RTGR_DEV float mlog(float x) { return logf(x); }
+RTGR_DT RTGR_DEV RTGR_DD mlog(const RTGR_DD& x) { return dchain(x, mlog(x.v), R(1) / x.v); }
 RTGR_DEV double msin(double x) { return sin(x); }
-template <class R> RTGR_DEV DDual<R> mcos(const DDual<R>& x) {
-    DDual<R> r; r.v = cos(x.v); const R c = -sin(x.v); for (int i = 0; i < 4; i++) r.e[i] = c * x.e[i]; return r; }
+RTGR_DEV float msin(float x) { return sinf(x); }
 RTGR_DEV double mcos(double x) { return cos(x); }
-template <class S> RTGR_DEV S mconst(double c);                       // a constant of the scalar type S
-template <> RTGR_DEV double mconst<double>(double c) { return c; }
-template <> RTGR_DEV DDual<double> mconst<DDual<double>>(double c) { return dconst<double>(c); }
-template <class R> RTGR_DEV DDual<R> operator-(const DDual<R>& x) {
-    DDual<R> r; r.v = -x.v; for (int i = 0; i < 4; i++) r.e[i] = -x.e[i]; return r; }
-template <class R> RTGR_DEV DDual<R> operator+(R a, const DDual<R>& x) { return x + a; }
-template <class R> RTGR_DEV DDual<R> operator-(R a, const DDual<R>& x) { return (-x) + a; }
-template <class R> RTGR_DEV DDual<R> operator/(const DDual<R>& x, R a) { return (R(1) / a) * x; }
-template <class R> RTGR_DEV DDual<R> operator/(R a, const DDual<R>& x) { return dconst<R>(a) / x; }
+RTGR_DEV float mcos(float x) { return cosf(x); }
+RTGR_DT RTGR_DEV RTGR_DD msin(const RTGR_DD& x) { return dchain(x, msin(x.v), mcos(x.v)); }
+RTGR_DT RTGR_DEV RTGR_DD mcos(const RTGR_DD& x) { return dchain(x, mcos(x.v), -msin(x.v)); }
+RTGR_DEV double mabs(double x) { return __builtin_fabs(x); }
+RTGR_DEV float mabs(float x) { return __builtin_fabsf(x); }
+RTGR_DT RTGR_DEV RTGR_DD mabs(const RTGR_DD& x) { return dchain(x, rabs(x.v), x.v < R(0) ? R(-1) : R(1)); }
+RTGR_DEV double macos(double x) { return acos(x); }
+RTGR_DEV float macos(float x) { return acosf(x); }
+RTGR_DT RTGR_DEV RTGR_DD macos(const RTGR_DD& x) { return dchain(x, macos(x.v), R(-1) / rsqrt_(R(1) - x.v * x.v)); }
+RTGR_DEV double masin(double x) { return asin(x); }
+RTGR_DEV float masin(float x) { return asinf(x); }
+RTGR_DT RTGR_DEV RTGR_DD masin(const RTGR_DD& x) { return dchain(x, masin(x.v), R(1) / rsqrt_(R(1) - x.v * x.v)); }
+RTGR_DEV double matan(double x) { return atan(x); }
+RTGR_DEV float matan(float x) { return atanf(x); }
+RTGR_DT RTGR_DEV RTGR_DD matan(const RTGR_DD& x) { return dchain(x, matan(x.v), R(1) / (R(1) + x.v * x.v)); }
+RTGR_DEV double matan2(double y, double x) { return atan2(y, x); }
+RTGR_DEV float matan2(float y, float x) { return atan2f(y, x); }
+RTGR_DT RTGR_DEV RTGR_DD matan2(const RTGR_DD& y, const RTGR_DD& x) {   // d atan2 = (x dy − y dx)/(x² + y²)
+    const R ir2 = R(1) / (x.v * x.v + y.v * y.v);
+    RTGR_DD r; r.v = matan2(y.v, x.v);
+    for (int i = 0; i < NE; i++) r.e[i] = (x.v * y.e[i] - y.v * x.e[i]) * ir2;
+    return r; }
+RTGR_DEV double mcbrt(double x) { return cbrt(x); }
+RTGR_DEV float mcbrt(float x) { return cbrtf(x); }
+RTGR_DT RTGR_DEV RTGR_DD mcbrt(const RTGR_DD& x) { const R c = mcbrt(x.v); return dchain(x, c, R(1) / (R(3) * c * c)); }
+RTGR_DEV double mpow(double x, double p) { return pow(x, p); }
+RTGR_DEV float mpow(float x, float p) { return powf(x, p); }
+RTGR_DT RTGR_DEV RTGR_DD mpow(const RTGR_DD& x, double p) {           // x^p, real constant exponent: p x^(p-1)
+    const R f = mpow(x.v, (R)p); return dchain(x, f, (R)p * f / x.v); }
+template <class S> struct MConst;                                     // a constant of the scalar type S
+template <> struct MConst<double> { static RTGR_DEV double make(double c) { return c; } };
+template <> struct MConst<float> { static RTGR_DEV float make(double c) { return (float)c; } };
+RTGR_DT struct MConst<RTGR_DD> { static RTGR_DEV RTGR_DD make(double c) { return dconst_<R, NE, FAST>((R)c); } };
+template <class S> RTGR_DEV S mconst(double c) { return MConst<S>::make(c); }
 #ifdef RTGR_USER_METRIC
 template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]);
 #endif
 
-// metric(x::SVector{4,Dual}) for the built-ins; symmetric result gd[a][b], a<=b filled for all (a,b)
-template <class R>
-RTGR_DEV void metric_dual(uint32_t metric, R M, R a, const DDual<R> xx[4], DDual<R> g[4][4]) {
+// metric(x::SVector{4,Dual}) for the built-ins; the UPPER triangle g[a][b], a <= b, is filled (and mirrored).
+// Written the way one would write kerr_schild for speed: k_t = 1 is a constant, so g_tt = −1 + f, g_ti = f k_i and only
+// g_ij = δ_ij + (f k_i) k_j costs dual products (9 of them instead of the 20 of `f * k[a] * k[b]` over all a <= b, :291).
+RTGR_DT RTGR_DEV void metric_dual(uint32_t metric, R M, R a, const RTGR_DD xx[4], RTGR_DD g[4][4]) {
 #ifdef RTGR_USER_METRIC
     if (metric == (uint32_t)RTGR_USER) {
-        if constexpr (sizeof(R) == 8) rtgr_user_metric<DDual<double>>(xx, M, a, g);
+        rtgr_user_metric<RTGR_DD>(xx, (double)M, (double)a, g);
         return;
     }
 #endif
     for (int p = 0; p < 4; p++)
-        for (int q = 0; q < 4; q++) g[p][q] = dconst<R>(p == q ? (p == 0 ? R(-1) : R(1)) : R(0));   // η  :263,:282
+        for (int q = 0; q < 4; q++) g[p][q] = dconst_<R, NE, FAST>(p == q ? (p == 0 ? R(-1) : R(1)) : R(0));   // η  :263,:282
     if (metric == RTGR_MINKOWSKI) return;
-    const DDual<R>&x = xx[1], &y = xx[2], &z = xx[3];
+    const RTGR_DD &x = xx[1], &y = xx[2], &z = xx[3];
     const R a2 = a * a;
-    DDual<R> rho2 = x * x + y * y + z * z;                                                          // :283
-    DDual<R> r;
+    const RTGR_DD zz = z * z;
+    RTGR_DD rho2 = x * x + y * y + zz;                                                              // :283
+    RTGR_DD r;
     if (metric == RTGR_KS_REF) {
-        DDual<R> q = rho2 - a2;
-        DDual<R> hq = R(0.5) * q;
-        r = R(0.5) * dsqrt(q) + dsqrt(a2 * (z * z) + hq * hq);                                      // :284
+        RTGR_DD q = rho2 - a2;
+        RTGR_DD hq = R(0.5) * q;
+        r = R(0.5) * dsqrt(q) + dsqrt(a2 * zz + hq * hq);                                           // :284
     } else {
-        DDual<R> q = rho2 - a2;
-        r = dsqrt(R(0.5) * (q + dsqrt(q * q + (R(4) * a2) * (z * z))));
+        RTGR_DD q = rho2 - a2;
+        r = dsqrt(R(0.5) * (q + dsqrt(q * q + (R(4) * a2) * zz)));
     }
-    DDual<R> r2 = r * r;
-    DDual<R> f = ((R(2) * M) * (r2 * r)) / (r2 * r2 + a2 * (z * z));                                // :285
-    DDual<R> k[4];
-    DDual<R> den = r2 + a2;
-    k[0] = dconst<R>(R(1));                                                                         // :286-289
+    RTGR_DD r2 = r * r;
+    RTGR_DD f = ((R(2) * M) * (r2 * r)) / (r2 * r2 + a2 * zz);                                      // :285
+    RTGR_DD k[4];
+    RTGR_DD den = r2 + a2;                                                                          // :286-289
     k[1] = (r * x + a * y) / den;
     k[2] = (r * y - a * x) / den;
     k[3] = z / r;
+    g[0][0] = f - R(1);                                                                             // η_tt + f k_t k_t   :291
+    for (int p = 1; p < 4; p++) {
+        const RTGR_DD fk = f * k[p];
+        g[0][p] = fk;                                                                               // f k_t k_p
+        for (int q = p; q < 4; q++) g[p][q] = g[p][q] + fk * k[q];
+    }
     for (int p = 0; p < 4; p++)
-        for (int q = p; q < 4; q++) {
-            g[p][q] = g[p][q] + f * k[p] * k[q];                                                    // :291
-            g[q][p] = g[p][q];
-        }
+        for (int q = 0; q < p; q++) g[p][q] = g[q][p];
 }
 
 template <class R>
@@ -493,10 +550,41 @@ RTGR_DEV void inv4sym(const R m[4][4], R o[4][4]) {  // cofactor inverse (Static
     o[3][3] = (m[2][0] * s3 - m[2][1] * s1 + m[2][2] * s0) * id;
 }
 
+// x = m^{-1} b for a SYMMETRIC 4x4 m (only m[i][j], i <= j, is read): adjugate by 2x2 minors (robust where g_tt = 0, which
+// elimination without pivoting is not), 10 cofactors instead of 16, one reciprocal.  SURVEY §8d "symmetric inverse by
+// 2x2 minors".
+template <class R, bool FAST>
+RTGR_DEV void solve4sym(const R m[4][4], const R b[4], R x[4]) {
+    const R m00 = m[0][0], m01 = m[0][1], m02 = m[0][2], m03 = m[0][3], m11 = m[1][1], m12 = m[1][2], m13 = m[1][3],
+            m22 = m[2][2], m23 = m[2][3], m33 = m[3][3];
+    // minors of rows {0,1} (s) and rows {2,3} (c), columns (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+    const R s0 = rfma(m00, m11, -m01 * m01), s1 = rfma(m00, m12, -m01 * m02), s2 = rfma(m00, m13, -m01 * m03);
+    const R s3 = rfma(m01, m12, -m11 * m02), s4 = rfma(m01, m13, -m11 * m03), s5 = rfma(m02, m13, -m12 * m03);
+    const R c0 = rfma(m02, m13, -m03 * m12), c1 = rfma(m02, m23, -m03 * m22), c2 = rfma(m02, m33, -m03 * m23);
+    const R c3 = rfma(m12, m23, -m13 * m22), c4 = rfma(m12, m33, -m13 * m23), c5 = rfma(m22, m33, -m23 * m23);
+    const R det = rfma(s0, c5, rfma(-s1, c4, rfma(s2, c3, rfma(s3, c2, rfma(-s4, c1, s5 * c0)))));
+    const R id = rcp_<FAST, R>(det);
+    // adjugate (symmetric): A_ij = cofactor_ji
+    const R a00 = rfma(m11, c5, rfma(-m12, c4, m13 * c3));
+    const R a01 = -rfma(m01, c5, rfma(-m02, c4, m03 * c3));
+    const R a02 = rfma(m13, s5, rfma(-m23, s4, m33 * s3));
+    const R a03 = -rfma(m12, s5, rfma(-m22, s4, m23 * s3));
+    const R a11 = rfma(m00, c5, rfma(-m02, c2, m03 * c1));
+    const R a12 = -rfma(m03, s5, rfma(-m23, s2, m33 * s1));
+    const R a13 = rfma(m02, s5, rfma(-m22, s2, m23 * s1));
+    const R a22 = rfma(m03, s4, rfma(-m13, s2, m33 * s0));
+    const R a23 = -rfma(m02, s4, rfma(-m12, s2, m23 * s0));
+    const R a33 = rfma(m02, s3, rfma(-m12, s1, m22 * s0));
+    x[0] = id * rfma(a00, b[0], rfma(a01, b[1], rfma(a02, b[2], a03 * b[3])));
+    x[1] = id * rfma(a01, b[0], rfma(a11, b[1], rfma(a12, b[2], a13 * b[3])));
+    x[2] = id * rfma(a02, b[0], rfma(a12, b[1], rfma(a22, b[2], a23 * b[3])));
+    x[3] = id * rfma(a03, b[0], rfma(a13, b[1], rfma(a23, b[2], a33 * b[3])));
+}
+
 // dmetric (src/RayTraceGR.jl:302-313): g[a][b], dg[a][b][c] = ∂_c g_ab
 // UPPER: read only the upper triangle of what the metric function returned (a metric is symmetric; the reference
-// asserts it, :307).  The integrate kernels use it so that a user function that fills all 16 entries pays for 10;
-// rtgr_eval_metric_f64 reports the function's output as is, which is where an asymmetric user metric shows.
+// asserts it, :307).  rtgr_eval_metric_f64 reports the function's output as is (UPPER = false), which is where an
+// asymmetric user metric shows.
 template <class R, bool UPPER = false>
 RTGR_DEV void dmetric_dev(uint32_t metric, R M, R a, const R x[4], R g[4][4], R dg[4][4][4]) {
     DDual<R> xdx[4], gd[4][4];
@@ -504,7 +592,7 @@ RTGR_DEV void dmetric_dev(uint32_t metric, R M, R a, const R x[4], R g[4][4], R 
         xdx[p] = dconst<R>(x[p]);
         xdx[p].e[p] = R(1);
     }
-    metric_dual<R>(metric, M, a, xdx, gd);
+    metric_dual<R, 4, false>(metric, M, a, xdx, gd);
     for (int p = 0; p < 4; p++)
         for (int q = 0; q < 4; q++) {
             const DDual<R>& e = (UPPER && q < p) ? gd[q][p] : gd[p][q];
@@ -513,38 +601,66 @@ RTGR_DEV void dmetric_dev(uint32_t metric, R M, R a, const R x[4], R g[4][4], R 
         }
 }
 
-// generic RHS: contract-then-raise.  L_d = ∂_b g_dc u^b u^c − ½ ∂_d g_bc u^b u^c ;  u̇ = −g^{-1} L
+// The generic acceleration u̇ = −g^{-1} L,  L_d = ∂_b g_dc u^b u^c − ½ ∂_d g_bc u^b u^c  (christoffel + the contraction of
+// geodesic, src/RayTraceGR.jl:321-331, :361-363, contracted BEFORE raising — SURVEY §8d's lean form).
+// Per derivative direction j the symmetric matrix G_j = ∂_j g is applied to u once: v_j = G_j u (16 FMA); then
+//     ∂_b g_dc u^b u^c = Σ_j u^j (v_j)_d        and        ∂_d g_bc u^b u^c = u · v_d
+// — 20 FMA per direction instead of the 2 x 16 x 2 of the two double sums over (b, c).  Only the upper triangle of the
+// metric function's output is read.  NE = 3: directions x, y, z only (stationary metric: ∂_t g = 0 exactly).
+template <class R, int NE, bool FAST>
+RTGR_DEV void generic_accel(uint32_t metric, R M, R a, const R x[4], const R u[4], R ud[4]) {
+    constexpr int J0 = 4 - NE;  // first seeded coordinate
+    DDual<R, NE, FAST> xdx[4], gd[4][4];
+    for (int p = 0; p < 4; p++) {
+        xdx[p] = dconst_<R, NE, FAST>(x[p]);
+        if (p >= J0) xdx[p].e[p - J0] = R(1);
+    }
+    metric_dual<R, NE, FAST>(metric, M, a, xdx, gd);
+    R t1[4] = {R(0), R(0), R(0), R(0)}, t2[NE];
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+        R v[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            R acc = R(0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc = rfma((d <= c ? gd[d][c] : gd[c][d]).e[j], u[c], acc);
+            v[d] = acc;
+        }
+        t2[j] = rfma(u[0], v[0], rfma(u[1], v[1], rfma(u[2], v[2], u[3] * v[3])));
+#pragma unroll
+        for (int d = 0; d < 4; d++) t1[d] = rfma(u[J0 + j], v[d], t1[d]);
+    }
+    R L[4], g[4][4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) L[d] = d >= J0 ? rfma(R(0.5), t2[d - J0], -t1[d]) : -t1[d];   // −L
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = p; q < 4; q++) g[p][q] = gd[p][q].v;
+    solve4sym<R, FAST>(g, L, ud);
+}
+
+// generic RHS as a function of the 8-vector state (parity hook rtgr_eval_geodesic path 1: IEEE division, all four
+// coordinates seeded — the reference's formulation to the letter)
 template <class R>
 RTGR_DEV void generic_rhs(uint32_t metric, R M, R a, const R s[8], R ds[8]) {
-    R g[4][4], dg[4][4][4], gu[4][4];
-    dmetric_dev<R, true>(metric, M, a, s, g, dg);
-    inv4sym<R>(g, gu);
-    const R* u = s + 4;
-    R L[4];
-    for (int d = 0; d < 4; d++) {
-        R t1 = R(0), t2 = R(0);
-        for (int b = 0; b < 4; b++)
-            for (int c = 0; c < 4; c++) {
-                t1 = rfma(dg[d][c][b] * u[b], u[c], t1);
-                t2 = rfma(dg[b][c][d] * u[b], u[c], t2);
-            }
-        L[d] = rfma(R(-0.5), t2, t1);
-    }
-    for (int p = 0; p < 4; p++) {
-        ds[p] = u[p];
-        ds[4 + p] = -(gu[p][0] * L[0] + gu[p][1] * L[1] + gu[p][2] * L[2] + gu[p][3] * L[3]);
-    }
+    for (int p = 0; p < 4; p++) ds[p] = s[4 + p];
+    generic_accel<R, 4, false>(metric, M, a, s, s + 4, ds + 4);
 }
 
 // acceleration through the GENERIC dual-number path (what the reference does for any metric callable): used by the
-// integrate kernel when the scene asks for it (RTGR_METRIC_GENERIC flag) — the measured counterpart of the 814-flop
-// RHS that defines the algorithmic work in SURVEY §8(d).
+// integrate kernels when the scene asks for it (RTGR_METRIC_GENERIC flag) and for every user metric.
+#ifndef RTGR_USER_NE
+#define RTGR_USER_NE 4   // a user unit built with -DRTGR_USER_NE=3 declares its metric stationary (api.UserMetric(stationary=True))
+#endif
 template <class R>
 RTGR_DEV void accel_generic(uint32_t metric, const R xs[3], const R u[4], R M, R a, R ud[4]) {
-    const R s[8] = {R(0), xs[0], xs[1], xs[2], u[0], u[1], u[2], u[3]};
-    R ds[8];
-    generic_rhs<R>(metric, M, a, s, ds);
-    ud[0] = ds[4]; ud[1] = ds[5]; ud[2] = ds[6]; ud[3] = ds[7];
+    const R x[4] = {R(0), xs[0], xs[1], xs[2]};
+#ifdef RTGR_USER_METRIC
+    if (metric == (uint32_t)RTGR_USER) { generic_accel<R, RTGR_USER_NE, true>(metric, M, a, x, u, ud); return; }
+#endif
+    generic_accel<R, 3, true>(metric, M, a, x, u, ud);   // the built-in metrics are stationary
 }
 
 // christoffel (src/RayTraceGR.jl:321-331): all 64 entries, for rtgr_eval_metric_f64

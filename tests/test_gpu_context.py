@@ -39,10 +39,8 @@ def _same(a, b):
     import torch
     for k in a:
         x, y = a[k], b[k]
-        if x.is_floating_point():
-            assert bool(((x == y) | (x.isnan() & y.isnan())).all()), k
-        else:
-            assert torch.equal(x, y), k
+        bad = ~((x == y) | (x.isnan() & y.isnan())) if x.is_floating_point() else (x != y)
+        assert not bool(bad.any()), (k, int(bad.sum()), bad.numel(), bad.nonzero()[:8].tolist())
 
 
 def test_explicit_context_equals_default_context(lib):
