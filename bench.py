@@ -90,7 +90,7 @@ def build_scene(rt, variant, generic=False):
         assert variant.startswith("ks_true"), "--rhs user: the example source is the textbook Kerr-Schild metric"
         sys.path.insert(0, os.path.join(ROOT, "examples"))
         import user_metrics
-        metric = rt.UserMetric(user_metrics.KERR_SCHILD, M=metric.M, a=metric.a)
+        metric = rt.UserMetric(user_metrics.KERR_SCHILD, M=metric.M, a=metric.a, stationary=True)
         generic = False
     sc = rt.make_scene(metric, objs)
     if generic and variant != "mink":

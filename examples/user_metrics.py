@@ -39,3 +39,23 @@ template <class S> __device__ void rtgr_user_metric(const S x[4], double M, doub
     g[1][1] = g[2][2] = g[3][3] = psi2 * psi2;
 }
 '''
+
+# A smooth, static, non-diagonal perturbation of flat space written with EVERY elementary function the reference's Dual
+# carries (src/RayTraceGR.jl:132-196) — not physics, a checker: the oracle has the same function (oracle/rtgr_oracle.cpp
+# helper_zoo) and tests compare g, dg, Christoffels and the RHS point by point.
+HELPER_ZOO = r'''
+template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) {
+    const S X = x[1], Y = x[2], Z = x[3];
+    const S rho = msqrt(X * X + Y * Y + Z * Z);
+    const S cth = Z / rho;
+    const S th = macos(cth), ph = matan2(Y, X), lat = masin(cth);
+    for (int p = 0; p < 4; p++)
+        for (int c = 0; c < 4; c++) g[p][c] = mconst<S>(0.0);
+    g[0][0] = mconst<S>(-1.0) - (0.1 * M) * mpow(rho, -1.5);
+    g[1][1] = mconst<S>(1.0) + 0.05 * mabs(lat) + 0.02 * mexp(-rho);
+    g[2][2] = mconst<S>(1.0) + 0.05 * mcbrt(1.0 + rho) / rho;
+    g[3][3] = mconst<S>(1.0) + 0.03 * matan(rho) * mlog(2.0 + rho) / rho;
+    g[1][2] = g[2][1] = 0.01 * msin(ph) * mcos(th);
+    g[0][3] = g[3][0] = (0.02 * M) * cth / rho;
+}
+'''

@@ -122,6 +122,40 @@ inline Dual<T> sqrt(const Dual<T>& x) {  // :193-196   r = sqrt(val); eps = 1/(2
     for (int i = 0; i < D; i++) r.eps[i] = c * x.eps[i];
     return r;
 }
+// The remaining elementary functions of the reference's Dual (abs :150, acos asin atan :154-163, atan(y,x) :165-169,
+// cbrt :171, ^ :138-148): value and TEXTBOOK derivative.  The hot path (minkowski / kerr_schild) reaches none of them;
+// they are the checker of the product's user-metric helpers (mabs macos masin matan matan2 mcbrt mpow).  Divergence from
+// the reference as written, on purpose and documented: its atan(y,x) drops a 1/ρ² on the first term
+// (:165-169); that is a bug off the reference's hot path, not behaviour to be faithful to.
+template <class T>
+inline Dual<T> chain(const Dual<T>& x, T f, T df) {
+    Dual<T> r;
+    r.val = f;
+    for (int i = 0; i < D; i++) r.eps[i] = df * x.eps[i];
+    return r;
+}
+template <class T> inline Dual<T> abs(const Dual<T>& x) { return chain(x, std::abs(x.val), x.val < T(0) ? T(-1) : T(1)); }          // :150
+template <class T> inline Dual<T> acos(const Dual<T>& x) { return chain(x, std::acos(x.val), T(-1) / std::sqrt(T(1) - x.val * x.val)); }  // :154
+template <class T> inline Dual<T> asin(const Dual<T>& x) { return chain(x, std::asin(x.val), T(1) / std::sqrt(T(1) - x.val * x.val)); }   // :157
+template <class T> inline Dual<T> atan(const Dual<T>& x) { return chain(x, std::atan(x.val), T(1) / (T(1) + x.val * x.val)); }            // :160
+template <class T> inline Dual<T> atan2(const Dual<T>& y, const Dual<T>& x) {                                                       // :165-169
+    Dual<T> r;
+    r.val = std::atan2(y.val, x.val);
+    T ir2 = T(1) / (x.val * x.val + y.val * y.val);
+    for (int i = 0; i < D; i++) r.eps[i] = (x.val * y.eps[i] - y.val * x.eps[i]) * ir2;
+    return r;
+}
+template <class T> inline Dual<T> cbrt(const Dual<T>& x) { T c = std::cbrt(x.val); return chain(x, c, T(1) / (T(3) * c * c)); }     // :171
+template <class T> inline Dual<T> powr(const Dual<T>& x, T p) { T f = std::pow(x.val, p); return chain(x, f, p * f / x.val); }      // :138-148
+template <class T> inline Dual<T> sin(const Dual<T>& x) { return chain(x, std::sin(x.val), std::cos(x.val)); }                      // :190
+template <class T> inline Dual<T> cos(const Dual<T>& x) { return chain(x, std::cos(x.val), -std::sin(x.val)); }                     // :176
+template <class T> inline Dual<T> exp(const Dual<T>& x) { T f = std::exp(x.val); return chain(x, f, f); }                           // :182
+template <class T> inline Dual<T> log(const Dual<T>& x) { return chain(x, std::log(x.val), T(1) / x.val); }                         // :186
+using std::abs; using std::acos; using std::asin; using std::atan; using std::atan2; using std::cbrt; using std::sin; using std::cos;
+using std::exp; using std::log;
+inline double powr(double x, double p) { return std::pow(x, p); }
+inline float powr(float x, float p) { return std::pow(x, p); }
+inline long double powr(long double x, long double p) { return std::pow(x, p); }
 // plain-scalar twins so the metric below is one template over S = T or Dual<T>
 inline double pow2(double x) { return x * x; }
 inline double pow3(double x) { return x * x * x; }
@@ -201,10 +235,32 @@ inline void schwarzschild_isotropic(const S xx[D], T M, S g[D][D]) {
     g[1][1] = g[2][2] = g[3][3] = pow2(psi2);
 }
 
+// A second user-metric stand-in ("zoo"): a smooth, static, non-diagonal perturbation of flat space that goes through EVERY
+// elementary function above — the checker of examples/user_metrics.py:HELPER_ZOO.  Selected by
+// rtgr_scene.user_metric == RTGR_ORACLE_ZOO (the oracle has no module ids; tests pass the marker in that field).
+constexpr uint64_t RTGR_ORACLE_ZOO = 0x200;
+template <class T, class S>
+inline void helper_zoo(const S xx[D], T M, S g[D][D]) {
+    const S &x = xx[1], &y = xx[2], &z = xx[3];
+    S rho = sqrt(pow2(x) + pow2(y) + pow2(z));
+    S cth = z / rho;
+    S th = acos(cth), ph = atan2(y, x), lat = asin(cth);
+    S m = cst<T, S>(M);
+    for (int p = 0; p < D; p++)
+        for (int q = 0; q < D; q++) g[p][q] = cst<T, S>(T(0));
+    g[0][0] = cst<T, S>(T(-1)) - (T(0.1) * m) * powr(rho, T(-1.5));
+    g[1][1] = cst<T, S>(T(1)) + T(0.05) * abs(lat) + T(0.02) * exp(cst<T, S>(T(0)) - rho);
+    g[2][2] = cst<T, S>(T(1)) + T(0.05) * cbrt(cst<T, S>(T(1)) + rho) / rho;
+    g[3][3] = cst<T, S>(T(1)) + T(0.03) * atan(rho) * log(cst<T, S>(T(2)) + rho) / rho;
+    g[1][2] = g[2][1] = T(0.01) * sin(ph) * cos(th);
+    g[0][3] = g[3][0] = T(0.02) * m * cth / rho;
+}
+
 template <class T, class S>
 inline void metric_eval(const rtgr_scene& sc, const S x[D], S g[D][D]) {
     const uint32_t kind = sc.metric & ~RTGR_METRIC_GENERIC;  // the flag picks a product code path, not a metric
     if (kind == RTGR_MINKOWSKI) minkowski<T, S>(x, g);
+    else if (kind == RTGR_USER && sc.user_metric == RTGR_ORACLE_ZOO) helper_zoo<T, S>(x, T(sc.M), g);
     else if (kind == RTGR_USER) schwarzschild_isotropic<T, S>(x, T(sc.M), g);
     else kerr_schild<T, S>(x, T(sc.M), T(sc.a), (int)kind, g);
 }
@@ -771,6 +827,48 @@ int rtgr_oracle_eval_geodesic_ld(const rtgr_scene* sc, const double* s, uint64_t
         for (int i = 0; i < 8; i++) si[i] = s[8 * p + i];
         geodesic<long double>(*sc, si, so);
         for (int i = 0; i < 8; i++) ds[8 * p + i] = (double)so[i];
+    }
+    return RTGR_OK;
+}
+// redshift g = (k.u_obs)/(k.u_emit) as include/rtgr.h (rtgr_ray_outputs.redshift) defines it — NO reference counterpart
+// (Sphere.vel is stored and never used, src/RayTraceGR.jl:411, :416): the oracle restates the DEFINITION independently,
+// with its own metric and its own 4x4 inverse.
+int rtgr_oracle_redshift_f64(const rtgr_scene* sc, const double* state0, const double* state_end, const uint8_t* hit,
+                             uint64_t n, double* out) {
+    if (!sc || !state0 || !state_end || !hit || !out) return RTGR_ERR_BAD_ARG;
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    auto observer = [](const double g[D][D], double t[D]) {
+        double gu[D][D];
+        inv4<double>(g, gu);
+        double t2 = 0;
+        for (int p = 0; p < D; p++) t[p] = gu[p][0];
+        for (int p = 0; p < D; p++) for (int q = 0; q < D; q++) t2 += t[p] * g[p][q] * t[q];
+        if (!(t2 < 0)) return false;
+        for (int p = 0; p < D; p++) t[p] /= std::sqrt(-t2);
+        return true;
+    };
+    auto dot = [](const double g[D][D], const double* a, const double* b) {
+        double s = 0;
+        for (int p = 0; p < D; p++) for (int q = 0; q < D; q++) s += a[p] * g[p][q] * b[q];
+        return s;
+    };
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t h = hit[i];
+        if (h == 0 || h > sc->nobj) { out[i] = nan; continue; }
+        double g0[D][D], ge[D][D], uo[D], ue[D];
+        metric_eval<double, double>(*sc, state0 + 8 * i, g0);
+        metric_eval<double, double>(*sc, state_end + 8 * i, ge);
+        bool ok = observer(g0, uo);
+        const rtgr_object& ob = sc->obj[h - 1];
+        if (ob.kind == RTGR_SPHERE) {
+            const double* v = ob.p + 4;
+            const double v2 = dot(ge, v, v);
+            ok = ok && v2 < 0;
+            for (int p = 0; p < D; p++) ue[p] = v[p] / std::sqrt(-v2);
+        } else {
+            ok = observer(ge, ue) && ok;
+        }
+        out[i] = ok ? dot(g0, state0 + 8 * i + 4, uo) / dot(ge, state_end + 8 * i + 4, ue) : nan;
     }
     return RTGR_OK;
 }

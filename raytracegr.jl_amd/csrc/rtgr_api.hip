@@ -406,7 +406,12 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
         A.hit = out->hit;
         A.n_accept = out->n_accept;
         A.n_reject = out->n_reject;
-        if (out->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
+        if (out->redshift) {
+            if (sizeof(R) != 8 || A.sc.metric == RTGR_USER)
+                return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift: Float64 entry points of the built-in metrics only");
+            if (!out->state_end || !out->hit)
+                return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift needs state_end and hit in the same call");
+        }
     }
     if (win) { A.plane_stride = win->plane_stride; A.out_offset = win->out_offset; A.nan_flag = win->nan_flag; }
     A.counters = (unsigned long long*)d_counters;
@@ -421,6 +426,13 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
     LaunchEnv E{D, *ss, user};
     rc = dispatch(E, A, generic, spin, st);
     if (rc) return rc;
+    if constexpr (sizeof(R) == 8) {
+        if (out && out->redshift) {   // one more kernel behind the pipeline: needs the end states and the hit map it wrote
+            rc = misc_redshift_f64(A.sc, A.cam, (const double*)A.state0, ni, nj, j0, jstride, ni * nrows, A.out_offset,
+                                   (const double*)A.state_end, A.hit, (double*)out->redshift, st);
+            if (rc) return rc;
+        }
+    }
     HIP_TRY(hipGetLastError());
     return RTGR_OK;
 }
@@ -481,28 +493,51 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     rtgr_ray_outputs dout;
     std::memset(&dout, 0, sizeof dout);
     if (out) {
-        if (out->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
+        if (out->redshift && (!out->state_end || !out->hit))
+            return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift needs state_end and hit in the same call");
         if (out->state_end) add(out->state_end, 8 * sizeof(R), 1);
         if (out->lambda_end) add(out->lambda_end, sizeof(R), 1);
         if (out->status) add(out->status, 1, 1);
         if (out->hit) add(out->hit, 1, 1);
         if (out->n_accept) add(out->n_accept, 4, 1);
         if (out->n_reject) add(out->n_reject, 4, 1);
+        if (out->redshift) add(out->redshift, sizeof(R), 1);
     }
     size_t out_bytes_per_ray = 0;
     for (auto& o : outs) out_bytes_per_ray += o.elem * o.planes;
 
     // ---- chunking ----------------------------------------------------------------------------------------------------
+    // Compute chunks of whole rows, sized P, 2P, 4P, 4P, …, 4P, 2P, P (P = one transfer piece, ~2^20 rays): the FIRST chunk
+    // is small so that integration starts after one piece has been packed and uploaded instead of four (the pipeline's
+    // fill), the LAST so that only a small unpack follows the last kernel (its drain); in between the chunks are big
+    // enough (4 M rays) that the persistent kernels lose nothing to their tails.  Measured at 4096² through
+    // rtgr_trace_pixels_f64: 119 ms with equal 4 M-ray chunks (device-resident: 86 ms).
     const uint64_t piece_target = D.knobs.host_chunk > 0 ? (uint64_t)D.knobs.host_chunk : (1ull << 20);
-    uint64_t rows_per_chunk = nrows;
-    if (!D.knobs.tile) {
-        const uint64_t chunk_target = 4 * piece_target;
-        rows_per_chunk = chunk_target / ni;
-        if (rows_per_chunk == 0) rows_per_chunk = 1;
-        if (rows_per_chunk > nrows) rows_per_chunk = nrows;
+    struct Chunk { uint64_t row0, rows; };
+    std::vector<Chunk> chunks;
+    if (D.knobs.tile) {
+        chunks.push_back({0, nrows});   // (the tile kernel writes whole slabs)
+    } else {
+        auto rows_for = [&](uint64_t rays) { const uint64_t r = rays / ni; return r ? r : (uint64_t)1; };
+        const uint64_t rP = rows_for(piece_target), r2 = rows_for(2 * piece_target), r4 = rows_for(4 * piece_target);
+        std::vector<uint64_t> head, tail;
+        uint64_t left = nrows;
+        const uint64_t ramp[2] = {rP, r2};
+        for (int k = 0; k < 2 && left > 0; k++) {            // P, 2P from the front ...
+            const uint64_t h = ramp[k] < left ? ramp[k] : left;
+            head.push_back(h); left -= h;
+            if (left == 0) break;
+            const uint64_t t = ramp[k] < left ? ramp[k] : left;   // ... and from the back
+            tail.push_back(t); left -= t;
+        }
+        while (left > 0) { const uint64_t m4 = r4 < left ? r4 : left; head.push_back(m4); left -= m4; }
+        uint64_t row0 = 0;
+        for (uint64_t r : head) { chunks.push_back({row0, r}); row0 += r; }
+        for (size_t k = tail.size(); k-- > 0;) { chunks.push_back({row0, tail[k]}); row0 += tail[k]; }
     }
-    const uint64_t nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk;
-    const uint64_t chunk_rays_max = rows_per_chunk * ni;
+    const uint64_t nchunks = chunks.size();
+    uint64_t chunk_rays_max = 0;
+    for (auto& ch : chunks) chunk_rays_max = ch.rows * ni > chunk_rays_max ? ch.rows * ni : chunk_rays_max;
     const uint64_t piece = chunk_rays_max < piece_target ? chunk_rays_max : piece_target;
 
     // ---- buffers (grow-only; device streams of the staging are idle here: every call ends synchronised) ----------------
@@ -529,6 +564,7 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
             if (out->hit) dout.hit = (uint8_t*)(dob + outs[k++].dev_off);
             if (out->n_accept) dout.n_accept = (uint32_t*)(dob + outs[k++].dev_off);
             if (out->n_reject) dout.n_reject = (uint32_t*)(dob + outs[k++].dev_off);
+            if (out->redshift) dout.redshift = dob + outs[k++].dev_off;
         }
     }
     R* d_in = (R*)S->d_in.p;
@@ -547,11 +583,7 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     std::atomic<bool> abort_flag{false};
     std::vector<std::atomic<int>> slot_busy(Staging::OUT_SLOTS);
     for (auto& b : slot_busy) b.store(0);
-    auto chunk_range = [&](uint64_t c, uint64_t& r0, uint64_t& m) {
-        const uint64_t row0 = c * rows_per_chunk;
-        const uint64_t rows = (nrows - row0) < rows_per_chunk ? (nrows - row0) : rows_per_chunk;
-        r0 = row0 * ni; m = rows * ni;
-    };
+    auto chunk_range = [&](uint64_t c, uint64_t& r0, uint64_t& m) { r0 = chunks[c].row0 * ni; m = chunks[c].rows * ni; };
     const int dev_ordinal = D.dev;
     std::thread downloader([&] {
         (void)hipSetDevice(dev_ordinal);
@@ -623,8 +655,7 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
         }
         Window win;
         win.plane_stride = n; win.out_offset = r0; win.nan_flag = have_in ? d_nan : nullptr;
-        const uint64_t row0 = c * rows_per_chunk;
-        const uint64_t rows = m / ni;
+        const uint64_t row0 = chunks[c].row0, rows = chunks[c].rows;
         if (D.knobs.tile) { win.plane_stride = 0; win.out_offset = 0; }
         rc = trace_device<R>(D, scene, opt, have_in ? d_in + r0 * 8 : nullptr, cam, ni, nj, j0 + row0, j0 + row0 + rows, d_rgb,
                              &dout, d_ctr, S->s_comp, 1, 0, &win);
@@ -929,7 +960,8 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
     if (!scene || !opt || !cam) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
     if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
     if (c->devs[0]->knobs.tile) return fail(RTGR_ERR_BAD_ARG, "the multi-device path needs the persistent pipeline (option tile = 0)");
-    if (out0 && out0->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
+    if (out0 && out0->redshift && (!out0->state_end || !out0->hit))
+        return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift needs state_end and hit in the same call");
     struct Arr { size_t elem; int planes; void* full; size_t off; };  // one per requested array
     std::vector<Arr> arrs;
     arrs.push_back({8, 3, d_rgb0, 0});
@@ -940,6 +972,7 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         if (out0->hit) arrs.push_back({1, 1, out0->hit, 0});
         if (out0->n_accept) arrs.push_back({4, 1, out0->n_accept, 0});
         if (out0->n_reject) arrs.push_back({4, 1, out0->n_reject, 0});
+        if (out0->redshift) arrs.push_back({8, 1, out0->redshift, 0});
     }
     const uint64_t nrows_max = (nj + N - 1) / N, nmax = ni * nrows_max;
     size_t part_bytes = 0;
@@ -981,6 +1014,7 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
             if (out0->hit) po.hit = (uint8_t*)(pb + arrs[q++].off);
             if (out0->n_accept) po.n_accept = (uint32_t*)(pb + arrs[q++].off);
             if (out0->n_reject) po.n_reject = (uint32_t*)(pb + arrs[q++].off);
+            if (out0->redshift) po.redshift = pb + arrs[q++].off;
         }
         rc = trace_device<double>(D, scene, opt, nullptr, cam, ni, nj, k, k + 1, (double*)pb, &po, (rtgr_counters*)S[k]->d_small.p,
                                   S[k]->s_comp, N, nrows[k]);
@@ -1052,13 +1086,13 @@ int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtg
     rtgr_ray_outputs dout;
     std::memset(&dout, 0, sizeof dout);
     if (out) {
-        if (out->redshift) return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift is not built yet");
         if (out->state_end) items.push_back({out->state_end, (size_t)n * 64, nullptr});
         if (out->lambda_end) items.push_back({out->lambda_end, (size_t)n * 8, nullptr});
         if (out->status) items.push_back({out->status, (size_t)n, nullptr});
         if (out->hit) items.push_back({out->hit, (size_t)n, nullptr});
         if (out->n_accept) items.push_back({out->n_accept, (size_t)n * 4, nullptr});
         if (out->n_reject) items.push_back({out->n_reject, (size_t)n * 4, nullptr});
+        if (out->redshift) items.push_back({out->redshift, (size_t)n * 8, nullptr});
     }
     size_t total = 0;
     for (auto& it : items) total += align256(it.bytes);
@@ -1075,6 +1109,7 @@ int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtg
             if (out->hit) dout.hit = (uint8_t*)items[k++].dev;
             if (out->n_accept) dout.n_accept = (uint32_t*)items[k++].dev;
             if (out->n_reject) dout.n_reject = (uint32_t*)items[k++].dev;
+            if (out->redshift) dout.redshift = items[k++].dev;
         }
     }
     if ((rc = trace_sharded(c, scene, opt, cam, ni, nj, (double*)items[0].dev, &dout, ctr))) return rc;

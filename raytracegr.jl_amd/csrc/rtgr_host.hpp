@@ -161,12 +161,10 @@ int misc_eval_metric_f32(const DevScene<float>& sc, const float* d_x, uint64_t n
 int misc_eval_geodesic_f64(const DevScene<double>& sc, const double* d_s, uint64_t n, int path, double* d_ds, hipStream_t st);
 int misc_eval_geodesic_f32(const DevScene<float>& sc, const float* d_s, uint64_t n, int path, float* d_ds, hipStream_t st);
 int misc_eval_fastmath_f64(const double* d_x, uint64_t n, double* d_rcp, double* d_rsq, hipStream_t st);
+int misc_redshift_f64(const DevScene<double>& sc, const DevCamera<double>& cam, const double* d_state0, uint64_t ni, uint64_t nj,
+                      uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const double* d_state_end,
+                      const uint8_t* d_hit, double* d_red, hipStream_t st);
 int misc_quantize(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, hipStream_t st);
-// Pixel{Float64} AoS (11 doubles) -> ray states, with the reference's NaN assertion (:279) evaluated on the device:
-// *d_nan_flag is set to 1 when any of the 8 input scalars of any pixel is NaN
-int misc_pixels_in(const double* d_px, uint64_t n, double* d_state0, uint32_t* d_nan_flag, hipStream_t st);
-int misc_pixels_out(const double* d_px_in, const double* d_rgb, uint64_t n_slab, uint64_t first, uint64_t n, double* d_px_out, hipStream_t st);
-int misc_nan_scan(const void* d_v, uint64_t count, bool f32, uint32_t* d_nan_flag, hipStream_t st);
 // multi-device gather on device 0: rows of rank r (cyclic over nranks) back into place
 int misc_place_rows_f64(const double* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,
                         double* d_full, hipStream_t st);

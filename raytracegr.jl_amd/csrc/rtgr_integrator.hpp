@@ -314,6 +314,29 @@ RTGR_DEV uint8_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, co
     return (uint8_t)omin;
 }
 
+// metric(x) with plain scalars (no duals): what make_canvas calls (:469)
+template <class R>
+RTGR_DEV void metric_plain(const DevScene<R>& sc, const R x[4], R g[4][4]) {
+#ifdef RTGR_USER_METRIC
+    if (sc.metric == (uint32_t)RTGR_USER) {
+        rtgr_user_metric<R>(x, (double)sc.M, (double)sc.a, g);
+        return;
+    }
+#endif
+    // built-ins are η + f k k
+    R f = R(0), kk[4] = {R(1), R(0), R(0), R(0)};
+    if (sc.metric != RTGR_MINKOWSKI) {
+        KSField<R> F;
+        if (sc.metric == RTGR_KS_REF) ks_field<R, RTGR_KS_REF, true>(x[1], x[2], x[3], sc.M, sc.a, F);
+        else ks_field<R, RTGR_KS_TRUE, true>(x[1], x[2], x[3], sc.M, sc.a, F);
+        f = F.f; kk[1] = F.k[0]; kk[2] = F.k[1]; kk[3] = F.k[2];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[p][q] = (p == q ? (p == 0 ? R(-1) : R(1)) : R(0)) + f * kk[p] * kk[q];
+}
+
 // ---- make_canvas pixel (src/RayTraceGR.jl:464-476): state (x, u) of pixel (i, j), 0-based -------------------------
 template <class R>
 RTGR_DEV void make_pixel(const DevScene<R>& sc, const DevCamera<R>& cam, uint64_t ni, uint64_t nj, uint64_t i0,
@@ -327,24 +350,7 @@ RTGR_DEV void make_pixel(const DevScene<R>& sc, const DevCamera<R>& cam, uint64_
         n[c] = cam.normal[c] + dx * cam.widthx[c] + dy * cam.widthy[c];               // :468
     }
     R g[4][4];
-#ifdef RTGR_USER_METRIC
-    if (sc.metric == (uint32_t)RTGR_USER) {
-        rtgr_user_metric<R>(x, (double)sc.M, (double)sc.a, g);   // metric(x) with plain scalars (:469)
-    } else
-#endif
-    {   // metric(x) with plain scalars (:469); built-ins are η + f k k
-        R f = R(0), kk[4] = {R(1), R(0), R(0), R(0)};
-        if (sc.metric != RTGR_MINKOWSKI) {
-            KSField<R> F;
-            if (sc.metric == RTGR_KS_REF) ks_field<R, RTGR_KS_REF, true>(x[1], x[2], x[3], sc.M, sc.a, F);
-            else ks_field<R, RTGR_KS_TRUE, true>(x[1], x[2], x[3], sc.M, sc.a, F);
-            f = F.f; kk[1] = F.k[0]; kk[2] = F.k[1]; kk[3] = F.k[2];
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) g[p][q] = (p == q ? (p == 0 ? R(-1) : R(1)) : R(0)) + f * kk[p] * kk[q];
-    }
+    metric_plain<R>(sc, x, g);                                                        // :469
     R gu[4][4];
     inv4sym<R>(g, gu);                                                                // :470
     R t[4];

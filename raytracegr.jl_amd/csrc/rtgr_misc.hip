@@ -3,7 +3,7 @@
 //   eval_metric_kernel / eval_geodesic_kernel / eval_fastmath_kernel   parity hooks (the reference's unit-test surface,
 //                                 test/runtests.jl:12-61; the hot loop's own RHS and reciprocal helpers)
 //   quantize_kernel               N0f8 rounding + transposed image layout of save() (:566-575)
-//   pixels_in / pixels_out        AoS Pixel{T} array <-> ray states / rgb (:446-450, :532), NaN assertion of :279 on the device
+//   redshift_kernel               frequency ratio observed/emitted from Sphere.vel (no reference counterpart)
 //   place_rows                    multi-device gather: a rank's cyclic rows back into the full frame on device 0
 #include "rtgr_host.hpp"
 #include "rtgr_integrator.hpp"
@@ -98,33 +98,6 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double* rgb, uint64
     }
 }
 
-// Pixel{Float64} AoS (11 doubles: pos 4, normal 4, rgb 3; src/RayTraceGR.jl:446-450) -> ray states.  One thread per
-// SCALAR so that both sides are coalesced (88-byte records read by one thread each waste 8/11 of every line twice).
-// The reference asserts !isnan on every metric call (:279): any NaN among the 8 inputs raises the flag.
-__global__ __launch_bounds__(256) void pixels_in_kernel(const double* px, uint64_t n, double* state0, uint32_t* nan_flag) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 8) return;
-    const uint64_t idx = t >> 3;
-    const uint32_t c = (uint32_t)(t & 7);
-    const double v = px[idx * 11 + c];
-    state0[t] = v;
-    if (v != v) atomicOr(nan_flag, 1u);
-}
-// Pixel{T}(p.pos, p.normal, col)  (:532): 11 scalars per pixel, one thread per scalar
-__global__ __launch_bounds__(256) void pixels_out_kernel(const double* px_in, const double* rgb, uint64_t n_slab, uint64_t first,
-                                                         uint64_t n, double* px_out) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 11) return;
-    const uint64_t idx = t / 11;
-    const uint32_t c = (uint32_t)(t - idx * 11);
-    px_out[t] = c < 8 ? px_in[t] : rgb[(uint64_t)(c - 8) * n_slab + first + idx];
-}
-template <class R>
-__global__ __launch_bounds__(256) void nan_scan_kernel(const R* v, uint64_t count, uint32_t* nan_flag) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < count && v[t] != v[t]) atomicOr(nan_flag, 1u);
-}
-
 // part: `planes` planes of ni*nrows elements, local row k = image row rank + k*nranks;  full: planes of ni*nj
 template <class T>
 __global__ __launch_bounds__(256) void place_rows_kernel(const T* part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks,
@@ -137,6 +110,67 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const T* part, uint64_t
     const uint64_t row_elems = ni * elem;
     const uint64_t k = r / row_elems, i = r - k * row_elems;
     full[pl * ni * nj * elem + (rank + k * nranks) * row_elems + i] = part[t];
+}
+
+// ---- redshift (rtgr_ray_outputs.redshift; SURVEY §8 f4: "Doppler/redshift via the unused Sphere.vel", :411, :416) --------
+// g = (k·u_obs) / (k·u_emit): the ratio observed / emitted frequency of the light that reaches a pixel.
+//   k      = tangent of the traced ray (an affinely parametrised null geodesic, so k is parallel-transported and the
+//            ratio does not depend on its normalisation or on the direction the ray was traced in)
+//   u_obs  = the static observer make_canvas builds every ray from: t̂ = g^{-1} e_t / sqrt(−g(t,t)) at the pixel (:471-472)
+//   u_emit = Sphere: its `vel` (coordinate 4-velocity as stored in the reference's struct) normalised with the metric at
+//            the hit point; Plane / Disk: the static observer t̂ there
+//   ·      = the metric at the respective end of the ray
+// NaN where nothing is hit, or where u_emit is not timelike (a static emitter inside the ergoregion, vel = 0, …).
+template <class R>
+RTGR_DEV void static_observer(const R g[4][4], R t[4], bool& ok) {
+    R gu[4][4];
+    inv4sym<R>(g, gu);
+    R t2 = R(0);
+    for (int p = 0; p < 4; p++) t[p] = gu[p][0];
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; q < 4; q++) t2 += t[p] * g[p][q] * t[q];
+    ok = t2 < R(0);
+    const R s = R(1) / rsqrt_(-t2);
+    for (int p = 0; p < 4; p++) t[p] *= s;
+}
+template <class R>
+RTGR_DEV R inner(const R g[4][4], const R a[4], const R b[4]) {
+    R acc = R(0);
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; q < 4; q++) acc += a[p] * g[p][q] * b[q];
+    return acc;
+}
+__global__ __launch_bounds__(256) void redshift_kernel(DevScene<double> sc, DevCamera<double> cam, const double* state0,
+                                                       uint64_t ni, uint64_t nj, uint64_t j0, uint64_t jstride, uint64_t n,
+                                                       uint64_t out_offset, const double* state_end, const uint8_t* hit,
+                                                       double* red) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const uint64_t idx = out_offset + w;
+    const double nan = __builtin_nan("");
+    const uint32_t h = hit[idx];
+    if (h == 0 || h > sc.nobj) { red[idx] = nan; return; }
+    double s0[8], se[8];
+    if (state0) for (int c = 0; c < 8; c++) s0[c] = state0[w * 8 + c];
+    else make_pixel<double>(sc, cam, ni, nj, w % ni, j0 + (w / ni) * jstride, s0);
+    for (int c = 0; c < 8; c++) se[c] = state_end[idx * 8 + c];
+    double g0[4][4], ge[4][4], tobs[4], uem[4];
+    bool ok0, oke;
+    metric_plain<double>(sc, s0, g0);
+    static_observer<double>(g0, tobs, ok0);
+    metric_plain<double>(sc, se, ge);
+    const DevObject<double>& ob = sc.obj[h - 1];
+    if (ob.kind == RTGR_SPHERE) {
+        const double v[4] = {ob.p[4], ob.p[5], ob.p[6], ob.p[7]};
+        const double v2 = inner<double>(ge, v, v);
+        oke = v2 < 0.0;
+        const double s = 1.0 / __builtin_sqrt(-v2);
+        for (int p = 0; p < 4; p++) uem[p] = v[p] * s;
+    } else {
+        static_observer<double>(ge, uem, oke);
+    }
+    const double num = inner<double>(g0, s0 + 4, tobs), den = inner<double>(ge, se + 4, uem);
+    red[idx] = (ok0 && oke) ? num / den : nan;
 }
 
 #define CHECK_LAUNCH()                                     \
@@ -181,22 +215,6 @@ int misc_quantize(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img,
     CHECK_LAUNCH();
     return RTGR_OK;
 }
-int misc_pixels_in(const double* d_px, uint64_t n, double* d_state0, uint32_t* d_nan_flag, hipStream_t st) {
-    hipLaunchKernelGGL(pixels_in_kernel, dim3(nblk(n * 8)), dim3(256), 0, st, d_px, n, d_state0, d_nan_flag);
-    CHECK_LAUNCH();
-    return RTGR_OK;
-}
-int misc_pixels_out(const double* d_px_in, const double* d_rgb, uint64_t n_slab, uint64_t first, uint64_t n, double* d_px_out, hipStream_t st) {
-    hipLaunchKernelGGL(pixels_out_kernel, dim3(nblk(n * 11)), dim3(256), 0, st, d_px_in, d_rgb, n_slab, first, n, d_px_out);
-    CHECK_LAUNCH();
-    return RTGR_OK;
-}
-int misc_nan_scan(const void* d_v, uint64_t count, bool f32, uint32_t* d_nan_flag, hipStream_t st) {
-    if (f32) hipLaunchKernelGGL(nan_scan_kernel<float>, dim3(nblk(count)), dim3(256), 0, st, (const float*)d_v, count, d_nan_flag);
-    else hipLaunchKernelGGL(nan_scan_kernel<double>, dim3(nblk(count)), dim3(256), 0, st, (const double*)d_v, count, d_nan_flag);
-    CHECK_LAUNCH();
-    return RTGR_OK;
-}
 int misc_place_rows_f64(const double* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,
                         double* d_full, hipStream_t st) {
     const uint64_t nrows = (nj - rank + nranks - 1) / nranks;
@@ -214,4 +232,15 @@ int misc_place_rows_u8(const uint8_t* d_part, uint64_t ni, uint64_t nj, uint64_t
     return RTGR_OK;
 }
 
+}  // namespace rtgr
+
+namespace rtgr {
+int misc_redshift_f64(const DevScene<double>& sc, const DevCamera<double>& cam, const double* d_state0, uint64_t ni, uint64_t nj,
+                      uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const double* d_state_end,
+                      const uint8_t* d_hit, double* d_red, hipStream_t st) {
+    hipLaunchKernelGGL(redshift_kernel, dim3(nblk(n)), dim3(256), 0, st, sc, cam, d_state0, ni, nj, j0, jstride, n, out_offset,
+                       d_state_end, d_hit, d_red);
+    CHECK_LAUNCH();
+    return RTGR_OK;
+}
 }  // namespace rtgr

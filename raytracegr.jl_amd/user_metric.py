@@ -38,9 +38,10 @@ def cache_dir():
     return d
 
 
-def _digest(source):
+def _digest(source, extra_flags=()):
     h = hashlib.sha256()
     h.update(source.encode())
+    h.update(" ".join(extra_flags).encode())
     for f in [TEMPLATE] + _HEADERS:
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -48,13 +49,16 @@ def _digest(source):
     return h.hexdigest()[:20]
 
 
-def compile_user_metric(source, verbose=False):
-    """Build (or fetch from the cache) the code object of a user metric; returns its path.  Needs hipcc, no GPU."""
+def compile_user_metric(source, verbose=False, stationary=False):
+    """Build (or fetch from the cache) the code object of a user metric; returns its path.  Needs hipcc, no GPU.
+    stationary=True declares that the metric does not depend on t: the integrate kernels then carry the three spatial
+    partials only (-DRTGR_USER_NE=3), a quarter less dual arithmetic."""
     if "rtgr_user_metric" not in source:
         raise ValueError("the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
                          "double M, double a, S g[4][4])`")
     d = cache_dir()
-    tag = _digest(source)
+    extra = ["-DRTGR_USER_NE=3"] if stationary else []
+    tag = _digest(source, extra)
     out = os.path.join(d, f"metric_{tag}.hsaco")
     if os.path.exists(out):
         return out
@@ -66,7 +70,7 @@ def compile_user_metric(source, verbose=False):
         fh.write(unit)
     os.replace(tmp_src, src)
     tmp = out + f".tmp{os.getpid()}"
-    cmd = [_build.HIPCC] + FLAGS + ["-I", CSRC, "-o", tmp, src]
+    cmd = [_build.HIPCC] + FLAGS + extra + ["-I", CSRC, "-o", tmp, src]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -99,9 +103,10 @@ class UserMetric:
     kind = _abi.USER
     generic = True
 
-    def __init__(self, source, M=1.0, a=0.0, name="user_metric", verbose=False):
+    def __init__(self, source, M=1.0, a=0.0, name="user_metric", verbose=False, stationary=False):
         self.source, self.M, self.a, self.name = source, float(M), float(a), name
-        self.code_object = compile_user_metric(source, verbose=verbose)
+        self.stationary = bool(stationary)
+        self.code_object = compile_user_metric(source, verbose=verbose, stationary=stationary)
 
     def module_id(self, ctx=None):
         """id of this metric's module in the context (loads the code object on first use)"""

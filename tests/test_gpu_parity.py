@@ -582,6 +582,72 @@ def test_8192_disk_frame_properties(lib):
     assert torch.equal(b["rgb"].reshape(3, 64, n), stats[n][2]["rgb"].reshape(3, n, n)[:, 77::128, :])
 
 
+def _trace_with_redshift(lib, sc, opt, ni, nj, cam):
+    n = ni * nj
+    rgb = np.zeros((3, n))
+    o, arrs = O._outs(n, np.float64, True)
+    red = np.zeros(n)
+    o.redshift = red.ctypes.data
+    abi.check(lib, lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), ni, nj, 0, nj, rgb.ctypes.data,
+                                      C.byref(o), None))
+    arrs.update(rgb=rgb, redshift=red)
+    return arrs
+
+
+def test_redshift_output_matches_its_definition(lib):
+    """rtgr_ray_outputs.redshift = (k.u_obs)/(k.u_emit) (the Doppler / gravitational frequency ratio from
+    the Sphere.vel field the reference stores and never uses, src/RayTraceGR.jl:411, :416).  No reference counterpart, so
+    the checks are the stated definition: (1) special relativity in Minkowski — a sphere moving with β along x seen by the
+    static camera: 1/(γ(1 − β n_x)); (2) Kerr–Schild a = 0.8: the oracle's independent evaluation of the definition from the
+    same end states (own metric, own inverse); (3) NaN where nothing is hit; (4) the same plane through the multi-device
+    entry point."""
+    import torch
+    # (1)
+    beta = 0.4
+    gam = 1 / np.sqrt(1 - beta * beta)
+    _, objs, cam = rt.example1_scene()
+    objs[2] = rt.Sphere((0, 0, 0, 0), (gam, gam * beta, 0, 0), 0.5)
+    sc, camera, opt = rt.make_scene(rt.minkowski, objs), rt.make_camera(**cam), rt.solver_defaults()
+    r = _trace_with_redshift(lib, sc, opt, 64, 64, camera)
+    on = r["hit"] == 3
+    u = r["state_end"][on, 4:]
+    want = 1 / (gam * (1 - beta * u[:, 1] / u[:, 0]))
+    assert on.sum() > 50 and np.abs(r["redshift"][on] / want - 1).max() < 1e-12
+    static = (r["hit"] == 1) | (r["hit"] == 2)      # sky sphere with vel = e_t, plane: static emitters in flat space
+    assert np.abs(r["redshift"][static] - 1).max() < 1e-12
+    # (2) + (3)
+    _, objs, cam = rt.example2_scene()
+    objs[2] = rt.Sphere((0, 4, 0, 0), (1.1, 0.2, -0.1, 0.3), 0.5)
+    sc, camera = rt.make_scene(rt.KerrSchild(1, 0.8), objs), rt.make_camera(**cam)
+    r = _trace_with_redshift(lib, sc, opt, 64, 64, camera)
+    s0 = O.make_canvas(sc, camera, 64, 64)
+    want = np.zeros(64 * 64)
+    assert O.lib().rtgr_oracle_redshift_f64(C.byref(sc), C.c_void_p(s0.ctypes.data), C.c_void_p(r["state_end"].ctypes.data),
+                                            C.c_void_p(r["hit"].ctypes.data), C.c_uint64(64 * 64), C.c_void_p(want.ctypes.data)) == 0
+    fin = np.isfinite(want)
+    assert np.array_equal(fin, np.isfinite(r["redshift"])) and fin.sum() > 3000 and (~fin).sum() > 0
+    assert np.abs(r["redshift"][fin] / want[fin] - 1).max() < 1e-11
+    assert (r["redshift"][fin] > 0).all() and r["redshift"][fin].std() > 1e-3
+    # (4)
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 2)
+    try:
+        n = 64 * 64
+        rgb = np.zeros((3, n))
+        o, arrs = O._outs(n, np.float64, True)
+        red = np.zeros(n)
+        o.redshift = red.ctypes.data
+        abi.check(lib, lib.rtgr_trace_sharded_f64(ctx, C.byref(sc), C.byref(opt), C.byref(camera), 64, 64, rgb.ctypes.data,
+                                                  C.byref(o), None))
+        assert np.array_equal(np.isnan(red), np.isnan(r["redshift"])) and np.array_equal(red[fin], r["redshift"][fin])
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+    # needs the end states and the hit map in the same call
+    o2 = abi.rtgr_ray_outputs()
+    o2.redshift = red.ctypes.data
+    assert lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(camera), 8, 8, 0, 8, rgb.ctypes.data,
+                              C.byref(o2), None) == abi.ERR_BAD_ARG
+
+
 def _random_scene(seed):
     """Seeded random scene: 1-6 objects (spheres incl. inside-out ones, planes, disks), random metric variant, random
     camera, random solver constants — exercises rays that start inside objects, end by λ1, miss everything, fall into

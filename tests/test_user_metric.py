@@ -134,6 +134,42 @@ def test_user_isotropic_schwarzschild_matches_the_oracle(lib):
 
 
 @pytest.mark.gpu
+def test_user_helper_functions_match_oracle_twins(lib):
+    """mabs macos masin matan matan2 mcbrt mpow mexp mlog msin mcos msqrt — the elementary functions of the reference's
+    Dual (src/RayTraceGR.jl:132-196) — through a metric that uses all of them, against the oracle's twins: g, dg, Γ and
+    the geodesic RHS point by point (Float64), and the Float32 unit against the Float64 oracle at a Float32 bar."""
+    user = rt.UserMetric(user_metrics.HELPER_ZOO, M=1.3, stationary=True)
+    sc_o = rt.make_scene(user, [])
+    sc_o.user_metric = 0x200          # the oracle's marker for its copy of this function (it has no module ids)
+    x, rng = _points(2048, 9, rmin=0.8)
+    x[:, 3] += 0.05 * np.sign(x[:, 3]) + (x[:, 3] == 0) * 0.05   # keep off the mabs kink z = 0
+    g, dg = rt.dmetric(user, x)
+    Gam = rt.christoffel(user, x)
+    go, dgo, Go = O.eval_metric(sc_o, x)
+    assert np.abs(g - go).max() <= 1e-14 and np.abs(dg - dgo).max() <= 5e-14 and np.abs(Gam - Go).max() <= 5e-13
+    assert np.abs(dg[..., 0]).max() == 0.0 and np.abs(dg).max() > 1e-3
+    s = np.concatenate([x, rng.normal(size=(len(x), 4))], axis=1)
+    got, ref = rt.geodesic(s, user, path=1), O.geodesic(sc_o, s)
+    scale = np.abs(ref[:, 4:]).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(got[:, 4:] - ref[:, 4:]) / scale).max() < 5e-12
+    # traced end to end in Float64 (3 spatial partials: stationary) and Float32 (the unit's Float32 kernels)
+    _, objs, cam = rt.example2_scene()
+    from test_gpu_parity import hip_trace
+    camera = rt.make_camera(**cam)
+    scn = rt.make_scene(user, objs)
+    sco = rt.make_scene(user, objs)
+    sco.user_metric = 0x200
+    opt = rt.solver_defaults()
+    compare(hip_trace(lib, scn, opt, 32, 32, cam=camera), O.trace(sco, opt, 32, 32, cam=camera), max_class_flips=2, max_step_diff=2)
+    opt32 = rt.solver_defaults(np.float32)
+    g32 = hip_trace(lib, scn, opt32, 32, 32, cam=camera, dtype=np.float32)
+    r32 = O.trace(sco, opt32, 32, 32, cam=camera, dtype=np.float32)
+    flips = g32["hit"] != r32["hit"]
+    assert flips.mean() <= 0.02
+    assert wrap_aware_rgb_err(g32["rgb"][:, ~flips].astype(float), r32["rgb"][:, ~flips].astype(float), g32["hit"][~flips], 3) < 2e-2
+
+
+@pytest.mark.gpu
 def test_scenes_of_two_resident_user_metrics_run_their_own_kernels(lib):
     """Several metric modules are resident at once and a scene names its own (rtgr_scene.user_metric): building the
     scene of metric B must not change what the scene of metric A computes (round 1 had ONE resident module, activated
