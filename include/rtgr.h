@@ -159,9 +159,11 @@ typedef struct rtgr_ray_outputs {
     uint32_t* n_reject;   /* n: rejected attempts per ray                                                   */
     void* redshift;       /* n scalars: g = (k.u_obs)/(k.u_emit), the frequency ratio observed/emitted of the light that
                              reaches the pixel (k = the ray's tangent, . = the metric's inner product).  u_obs = the
-                             camera's static observer (make_canvas' normalised g^-1 e_t, :471-472) at the pixel;
-                             u_emit = the hit Sphere's `vel` (:411) normalised at the end point, or the static observer
-                             there for planes / disks; NaN where the ray hits nothing or u_emit is not timelike.
+                             camera's static observer at the pixel, future-directed: -g^-1 e_t normalised (make_canvas
+                             builds its past-directed rays from +g^-1 e_t, :471-472); u_emit = the hit Sphere's `vel`
+                             (:411; a future-directed coordinate 4-velocity such as the examples' (1,0,0,0)) normalised
+                             at the end point, or the static observer there for planes / disks; NaN where the ray hits
+                             nothing or u_emit is not timelike.
                              No reference counterpart (`vel` is stored and never used, :411, :416).  Float64 entry
                              points of the built-in metrics only. */
 } rtgr_ray_outputs;

@@ -844,7 +844,7 @@ int rtgr_oracle_redshift_f64(const rtgr_scene* sc, const double* state0, const d
         for (int p = 0; p < D; p++) t[p] = gu[p][0];
         for (int p = 0; p < D; p++) for (int q = 0; q < D; q++) t2 += t[p] * g[p][q] * t[q];
         if (!(t2 < 0)) return false;
-        for (int p = 0; p < D; p++) t[p] /= std::sqrt(-t2);
+        for (int p = 0; p < D; p++) t[p] /= -std::sqrt(-t2);   // future-directed (g^{-1} e_t itself points to the past)
         return true;
     };
     auto dot = [](const double g[D][D], const double* a, const double* b) {

@@ -523,9 +523,11 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
         std::vector<uint64_t> head, tail;
         uint64_t left = nrows;
         const uint64_t ramp[2] = {rP, r2};
-        for (int k = 0; k < 2 && left > 0; k++) {            // P, 2P from the front ...
-            const uint64_t h = ramp[k] < left ? ramp[k] : left;
-            head.push_back(h); left -= h;
+        for (int k = 0; k < 2 && left > 0; k++) {            // P, 2P from the front (only when there is input to wait for) ...
+            if (have_in) {
+                const uint64_t h = ramp[k] < left ? ramp[k] : left;
+                head.push_back(h); left -= h;
+            }
             if (left == 0) break;
             const uint64_t t = ramp[k] < left ? ramp[k] : left;   // ... and from the back
             tail.push_back(t); left -= t;

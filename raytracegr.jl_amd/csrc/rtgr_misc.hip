@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const T* part, uint64_t
 // g = (k·u_obs) / (k·u_emit): the ratio observed / emitted frequency of the light that reaches a pixel.
 //   k      = tangent of the traced ray (an affinely parametrised null geodesic, so k is parallel-transported and the
 //            ratio does not depend on its normalisation or on the direction the ray was traced in)
-//   u_obs  = the static observer make_canvas builds every ray from: t̂ = g^{-1} e_t / sqrt(−g(t,t)) at the pixel (:471-472)
+//   u_obs  = the static observer make_canvas builds every ray from, future-directed: −g^{-1} e_t / sqrt(−g(t,t)) at the
+//            pixel (:471-472; the reference uses the past-directed sign because it traces rays backwards in time)
 //   u_emit = Sphere: its `vel` (coordinate 4-velocity as stored in the reference's struct) normalised with the metric at
 //            the hit point; Plane / Disk: the static observer t̂ there
 //   ·      = the metric at the respective end of the ray
@@ -130,7 +131,7 @@ RTGR_DEV void static_observer(const R g[4][4], R t[4], bool& ok) {
     for (int p = 0; p < 4; p++)
         for (int q = 0; q < 4; q++) t2 += t[p] * g[p][q] * t[q];
     ok = t2 < R(0);
-    const R s = R(1) / rsqrt_(-t2);
+    const R s = R(-1) / rsqrt_(-t2);   // g^{-1} e_t points to the past (make_canvas builds past-directed rays from it); −: future
     for (int p = 0; p < 4; p++) t[p] *= s;
 }
 template <class R>

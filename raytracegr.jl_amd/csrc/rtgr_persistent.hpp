@@ -38,6 +38,15 @@
 #ifndef RTGR_WAVES_PER_SIMD_GENERIC
 #define RTGR_WAVES_PER_SIMD_GENERIC 2  // generic dual-number RHS: ~270 registers wanted; 2 waves with a small spill beat 1 wave (measured 6.72 vs 6.22 Gstep/s)
 #endif
+#ifndef RTGR_LDSK_GENERIC
+#define RTGR_LDSK_GENERIC 0   // generic RHS kernels keep k[1..5] in LDS (experiment: see DESIGN §4.2 "LDS stage storage")
+#endif
+#ifndef RTGR_LDSK_SPIN_FAR
+#define RTGR_LDSK_SPIN_FAR 0  // the a != 0 FAR pass keeps k[1..5] in LDS (experiment, with RTGR_WAVES_PER_SIMD_SPIN_FAR=4)
+#endif
+#ifndef RTGR_WAVES_PER_SIMD_SPIN_FAR
+#define RTGR_WAVES_PER_SIMD_SPIN_FAR RTGR_WAVES_PER_SIMD_FAR
+#endif
 #ifndef RTGR_WAVES_PER_SIMD_GENERIC_F32
 #define RTGR_WAVES_PER_SIMD_GENERIC_F32 3  // generic dual-number RHS in Float32: half the register bytes of the f64 kernel
 #endif
@@ -130,7 +139,7 @@ RTGR_DEV void flush_early(const IntegrateArgs<R>& A, const uint32_t* buf, uint32
 // ---------------------------------------------------------------------------------------------------------------------
 // The kernel body is a device function so that run-time generated units (user metrics, rtgr_user_template.hip) can
 // wrap it in extern "C" kernels of their own.
-template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE>
+template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE, bool LDSK = false>
 RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     using N = Tsit5N<R>;
     const uint32_t lane = threadIdx.x & 63;
@@ -174,6 +183,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     bool first_pop = true;
     bool first_early = true, early_done = false;  // NEAR: the early list's own cursor (ctrl[7])
     __shared__ uint32_t early_buf[RTGR_EARLY_BUF];  // one wave per workgroup: private to the wave (used by the FAR pass)
+    __shared__ R ldsk_mem[LDSK ? 20 * 64 : 1];
+    volatile R* const ldsk = ldsk_mem + lane;   // (volatile: re-read at each use instead of being kept live in registers)
     uint32_t e_cnt = 0;                             // entries in early_buf (wave-uniform)
 #ifdef RTGR_ROOT_STATS
     const unsigned long long dbg_t0 = wall_clock64();
@@ -307,6 +318,15 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         bool commit = false;
         bool list_it = false;  // FAR: this lane's ray goes on the early list (set at hand-over)
         R xn[4], un[4], k[7][4];  // k[l] = acceleration at stage l+1 (k[0] is the FSAL slot, k[6] the next one)
+        // LDSK (SURVEY §7.4 "k-stage storage in LDS if VGPR > 256"; BASELINE config 4's "LDS-tiled variant"): the stage
+        // accelerations k[1..5] — 20 scalars, 40 VGPRs in f64 — live in LDS between the stage that produces them and the
+        // stage sums / error estimate / reach bound that read them; slot (l, q) of lane i is word ((l−1)·4 + q)·64 + i, so
+        // every access of a wave is 64 consecutive scalars (conflict-free ds_read/write_b64)
+#define KL(l, q) ((LDSK && (l) >= 1 && (l) <= 5) ? (R)ldsk[(((l) - 1) * 4 + (q)) * 64] : k[l][q])
+#define KSTORE(l)                                                                   \
+        if constexpr (LDSK) {                                                       \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) ldsk[(((l) - 1) * 4 + q_) * 64] = k[l][q_]; \
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) k[0][q] = k0[q];
         {
@@ -323,49 +343,54 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 for (int q = 0; q < 3; q++) X[q] = rfma(hc, u[1 + q], x[1 + q]);
             }
             accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[1]);
+            KSTORE(1);
             // ---- stage 3 -------------------------------------------------------------------------------------
             {
                 const R w1 = h * N::a[2][1], w0 = h * N::a[2][0], hc = h * N::c[2], h2a = h2 * N::A2[2][0];
 #pragma unroll
-                for (int q = 0; q < 4; q++) U[q] = rfma(w1, k[1][q], rfma(w0, k[0][q], u[q]));
+                for (int q = 0; q < 4; q++) U[q] = rfma(w1, KL(1, q), rfma(w0, k[0][q], u[q]));
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(h2a, k[0][1 + q], rfma(hc, u[1 + q], x[1 + q]));
             }
             accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[2]);
+            KSTORE(2);
             // ---- stages 4, 5, 6 ----------------------------------------------------------------------------------
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                U[q] = rfma(h, rfma(N::a[3][2], k[2][q], rfma(N::a[3][1], k[1][q], N::a[3][0] * k[0][q])), u[q]);
+                U[q] = rfma(h, rfma(N::a[3][2], KL(2, q), rfma(N::a[3][1], KL(1, q), N::a[3][0] * k[0][q])), u[q]);
 #pragma unroll
             for (int q = 0; q < 3; q++)
-                X[q] = rfma(h2, rfma(N::A2[3][1], k[1][1 + q], N::A2[3][0] * k[0][1 + q]),
+                X[q] = rfma(h2, rfma(N::A2[3][1], KL(1, 1 + q), N::A2[3][0] * k[0][1 + q]),
                             rfma(h * N::c[3], u[1 + q], x[1 + q]));
             accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[3]);
+            KSTORE(3);
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                U[q] = rfma(h, rfma(N::a[4][3], k[3][q], rfma(N::a[4][2], k[2][q], rfma(N::a[4][1], k[1][q],
+                U[q] = rfma(h, rfma(N::a[4][3], KL(3, q), rfma(N::a[4][2], KL(2, q), rfma(N::a[4][1], KL(1, q),
                             N::a[4][0] * k[0][q]))), u[q]);
 #pragma unroll
             for (int q = 0; q < 3; q++)
-                X[q] = rfma(h2, rfma(N::A2[4][2], k[2][1 + q], rfma(N::A2[4][1], k[1][1 + q], N::A2[4][0] * k[0][1 + q])),
+                X[q] = rfma(h2, rfma(N::A2[4][2], KL(2, 1 + q), rfma(N::A2[4][1], KL(1, 1 + q), N::A2[4][0] * k[0][1 + q])),
                             rfma(h * N::c[4], u[1 + q], x[1 + q]));
             accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[4]);
+            KSTORE(4);
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                U[q] = rfma(h, rfma(N::a[5][4], k[4][q], rfma(N::a[5][3], k[3][q], rfma(N::a[5][2], k[2][q],
-                            rfma(N::a[5][1], k[1][q], N::a[5][0] * k[0][q])))), u[q]);
+                U[q] = rfma(h, rfma(N::a[5][4], KL(4, q), rfma(N::a[5][3], KL(3, q), rfma(N::a[5][2], KL(2, q),
+                            rfma(N::a[5][1], KL(1, q), N::a[5][0] * k[0][q])))), u[q]);
 #pragma unroll
             for (int q = 0; q < 3; q++)
-                X[q] = rfma(h2, rfma(N::A2[5][3], k[3][1 + q], rfma(N::A2[5][2], k[2][1 + q], rfma(N::A2[5][1], k[1][1 + q],
+                X[q] = rfma(h2, rfma(N::A2[5][3], KL(3, 1 + q), rfma(N::A2[5][2], KL(2, 1 + q), rfma(N::A2[5][1], KL(1, 1 + q),
                             N::A2[5][0] * k[0][1 + q]))), rfma(h * N::c[5], u[1 + q], x[1 + q]));
             accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[5]);
+            KSTORE(5);
             // ---- stage 7 = the step result (FSAL) ----------------------------------------------------------------
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                un[q] = rfma(h, rfma(N::a[6][5], k[5][q], rfma(N::a[6][4], k[4][q], rfma(N::a[6][3], k[3][q],
-                             rfma(N::a[6][2], k[2][q], rfma(N::a[6][1], k[1][q], N::a[6][0] * k[0][q]))))), u[q]);
-                xn[q] = rfma(h2, rfma(N::A2[6][4], k[4][q], rfma(N::A2[6][3], k[3][q], rfma(N::A2[6][2], k[2][q],
-                             rfma(N::A2[6][1], k[1][q], N::A2[6][0] * k[0][q])))), rfma(h * N::c[6], u[q], x[q]));
+                un[q] = rfma(h, rfma(N::a[6][5], KL(5, q), rfma(N::a[6][4], KL(4, q), rfma(N::a[6][3], KL(3, q),
+                             rfma(N::a[6][2], KL(2, q), rfma(N::a[6][1], KL(1, q), N::a[6][0] * k[0][q]))))), u[q]);
+                xn[q] = rfma(h2, rfma(N::A2[6][4], KL(4, q), rfma(N::A2[6][3], KL(3, q), rfma(N::A2[6][2], KL(2, q),
+                             rfma(N::A2[6][1], KL(1, q), N::A2[6][0] * k[0][q])))), rfma(h * N::c[6], u[q], x[q]));
             }
             accel<R, METRIC, SPIN, true>(xn + 1, un, M, aspin, k[6]);
 
@@ -374,10 +399,10 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 float acc = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const R eu = h * rfma(N::bt[6], k[6][q], rfma(N::bt[5], k[5][q], rfma(N::bt[4], k[4][q],
-                                     rfma(N::bt[3], k[3][q], rfma(N::bt[2], k[2][q], rfma(N::bt[1], k[1][q], N::bt[0] * k[0][q]))))));
-                    const R ex = h * rfma(h, rfma(N::BT2[5], k[5][q], rfma(N::BT2[4], k[4][q], rfma(N::BT2[3], k[3][q],
-                                     rfma(N::BT2[2], k[2][q], rfma(N::BT2[1], k[1][q], N::BT2[0] * k[0][q]))))), N::sbt * u[q]);
+                    const R eu = h * rfma(N::bt[6], k[6][q], rfma(N::bt[5], KL(5, q), rfma(N::bt[4], KL(4, q),
+                                     rfma(N::bt[3], KL(3, q), rfma(N::bt[2], KL(2, q), rfma(N::bt[1], KL(1, q), N::bt[0] * k[0][q]))))));
+                    const R ex = h * rfma(h, rfma(N::BT2[5], KL(5, q), rfma(N::BT2[4], KL(4, q), rfma(N::BT2[3], KL(3, q),
+                                     rfma(N::BT2[2], KL(2, q), rfma(N::BT2[1], KL(1, q), N::BT2[0] * k[0][q]))))), N::sbt * u[q]);
                     const float isku = __builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(u[q], un[q]), reltol, abstol));
                     const float iskx = __builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(x[q], xn[q]), reltol, abstol));
                     const float ru = (float)eu * isku, rx = (float)ex * iskx;
@@ -410,7 +435,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             for (int q = 0; q < 4; q++) {
                                 R acc2 = N::beta[0] * rabs(k[0][q]);
 #pragma unroll
-                                for (int l = 1; l < 6; l++) acc2 = rfma(N::beta[l], rabs(k[l][q]), acc2);
+                                for (int l = 1; l < 6; l++) acc2 = rfma(N::beta[l], rabs(KL(l, q)), acc2);
                                 dl[q] = h * rfma(h, acc2, rabs(u[q]));
                             }
                             bool safe = true;
@@ -476,8 +501,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             cc[0][q] = h * u[q];
 #pragma unroll
                             for (int m = 1; m < 4; m++)
-                                cc[m][q] = h2 * rfma(N::R2[5][m], k[5][q], rfma(N::R2[4][m], k[4][q], rfma(N::R2[3][m], k[3][q],
-                                                rfma(N::R2[2][m], k[2][q], rfma(N::R2[1][m], k[1][q], N::R2[0][m] * k[0][q])))));
+                                cc[m][q] = h2 * rfma(N::R2[5][m], KL(5, q), rfma(N::R2[4][m], KL(4, q), rfma(N::R2[3][m], KL(3, q),
+                                                rfma(N::R2[2][m], KL(2, q), rfma(N::R2[1][m], KL(1, q), N::R2[0][m] * k[0][q])))));
                         }
                         bool found = false;
                         R nextc;
@@ -585,9 +610,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             rec[REC_U + q] = u[q];
 #pragma unroll
                             for (int m = 0; m < 4; m++)
-                                rec[REC_CU + 4 * m + q] = h * rfma(N::r[6][m], k[6][q], rfma(N::r[5][m], k[5][q],
-                                    rfma(N::r[4][m], k[4][q], rfma(N::r[3][m], k[3][q], rfma(N::r[2][m], k[2][q],
-                                    rfma(N::r[1][m], k[1][q], N::r[0][m] * k[0][q]))))));
+                                rec[REC_CU + 4 * m + q] = h * rfma(N::r[6][m], k[6][q], rfma(N::r[5][m], KL(5, q),
+                                    rfma(N::r[4][m], KL(4, q), rfma(N::r[3][m], KL(3, q), rfma(N::r[2][m], KL(2, q),
+                                    rfma(N::r[1][m], KL(1, q), N::r[0][m] * k[0][q]))))));
                         }
                     }
                 }
@@ -695,12 +720,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     }
 }
 
+#undef KL
+#undef KSTORE
 template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE>
 __global__ __launch_bounds__(64, METRIC >= RTGR_GENERIC_BASE ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_GENERIC : RTGR_WAVES_PER_SIMD_GENERIC_F32)
-                                 : (MODE == MODE_FAR ? (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4)
+                                 : (MODE == MODE_FAR ? (sizeof(R) == 8 ? (SPIN ? RTGR_WAVES_PER_SIMD_SPIN_FAR : RTGR_WAVES_PER_SIMD_FAR) : 4)
                                                      : (sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32)))
 void integrate_kernel(const IntegrateArgs<R> A) {
-    integrate_body<R, METRIC, SPIN, NPTS10, MODE>(A);
+    integrate_body<R, METRIC, SPIN, NPTS10, MODE, (METRIC >= RTGR_GENERIC_BASE ? RTGR_LDSK_GENERIC != 0 : (SPIN && MODE == MODE_FAR && RTGR_LDSK_SPIN_FAR != 0))>(A);
 }
 
 // The a = 0 FAR pass once more at FOUR waves per SIMD (128 registers: 28 B/lane of scratch for KS_REF, none for KS_TRUE).

@@ -468,7 +468,7 @@ RTGR_DEV double mcbrt(double x) { return cbrt(x); }
 RTGR_DEV float mcbrt(float x) { return cbrtf(x); }
 RTGR_DT RTGR_DEV RTGR_DD mcbrt(const RTGR_DD& x) { const R c = mcbrt(x.v); return dchain(x, c, R(1) / (R(3) * c * c)); }
 RTGR_DEV double mpow(double x, double p) { return pow(x, p); }
-RTGR_DEV float mpow(float x, float p) { return powf(x, p); }
+RTGR_DEV float mpow(float x, double p) { return powf(x, (float)p); }
 RTGR_DT RTGR_DEV RTGR_DD mpow(const RTGR_DD& x, double p) {           // x^p, real constant exponent: p x^(p-1)
     const R f = mpow(x.v, (R)p); return dchain(x, f, (R)p * f / x.v); }
 template <class S> struct MConst;                                     // a constant of the scalar type S

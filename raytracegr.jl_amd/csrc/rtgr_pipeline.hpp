@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
     }
 }
 
-template <class R, int METRIC> constexpr int waves_per_simd_of(int mode) {
+template <class R, int METRIC, bool SPIN = false> constexpr int waves_per_simd_of(int mode) {
     if (METRIC >= RTGR_GENERIC_BASE) return sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_GENERIC : RTGR_WAVES_PER_SIMD_GENERIC_F32;
-    if (mode == MODE_FAR) return sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD_FAR : 4;
+    if (mode == MODE_FAR) return sizeof(R) == 8 ? (SPIN ? RTGR_WAVES_PER_SIMD_SPIN_FAR : RTGR_WAVES_PER_SIMD_FAR) : 4;
     return sizeof(R) == 8 ? RTGR_WAVES_PER_SIMD : RTGR_WAVES_PER_SIMD_F32;
 }
 
@@ -121,7 +121,7 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
                       if (four) hipLaunchKernelGGL((integrate_far4_kernel<R, METRIC>), grid(4), dim3(64), 0, st, P);
                   }
                   if (!four) hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_FAR>),
-                                                grid(waves_per_simd_of<R, METRIC>(MODE_FAR)), dim3(64), 0, st, P);
+                                                grid(waves_per_simd_of<R, METRIC, SPIN>(MODE_FAR)), dim3(64), 0, st, P);
               } }
             P.pick_flag = META_HANDED;
             P.allow_handback = (r + 1 < rounds) ? 1u : 0u;

@@ -154,7 +154,7 @@ def test_user_helper_functions_match_oracle_twins(lib):
     assert (np.abs(got[:, 4:] - ref[:, 4:]) / scale).max() < 5e-12
     # traced end to end in Float64 (3 spatial partials: stationary) and Float32 (the unit's Float32 kernels)
     _, objs, cam = rt.example2_scene()
-    from test_gpu_parity import hip_trace
+    from test_gpu_parity import compare, hip_trace
     camera = rt.make_camera(**cam)
     scn = rt.make_scene(user, objs)
     sco = rt.make_scene(user, objs)
