@@ -233,15 +233,19 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                     // the early list has a head of its own and goes out 64 entries at a time: they are long-stayers, and
                     // a 256-entry chunk would be four rounds of them one after the other in the same wave (measured:
                     // the late waves of the pass were the ones that had popped such a chunk)
+                    // (… unless the list is most of the job — a distant camera, every ray shorter than near_early steps:
+                    //  then it is not a list of exceptions any more and goes out in full queue chunks, or its 64-id pops
+                    //  are 260 k atomics at 4096², 3 ms: tools/scheduler_check.py, camera far20)
+                    const unsigned long long echunk = (n_early * 8ull > A.n) ? qchunk : 64ull;
                     unsigned long long eb = 0;
-                    if (first_early) eb = 64ull * blockIdx.x;
-                    else if (lane == 0) eb = atomicAdd(A.ctrl + 7, 64ull) + first_span;
+                    if (first_early) eb = echunk * blockIdx.x;
+                    else if (lane == 0) eb = atomicAdd(A.ctrl + 7, echunk) + echunk * gridDim.x;
                     first_early = false;
                     eb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(eb >> 32)) << 32) |
                          (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)eb);
                     if (eb >= n_early) { early_done = true; continue; }
                     q_next = eb;
-                    q_end = (eb + 64ull) < n_early ? (eb + 64ull) : n_early;
+                    q_end = (eb + echunk) < n_early ? (eb + echunk) : n_early;
                     continue;
                 }
                 const unsigned long long amount = first_pop ? 64ull : qchunk;

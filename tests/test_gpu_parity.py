@@ -652,6 +652,36 @@ def test_redshift_output_matches_its_definition(lib):
                               C.byref(o2), None) == abi.ERR_BAD_ARG
 
 
+def test_nan_states_end_rays_cleanly_on_every_pass(lib):
+    """kerr_schild as written with a != 0 takes sqrt(rho² - a²) (src/RayTraceGR.jl:284): NaN for rho < a, where the
+    reference would throw (`@assert !any(isnan, …)`, :279).  Here the ray ends with status RTGR_RAY_NAN — in the FAR
+    pass, in the NEAR pass (rays next to an object when it happens) and in the single FULL pass alike, with identical
+    bits, and in agreement with the oracle.  (The one-instruction min/max of the hot loop are IEEE minNum/maxNum and drop
+    NaNs; the NaN test on the error estimate is what ends such a ray — this test keeps that true.)"""
+    _, _, cam = rt.example2_scene()
+    # a = 3: the NaN region rho < 3 is big enough that rays from the camera (rho = 4.5) run into it — some of them right
+    # after passing the small sphere that sits at its edge, i.e. while they are in the NEAR pass
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10), rt.Sphere((0, 3.4, -0.3, 0), (1, 0, 0, 0), 0.3)]
+    sc, camera = rt.make_scene(rt.KerrSchild(1, 3.0, textbook=False), objs), rt.make_camera(**cam)
+    opt = rt.solver_defaults(max_steps=4000)
+    a = hip_trace(lib, sc, opt, 96, 64, cam=camera)
+    assert (a["status"] == abi.RAY_NAN).sum() > 100 and (a["status"] == abi.RAY_EVENT).sum() > 1000
+    with abi.options(lib, split=0):
+        b = hip_trace(lib, sc, opt, 96, 64, cam=camera)
+    for k in ("status", "hit", "n_accept", "n_reject"):
+        assert np.array_equal(a[k], b[k]), k
+    ok = a["status"] != abi.RAY_NAN
+    assert np.array_equal(a["rgb"][:, ok], b["rgb"][:, ok])
+    # against the oracle: WHICH rays end by an event and what they hit must agree; how a ray that runs into the singular
+    # boundary dies (NaN, dt underflow or the step cap — sqrt(rho² − a²) has an infinite slope there) is decided by
+    # rounding in the step controller and is not compared
+    ref = O.trace(sc, opt, 96, 64, cam=camera)
+    ev_a, ev_r = a["status"] == abi.RAY_EVENT, ref["status"] == abi.RAY_EVENT
+    assert (ev_a == ev_r).mean() > 0.995 and (a["hit"][ev_a & ev_r] == ref["hit"][ev_a & ev_r]).mean() > 0.995
+    assert (ref["status"] >= 2).sum() > 100
+    assert a["counters"]["not_finished"] == int((a["status"] >= 2).sum())
+
+
 def _random_scene(seed):
     """Seeded random scene: 1-6 objects (spheres incl. inside-out ones, planes, disks), random metric variant, random
     camera, random solver constants — exercises rays that start inside objects, end by λ1, miss everything, fall into
