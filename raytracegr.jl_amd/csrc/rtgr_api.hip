@@ -519,7 +519,10 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
         chunks.push_back({0, nrows});   // (the tile kernel writes whole slabs)
     } else {
         auto rows_for = [&](uint64_t rays) { const uint64_t r = rays / ni; return r ? r : (uint64_t)1; };
-        const uint64_t rP = rows_for(piece_target), r2 = rows_for(2 * piece_target), r4 = rows_for(4 * piece_target);
+        // (middle chunks: 4P, or an eighth of a big job — 8192² with the disk loses 10 % of its FAR pass to the tails of
+        //  sixteen 4 M-ray launches, nothing to those of eight 8 M-ray ones)
+        const uint64_t mid = 4 * piece_target > n / 8 ? 4 * piece_target : n / 8;
+        const uint64_t rP = rows_for(piece_target), r2 = rows_for(2 * piece_target), r4 = rows_for(mid);
         std::vector<uint64_t> head, tail;
         uint64_t left = nrows;
         const uint64_t ramp[2] = {rP, r2};

@@ -2,12 +2,12 @@
 # The five BASELINE.json configurations on one GPU (config 1 is the CPU-runnable 200² Minkowski case; config 3 is the
 # bench default).  usage: tools/configs.sh <outfile>
 OUT=${1:-gpurun_out/configs.log}
-run() { echo "### $1" | tee -a $OUT; shift; python bench.py --cpu-sample 0 --steps 2 --warmup 1 "$@" 2>/dev/null | python -c "
+run() { echo "### $1" | tee -a $OUT; shift; python bench.py --cpu-sample 0 --extras 0 --steps 2 --warmup 1 "$@" 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('   steps/s %.4g  rays/s %.4g  ms/pass %.3f  steps/ray %.1f  rejected %d  (far %.2f near %.2f ms)' % (d['value'], d['rays_per_s'], d['ms_per_step'], d['step_attempts_per_pass']/d['rays'], d['rejected'], r['far_pass_ms_avg'], r['near_pass_ms_avg']))
+        print('   steps/s %.4g  rays/s %.4g  ms/pass %.3f  steps/ray %.1f  rejected %d  (far %.2f near %.2f ms)' % (d['value'], d['rays_per_s'], d['ms_per_step'], d['step_attempts_per_pass']/d['rays'], d['rejected'], r['far_pass_ms_per_pass'], r['near_pass_ms_per_pass']))
 " | tee -a $OUT; }
 run "C1 example1 Minkowski 200x200" --variant mink --size 200
 run "C2 example2 as written (KS_REF a=0) 1024x1024" --variant ks_ref0 --size 1024
@@ -17,3 +17,8 @@ run "C3' Kerr-Schild a=0.8 4096x4096" --variant ks_true08 --size 4096
 run "C4 Kerr-Schild a=0.8 2048x2048 Float32" --variant ks_true08 --size 2048 --dtype f32
 run "C4' example2 as written 2048x2048 Float32" --variant ks_ref0 --size 2048 --dtype f32
 run "C5 Kerr a=0.998 + thin disk 8192x8192" --variant ks_true0998_disk --size 8192
+run "C3 through rtgr_trace_pixels_f64 (Array{Pixel} in/out over PCIe)" --variant ks_ref0 --size 4096 --entry pixels
+run "C3 through rtgr_trace_f64 (camera on device, RGB to host)" --variant ks_ref0 --size 4096 --entry host
+run "C5 through rtgr_trace_pixels_f64 (5.9 GB of pixels each way)" --variant ks_true0998_disk --size 8192 --entry pixels
+run "generic dual-number RHS 2048x2048 (reference formulation)" --variant ks_ref0 --size 2048 --rhs generic
+run "user metric (textbook Kerr-Schild as run-time compiled source) 2048x2048" --variant ks_true08 --size 2048 --rhs user
