@@ -1,5 +1,8 @@
+"""Builds the macro-gated experiment variants of the library (LDS stage storage, other waves/SIMD) into
+raytracegr.jl_amd/build/variants/librtgr_<name>.so; tools/ab_variants.sh times them against the default build (RTGR_LIB).
+Results of round 2: DESIGN.md §4.2 "LDS stage storage"."""
 import importlib.util, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))
 b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 V = {"ldsk_gen2": ["-DRTGR_LDSK_GENERIC=1"],

@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B of the experiment builds of tools/ab_build_variants.py against the default library (selected with RTGR_LIB).
 summ() { python - "$1" "$2" <<'PY'
 import json,sys
 for l in open(sys.argv[1]):

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<round>_<config>/ (tools/collect_profiles.sh) -> profiles/<round>/<config>/{summary.txt, entry.json,
+kernel_stats.csv, bench_line.json} and profiles/<round>/flops.json, which records the kernel-source hash the counters were
+collected from (bench.py only uses an entry when that hash equals the current sources').
+
+    python tools/merge_flops.py r02
+"""
+import glob
+import importlib.util
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))
+b = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(b)
+out = {"kernel_source_hash": b.kernel_source_hash(), "hash_of": "sha256 of csrc/{%s} + compile flags" % ", ".join(b.KERNEL_HEADERS),
+       "how": "tools/collect_profiles.sh on one MI355X; rocprofv3 --pmc passes separate from the --kernel-trace pass", "entries": {}}
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
+    cfg = os.path.basename(d)[len(f"prof_{rnd}_"):]
+    ej = os.path.join(d, "entry.json")
+    if not os.path.exists(ej):
+        print("no entry for", cfg)
+        continue
+    line = None
+    for l in open(os.path.join(d, "bench_plain.log")):
+        if l.startswith("{"):
+            line = json.loads(l)
+    e = json.load(open(ej))
+    key = f'{line["config"]["variant"]}/{line["dtype"]}/{line["config"]["rhs"]}'
+    e["config_dir"] = f"profiles/{rnd}/{cfg}"
+    out["entries"][key] = e
+    dst = os.path.join(ROOT, "profiles", rnd, cfg)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(d, "summary.txt"), dst)
+    shutil.copy(ej, dst)
+    for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+    json.dump(line, open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
+    print(key, "flop/attempt %.1f" % e["flop_per_step_attempt"], "->", dst)
+json.dump(out, open(os.path.join(ROOT, "profiles", rnd, "flops.json"), "w"), indent=1)
+print("wrote profiles/%s/flops.json for kernel sources %s" % (rnd, out["kernel_source_hash"]))
