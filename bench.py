@@ -308,7 +308,10 @@ def main():
         name = C_name(lib)
         extras = {}
         if a.extras and ws == 1 and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64":
-            extras = run_extras(a, rt, host_pass, pixels_pass, dt / a.steps)
+            try:   # (outside the timed region; a failure here must not cost the headline line)
+                extras = run_extras(a, rt, host_pass, pixels_pass, dt / a.steps)
+            except Exception as e:  # noqa: BLE001
+                extras = {"extras_error": repr(e)}
         cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and ws == 1) else None  # N=1 only
         line = {
             "metric": "geodesic RK step attempts/s (Tsit5, 6 RHS each), Kerr-Schild screen, whole job",

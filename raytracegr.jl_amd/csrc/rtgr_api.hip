@@ -535,7 +535,13 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
             const uint64_t t = ramp[k] < left ? ramp[k] : left;   // ... and from the back
             tail.push_back(t); left -= t;
         }
-        while (left > 0) { const uint64_t m4 = r4 < left ? r4 : left; head.push_back(m4); left -= m4; }
+        if (left > 0) {                                       // the middle, in equal chunks of at most r4 rows
+            const uint64_t parts = (left + r4 - 1) / r4;
+            for (uint64_t k = 0; k < parts; k++) {
+                const uint64_t m4 = (left + (parts - k) - 1) / (parts - k);
+                head.push_back(m4); left -= m4;
+            }
+        }
         uint64_t row0 = 0;
         for (uint64_t r : head) { chunks.push_back({row0, r}); row0 += r; }
         for (size_t k = tail.size(); k-- > 0;) { chunks.push_back({row0, tail[k]}); row0 += tail[k]; }
