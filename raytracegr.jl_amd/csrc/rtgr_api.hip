@@ -535,8 +535,10 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
             const uint64_t t = ramp[k] < left ? ramp[k] : left;   // ... and from the back
             tail.push_back(t); left -= t;
         }
-        if (left > 0) {                                       // the middle, in equal chunks of at most r4 rows
-            const uint64_t parts = (left + r4 - 1) / r4;
+        if (left > 0) {                                       // the middle, in equal chunks of at most r4 rows — ONE chunk when
+            // there is no input to wait for (camera on the device): every extra launch costs its tails (~1.2 ms at 4 M rays),
+            // and the only reason to cut at all is to hide the last download behind the small chunks at the end
+            const uint64_t parts = have_in ? (left + r4 - 1) / r4 : 1;
             for (uint64_t k = 0; k < parts; k++) {
                 const uint64_t m4 = (left + (parts - k) - 1) / (parts - k);
                 head.push_back(m4); left -= m4;
