@@ -193,7 +193,7 @@ int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len
 
 /* Launch-policy options (experiments and schedule-invariance tests; none changes a result bit).  Names: "waves_per_cu",
  * "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early", "far4", "rounds", "qchunk", "qchunk_near",
- * "tile", "lds_stages", "host_chunk".  value -1 = automatic.  Initial values come from the environment variables
+ * "tile", "host_chunk".  value -1 = automatic.  Initial values come from the environment variables
  * RTGR_<NAME> read ONCE when the context is created. */
 int rtgr_set_option(rtgr_context* ctx, const char* name, long value);
 int rtgr_get_option(rtgr_context* ctx, const char* name, long* value);

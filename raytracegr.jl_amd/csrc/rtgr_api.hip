@@ -28,13 +28,13 @@ int fail(int code, const std::string& msg) {
 // knobs
 // ---------------------------------------------------------------------------------------------------------------------
 static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
-                                         "far4", "rounds", "qchunk", "qchunk_near", "tile", "lds_stages", "host_chunk",
+                                         "far4", "rounds", "qchunk", "qchunk_near", "tile", "host_chunk",
                                          "dbg_pass_far", nullptr};
 const char* const* knob_names() { return KNOB_NAMES; }
 long* knob_slot(Knobs& k, const char* name) {
     if (!name) return nullptr;
     long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
-                     &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.lds_stages, &k.host_chunk, &k.dbg_pass_far};
+                     &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far};
     for (int i = 0; KNOB_NAMES[i]; i++)
         if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
     return nullptr;
@@ -479,6 +479,10 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     int rc;
     { std::lock_guard<std::mutex> lk(D.mu); if ((rc = staging_of(D, &S))) return rc; }
     std::lock_guard<std::mutex> call_lock(S->mu);
+    // a previous call that failed half-way may have left copies in flight on the staging streams: they are idle otherwise
+    HIP_TRY(hipStreamSynchronize(S->s_up));
+    HIP_TRY(hipStreamSynchronize(S->s_comp));
+    HIP_TRY(hipStreamSynchronize(S->s_down));
     const uint64_t nrows = j1 - j0, n = ni * nrows;
     const bool have_in = state0 != nullptr || px_in != nullptr;
 

@@ -59,7 +59,6 @@ struct Knobs {
     long qchunk = -1;             // ray ids per queue atomic, FAR / FULL pass (auto)
     long qchunk_near = -1;        // ... NEAR pass (auto)
     long tile = 0;                // 1: the simple tile-per-wave kernel (RTGR_KERNEL=tile), an independent formulation
-    long lds_stages = -1;         // generic RHS: keep the stage accelerations k[1..5] in LDS (auto: on)
     long host_chunk = -1;         // host entry points: rays per H2D/compute/D2H pipeline piece (auto: 2^20)
     long dbg_pass_far = 0;        // debug builds: which pass reports its wave timeline
 };
