@@ -318,6 +318,12 @@ int rtgr_eval_fastmath_f64(rtgr_context* ctx, const double* x, uint64_t n, doubl
  * eval_geodesic path 1); M and a of the scene are passed through to the function.  Several metrics may be resident at
  * once.  The Python mirror automates the steps (api.UserMetric). */
 int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out);
+/* The same in ONE call from source text: `source` (the definition of rtgr_user_metric<S>, as above) is pasted into the
+ * unit template, compiled IN-PROCESS with hiprtc (libhiprtc is resolved with dlopen at first use; ~3 s; no hipcc needed on
+ * the box) and loaded.  stationary != 0 declares that the metric does not depend on t (-DRTGR_USER_NE=3: the integrate
+ * kernels carry the three spatial partials only).  The unit template and device headers are read from the `csrc`
+ * directory next to librtgr_hip.so (or $RTGR_CSRC).  On a compile error the compiler's log is the rtgr_last_error(). */
+int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out);
 int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
 /* 1 if module `id` is resident (id 0: any module), else 0 */
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id);

@@ -90,19 +90,28 @@ handle(c::Context) = c.handle
 """
     DeviceMetric(code_object; M = 1.0, a = 0.0)
 
-A metric function of the user's own, given as a gfx950 code object built from `rtgr_user_unit.hip.in`
-(INTEGRATION.md "A new metric") — the native stand-in for passing a new Julia function as `metric` (:302-309).
+A metric function of the user's own — the native stand-in for passing a new Julia function as `metric` (:302-309) —
+given as C++ source text (`DeviceMetric(source = "...")`: compiled in-process with hiprtc by `rtgr_user_metric_compile`) or
+as a gfx950 code object built from `rtgr_user_unit.hip.in` (INTEGRATION.md "A new metric").
 Several may be resident at once; a scene names its own by id.
 """
 struct DeviceMetric
-    code_object::String
+    code_object::String     # path of a code object built with hipcc --genco, or "" when `source` is given
+    source::String          # C++ source of rtgr_user_metric<S>: compiled in-process by the library (hiprtc), one ccall
+    stationary::Bool
     M::Float64
     a::Float64
 end
-DeviceMetric(path; M = 1.0, a = 0.0) = DeviceMetric(path, M, a)
+DeviceMetric(path::AbstractString; M = 1.0, a = 0.0) = DeviceMetric(path, "", false, M, a)
+DeviceMetric(; source::AbstractString, stationary = false, M = 1.0, a = 0.0) = DeviceMetric("", source, stationary, M, a)
 function module_id(m::DeviceMetric, ctx)
     id = Ref{UInt64}(0)
-    check(ccall((:rtgr_user_metric_load, librtgr), Cint, (Ctx, Cstring, Ptr{UInt64}), handle(ctx), m.code_object, id))
+    if isempty(m.source)
+        check(ccall((:rtgr_user_metric_load, librtgr), Cint, (Ctx, Cstring, Ptr{UInt64}), handle(ctx), m.code_object, id))
+    else
+        check(ccall((:rtgr_user_metric_compile, librtgr), Cint, (Ctx, Cstring, Cint, Ptr{UInt64}),
+                    handle(ctx), m.source, m.stationary, id))
+    end
     id[]
 end
 

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <thread>
 
+#include <dlfcn.h>
+
 #include "rtgr_host.hpp"
 
 namespace rtgr {
@@ -1297,24 +1299,10 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
     return RTGR_OK;
 }
 
-int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out) {
-    rtgr_context* c = nullptr;
-    int rc = resolve_ctx(ctx, &c);
-    if (rc) return rc;
-    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
-    std::vector<char> image;
-    {
-        FILE* f = std::fopen(code_object_path, "rb");
-        if (!f) return fail(RTGR_ERR_BAD_ARG, std::string("cannot open ") + code_object_path);
-        std::fseek(f, 0, SEEK_END);
-        const long sz = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        if (sz <= 0) { std::fclose(f); return fail(RTGR_ERR_BAD_ARG, std::string(code_object_path) + ": empty file"); }
-        image.resize((size_t)sz);
-        const size_t got = std::fread(image.data(), 1, (size_t)sz, f);
-        std::fclose(f);
-        if (got != (size_t)sz) return fail(RTGR_ERR_BAD_ARG, std::string("short read on ") + code_object_path);
-    }
+}  // extern "C"
+
+// load a gfx950 code object image into every device of the context; its id is a hash of the image
+static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out) {
     const uint64_t id = fnv1a(image);
     for (auto& d : c->devs) {
         DeviceGuard guard(d->dev);
@@ -1329,10 +1317,10 @@ int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint6
         u.id = id;
         hipError_t e = hipModuleLoadData(&u.module, image.data());
         if (e != hipSuccess)
-            return fail(RTGR_ERR_HIP, std::string("hipModuleLoadData(") + code_object_path + "): " + hipGetErrorString(e));
+            return fail(RTGR_ERR_HIP, std::string("hipModuleLoadData(") + what + "): " + hipGetErrorString(e));
         auto bail = [&](const std::string& why) {
             (void)hipModuleUnload(u.module);
-            return fail(RTGR_ERR_BAD_ARG, std::string(code_object_path) + ": " + why);
+            return fail(RTGR_ERR_BAD_ARG, what + ": " + why);
         };
         {   // the unit must have been built against this library's headers
             hipDeviceptr_t dptr = nullptr;
@@ -1361,6 +1349,123 @@ int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint6
     }
     if (id_out) *id_out = id;
     return RTGR_OK;
+}
+
+static int read_file(const std::string& path, std::vector<char>& out) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return fail(RTGR_ERR_BAD_ARG, "cannot open " + path);
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz <= 0) { std::fclose(f); return fail(RTGR_ERR_BAD_ARG, path + ": empty file"); }
+    out.resize((size_t)sz);
+    const size_t got = std::fread(out.data(), 1, (size_t)sz, f);
+    std::fclose(f);
+    if (got != (size_t)sz) return fail(RTGR_ERR_BAD_ARG, "short read on " + path);
+    return RTGR_OK;
+}
+
+// ---- in-process compilation with hiprtc (resolved lazily with dlopen: no link-time dependency) ----------------------------
+namespace {
+struct Hiprtc {
+    void* h = nullptr;
+    int (*create)(void**, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    int (*compile)(void*, int, const char* const*) = nullptr;
+    int (*log_size)(void*, size_t*) = nullptr;
+    int (*log)(void*, char*) = nullptr;
+    int (*code_size)(void*, size_t*) = nullptr;
+    int (*code)(void*, char*) = nullptr;
+    int (*destroy)(void**) = nullptr;
+    bool ok() const { return create && compile && log_size && log && code_size && code && destroy; }
+};
+Hiprtc& hiprtc() {
+    static Hiprtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+        }
+        if (!r.h) return;
+        r.create = (decltype(r.create))dlsym(r.h, "hiprtcCreateProgram");
+        r.compile = (decltype(r.compile))dlsym(r.h, "hiprtcCompileProgram");
+        r.log_size = (decltype(r.log_size))dlsym(r.h, "hiprtcGetProgramLogSize");
+        r.log = (decltype(r.log))dlsym(r.h, "hiprtcGetProgramLog");
+        r.code_size = (decltype(r.code_size))dlsym(r.h, "hiprtcGetCodeSize");
+        r.code = (decltype(r.code))dlsym(r.h, "hiprtcGetCode");
+        r.destroy = (decltype(r.destroy))dlsym(r.h, "hiprtcDestroyProgram");
+    });
+    return r;
+}
+std::string csrc_dir() {  // the device headers ship next to the library: <dir of librtgr_hip.so>/csrc (RTGR_CSRC overrides)
+    if (const char* e = std::getenv("RTGR_CSRC")) if (*e) return e;
+    Dl_info info;
+    if (dladdr((const void*)&rtgr_abi_version, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t s = p.rfind('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/csrc";
+    }
+    return "csrc";
+}
+}  // namespace
+
+extern "C" {
+
+int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
+    std::vector<char> image;
+    if ((rc = read_file(code_object_path, image))) return rc;
+    return load_module_image(c, image, code_object_path, id_out);
+}
+
+int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!source || !std::strstr(source, "rtgr_user_metric"))
+        return fail(RTGR_ERR_BAD_ARG, "the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
+                                      "double M, double a, S g[4][4])`");
+    Hiprtc& R = hiprtc();
+    if (!R.ok()) return fail(RTGR_ERR_BAD_ARG, "libhiprtc not found: build the unit with hipcc --genco and use rtgr_user_metric_load");
+    const std::string dir = csrc_dir();
+    std::vector<char> tmpl;
+    if ((rc = read_file(dir + "/rtgr_user_unit.hip.in", tmpl))) return rc;
+    std::string unit(tmpl.begin(), tmpl.end());
+    const std::string mark = "@RTGR_USER_SOURCE@";
+    const size_t at = unit.find(mark);
+    if (at == std::string::npos) return fail(RTGR_ERR_BAD_ARG, dir + "/rtgr_user_unit.hip.in: no " + mark);
+    unit.replace(at, mark.size(), source);
+    // hiprtc pre-includes the HIP device API and has no system headers: the two the units ask for are given in memory
+    static const char* const hdr_src[] = {
+        "#pragma once\n",
+        "#pragma once\ntypedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+        "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"};
+    static const char* const hdr_name[] = {"hip/hip_runtime.h", "stdint.h"};
+    void* prog = nullptr;
+    if (R.create(&prog, unit.c_str(), "rtgr_user_unit.hip", 2, hdr_src, hdr_name) != 0) return fail(RTGR_ERR_HIP, "hiprtcCreateProgram failed");
+    const std::string inc = "-I" + dir;
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+    if (stationary) opts.push_back("-DRTGR_USER_NE=3");
+    const int cr = R.compile(prog, (int)opts.size(), opts.data());
+    if (cr != 0) {
+        size_t ls = 0;
+        std::string log;
+        if (R.log_size(prog, &ls) == 0 && ls > 1) { log.resize(ls); (void)R.log(prog, &log[0]); }
+        (void)R.destroy(&prog);
+        if (log.size() > 6000) log.resize(6000);
+        return fail(RTGR_ERR_BAD_ARG, "hiprtc failed on the user metric:\n" + log);
+    }
+    size_t cs = 0;
+    std::vector<char> image;
+    if (R.code_size(prog, &cs) != 0 || cs == 0) { (void)R.destroy(&prog); return fail(RTGR_ERR_HIP, "hiprtcGetCodeSize failed"); }
+    image.resize(cs);
+    const int gr = R.code(prog, image.data());
+    (void)R.destroy(&prog);
+    if (gr != 0) return fail(RTGR_ERR_HIP, "hiprtcGetCode failed");
+    return load_module_image(c, image, "compiled user metric", id_out);
 }
 
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id) {

@@ -103,18 +103,34 @@ class UserMetric:
     kind = _abi.USER
     generic = True
 
-    def __init__(self, source, M=1.0, a=0.0, name="user_metric", verbose=False, stationary=False):
+    def __init__(self, source, M=1.0, a=0.0, name="user_metric", verbose=False, stationary=False, jit=False):
+        """jit=False: the unit is built with `hipcc --genco` here and now (needs hipcc, not a GPU; cached on disk by content
+        hash) and loaded with rtgr_user_metric_load on first use.  jit=True: the SOURCE is handed to the library, which
+        compiles it in-process with hiprtc when the metric is first used in a context (rtgr_user_metric_compile: one call,
+        no hipcc on the box, ~3 s, not cached across processes)."""
         self.source, self.M, self.a, self.name = source, float(M), float(a), name
-        self.stationary = bool(stationary)
-        self.code_object = compile_user_metric(source, verbose=verbose, stationary=stationary)
+        self.stationary, self.jit = bool(stationary), bool(jit)
+        self.code_object = None if jit else compile_user_metric(source, verbose=verbose, stationary=stationary)
+        self._jit_ids = {}
 
     def module_id(self, ctx=None):
-        """id of this metric's module in the context (loads the code object on first use)"""
-        return load(self.code_object, ctx)
+        """id of this metric's module in the context (loads the code object — or compiles the source — on first use)"""
+        if not self.jit:
+            return load(self.code_object, ctx)
+        import ctypes as C
+        lib = _abi.load()
+        key = getattr(ctx, "value", ctx)
+        mid = self._jit_ids.get(key)
+        if mid is not None and lib.rtgr_user_metric_loaded(ctx, mid) == 1:
+            return mid
+        out = C.c_uint64(0)
+        _abi.check(lib, lib.rtgr_user_metric_compile(ctx, self.source.encode(), 1 if self.stationary else 0, C.byref(out)))
+        self._jit_ids[key] = out.value
+        return out.value
 
     def __call__(self, x):
         from . import api
         return api._eval_metric(self, x, want=(True, False, False))[0]
 
     def __repr__(self):
-        return f"UserMetric({self.name}, M={self.M}, a={self.a}, {os.path.basename(self.code_object)})"
+        return f"UserMetric({self.name}, M={self.M}, a={self.a}, {'hiprtc' if self.jit else os.path.basename(self.code_object)})"

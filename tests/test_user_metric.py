@@ -170,6 +170,31 @@ def test_user_helper_functions_match_oracle_twins(lib):
 
 
 @pytest.mark.gpu
+def test_metric_from_source_text_in_one_call(lib):
+    """rtgr_user_metric_compile: the metric as SOURCE TEXT, compiled in-process with hiprtc and loaded — what a Julia host
+    does in one ccall instead of shelling out to hipcc.  Same kernels as the hipcc-built unit: the traced frame must agree
+    with it to rounding (the two front ends may schedule differently), pointwise metric derivatives to 1e-13; a broken
+    source returns the compiler's log, not a crash."""
+    from test_gpu_parity import hip_trace
+    jit = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0, stationary=True, jit=True)
+    aot = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0, stationary=True)
+    x, rng = _points(512, 21, rmin=0.9)
+    for got, ref in zip(rt.dmetric(jit, x), rt.dmetric(aot, x)):
+        assert np.abs(got - ref).max() <= 1e-13
+    _, objs, cam = rt.example2_scene()
+    opt, camera = rt.solver_defaults(), rt.make_camera(**cam)
+    a = hip_trace(lib, rt.make_scene(jit, objs), opt, 40, 40, cam=camera)
+    b = hip_trace(lib, rt.make_scene(aot, objs), opt, 40, 40, cam=camera)
+    same = a["hit"] == b["hit"]
+    assert (~same).sum() <= 1 and wrap_aware_rgb_err(a["rgb"][:, same], b["rgb"][:, same], a["hit"][same], 3) <= 1e-6
+    assert np.abs(a["n_accept"].astype(int) - b["n_accept"].astype(int)).max() <= 1
+    out = C.c_uint64(0)
+    rc = lib.rtgr_user_metric_compile(None, b"template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) { g[0][0] = undefined_symbol; }", 0, C.byref(out))
+    assert rc == abi.ERR_BAD_ARG and b"undefined_symbol" in lib.rtgr_last_error()
+    assert lib.rtgr_user_metric_compile(None, b"int x;", 0, C.byref(out)) == abi.ERR_BAD_ARG
+
+
+@pytest.mark.gpu
 def test_scenes_of_two_resident_user_metrics_run_their_own_kernels(lib):
     """Several metric modules are resident at once and a scene names its own (rtgr_scene.user_metric): building the
     scene of metric B must not change what the scene of metric A computes (round 1 had ONE resident module, activated
