@@ -217,7 +217,7 @@ void free_device_state(DeviceCtx& d, bool all) {
     d.staging.reset();
     if (all) {
         d.streams.clear();
-        for (auto& m : d.modules) if (m.module) (void)hipModuleUnload(m.module);
+        for (auto& m : d.modules) if (m.module && m.owned) (void)hipModuleUnload(m.module);
         d.modules.clear();
         for (auto& t : d.timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
         d.timed.clear();
@@ -1291,7 +1291,7 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
         HIP_TRY(hipDeviceSynchronize());  // kernels of the module may still be in flight
         for (size_t k = 0; k < d->modules.size();) {
             if (id == 0 || d->modules[k].id == id) {
-                (void)hipModuleUnload(d->modules[k].module);
+                if (d->modules[k].owned) (void)hipModuleUnload(d->modules[k].module);
                 d->modules.erase(d->modules.begin() + (long)k);
             } else k++;
         }
@@ -1311,7 +1311,7 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
         bool same_phys = false;  // a logical duplicate of a device shares the module of its twin
         for (auto& o : c->devs)
             if (o.get() != d.get() && o->dev == d->dev)
-                if (const UserModule* m = o->find_module(id)) { d->modules.push_back(*m); same_phys = true; break; }
+                if (const UserModule* m = o->find_module(id)) { d->modules.push_back(*m); d->modules.back().owned = false; same_phys = true; break; }
         if (same_phys) continue;
         UserModule u;
         u.id = id;

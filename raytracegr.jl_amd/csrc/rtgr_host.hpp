@@ -69,6 +69,7 @@ long* knob_slot(Knobs& k, const char* name);
 struct UserModule {
     uint64_t id = 0;
     hipModule_t module = nullptr;
+    bool owned = true;   // false: a logical duplicate of a device shares its twin's module and must not unload it
     hipFunction_t far = nullptr, near = nullptr, full10 = nullptr, fulln = nullptr, canvas = nullptr, prepare = nullptr,
                   eval_metric = nullptr, eval_geodesic = nullptr;
     // Float32 twins (absent in units built without them)

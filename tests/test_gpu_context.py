@@ -185,6 +185,36 @@ def test_single_process_multi_device_trace(lib, ndev):
         abi.check(lib, lib.rtgr_destroy(ctx))
 
 
+def test_user_metric_on_a_multi_device_context(lib):
+    """A run-time compiled metric is loaded on every device of a context (logical duplicates of one GPU share the
+    module); the multi-device frame equals the single-device one, and unload / destroy release it exactly once."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import user_metrics
+    from test_gpu_parity import hip_trace
+    user = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0, stationary=True)
+    _, objs, cam = rt.example2_scene()
+    opt, camera = rt.solver_defaults(), rt.make_camera(**cam)
+    ref = hip_trace(lib, rt.make_scene(user, objs), opt, 48, 33, cam=camera)
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 2)
+    try:
+        sc = rt.make_scene(user, objs, ctx=ctx)          # loads the module into THIS context
+        assert lib.rtgr_user_metric_loaded(ctx, sc.user_metric) == 1
+        rgb = np.zeros((3, 48 * 33))
+        ctr = abi.rtgr_counters()
+        abi.check(lib, lib.rtgr_trace_sharded_f64(ctx, C.byref(sc), C.byref(opt), C.byref(camera), 48, 33, rgb.ctypes.data, None, C.byref(ctr)))
+        assert np.array_equal(rgb, ref["rgb"]) and ctr.as_dict() == ref["counters"]
+        abi.check(lib, lib.rtgr_user_metric_unload(ctx, sc.user_metric))
+        assert lib.rtgr_user_metric_loaded(ctx, sc.user_metric) == 0
+        assert lib.rtgr_trace_sharded_f64(ctx, C.byref(sc), C.byref(opt), C.byref(camera), 48, 33, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
+        sc = rt.make_scene(rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0, stationary=True), objs, ctx=ctx)   # and again
+        abi.check(lib, lib.rtgr_trace_sharded_f64(ctx, C.byref(sc), C.byref(opt), C.byref(camera), 48, 33, rgb.ctypes.data, None, None))
+        assert np.array_equal(rgb, ref["rgb"])
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
 def test_more_devices_than_rows(lib):
     import torch
     from test_gpu_parity import hip_trace
