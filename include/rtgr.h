@@ -281,6 +281,11 @@ int rtgr_make_canvas_device_f64(rtgr_context* ctx, const rtgr_scene* scene, cons
                                 uint64_t nj, uint64_t j0, uint64_t j1, double* d_state0, void* stream);
 int rtgr_make_canvas_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
                          uint64_t j0, uint64_t j1, double* state0);
+/* T = Float32 (make_canvas is generic in T, :457-462) */
+int rtgr_make_canvas_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni,
+                                uint64_t nj, uint64_t j0, uint64_t j1, float* d_state0, void* stream);
+int rtgr_make_canvas_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
+                         uint64_t j0, uint64_t j1, float* state0);
 
 /* ---- physics kernels exposed for parity tests (test/runtests.jl:12-61 exercises exactly these) -------------
  * Evaluated ON THE DEVICE for n points (host pointers in/out):

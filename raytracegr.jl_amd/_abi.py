@@ -64,7 +64,7 @@ EXPORTS = [
     "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_rows_device_f64", "rtgr_trace_rows_device_f32",
     "rtgr_trace_f64", "rtgr_trace_f32", "rtgr_trace_pixels_f64", "rtgr_trace_one_f64",
     "rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64",
-    "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64",
+    "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64", "rtgr_make_canvas_device_f32", "rtgr_make_canvas_f32",
     "rtgr_eval_metric_f64", "rtgr_eval_metric_f32", "rtgr_eval_geodesic_f64", "rtgr_eval_geodesic_f32",
     "rtgr_eval_fastmath_f64", "rtgr_quantize_device_f64",
     "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded",
@@ -120,8 +120,9 @@ def _declare(lib):
     for name in ("rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64"):
         getattr(lib, name).argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, vp,
                                        P(rtgr_ray_outputs), P(rtgr_counters)]
-    lib.rtgr_make_canvas_device_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp, vp]
-    lib.rtgr_make_canvas_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp]
+    for suf in ("f64", "f32"):
+        getattr(lib, f"rtgr_make_canvas_device_{suf}").argtypes = [ctx, P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp, vp]
+        getattr(lib, f"rtgr_make_canvas_{suf}").argtypes = [ctx, P(rtgr_scene), P(rtgr_camera), u64, u64, u64, u64, vp]
     lib.rtgr_eval_fastmath_f64.argtypes = [ctx, vp, u64, vp, vp]
     lib.rtgr_quantize_device_f64.argtypes = [ctx, vp, u64, u64, vp, vp]
     lib.rtgr_user_metric_load.argtypes = [ctx, C.c_char_p, P(u64)]

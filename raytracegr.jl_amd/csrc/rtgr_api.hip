@@ -1137,28 +1137,34 @@ int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtg
 }
 
 // ---- camera / hooks ------------------------------------------------------------------------------------------------------
-int rtgr_make_canvas_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
-                                uint64_t j0, uint64_t j1, double* d_state0, void* stream) {
+}  // extern "C"
+template <class R>
+static int make_canvas_device(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
+                              uint64_t j0, uint64_t j1, R* d_state0, void* stream) {
     if (!cam || !d_state0) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
     RESOLVE_DEVICE(d_state0);
     if (ni == 0 || nj == 0 || j1 <= j0 || j1 > nj) return fail(RTGR_ERR_BAD_ARG, "bad canvas range");
     DeviceGuard guard(D->dev);
     std::lock_guard<std::mutex> lk(D->mu);
-    DevScene<double> sc;
+    DevScene<R> sc;
     const UserModule* user = nullptr;
-    if ((rc = convert_scene<double>(*D, scene, sc, &user))) return rc;
-    DevCamera<double> cm;
-    convert_camera<double>(cam, cm);
+    if ((rc = convert_scene<R>(*D, scene, sc, &user))) return rc;
+    DevCamera<R> cm;
+    convert_camera<R>(cam, cm);
     const uint64_t n = ni * (j1 - j0);
     if (sc.metric == RTGR_USER) {
-        HIP_TRY(launch_module(user->canvas, (unsigned)((n + 255) / 256), 256, (hipStream_t)stream, sc, cm, ni, nj, j0, (uint64_t)1,
+        hipFunction_t f = sizeof(R) == 8 ? user->canvas : user->canvas_f32;
+        if (!f) return fail(RTGR_ERR_BAD_ARG, "this user-metric code object carries no Float32 kernels");
+        HIP_TRY(launch_module(f, (unsigned)((n + 255) / 256), 256, (hipStream_t)stream, sc, cm, ni, nj, j0, (uint64_t)1,
                               (uint64_t)0, n, d_state0));
         return RTGR_OK;
     }
-    return misc_canvas_f64(sc, cm, ni, nj, j0, n, d_state0, (hipStream_t)stream);
+    if constexpr (sizeof(R) == 8) return misc_canvas_f64(sc, cm, ni, nj, j0, n, d_state0, (hipStream_t)stream);
+    else return misc_canvas_f32(sc, cm, ni, nj, j0, n, d_state0, (hipStream_t)stream);
 }
-int rtgr_make_canvas_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0,
-                         uint64_t j1, double* state0) {
+template <class R>
+static int make_canvas_host(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                            uint64_t j1, R* state0) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
     if (rc) return rc;
@@ -1167,11 +1173,28 @@ int rtgr_make_canvas_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_
     const uint64_t n = ni * (j1 - j0);
     DeviceGuard guard(c->devs[0]->dev);
     DevBuf b;
-    if ((rc = b.alloc(n * 64))) return rc;
-    if ((rc = rtgr_make_canvas_device_f64(c, scene, cam, ni, nj, j0, j1, (double*)b.p, nullptr))) return rc;
+    if ((rc = b.alloc(n * 8 * sizeof(R)))) return rc;
+    if ((rc = make_canvas_device<R>(c, scene, cam, ni, nj, j0, j1, (R*)b.p, nullptr))) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(state0, b.p, n * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(state0, b.p, n * 8 * sizeof(R), hipMemcpyDeviceToHost));
     return RTGR_OK;
+}
+extern "C" {
+int rtgr_make_canvas_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
+                                uint64_t j0, uint64_t j1, double* d_state0, void* stream) {
+    return make_canvas_device<double>(ctx, scene, cam, ni, nj, j0, j1, d_state0, stream);
+}
+int rtgr_make_canvas_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj,
+                                uint64_t j0, uint64_t j1, float* d_state0, void* stream) {
+    return make_canvas_device<float>(ctx, scene, cam, ni, nj, j0, j1, d_state0, stream);
+}
+int rtgr_make_canvas_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                         uint64_t j1, double* state0) {
+    return make_canvas_host<double>(ctx, scene, cam, ni, nj, j0, j1, state0);
+}
+int rtgr_make_canvas_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                         uint64_t j1, float* state0) {
+    return make_canvas_host<float>(ctx, scene, cam, ni, nj, j0, j1, state0);
 }
 
 }  // extern "C"

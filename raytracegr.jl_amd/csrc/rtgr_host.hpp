@@ -156,6 +156,8 @@ int launch_f32_generic(LaunchEnv& E, const TraceArgs<float>& A, hipStream_t st);
 // ---- small kernels (rtgr_misc.hip) -------------------------------------------------------------------------------------
 int misc_canvas_f64(const DevScene<double>& sc, const DevCamera<double>& cam, uint64_t ni, uint64_t nj, uint64_t j0,
                     uint64_t n, double* d_state0, hipStream_t st);
+int misc_canvas_f32(const DevScene<float>& sc, const DevCamera<float>& cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                    uint64_t n, float* d_state0, hipStream_t st);
 int misc_eval_metric_f64(const DevScene<double>& sc, const double* d_x, uint64_t n, double* g, double* dg, double* Gam, hipStream_t st);
 int misc_eval_metric_f32(const DevScene<float>& sc, const float* d_x, uint64_t n, float* g, float* dg, float* Gam, hipStream_t st);
 int misc_eval_geodesic_f64(const DevScene<double>& sc, const double* d_s, uint64_t n, int path, double* d_ds, hipStream_t st);

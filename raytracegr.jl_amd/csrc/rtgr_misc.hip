@@ -186,6 +186,12 @@ int misc_canvas_f64(const DevScene<double>& sc, const DevCamera<double>& cam, ui
     CHECK_LAUNCH();
     return RTGR_OK;
 }
+int misc_canvas_f32(const DevScene<float>& sc, const DevCamera<float>& cam, uint64_t ni, uint64_t nj, uint64_t j0,
+                    uint64_t n, float* d_state0, hipStream_t st) {
+    hipLaunchKernelGGL(canvas_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, sc, cam, ni, nj, j0, (uint64_t)1, (uint64_t)0, n, d_state0);
+    CHECK_LAUNCH();
+    return RTGR_OK;
+}
 int misc_eval_metric_f64(const DevScene<double>& sc, const double* d_x, uint64_t n, double* g, double* dg, double* Gam, hipStream_t st) {
     hipLaunchKernelGGL(eval_metric_kernel<double>, dim3(nblk(n)), dim3(256), 0, st, sc, d_x, n, g, dg, Gam);
     CHECK_LAUNCH();

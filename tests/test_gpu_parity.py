@@ -210,6 +210,16 @@ def test_make_canvas_matches_oracle(lib, which):
     assert (flat["normal"][:, 0] < 0).all()
 
 
+def test_make_canvas_float32_matches_f32_oracle(lib):
+    """make_canvas is generic in T (src/RayTraceGR.jl:457-462): T = Float32 on the device against the Float32 oracle."""
+    sc, cam = example(2)
+    st = np.zeros((37 * 23, 8), np.float32)
+    abi.check(lib, lib.rtgr_make_canvas_f32(None, C.byref(sc), C.byref(cam), 37, 23, 0, 23, st.ctypes.data))
+    ref = O.make_canvas(sc, cam, 37, 23, dtype=np.float32)
+    assert np.abs(st[:, :4] - ref[:, :4]).max() <= 4e-7 and np.abs(st[:, 4:] - ref[:, 4:]).max() <= 2e-6
+    assert (st[:, 4] < 0).all()
+
+
 # ---- whole-path parity ------------------------------------------------------------------------------------------------
 def _golden(name):
     from raytracegr_jl_amd.png import read_png
