@@ -513,11 +513,14 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     for (auto& o : outs) out_bytes_per_ray += o.elem * o.planes;
 
     // ---- chunking ----------------------------------------------------------------------------------------------------
-    // Compute chunks of whole rows, sized P, 2P, 4P, 4P, …, 4P, 2P, P (P = one transfer piece, ~2^20 rays): the FIRST chunk
+    // Compute chunks of whole rows, sized P, 2P, 4P, 4P, …, 4P, P (P = one transfer piece, ~2^20 rays): the FIRST chunk
     // is small so that integration starts after one piece has been packed and uploaded instead of four (the pipeline's
     // fill), the LAST so that only a small unpack follows the last kernel (its drain); in between the chunks are big
     // enough (4 M rays) that the persistent kernels lose nothing to their tails.  Measured at 4096² through
-    // rtgr_trace_pixels_f64: 119 ms with equal 4 M-ray chunks (device-resident: 86 ms).
+    // rtgr_trace_pixels_f64: 119 ms with equal 4 M-ray chunks, 106-112 ms with the ramp (device-resident: 86-88 ms;
+    // measured split of a 106 ms call: chunked compute 95, fill 5, drain 3, the rest host noise).  Measured and rejected:
+    // alternating the chunks between TWO compute streams so that their tails overlap — the persistent kernels of two
+    // pipelines in flight slow each other down more than the tails cost (pixels 109 -> 123 ms, host 91 -> 98 ms).
     const uint64_t piece_target = D.knobs.host_chunk > 0 ? (uint64_t)D.knobs.host_chunk : (1ull << 20);
     struct Chunk { uint64_t row0, rows; };
     std::vector<Chunk> chunks;
@@ -538,7 +541,8 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
                 head.push_back(h); left -= h;
             }
             if (left == 0) break;
-            const uint64_t t = ramp[k] < left ? ramp[k] : left;   // ... and from the back
+            if (have_in && k > 0) continue;                       // ... and from the back: P (and 2P when nothing is uploaded)
+            const uint64_t t = ramp[k] < left ? ramp[k] : left;
             tail.push_back(t); left -= t;
         }
         if (left > 0) {                                       // the middle, in equal chunks of at most r4 rows — ONE chunk when
