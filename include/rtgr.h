@@ -274,6 +274,11 @@ int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtg
 int rtgr_trace_sharded_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt,
                                   const rtgr_camera* cam, uint64_t ni, uint64_t nj, double* d_rgb,
                                   const rtgr_ray_outputs* out, rtgr_counters* ctr);
+int rtgr_trace_sharded_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                           uint64_t ni, uint64_t nj, float* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr);
+int rtgr_trace_sharded_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt,
+                                  const rtgr_camera* cam, uint64_t ni, uint64_t nj, float* d_rgb,
+                                  const rtgr_ray_outputs* out, rtgr_counters* ctr);
 
 /* ---- camera: make_canvas (src/RayTraceGR.jl:457-478) on the device ------------------------------------------
  * Writes n x 8 ray states (pos, null past-directed 4-velocity) for rows [j0, j1).  Device / host variants. */

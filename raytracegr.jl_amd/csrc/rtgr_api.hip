@@ -977,8 +977,10 @@ int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_so
 // ---- all devices of the context ------------------------------------------------------------------------------------------
 // per-device scratch of the sharded path lives in the device's Staging: d_out = this rank's rows (all requested arrays),
 // d_small = counters; device 0 additionally d_recv = the peers' rows as they arrive.
+}  // extern "C"
+template <class R>
 static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
-                         uint64_t nj, double* d_rgb0, const rtgr_ray_outputs* out0, rtgr_counters* ctr) {
+                         uint64_t nj, R* d_rgb0, const rtgr_ray_outputs* out0, rtgr_counters* ctr) {
     const uint64_t N = c->devs.size();
     if (!scene || !opt || !cam) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
     if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
@@ -987,10 +989,10 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift needs state_end and hit in the same call");
     struct Arr { size_t elem; int planes; void* full; size_t off; };  // one per requested array
     std::vector<Arr> arrs;
-    arrs.push_back({8, 3, d_rgb0, 0});
+    arrs.push_back({sizeof(R), 3, d_rgb0, 0});
     if (out0) {
-        if (out0->state_end) arrs.push_back({64, 1, out0->state_end, 0});
-        if (out0->lambda_end) arrs.push_back({8, 1, out0->lambda_end, 0});
+        if (out0->state_end) arrs.push_back({8 * sizeof(R), 1, out0->state_end, 0});
+        if (out0->lambda_end) arrs.push_back({sizeof(R), 1, out0->lambda_end, 0});
         if (out0->status) arrs.push_back({1, 1, out0->status, 0});
         if (out0->hit) arrs.push_back({1, 1, out0->hit, 0});
         if (out0->n_accept) arrs.push_back({4, 1, out0->n_accept, 0});
@@ -1039,7 +1041,7 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
             if (out0->n_reject) po.n_reject = (uint32_t*)(pb + arrs[q++].off);
             if (out0->redshift) po.redshift = pb + arrs[q++].off;
         }
-        rc = trace_device<double>(D, scene, opt, nullptr, cam, ni, nj, k, k + 1, (double*)pb, &po, (rtgr_counters*)S[k]->d_small.p,
+        rc = trace_device<R>(D, scene, opt, nullptr, cam, ni, nj, k, k + 1, (R*)pb, &po, (rtgr_counters*)S[k]->d_small.p,
                                   S[k]->s_comp, N, nrows[k]);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(S[k]->pin_small.p, S[k]->d_small.p, sizeof(rtgr_counters), hipMemcpyDeviceToHost, S[k]->s_comp));
@@ -1063,7 +1065,8 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
             const char* src = k == 0 ? (const char*)S[0]->d_out.p : (const char*)S[0]->d_recv.p + (k - 1) * part_bytes;
             for (auto& a : arrs) {
                 if (a.planes == 3) {  // rgb: the part's planes are ni*nrows[k] apart
-                    if ((rc = misc_place_rows_f64((const double*)(src + a.off), ni, nj, k, N, 3, (double*)a.full, s0))) return rc;
+                    if constexpr (sizeof(R) == 8) { if ((rc = misc_place_rows_f64((const double*)(src + a.off), ni, nj, k, N, 3, (double*)a.full, s0))) return rc; }
+                    else if ((rc = misc_place_rows_f32((const float*)(src + a.off), ni, nj, k, N, 3, (float*)a.full, s0))) return rc;
                 } else if ((rc = misc_place_rows_u8((const uint8_t*)(src + a.off), ni, nj, k, N, a.elem, (uint8_t*)a.full, s0))) return rc;
             }
         }
@@ -1083,17 +1086,11 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
     return RTGR_OK;
 }
 
-int rtgr_trace_sharded_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
-                                  uint64_t ni, uint64_t nj, double* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
-    rtgr_context* c = nullptr;
-    int rc = resolve_ctx(ctx, &c);
-    if (rc) return rc;
-    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
-    return trace_sharded(c, scene, opt, cam, ni, nj, d_rgb, out, ctr);
-}
-
-int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
-                           uint64_t ni, uint64_t nj, double* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+extern "C" {
+}  // extern "C"
+template <class R>
+static int trace_sharded_host(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
+                              uint64_t nj, R* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
     if (rc) return rc;
@@ -1105,12 +1102,12 @@ int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtg
     // the full frame on device 0, then one download per array
     struct Item { void* host; size_t bytes; void* dev; };
     std::vector<Item> items;
-    items.push_back({rgb, (size_t)n * 24, nullptr});
+    items.push_back({rgb, (size_t)n * 3 * sizeof(R), nullptr});
     rtgr_ray_outputs dout;
     std::memset(&dout, 0, sizeof dout);
     if (out) {
-        if (out->state_end) items.push_back({out->state_end, (size_t)n * 64, nullptr});
-        if (out->lambda_end) items.push_back({out->lambda_end, (size_t)n * 8, nullptr});
+        if (out->state_end) items.push_back({out->state_end, (size_t)n * 8 * sizeof(R), nullptr});
+        if (out->lambda_end) items.push_back({out->lambda_end, (size_t)n * sizeof(R), nullptr});
         if (out->status) items.push_back({out->status, (size_t)n, nullptr});
         if (out->hit) items.push_back({out->hit, (size_t)n, nullptr});
         if (out->n_accept) items.push_back({out->n_accept, (size_t)n * 4, nullptr});
@@ -1135,9 +1132,35 @@ int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtg
             if (out->redshift) dout.redshift = items[k++].dev;
         }
     }
-    if ((rc = trace_sharded(c, scene, opt, cam, ni, nj, (double*)items[0].dev, &dout, ctr))) return rc;
+    if ((rc = trace_sharded<R>(c, scene, opt, cam, ni, nj, (R*)items[0].dev, &dout, ctr))) return rc;
     for (auto& it : items) HIP_TRY(hipMemcpy(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost));
     return RTGR_OK;
+}
+template <class R>
+static int trace_sharded_device(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
+                                uint64_t nj, R* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
+    return trace_sharded<R>(c, scene, opt, cam, ni, nj, d_rgb, out, ctr);
+}
+extern "C" {
+int rtgr_trace_sharded_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                                  uint64_t ni, uint64_t nj, double* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    return trace_sharded_device<double>(ctx, scene, opt, cam, ni, nj, d_rgb, out, ctr);
+}
+int rtgr_trace_sharded_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                                  uint64_t ni, uint64_t nj, float* d_rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    return trace_sharded_device<float>(ctx, scene, opt, cam, ni, nj, d_rgb, out, ctr);
+}
+int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                           uint64_t ni, uint64_t nj, double* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    return trace_sharded_host<double>(ctx, scene, opt, cam, ni, nj, rgb, out, ctr);
+}
+int rtgr_trace_sharded_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
+                           uint64_t ni, uint64_t nj, float* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    return trace_sharded_host<float>(ctx, scene, opt, cam, ni, nj, rgb, out, ctr);
 }
 
 // ---- camera / hooks ------------------------------------------------------------------------------------------------------

@@ -170,6 +170,8 @@ int misc_quantize(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img,
 // multi-device gather on device 0: rows of rank r (cyclic over nranks) back into place
 int misc_place_rows_f64(const double* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,
                         double* d_full, hipStream_t st);
+int misc_place_rows_f32(const float* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,
+                        float* d_full, hipStream_t st);
 int misc_place_rows_u8(const uint8_t* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t elem,
                        uint8_t* d_full, hipStream_t st);
 

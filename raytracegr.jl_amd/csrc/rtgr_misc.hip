@@ -230,6 +230,14 @@ int misc_place_rows_f64(const double* d_part, uint64_t ni, uint64_t nj, uint64_t
     CHECK_LAUNCH();
     return RTGR_OK;
 }
+int misc_place_rows_f32(const float* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,
+                        float* d_full, hipStream_t st) {
+    const uint64_t nrows = (nj - rank + nranks - 1) / nranks;
+    hipLaunchKernelGGL(place_rows_kernel<float>, dim3(nblk(ni * nrows * planes)), dim3(256), 0, st, d_part, ni, nj, rank, nranks,
+                       planes, (uint64_t)1, d_full);
+    CHECK_LAUNCH();
+    return RTGR_OK;
+}
 int misc_place_rows_u8(const uint8_t* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t elem,
                        uint8_t* d_full, hipStream_t st) {
     const uint64_t nrows = (nj - rank + nranks - 1) / nranks;

@@ -181,6 +181,16 @@ def test_single_process_multi_device_trace(lib, ndev):
         abi.check(lib, lib.rtgr_trace_sharded_device_f64(ctx, C.byref(sc), C.byref(opt), C.byref(cam), ni, nj,
                                                          d_rgb.data_ptr(), C.byref(od), None))
         assert np.array_equal(d_rgb.cpu().numpy(), ref["rgb"]) and np.array_equal(d_st.cpu().numpy(), ref["status"])
+        # Float32 twin
+        opt32 = rt.solver_defaults(np.float32)
+        ref32 = hip_trace(lib, sc, opt32, ni, nj, cam=cam, dtype=np.float32)
+        rgb32 = np.zeros((3, n), np.float32)
+        o32, arrs32 = O._outs(n, np.float32, True)
+        abi.check(lib, lib.rtgr_trace_sharded_f32(ctx, C.byref(sc), C.byref(opt32), C.byref(cam), ni, nj, rgb32.ctypes.data,
+                                                  C.byref(o32), C.byref(ctr)))
+        assert np.array_equal(rgb32, ref32["rgb"]) and ctr.as_dict() == ref32["counters"]
+        for k in OUT_KEYS[1:]:
+            assert np.array_equal(arrs32[k], ref32[k], equal_nan=True), k
     finally:
         abi.check(lib, lib.rtgr_destroy(ctx))
 
