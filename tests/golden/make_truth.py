@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/truth_<variant>.npz: for 64 pixels of a 200 x 200 render of every BASELINE.json scene variant,
+the end state, λ_end, hit object and RGB of the TRUE geodesic as tests/truth.py integrates it (sympy-differentiated
+metric, scipy DOP853 at rtol 1e-13 — no code or algorithm shared with the oracle or the HIP path), plus
+
+  self_err   |end state(rtol 1e-13) − end state(rtol 1e-11)|∞ — the truth's own convergence (the error of the LOOSER run)
+  clearance  smallest |distance| to any object other than the one hit, along the ray (small = grazing; see truth.py)
+
+Pixels: one per cell of an 8 x 8 grid over the image, jittered with a fixed seed (no look at any solver's output).
+
+    python tests/golden/make_truth.py            # ≈ 2 min on 8 cores
+"""
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk"]
+N, GRID = 200, 8
+
+
+def pixels():
+    rng = np.random.default_rng(20261004)
+    cell = N // GRID
+    ij = [(gi * cell + int(rng.integers(cell)), gj * cell + int(rng.integers(cell))) for gj in range(GRID) for gi in range(GRID)]
+    return np.array(ij, dtype=np.int64)
+
+
+def one(job):
+    import truth
+    from scenes import scene_variant, rt
+    name, i, j = job
+    sc, cam = scene_variant(name)
+    opt = rt.solver_defaults()
+    s0 = truth.pixel_state(sc, cam, N, N, i, j)
+    r = truth.trace_ray(sc, opt, s0)
+    loose = truth.trace_ray(sc, opt, s0, rtol=1e-11, atol=1e-13)
+    self_err = np.abs(r["state_end"] - loose["state_end"]).max() if loose["hit"] == r["hit"] else np.inf
+    return s0, r["state_end"], r["lambda_end"], r["hit"], r["rgb"], r["clearance"], self_err, r["nfev"]
+
+
+if __name__ == "__main__":
+    ij = pixels()
+    with Pool(min(8, os.cpu_count() or 1)) as pool:
+        for name in VARIANTS:
+            res = pool.map(one, [(name, int(i), int(j)) for i, j in ij], chunksize=2)
+            out = os.path.join(HERE, f"truth_{name}.npz")
+            np.savez_compressed(out, n=N, ij=ij, state0=np.array([r[0] for r in res]),
+                                state_end=np.array([r[1] for r in res]), lambda_end=np.array([r[2] for r in res]),
+                                hit=np.array([r[3] for r in res], dtype=np.uint8), rgb=np.array([r[4] for r in res]),
+                                clearance=np.array([r[5] for r in res]), self_err=np.array([r[6] for r in res]),
+                                nfev=np.array([r[7] for r in res]))
+            se = np.array([r[6] for r in res])
+            print(name, os.path.getsize(out), "bytes; hit classes", np.bincount([r[3] for r in res], minlength=4),
+                  "self_err median %.1e max %.1e" % (np.median(se), se.max()), flush=True)

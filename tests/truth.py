@@ -1,0 +1,156 @@
+"""An independent, much-tighter solution of the same physics — TEST-SIDE ONLY (like oracle/, never imported by the product).
+
+Why it exists.  The oracle restates OrdinaryDiffEq's Tsit5 + PI controller + ContinuousCallback from their published
+algorithms, and the only artefacts of the reference that pin it are two 8-bit images: everything below
+1/255 would otherwise be HIP-vs-oracle only.  This module removes the shared assumptions: it knows nothing of Tsit5,
+dual numbers, the closed contraction or the event machinery —
+
+  * the metric is typed as a sympy expression (same formulas as `kerr_schild`, src/RayTraceGR.jl:283-291, and the
+    textbook radius), its derivative is SYMBOLIC (`sympy.diff`), both are lambdified;
+  * the geodesic equation (:358-370) is evaluated from them with a linear solve (no Christoffel symbols, no inverse);
+  * the integrator is scipy's DOP853 (8th order) at rtol 1e-13 / atol 1e-15 — three to four orders tighter than the
+    path's own tolerance 2⁻³⁹ ≈ 1.8·10⁻¹² — with its own dense-output root finder for the object events;
+  * `make_canvas` (:457-478) and the colouring rule (:513-533, :402-404, :420-428) are restated in numpy.
+
+So `|x_oracle − x_truth|` and `|x_hip − x_truth|` measure each path's GLOBAL integration error.  The reference (same
+method, same tolerances) has a global error of the same size, which is what turns "within 1e-6 RGB of the Julia reference"
+(BASELINE.json north_star) from an untestable statement into a bounded one: two solutions that are each within ε of the
+true geodesic are within 2ε of each other, whatever the controller details.
+"""
+import functools
+
+import numpy as np
+
+
+@functools.lru_cache(maxsize=None)
+def _metric_fn(kind):
+    """kind: 'mink' | 'ks_ref' (r as written, :284) | 'ks_true' (textbook r).  Returns f(x, y, z, M, a) ->
+    (g[4][4], dg[3][4][4]) with dg[j] = ∂g/∂x_j, j = x,y,z (every metric here is stationary: ∂_t g = 0)."""
+    import sympy as sp
+    x, y, z, M, a = sp.symbols("x y z M a", real=True)
+    eta = sp.diag(-1, 1, 1, 1)
+    if kind == "mink":
+        g = eta
+    else:
+        rho2 = x * x + y * y + z * z
+        q = rho2 - a * a
+        if kind == "ks_ref":
+            r = sp.sqrt(q) / 2 + sp.sqrt(a * a * z * z + (q / 2) ** 2)
+        else:
+            r = sp.sqrt((q + sp.sqrt(q * q + 4 * a * a * z * z)) / 2)
+        f = 2 * M * r ** 3 / (r ** 4 + a * a * z * z)
+        k = sp.Matrix([1, (r * x + a * y) / (r * r + a * a), (r * y - a * x) / (r * r + a * a), z / r])
+        g = eta + f * k * k.T
+    dg = [sp.diff(g, v) for v in (x, y, z)]
+    fn = sp.lambdify((x, y, z, M, a), [g.tolist(), [d.tolist() for d in dg]], modules="numpy", cse=True)
+
+    def call(px, py, pz, m, sa):
+        gg, dd = fn(px, py, pz, m, sa)
+        return np.array(gg, dtype=np.float64), np.array(dd, dtype=np.float64)
+    return call
+
+
+def _kind(scene):
+    from conftest import load_package
+    abi = load_package()._abi
+    k = scene.metric & ~abi.METRIC_GENERIC
+    return {abi.MINKOWSKI: "mink", abi.KS_REF: "ks_ref", abi.KS_TRUE: "ks_true"}[k]
+
+
+def metric(scene, pos):
+    return _metric_fn(_kind(scene))(pos[1], pos[2], pos[3], scene.M, scene.a)[0]
+
+
+def rhs(scene):
+    """s = (x^a, u^a) -> (u^a, u̇^a),  g_ad u̇^d = −(∂_b g_ac − ½ ∂_a g_bc) u^b u^c  (the lowered form of :358-370)."""
+    fn, M, a = _metric_fn(_kind(scene)), scene.M, scene.a
+
+    def f(_lam, s):
+        g, dgs = fn(s[1], s[2], s[3], M, a)
+        dg = np.zeros((4, 4, 4))        # dg[b][a][c] = ∂_b g_ac
+        dg[1:] = dgs
+        u = s[4:]
+        low = np.einsum("bac,b,c->a", dg, u, u) - 0.5 * np.einsum("abc,b,c->a", dg, u, u)
+        return np.concatenate([u, -np.linalg.solve(g, low)])
+    return f
+
+
+def object_distance(o, pos):
+    """distance(obj, pos): Plane :399-401, Sphere :415-419 (signed by the radius' sign), Disk (no reference)."""
+    from conftest import load_package
+    abi = load_package()._abi
+    p = o.p
+    if o.kind == abi.PLANE:
+        return pos[0] - p[0]
+    if o.kind == abi.SPHERE:
+        d2 = sum((pos[i] - p[i]) ** 2 for i in (1, 2, 3))
+        return np.sign(p[8]) * (d2 - p[8] ** 2)
+    rc = np.hypot(pos[1], pos[2])
+    return max(abs(pos[3]) - p[0], p[1] - rc, rc - p[2])
+
+
+def object_colour(o, pos):
+    from conftest import load_package
+    abi = load_package()._abi
+    if o.kind == abi.PLANE:
+        return np.array([0.0, 0.5, 0.0])
+    if o.kind == abi.SPHERE:
+        d = np.array([pos[i] - o.p[i] for i in (1, 2, 3)])
+        th = np.arccos(d[2] / np.linalg.norm(d))
+        ph = np.arctan2(d[1], d[0])
+        return np.array([np.mod(12 * th / np.pi, 1.0), np.mod(12 * ph / np.pi, 1.0), 1.0])
+    rc = np.hypot(pos[1], pos[2])
+    return np.array([1.0, np.mod(rc, 1.0), np.mod(12 * np.arctan2(pos[2], pos[1]) / np.pi, 1.0)])
+
+
+def pixel_state(scene, cam, ni, nj, i, j):
+    """make_canvas for pixel (i, j), 0-based (:463-476)."""
+    dx = (i + 0.5) / ni - 0.5
+    dy = (j + 0.5) / nj - 0.5
+    pos = np.array(cam.pos) + dx * np.array(cam.widthx) + dy * np.array(cam.widthy)
+    n = np.array(cam.normal) + dx * np.array(cam.widthx) + dy * np.array(cam.widthy)
+    g = metric(scene, pos)
+    t = np.linalg.solve(g, np.array([1.0, 0, 0, 0]))
+    u = (t / np.sqrt(-t @ g @ t) + n / np.sqrt(n @ g @ n)) / np.sqrt(2.0)
+    return np.concatenate([pos, u])
+
+
+def trace_ray(scene, opt, s0, rtol=1e-13, atol=1e-15, max_step=0.2):
+    """-> dict(state_end, lambda_end, hit (1-based object, 0 = nothing), rgb, nfev, clearance).
+
+    `max_step`: scipy looks for an event only between the END POINTS of its steps, and an 8th-order method crosses flat
+    space in a handful of them; 0.2 (objects here are ≥ 0.5 across, |ẋ| ≈ 1) keeps a chord from being stepped over.
+
+    `clearance`: the smallest |distance| to any object OTHER than the one hit, over the whole ray, relative to that
+    object's size scale — rays with a tiny clearance graze an object, and whether the reference's sampled sign test sees
+    the graze is decided by where its steps happen to fall; callers exclude them from tolerance statistics."""
+    from scipy.integrate import solve_ivp
+    objs = [scene.obj[k] for k in range(scene.nobj)]
+    events = []
+    for o in objs:
+        ev = (lambda o: lambda lam, s: object_distance(o, s))(o)
+        ev.terminal = True
+        events.append(ev)
+    sol = solve_ivp(rhs(scene), (opt.lambda0, opt.lambda1), s0, method="DOP853", rtol=rtol, atol=atol, events=events,
+                    dense_output=True, max_step=max_step)
+    hit_events = [k for k, te in enumerate(sol.t_events) if len(te)]
+    if hit_events:
+        k = hit_events[0]
+        lam_end, s_end = sol.t_events[k][0], sol.y_events[k][0]
+    else:
+        lam_end, s_end = sol.t[-1], sol.y[:, -1]
+    # colouring rule (:518-530): the object of smallest signed distance below the threshold
+    omin, dmin = 0, opt.hit_threshold
+    for k, o in enumerate(objs):
+        d = object_distance(o, s_end)
+        if d < dmin:
+            omin, dmin = k + 1, d
+    rgb = np.array(opt.miss_rgb[:]) if omin == 0 else object_colour(objs[omin - 1], s_end) * omin / len(objs)
+    lam = np.linspace(opt.lambda0, lam_end, 400)
+    path = sol.sol(lam)
+    clearance = np.inf
+    for k, o in enumerate(objs):
+        if k + 1 == omin:
+            continue
+        clearance = min(clearance, min(abs(object_distance(o, path[:, m])) for m in range(path.shape[1])))
+    return dict(state_end=s_end, lambda_end=lam_end, hit=omin, rgb=rgb, nfev=sol.nfev, clearance=clearance)
