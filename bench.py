@@ -69,6 +69,8 @@ def parse():
                     help="1: after the timed region (rank 0, N = 1, default workload) also time the host and pixels entry "
                          "points and the Kerr a = 0.8 variant, reported in entry_points / variants; 0: skip")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: do not overlap the gather of pass k with the tracing of pass k+1")
     ap.add_argument("--layout", default="cyclic", choices=["cyclic", "slab"], help="row distribution over ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real thing) or gloo (CPU-staged; lets "
@@ -188,14 +190,35 @@ def main():
     # rows are dealt cyclically (rank r: rows r, r+N, …): contiguous slabs of a black-hole image are unbalanced
     j0, jstride, nrows = sharded.row_assignment(nj, ws, rank, a.layout)
     ctr = torch.zeros(8, dtype=torch.int64, device=dev)
-    out = {}
     host = {}
+    # N > 1: the exchange of pass k runs on a side stream while pass k+1 is traced into the other output buffer (a render
+    # loop delivers frame after frame; only the LAST gather is exposed, and the timed region ends with a device-wide
+    # synchronize, so all K gathers are inside it).  --no-overlap: trace and gather strictly in turn.
+    overlap = ws > 1 and not a.no_gather and not a.no_overlap
+    outs = [{}, {}] if overlap else [{}]
+    gathered = [None] * len(outs)          # event on the exchange stream: this buffer's rows have left
+    comm = torch.cuda.Stream(device=dev) if overlap else None
+    npass = [0]
 
     def device_pass():
+        k = npass[0] % len(outs)
+        npass[0] += 1
+        out = outs[k]
+        if gathered[k] is not None:
+            torch.cuda.current_stream(dev).wait_event(gathered[k])
         sharded.trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device=dev, dtype=npdt, counters=ctr,
                                  out=out, status=(ws > 1))
         if ws > 1 and not a.no_gather:
-            gather(out["rgb"], out["status"])
+            if not overlap:
+                gather(out["rgb"], out["status"])
+                return
+            traced = torch.cuda.Event()
+            traced.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(comm):
+                comm.wait_event(traced)
+                gather(out["rgb"], out["status"])
+                gathered[k] = torch.cuda.Event()
+                gathered[k].record(comm)
 
     def host_pass():   # rtgr_trace_f64/_f32: camera on the device, RGB planes to (pageable) host memory
         if "rgb" not in host:
@@ -329,6 +352,12 @@ def main():
         line.update(extras)
         if ws > 1 and not a.no_gather:
             line["gathered_status_not_event"] = int((image["status"] != 0).sum())
+            line["exchange"] = "overlapped with the next pass" if overlap else "in turn"
+        # order-independent bit-level checksum of the delivered frame: equal at every N iff the frames are bit-identical
+        frame = image["rgb"] if (ws > 1 and not a.no_gather) else (outs[0]["rgb"] if ws == 1 else None)
+        if frame is not None and a.entry == "device":
+            bits = frame.contiguous().view(torch.int64 if a.dtype == "f64" else torch.int32).to(torch.int64)
+            line["frame_checksum"] = int(bits.sum().item())
         print(json.dumps(line), flush=True)
     if ws > 1:
         dist.barrier()
