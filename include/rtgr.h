@@ -257,10 +257,15 @@ int rtgr_trace_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver
  * writes rgb back into the same AoS layout of `pixels_out` (may alias pixels_in), as trace_rays does (:532). */
 int rtgr_trace_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in,
                           uint64_t ni, uint64_t nj, double* pixels_out, rtgr_counters* ctr);
+/* ... of an Array{Pixel{Float32},2}: 11 floats (44 bytes) per pixel — `Canvas{T}` is generic in T (:452-455). */
+int rtgr_trace_pixels_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* pixels_in,
+                          uint64_t ni, uint64_t nj, float* pixels_out, rtgr_counters* ctr);
 
 /* Legacy single-ray shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:76): one pixel in, rgb out. */
 int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
                        const double normal[4], double rgb[3], double state_end[8], uint8_t* status);
+int rtgr_trace_one_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float pos[4],
+                       const float normal[4], float rgb[3], float state_end[8], uint8_t* status);
 
 /* ---- the hot path over ALL devices of the context -------------------------------------------------
  * One blocking call from one host thread: image rows are dealt cyclically to the context's N devices (device k traces

@@ -15,6 +15,7 @@
 #   RtgrSolver      72   reltol 0, abstol 8, lambda0 16, lambda1 24, hit_threshold 32, miss_rgb 40, max_steps 64, interp_points 68
 #   RtgrCounters    64   rays 0, accepted 8, rejected 16, rhs_evals 24, events 32, events_interior 40, not_finished 48, reserved 56
 #   Pixel{Float64}  88   pos 0, normal 32, rgb 64          (the reference's own type, src/RayTraceGR.jl:446-450)
+#   Pixel{Float32}  44   pos 0, normal 16, rgb 32
 #
 # It is a thin `ccall` layer; host code stays Julia, the metric/object/Pixel signatures of the reference are preserved,
 # and anything that cannot cross the C ABI (an arbitrary metric callable) falls back to the reference's own CPU path.
@@ -128,26 +129,37 @@ function scene_of(metric, objs, ctx)
     Ref(RtgrScene(d[1], length(objs), d[2], d[3], d[4], packed))
 end
 
+# the objects' own parameters stay Float64 across the ABI (rtgr_object.p); T selects the arithmetic of the path
+pack(pl::RayTraceGR.Plane{Float32}) = RtgrObject(RTGR_PLANE, 0, (Float64(pl.time), 0, 0, 0, 0, 0, 0, 0, 0))
+pack(s::RayTraceGR.Sphere{Float32}) = RtgrObject(RTGR_SPHERE, 0, (Float64.(s.pos)..., Float64.(s.vel)..., Float64(s.radius)))
+
 """
-    trace_rays(metric, objs, c::Canvas{Float64}; ctx = nothing) -> Canvas{Float64}
+    trace_rays(metric, objs, c::Canvas{T}; ctx = nothing) -> Canvas{T},   T = Float64 | Float32
 
 Drop-in for `RayTraceGR.trace_rays` (src/RayTraceGR.jl:483-484).  Passes `pointer(c.pixels)` — the reference's own
-88-byte `Pixel{Float64}` AoS (:446-450) — across the ABI; returns a new canvas with `rgb` filled (:532).
+`Pixel{T}` AoS (:446-450; 88 bytes for Float64, 44 for Float32) — across the ABI; returns a new canvas with `rgb`
+filled (:532).  The tolerance is `eps(T)^(3/4)` as in the reference (:485).
 """
-function trace_rays(metric, objs::Vector{RayTraceGR.Object{Float64}}, c::RayTraceGR.Canvas{Float64}; ctx = nothing)
+function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Canvas{T}; ctx = nothing) where {T<:Union{Float64,Float32}}
     scene = scene_of(metric, objs, ctx)
     scene === nothing && return RayTraceGR.trace_rays(metric, objs, c)        # arbitrary metric callable: reference CPU path
     opt = Ref{RtgrSolver}()
-    check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, 0))
+    check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, T === Float32 ? 1 : 0))
     ni, nj = size(c.pixels)
     out = similar(c.pixels)
     ctr = Ref{RtgrCounters}()
     GC.@preserve c out begin
-        check(ccall((:rtgr_trace_pixels_f64, librtgr), Cint,
-                    (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, UInt64, UInt64, Ptr{Cvoid}, Ptr{RtgrCounters}),
-                    handle(ctx), scene, opt, pointer(c.pixels), ni, nj, pointer(out), ctr))
+        if T === Float64
+            check(ccall((:rtgr_trace_pixels_f64, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, UInt64, UInt64, Ptr{Cvoid}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, pointer(c.pixels), ni, nj, pointer(out), ctr))
+        else
+            check(ccall((:rtgr_trace_pixels_f32, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, UInt64, UInt64, Ptr{Cvoid}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, pointer(c.pixels), ni, nj, pointer(out), ctr))
+        end
     end
-    RayTraceGR.Canvas{Float64}(out)
+    RayTraceGR.Canvas{T}(out)
 end
 
 """

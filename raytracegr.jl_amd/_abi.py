@@ -62,7 +62,7 @@ EXPORTS = [
     "rtgr_abi_version", "rtgr_solver_defaults", "rtgr_device_info", "rtgr_set_option", "rtgr_get_option",
     "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read",
     "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_rows_device_f64", "rtgr_trace_rows_device_f32",
-    "rtgr_trace_f64", "rtgr_trace_f32", "rtgr_trace_pixels_f64", "rtgr_trace_one_f64",
+    "rtgr_trace_f64", "rtgr_trace_f32", "rtgr_trace_pixels_f64", "rtgr_trace_pixels_f32", "rtgr_trace_one_f64", "rtgr_trace_one_f32",
     "rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64", "rtgr_trace_sharded_f32", "rtgr_trace_sharded_device_f32",
     "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64", "rtgr_make_canvas_device_f32", "rtgr_make_canvas_f32",
     "rtgr_eval_metric_f64", "rtgr_eval_metric_f32", "rtgr_eval_geodesic_f64", "rtgr_eval_geodesic_f32",
@@ -115,8 +115,10 @@ def _declare(lib):
             P(rtgr_counters)]
         getattr(lib, f"rtgr_eval_metric_{suf}").argtypes = [ctx, P(rtgr_scene), vp, u64, vp, vp, vp]
         getattr(lib, f"rtgr_eval_geodesic_{suf}").argtypes = [ctx, P(rtgr_scene), vp, u64, i32, vp]
-    lib.rtgr_trace_pixels_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, u64, u64, vp, P(rtgr_counters)]
-    lib.rtgr_trace_one_f64.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, vp, vp, vp, vp]
+    for f in (lib.rtgr_trace_pixels_f64, lib.rtgr_trace_pixels_f32):
+        f.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, u64, u64, vp, P(rtgr_counters)]
+    for f in (lib.rtgr_trace_one_f64, lib.rtgr_trace_one_f32):
+        f.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, vp, vp, vp, vp]
     for name in ("rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64", "rtgr_trace_sharded_f32", "rtgr_trace_sharded_device_f32"):
         getattr(lib, name).argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, vp,
                                        P(rtgr_ray_outputs), P(rtgr_counters)]

@@ -193,36 +193,44 @@ def _lib():
     return lib
 
 
-def make_canvas(metric, pos, widthx, widthy, normal, ni, nj):
-    """make_canvas(metric, pos, widthx, widthy, normal, ni, nj)::Canvas  (src/RayTraceGR.jl:457-478), on the GPU."""
+def make_canvas(metric, pos, widthx, widthy, normal, ni, nj, dtype=np.float64):
+    """make_canvas(metric, pos, widthx, widthy, normal, ni, nj)::Canvas{T}  (src/RayTraceGR.jl:457-478), on the GPU.
+    `dtype` plays the reference's type parameter T (np.float64 or np.float32)."""
     lib = _lib()
     sc = make_scene(metric, [])
     cam = make_camera(pos, widthx, widthy, normal)
-    st = np.empty((ni * nj, 8), dtype=np.float64)
-    _abi.check(lib, lib.rtgr_make_canvas_f64(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
-    px = np.zeros((ni, nj), dtype=pixel_dtype(), order="F")
+    st = np.empty((ni * nj, 8), dtype=dtype)
+    fn = lib.rtgr_make_canvas_f64 if dtype == np.float64 else lib.rtgr_make_canvas_f32
+    _abi.check(lib, fn(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
+    px = np.zeros((ni, nj), dtype=pixel_dtype(dtype), order="F")
     flat = px.reshape(-1, order="F")
     flat["pos"] = st[:, :4]
     flat["normal"] = st[:, 4:]
     return Canvas(px)
 
 
-def trace_rays(metric, objs, c, opt=None, return_info=False):
-    """trace_rays(metric, objs, c::Canvas)::Canvas  (src/RayTraceGR.jl:482-536).
+def _canvas_scalar(px_dtype):
+    for t in (np.float64, np.float32):
+        if px_dtype == pixel_dtype(t):
+            return t
+    raise TypeError("Canvas{Float64} or Canvas{Float32} expected")
 
-    Passes the reference's own AoS pixel array across the ABI (rtgr_trace_pixels_f64) and returns a NEW canvas
-    with pos/normal copied and rgb set (:532).  Pure, like the reference."""
+
+def trace_rays(metric, objs, c, opt=None, return_info=False):
+    """trace_rays(metric, objs, c::Canvas{T})::Canvas{T}  (src/RayTraceGR.jl:482-536), T = Float64 or Float32.
+
+    Passes the reference's own AoS pixel array across the ABI (rtgr_trace_pixels_f64 / _f32) and returns a NEW canvas
+    with pos/normal copied and rgb set (:532).  Pure, like the reference.  The tolerance is eps(T)^(3/4) (:485)."""
     lib = _lib()
     sc = make_scene(metric, objs)
-    opt = opt or solver_defaults()
     ni, nj = c.pixels.shape
     pin = np.asfortranarray(c.pixels)
-    if pin.dtype != pixel_dtype():
-        raise TypeError("Canvas{Float64} expected")
+    t = _canvas_scalar(pin.dtype)
+    opt = opt or solver_defaults(t)
     pout = np.empty_like(pin, order="F")
     ctr = rtgr_counters()
-    _abi.check(lib, lib.rtgr_trace_pixels_f64(None, C.byref(sc), C.byref(opt), pin.ctypes.data, ni, nj,
-                                              pout.ctypes.data, C.byref(ctr)))
+    fn = lib.rtgr_trace_pixels_f64 if t == np.float64 else lib.rtgr_trace_pixels_f32
+    _abi.check(lib, fn(None, C.byref(sc), C.byref(opt), pin.ctypes.data, ni, nj, pout.ctypes.data, C.byref(ctr)))
     out = Canvas(pout)
     return (out, ctr.as_dict()) if return_info else out
 
@@ -233,15 +241,17 @@ def trace_ray(metric, objs, cb, p, opt=None):
     ContinuousCallback(min_distance(objs, ·), terminate!) (src/RayTraceGR.jl:488-490)."""
     lib = _lib()
     sc = make_scene(metric, objs)
-    opt = opt or solver_defaults()
-    pos = np.ascontiguousarray(p["pos"], dtype=np.float64)
-    nrm = np.ascontiguousarray(p["normal"], dtype=np.float64)
-    rgb = np.zeros(3)
-    se = np.zeros(8)
+    t = _canvas_scalar(p.dtype)
+    opt = opt or solver_defaults(t)
+    pos = np.ascontiguousarray(p["pos"], dtype=t)
+    nrm = np.ascontiguousarray(p["normal"], dtype=t)
+    rgb = np.zeros(3, t)
+    se = np.zeros(8, t)
     st = C.c_uint8(0)
-    _abi.check(lib, lib.rtgr_trace_one_f64(None, C.byref(sc), C.byref(opt), pos.ctypes.data, nrm.ctypes.data,
-                                           rgb.ctypes.data, se.ctypes.data, C.addressof(st)))
-    return Pixel(pos, nrm, rgb)
+    fn = lib.rtgr_trace_one_f64 if t == np.float64 else lib.rtgr_trace_one_f32
+    _abi.check(lib, fn(None, C.byref(sc), C.byref(opt), pos.ctypes.data, nrm.ctypes.data, rgb.ctypes.data, se.ctypes.data,
+                       C.addressof(st)))
+    return Pixel(pos, nrm, rgb, dtype=t)
 
 
 # ---- physics kernels for the reference's unit tests (test/runtests.jl:12-61), evaluated on the GPU ------------

@@ -469,11 +469,11 @@ struct OutArray { void* host; size_t elem; int planes; size_t dev_off; };
 //     s_down: D2H of chunk c's outputs into pinned staging; a helper thread unpacks them into the caller's arrays
 // so that upload, integration and download of successive chunks overlap, and PCIe carries 64 B/ray in (ray states; nothing
 // when the camera generates them on the device) and 24 B/ray out (+ what `out` asks for) — never the 88-byte pixels.
-// `px_in` != NULL: the input is the reference's Pixel{Float64} array (11 doubles per pixel, pos + normal are packed
+// `px_in` != NULL: the input is the reference's Pixel{T} array (11 scalars per pixel, pos + normal are packed
 // out of it on the way up) and `px_out` receives Pixel(p.pos, p.normal, rgb) (:532).
 template <class R>
-int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const R* state0, const double* px_in,
-                         double* px_out, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* rgb,
+int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const R* state0, const R* px_in,
+                         R* px_out, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* rgb,
                          const rtgr_ray_outputs* out, rtgr_counters* ctr) {
     DeviceGuard guard(D.dev);
     if (!guard.ok) return fail(RTGR_ERR_HIP, "hipSetDevice failed");
@@ -623,11 +623,11 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
             for (size_t k = 0; k < outs.size(); k++) {
                 const OutArray& o = outs[k];
                 if (k == 0 && px_in) {  // Pixel(p.pos, p.normal, col)  (:532)
-                    const double* pr = (const double*)(src + off);
-                    parallel_rows(m, 88, [&](uint64_t a, uint64_t cnt) {
+                    const R* pr = (const R*)(src + off);
+                    parallel_rows(m, 11 * sizeof(R), [&](uint64_t a, uint64_t cnt) {
                         for (uint64_t w = a; w < a + cnt; w++) {
-                            double* po = px_out + (r0 + w) * 11;
-                            const double* pi = px_in + (r0 + w) * 11;
+                            R* po = px_out + (r0 + w) * 11;
+                            const R* pi = px_in + (r0 + w) * 11;
                             if (po != pi) for (int q = 0; q < 8; q++) po[q] = pi[q];
                             po[8] = pr[w]; po[9] = pr[m + w]; po[10] = pr[2 * m + w];
                         }
@@ -659,10 +659,10 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
                 R* pin = (R*)S->pin_in[slot].p;
                 const uint64_t g0 = r0 + p0;
                 if (px_in) {
-                    parallel_rows(pm, 64, [&](uint64_t a, uint64_t cnt) {
+                    parallel_rows(pm, 8 * sizeof(R), [&](uint64_t a, uint64_t cnt) {
                         for (uint64_t w = a; w < a + cnt; w++) {
-                            const double* pi = px_in + (g0 + w) * 11;
-                            double* d = (double*)pin + w * 8;
+                            const R* pi = px_in + (g0 + w) * 11;
+                            R* d = pin + w * 8;
                             for (int q = 0; q < 8; q++) d[q] = pi[q];
                         }
                     });
@@ -950,28 +950,47 @@ int rtgr_trace_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver
     return trace_host<float>(ctx, scene, opt, state0, cam, ni, nj, j0, j1, rgb, out, ctr);
 }
 
-int rtgr_trace_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in,
-                          uint64_t ni, uint64_t nj, double* pixels_out, rtgr_counters* ctr) {
+}  // extern "C"
+template <class R>
+static int trace_pixels(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const R* pixels_in, uint64_t ni,
+                        uint64_t nj, R* pixels_out, rtgr_counters* ctr) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
     if (rc) return rc;
     if (!pixels_in || !pixels_out) return fail(RTGR_ERR_BAD_ARG, "pixels is NULL");
     if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
     if (!scene) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
-    return trace_host_pipelined<double>(*c->devs[0], scene, opt, nullptr, pixels_in, pixels_out, nullptr, ni, nj, 0, nj, nullptr,
-                                        nullptr, ctr);
+    return trace_host_pipelined<R>(*c->devs[0], scene, opt, nullptr, pixels_in, pixels_out, nullptr, ni, nj, 0, nj, nullptr,
+                                   nullptr, ctr);
 }
-
-int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
-                       const double normal[4], double rgb[3], double state_end[8], uint8_t* status) {
+template <class R>
+static int trace_one(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const R pos[4], const R normal[4],
+                     R rgb[3], R state_end[8], uint8_t* status) {
     if (!pos || !normal || !rgb) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
-    double s0[8];
+    R s0[8];
     for (int q = 0; q < 4; q++) { s0[q] = pos[q]; s0[4 + q] = normal[q]; }
     rtgr_ray_outputs out;
     std::memset(&out, 0, sizeof out);
     out.state_end = state_end;
     out.status = status;
-    return trace_host<double>(ctx, scene, opt, s0, nullptr, 1, 1, 0, 1, rgb, &out, nullptr);
+    return trace_host<R>(ctx, scene, opt, s0, nullptr, 1, 1, 0, 1, rgb, &out, nullptr);
+}
+extern "C" {
+int rtgr_trace_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in,
+                          uint64_t ni, uint64_t nj, double* pixels_out, rtgr_counters* ctr) {
+    return trace_pixels<double>(ctx, scene, opt, pixels_in, ni, nj, pixels_out, ctr);
+}
+int rtgr_trace_pixels_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* pixels_in,
+                          uint64_t ni, uint64_t nj, float* pixels_out, rtgr_counters* ctr) {
+    return trace_pixels<float>(ctx, scene, opt, pixels_in, ni, nj, pixels_out, ctr);
+}
+int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
+                       const double normal[4], double rgb[3], double state_end[8], uint8_t* status) {
+    return trace_one<double>(ctx, scene, opt, pos, normal, rgb, state_end, status);
+}
+int rtgr_trace_one_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float pos[4],
+                       const float normal[4], float rgb[3], float state_end[8], uint8_t* status) {
+    return trace_one<float>(ctx, scene, opt, pos, normal, rgb, state_end, status);
 }
 
 // ---- all devices of the context ------------------------------------------------------------------------------------------

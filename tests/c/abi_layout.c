@@ -48,9 +48,11 @@ _Static_assert(offsetof(rtgr_ray_outputs, state_end) == 0 && offsetof(rtgr_ray_o
 /* Pixel{Float64} of the reference (src/RayTraceGR.jl:446-450): pos::SVector{4}, normal::SVector{4}, rgb::SVector{3} */
 typedef struct { double pos[4], normal[4], rgb[3]; } pixel_f64;
 _Static_assert(sizeof(pixel_f64) == 88 && offsetof(pixel_f64, normal) == 32 && offsetof(pixel_f64, rgb) == 64, "Pixel{Float64}");
+typedef struct { float pos[4], normal[4], rgb[3]; } pixel_f32;   /* Pixel{Float32}: what rtgr_trace_pixels_f32 takes */
+_Static_assert(sizeof(pixel_f32) == 44 && offsetof(pixel_f32, normal) == 16 && offsetof(pixel_f32, rgb) == 32, "Pixel{Float32}");
 
 static const char* const BOUND[] = {"rtgr_create", "rtgr_destroy", "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version",
-                                    "rtgr_solver_defaults", "rtgr_trace_pixels_f64", "rtgr_trace_one_f64", "rtgr_trace_f64",
+                                    "rtgr_solver_defaults", "rtgr_trace_pixels_f64", "rtgr_trace_pixels_f32", "rtgr_trace_one_f64", "rtgr_trace_one_f32", "rtgr_trace_f64",
                                     "rtgr_trace_sharded_f64", "rtgr_make_canvas_f64", "rtgr_user_metric_load", "rtgr_user_metric_compile",
                                     "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", NULL};
 

@@ -265,6 +265,39 @@ def test_pixels_entry_point_is_pipelined_in_pieces(lib):
     assert rc == abi.ERR_NAN_INPUT   # `@assert !any(isnan, …)` (src/RayTraceGR.jl:279), evaluated on the device
 
 
+def test_float32_canvas_through_the_pixel_entry_points(lib):
+    """`Canvas{T}` is generic in T (src/RayTraceGR.jl:452-455; the reference's own tests instantiate T = Float32,
+    test/runtests.jl:37): trace_rays on a Canvas{Float32} goes through rtgr_trace_pixels_f32 with 44-byte pixels.  It must
+    agree bit for bit with the planar Float32 entry point (same kernels, different packing), preserve pos/normal, work
+    in pieces, and trace_ray (rtgr_trace_one_f32) must return the canvas' own pixel."""
+    metric, objs, cam = rt.example2_scene()
+    ni, nj = 60, 45
+    canvas = rt.make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], ni, nj, dtype=np.float32)
+    assert canvas.pixels.dtype.itemsize == 44
+    out = rt.trace_rays(metric, objs, canvas)
+    assert out.pixels.dtype == canvas.pixels.dtype and (canvas.pixels["rgb"] == 0).all()
+    for f in ("pos", "normal"):
+        assert np.array_equal(out.pixels[f], canvas.pixels[f]), f
+    # planar entry point on the same start states
+    sc, opt = rt.make_scene(metric, objs), rt.solver_defaults(np.float32)
+    st = np.concatenate([canvas.pixels["pos"].reshape(-1, 4, order="F"), canvas.pixels["normal"].reshape(-1, 4, order="F")], axis=1)
+    st = np.ascontiguousarray(st, np.float32)
+    rgb = np.zeros((3, ni * nj), np.float32)
+    abi.check(lib, lib.rtgr_trace_f32(None, C.byref(sc), C.byref(opt), st.ctypes.data, None, ni, nj, 0, nj, rgb.ctypes.data, None, None))
+    got = out.pixels["rgb"].reshape(-1, 3, order="F")
+    assert np.array_equal(got.T, rgb)
+    with abi.options(lib, host_chunk=256):
+        many = rt.trace_rays(metric, objs, canvas)
+    assert np.array_equal(many.pixels["rgb"], out.pixels["rgb"])
+    # against the Float64 canvas: same image up to Float32's global error (tests/test_truth.py prices it at <= 5e-4)
+    c64 = rt.make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], ni, nj)
+    o64 = rt.trace_rays(metric, objs, c64)
+    d = np.abs(out.pixels["rgb"].astype(np.float64) - o64.pixels["rgb"])
+    assert np.mean(d.max(axis=-1) < 2e-3) > 0.97       # (the rest: silhouette pixels and sawtooth wraps)
+    p = rt.trace_ray(metric, objs, None, canvas.pixels[30, 22])
+    assert p.dtype == canvas.pixels.dtype and np.array_equal(p["rgb"], out.pixels["rgb"][30, 22])
+
+
 def _hip_runtime():
     """the HIP runtime already loaded in this process (torch's bundled libamdhip64)"""
     import importlib.util

@@ -33,7 +33,7 @@ def _truth(name):
 
 
 def _check_against_truth(name, got, f, tol_sphere=TOL_SPHERE, tol_cap_lambda=TOL_CAPTURED_LAMBDA,
-                         tol_cap_state=TOL_CAPTURED_STATE, extra_flips=0):
+                         tol_cap_state=TOL_CAPTURED_STATE, extra_flips=0, tol_cap_rgb=0.0):
     """got: dict(hit, state_end, lambda_end, rgb[3, n]) of a full 200² frame."""
     n = int(f["n"])
     p = f["ij"][:, 0] + n * f["ij"][:, 1]
@@ -61,7 +61,7 @@ def _check_against_truth(name, got, f, tol_sphere=TOL_SPHERE, tol_cap_lambda=TOL
     if cap.any():
         assert dl[cap].max() <= tol_cap_lambda, dl[cap].max()
         assert tol_cap_state is None or ds[cap].max() <= tol_cap_state, ds[cap].max()
-        assert drgb[cap].max() == 0.0
+        assert drgb[cap].max() <= tol_cap_rgb          # a constant of the object: exact in Float64
     return ds[sph].max(), drgb[sph].max()
 
 
@@ -169,4 +169,5 @@ def test_hip_float32_global_error_against_true_geodesics(name):
     sc, cam = scene_variant(name)
     n = int(f["n"])
     r = hip_trace(lib, sc, rt.solver_defaults(np.float32), n, n, cam=cam, dtype=np.float32)
-    _check_against_truth(name, r, f, tol_sphere=5e-4, tol_cap_lambda=5e-3, tol_cap_state=None, extra_flips=1)
+    _check_against_truth(name, r, f, tol_sphere=5e-4, tol_cap_lambda=5e-3, tol_cap_state=None, extra_flips=1,
+                         tol_cap_rgb=1e-7)   # (1/3 in Float32)
