@@ -70,7 +70,9 @@ def parse():
                          "points and the Kerr a = 0.8 variant, reported in entry_points / variants; 0: skip")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: do not overlap the gather of pass k with the tracing of pass k+1")
+                    help="N > 1: one stream, trace and gather strictly in turn (no frames in flight)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="frames traced concurrently on alternating streams (0 = auto: 1 at N = 1, 2 at N > 1)")
     ap.add_argument("--layout", default="cyclic", choices=["cyclic", "slab"], help="row distribution over ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real thing) or gloo (CPU-staged; lets "
@@ -191,34 +193,46 @@ def main():
     j0, jstride, nrows = sharded.row_assignment(nj, ws, rank, a.layout)
     ctr = torch.zeros(8, dtype=torch.int64, device=dev)
     host = {}
-    # N > 1: the exchange of pass k runs on a side stream while pass k+1 is traced into the other output buffer (a render
-    # loop delivers frame after frame; only the LAST gather is exposed, and the timed region ends with a device-wide
-    # synchronize, so all K gathers are inside it).  --no-overlap: trace and gather strictly in turn.
+    # N > 1: frames are delivered one after another, so two are kept in flight — (1) the exchange of pass k runs on a side
+    # stream while pass k+1 is traced, and (2) the passes alternate between two streams (each has its own pipeline
+    # workspace inside the library), so that the low-occupancy end of one frame's passes (a rank's share is ~10 rays per
+    # lane) overlaps the start of the next: measured on one GPU with the N = 8 share, 12.44 -> 11.61 ms per frame, frames
+    # bit-identical (tools/two_frames_in_flight.py; 0.4 % at the full frame, so N = 1 keeps one stream and clean kernel
+    # timings).  All K traces and all K gathers are inside the timed region, which ends with a device-wide synchronize.
+    # --no-overlap: one stream, trace and gather strictly in turn.
     overlap = ws > 1 and not a.no_gather and not a.no_overlap
-    outs = [{}, {}] if overlap else [{}]
-    gathered = [None] * len(outs)          # event on the exchange stream: this buffer's rows have left
+    nflight = 1 if (a.no_overlap or a.entry != "device") else (a.in_flight if a.in_flight > 0 else (2 if ws > 1 else 1))
+    nbuf = nflight + (1 if overlap else 0)   # one more output buffer than frames in flight: the exchange holds one
+    outs = [{} for _ in range(nbuf)]
+    traced = [None] * nbuf                 # event on the tracing stream: this buffer's frame is complete
+    gathered = [None] * nbuf               # event on the exchange stream: this buffer's rows have left
     comm = torch.cuda.Stream(device=dev) if overlap else None
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(nflight)] if nflight > 1 else [None]
     npass = [0]
 
     def device_pass():
-        k = npass[0] % len(outs)
+        p = npass[0]
         npass[0] += 1
-        out = outs[k]
-        if gathered[k] is not None:
-            torch.cuda.current_stream(dev).wait_event(gathered[k])
-        sharded.trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device=dev, dtype=npdt, counters=ctr,
-                                 out=out, status=(ws > 1))
-        if ws > 1 and not a.no_gather:
-            if not overlap:
-                gather(out["rgb"], out["status"])
-                return
-            traced = torch.cuda.Event()
-            traced.record(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(comm):
-                comm.wait_event(traced)
-                gather(out["rgb"], out["status"])
-                gathered[k] = torch.cuda.Event()
-                gathered[k].record(comm)
+        b = p % nbuf
+        out = outs[b]
+        st = lanes[p % nflight] or torch.cuda.current_stream(dev)
+        for ev in (traced[b], gathered[b]):   # the buffer's previous frame must have been traced and sent
+            if ev is not None:
+                st.wait_event(ev)
+        with torch.cuda.stream(st):
+            sharded.trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device=dev, dtype=npdt, counters=ctr,
+                                     out=out, status=(ws > 1))
+            traced[b] = torch.cuda.Event()
+            traced[b].record(st)
+            if ws > 1 and not a.no_gather:
+                if not overlap:
+                    gather(out["rgb"], out["status"])
+                    return
+                with torch.cuda.stream(comm):
+                    comm.wait_event(traced[b])
+                    gather(out["rgb"], out["status"])
+                    gathered[b] = torch.cuda.Event()
+                    gathered[b].record(comm)
 
     def host_pass():   # rtgr_trace_f64/_f32: camera on the device, RGB planes to (pageable) host memory
         if "rgb" not in host:
@@ -262,7 +276,10 @@ def main():
             image["status"] = sharded.assemble_rows([p[None] for p in parts["status"]], ni, nj, ws, a.layout)[0]
 
     one_pass = {"device": device_pass, "host": host_pass, "pixels": pixels_pass}[a.entry]
-    for _ in range(a.warmup):
+    # untimed: W warm-up passes, and at least one pass through every stream / output buffer of the frames in flight, so that
+    # no workspace is allocated inside the timed region whatever W is
+    extra_warm = max(0, nbuf - a.warmup) if a.entry == "device" else 0
+    for _ in range(a.warmup + extra_warm):
         one_pass()
     torch.cuda.synchronize()
     ctr.zero_()
@@ -353,6 +370,12 @@ def main():
         if ws > 1 and not a.no_gather:
             line["gathered_status_not_event"] = int((image["status"] != 0).sum())
             line["exchange"] = "overlapped with the next pass" if overlap else "in turn"
+        line["frames_in_flight"] = nflight
+        if extra_warm:
+            line["allocation_passes"] = extra_warm   # untimed passes beyond `warmup` (one per stream / output buffer)
+        if nflight > 1:
+            roof["note"] = ("kernel durations overlap between the frames in flight: kernel_ms_per_pass is a sum of stretched "
+                            "durations and `achieved` an underestimate; the N = 1 line carries the clean figure")
         # order-independent bit-level checksum of the delivered frame: equal at every N iff the frames are bit-identical
         frame = image["rgb"] if (ws > 1 and not a.no_gather) else (outs[0]["rgb"] if ws == 1 else None)
         if frame is not None and a.entry == "device":
