@@ -323,6 +323,41 @@ def test_bad_arguments_are_rejected(lib):
     assert f(None, C.byref(sc), C.byref(opt), s0.ctypes.data, None, 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_NAN_INPUT
 
 
+def test_maximum_object_count_and_empty_scene(lib):
+    """The edges of the object list: RTGR_MAX_OBJECTS (16) objects — a ring of small spheres around the hole inside the sky
+    sphere, the colour scale omin/length(objs) (src/RayTraceGR.jl:530) and first-smaller-wins (:520-526) over all of them —
+    against the oracle; one more than the maximum is refused; an EMPTY list means min_distance = +Inf (:433-441), no event,
+    every ray runs to λ1 and gets the miss colour (:527-528)."""
+    _, _, cam = rt.example2_scene()
+    cam = rt.make_camera(**cam)
+    ring = [rt.Sphere((0, 4.5 * np.cos(t), 4.5 * np.sin(t), 0.6 * np.sin(3 * t)), (1, 0, 0, 0), 0.45)
+            for t in np.linspace(0.3, 2 * np.pi + 0.3, 14, endpoint=False)]
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -12.0), rt.Plane(-25.0)] + ring
+    assert len(objs) == abi.RTGR_MAX_OBJECTS
+    sc = rt.make_scene(rt.KerrSchild(1.0, 0.5), objs)
+    opt = rt.solver_defaults()
+    n = 72
+    g = hip_trace(lib, sc, opt, n, n, cam=cam)
+    r = O.trace(sc, opt, n, n, cam=cam)
+    assert len(np.unique(r["hit"])) >= 6                       # several of the ring's spheres are in view
+    compare(g, r, nobj=16, max_class_flips=6, max_step_diff=2)
+    sc.nobj = abi.RTGR_MAX_OBJECTS + 1
+    rgb = np.zeros((3, 4))
+    assert lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
+    with pytest.raises(ValueError):
+        rt.make_scene(rt.kerr_schild, objs + [rt.Plane(-30.0)])
+    empty = rt.make_scene(rt.KerrSchild(1.0, 0.5), [])
+    opt15 = rt.solver_defaults(lambda1=15.0, miss_rgb=(0.25, 0.5, 0.75))
+    g = hip_trace(lib, empty, opt15, 24, 24, cam=cam)
+    r = O.trace(empty, opt15, 24, 24, cam=cam)
+    assert (g["hit"] == 0).all() and (g["status"] != 0).all()
+    far = g["status"] == 1                                     # RTGR_RAY_LAMBDA1; the others fall into the hole, where WHICH
+    assert np.array_equal(far, r["status"] == 1)               # of step cap / dt underflow / NaN ends them is rounding noise
+    assert far.sum() > 300 and np.allclose(g["lambda_end"][far], 15.0)
+    assert (g["rgb"] == np.array([[0.25], [0.5], [0.75]])).all()
+    assert np.abs(g["state_end"][far] - r["state_end"][far]).max() < 1e-8
+
+
 def test_max_steps_status(lib):
     sc, cam = example(2)
     opt = rt.solver_defaults(max_steps=50)
