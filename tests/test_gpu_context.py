@@ -195,6 +195,73 @@ def test_single_process_multi_device_trace(lib, ndev):
         abi.check(lib, lib.rtgr_destroy(ctx))
 
 
+def test_device_resident_float32_and_support_entry_points(lib):
+    """The entry points the other tests reach only through wrappers or not at all: rtgr_make_canvas_device_f64/_f32
+    (== the host variants), rtgr_trace_rows_device_f32 (strided rows == the rows of the full Float32 frame),
+    rtgr_trace_sharded_device_f32 (== the single-device frame), rtgr_device_info, rtgr_timing_enable/_read."""
+    import torch
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_true08")
+    ni, nj = 64, 48
+    n = ni * nj
+    stream = torch.cuda.current_stream().cuda_stream
+    for suf, td, nd in (("f64", torch.float64, np.float64), ("f32", torch.float32, np.float32)):
+        host = np.zeros((n, 8), nd)
+        abi.check(lib, getattr(lib, f"rtgr_make_canvas_{suf}")(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, host.ctypes.data))
+        dev = torch.zeros((n, 8), dtype=td, device="cuda")
+        abi.check(lib, getattr(lib, f"rtgr_make_canvas_device_{suf}")(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, dev.data_ptr(), stream))
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), host)
+        part = torch.zeros((ni * 5, 8), dtype=td, device="cuda")        # rows [7, 12)
+        abi.check(lib, getattr(lib, f"rtgr_make_canvas_device_{suf}")(None, C.byref(sc), C.byref(cam), ni, nj, 7, 12, part.data_ptr(), stream))
+        torch.cuda.synchronize()
+        assert np.array_equal(part.cpu().numpy(), host[7 * ni:12 * ni])
+    opt32 = rt.solver_defaults(np.float32)
+    ref = hip_trace(lib, sc, opt32, ni, nj, cam=cam, dtype=np.float32)
+    # rows 1, 4, 7, … of the frame, Float32, device-resident, with per-kernel timing on
+    abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
+    rows = list(range(1, nj, 3))
+    d_rgb = torch.zeros((3, ni * len(rows)), dtype=torch.float32, device="cuda")
+    d_st = torch.full((ni * len(rows),), 255, dtype=torch.uint8, device="cuda")
+    d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+    o = abi.rtgr_ray_outputs()
+    o.status = d_st.data_ptr()
+    abi.check(lib, lib.rtgr_trace_rows_device_f32(None, C.byref(sc), C.byref(opt32), C.byref(cam), ni, nj, 1, 3, len(rows),
+                                                  d_rgb.data_ptr(), C.byref(o), d_ctr.data_ptr(), stream))
+    torch.cuda.synchronize()
+    want = ref["rgb"].reshape(3, nj, ni)[:, rows, :].reshape(3, -1)
+    assert np.array_equal(d_rgb.cpu().numpy(), want)
+    assert np.array_equal(d_st.cpu().numpy(), ref["status"].reshape(nj, ni)[rows].reshape(-1))
+    assert int(d_ctr[0]) == ni * len(rows)
+    ms, launches = (C.c_double * 4)(), (C.c_uint64 * 4)()
+    abi.check(lib, lib.rtgr_timing_read(None, 0, C.byref(ms), C.byref(launches)))
+    abi.check(lib, lib.rtgr_timing_enable(None, 0, 0))
+    assert launches[1] == 1 and launches[2] == 1 and launches[0] >= 1 and launches[3] == 0   # Float32: one FULL pass, no NEAR
+    assert all(0.0 < ms[k] < 1e3 for k in (0, 1, 2)) and ms[3] == 0.0
+    abi.check(lib, lib.rtgr_timing_read(None, 0, C.byref(ms), C.byref(launches)))            # read = since the previous read
+    assert list(launches) == [0, 0, 0, 0]
+    # device info
+    name = C.create_string_buffer(64)
+    cu, mhz, wf = C.c_int(0), C.c_int(0), C.c_int(0)
+    abi.check(lib, lib.rtgr_device_info(None, 0, name, 64, C.byref(cu), C.byref(mhz), C.byref(wf)))
+    assert name.value and cu.value >= 64 and mhz.value > 500 and wf.value == 64
+    assert lib.rtgr_device_info(None, 5, name, 64, C.byref(cu), C.byref(mhz), C.byref(wf)) == abi.ERR_BAD_ARG
+    # multi-device, Float32, frame left on device 0
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 3)
+    try:
+        d_full = torch.zeros((3, n), dtype=torch.float32, device="cuda")
+        d_hit = torch.full((n,), 255, dtype=torch.uint8, device="cuda")
+        od = abi.rtgr_ray_outputs()
+        od.hit = d_hit.data_ptr()
+        ctr = abi.rtgr_counters()
+        abi.check(lib, lib.rtgr_trace_sharded_device_f32(ctx, C.byref(sc), C.byref(opt32), C.byref(cam), ni, nj, d_full.data_ptr(),
+                                                         C.byref(od), C.byref(ctr)))
+        assert np.array_equal(d_full.cpu().numpy(), ref["rgb"]) and np.array_equal(d_hit.cpu().numpy(), ref["hit"])
+        assert ctr.as_dict() == ref["counters"]
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
 def test_user_metric_on_a_multi_device_context(lib):
     """A run-time compiled metric is loaded on every device of a context (logical duplicates of one GPU share the
     module); the multi-device frame equals the single-device one, and unload / destroy release it exactly once."""
