@@ -185,6 +185,8 @@ def main():
     lib = abi.load()
     abi.check(lib, lib.rtgr_init(local))
 
+    if ws > 1:
+        os.environ["RTGR_NO_COMPILE"] = "1"   # --rhs user on a cold cache: fail fast instead of N ranks starting hipcc
     npdt = np.float64 if a.dtype == "f64" else np.float32
     scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user"}[a.rhs])
     opt = rt.solver_defaults(npdt)

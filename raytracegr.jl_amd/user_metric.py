@@ -62,6 +62,12 @@ def compile_user_metric(source, verbose=False, stationary=False):
     out = os.path.join(d, f"metric_{tag}.hsaco")
     if os.path.exists(out):
         return out
+    if os.environ.get("RTGR_NO_COMPILE") == "1":
+        # set by multi-rank and profiled runs (bench.py, tools/prof.sh): N ranks must not all start hipcc on a cold cache, and
+        # a child process must not be spawned from inside a rocprofv3 --pmc session (the preloaded tool has initialised the GPU)
+        raise RuntimeError(f"user metric {tag} is not in the cache ({d}) and RTGR_NO_COMPILE=1: build it first in a single "
+                           f"plain process (__graft_entry__.build() precompiles the example metrics; "
+                           f"user_metric.compile_user_metric(source) any other)")
     with open(TEMPLATE) as fh:
         unit = fh.read().replace("@RTGR_USER_SOURCE@", source)
     src = os.path.join(d, f"metric_{tag}.hip")
