@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one stream, trace and gather strictly in turn (no frames in flight)")
+    ap.add_argument("--exchange-at-n1", action="store_true",
+                    help="debug: run the N > 1 code path (process group, gather, frames in flight) with a one-rank group")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames traced concurrently on alternating streams (0 = auto: 1 at N = 1, 2 at N > 1)")
     ap.add_argument("--layout", default="cyclic", choices=["cyclic", "slab"], help="row distribution over ranks")
@@ -174,8 +176,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = dev if a.backend == "nccl" else torch.device("cpu")  # where collective buffers live
-    if ws > 1:
+    # the N > 1 code path (process group, exchange, frames in flight); --exchange-at-n1 runs it with a one-rank group, which
+    # is how the RCCL calls themselves (not just the gloo-staged logic) are exercised on a one-GPU box
+    multi = ws > 1 or a.exchange_at_n1
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if ws == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -202,8 +212,8 @@ def main():
     # bit-identical (tools/two_frames_in_flight.py; 0.4 % at the full frame, so N = 1 keeps one stream and clean kernel
     # timings).  All K traces and all K gathers are inside the timed region, which ends with a device-wide synchronize.
     # --no-overlap: one stream, trace and gather strictly in turn.
-    overlap = ws > 1 and not a.no_gather and not a.no_overlap
-    nflight = 1 if (a.no_overlap or a.entry != "device") else (a.in_flight if a.in_flight > 0 else (2 if ws > 1 else 1))
+    overlap = multi and not a.no_gather and not a.no_overlap
+    nflight = 1 if (a.no_overlap or a.entry != "device") else (a.in_flight if a.in_flight > 0 else (2 if multi else 1))
     nbuf = nflight + (1 if overlap else 0)   # one more output buffer than frames in flight: the exchange holds one
     outs = [{} for _ in range(nbuf)]
     traced = [None] * nbuf                 # event on the tracing stream: this buffer's frame is complete
@@ -223,10 +233,10 @@ def main():
                 st.wait_event(ev)
         with torch.cuda.stream(st):
             sharded.trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device=dev, dtype=npdt, counters=ctr,
-                                     out=out, status=(ws > 1))
+                                     out=out, status=multi)
             traced[b] = torch.cuda.Event()
             traced[b].record(st)
-            if ws > 1 and not a.no_gather:
+            if multi and not a.no_gather:
                 if not overlap:
                     gather(out["rgb"], out["status"])
                     return
@@ -286,7 +296,7 @@ def main():
     torch.cuda.synchronize()
     ctr.zero_()
     abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
-    if ws > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -294,7 +304,7 @@ def main():
     for k in range(a.steps):
         hc.append(one_pass())
     torch.cuda.synchronize()
-    if ws > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -305,7 +315,7 @@ def main():
 
     tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
     totals = ctr.clone().to(cdev)
-    if ws > 1:
+    if multi:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     dt = float(tt[0])
@@ -349,12 +359,12 @@ def main():
             roof["stale_profile"] = why
         name = C_name(lib)
         extras = {}
-        if a.extras and ws == 1 and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64":
+        if a.extras and not multi and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64":
             try:   # (outside the timed region; a failure here must not cost the headline line)
                 extras = run_extras(a, rt, host_pass, pixels_pass, dt / a.steps)
             except Exception as e:  # noqa: BLE001
                 extras = {"extras_error": repr(e)}
-        cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and ws == 1) else None  # N=1 only
+        cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and not multi) else None  # N=1 only
         line = {
             "metric": "geodesic RK step attempts/s (Tsit5, 6 RHS each), Kerr-Schild screen, whole job",
             "value": attempts / dt, "unit": "RK step attempts/s", "n_gpus": ws, "steps": a.steps,
@@ -369,7 +379,7 @@ def main():
             "device": name, "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extras)
-        if ws > 1 and not a.no_gather:
+        if multi and not a.no_gather:
             line["gathered_status_not_event"] = int((image["status"] != 0).sum())
             line["exchange"] = "overlapped with the next pass" if overlap else "in turn"
         line["frames_in_flight"] = nflight
@@ -379,12 +389,12 @@ def main():
             roof["note"] = ("kernel durations overlap between the frames in flight: kernel_ms_per_pass is a sum of stretched "
                             "durations and `achieved` an underestimate; the N = 1 line carries the clean figure")
         # order-independent bit-level checksum of the delivered frame: equal at every N iff the frames are bit-identical
-        frame = image["rgb"] if (ws > 1 and not a.no_gather) else (outs[0]["rgb"] if ws == 1 else None)
+        frame = image["rgb"] if (multi and not a.no_gather) else (outs[0]["rgb"] if ws == 1 else None)
         if frame is not None and a.entry == "device":
             bits = frame.contiguous().view(torch.int64 if a.dtype == "f64" else torch.int32).to(torch.int64)
             line["frame_checksum"] = int(bits.sum().item())
         print(json.dumps(line), flush=True)
-    if ws > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
