@@ -520,7 +520,9 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     // rtgr_trace_pixels_f64: 119 ms with equal 4 M-ray chunks, 106-112 ms with the ramp (device-resident: 86-88 ms;
     // measured split of a 106 ms call: chunked compute 95, fill 5, drain 3, the rest host noise).  Measured and rejected:
     // alternating the chunks between TWO compute streams so that their tails overlap — the persistent kernels of two
-    // pipelines in flight slow each other down more than the tails cost (pixels 109 -> 123 ms, host 91 -> 98 ms).
+    // pipelines in flight slow each other down more than the tails cost (pixels 109 -> 123 ms, host 91 -> 98 ms; re-measured
+    // with event-only dependencies: 114 -> 118, 95 -> 98).  Two whole FRAMES in flight on two caller streams do pay — equal,
+    // independent jobs (tools/two_frames_in_flight.py) — but that is the caller's loop, not this call's.
     const uint64_t piece_target = D.knobs.host_chunk > 0 ? (uint64_t)D.knobs.host_chunk : (1ull << 20);
     struct Chunk { uint64_t row0, rows; };
     std::vector<Chunk> chunks;
