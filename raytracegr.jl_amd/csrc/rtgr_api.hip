@@ -367,7 +367,7 @@ int dispatch(LaunchEnv& E, const TraceArgs<float>& A, bool generic, bool spin, h
 }
 
 // window of a larger output: see TraceArgs::plane_stride / out_offset
-struct Window { uint64_t plane_stride = 0, out_offset = 0; uint32_t* nan_flag = nullptr; };
+struct Window { uint64_t plane_stride = 0, out_offset = 0; uint32_t* nan_flag = nullptr; hipEvent_t after_setup = nullptr; };
 
 // Enqueue the pipeline for rows of a canvas on device D, stream st.  The caller holds no lock; this takes D.mu for the
 // duration of the enqueue.
@@ -425,7 +425,7 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
     }
     StreamState* ss = nullptr;
     if ((rc = stream_state(D, st, &ss))) return rc;
-    LaunchEnv E{D, *ss, user};
+    LaunchEnv E{D, *ss, user, win ? win->after_setup : nullptr};
     rc = dispatch(E, A, generic, spin, st);
     if (rc) return rc;
     if constexpr (sizeof(R) == 8) {
@@ -594,10 +594,11 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     }
     R* d_in = (R*)S->d_in.p;
 
-    std::vector<hipEvent_t> ev_comp(nchunks), ev_down(nchunks);
+    std::vector<hipEvent_t> ev_comp(nchunks), ev_down(nchunks), ev_setup(nchunks);
     for (auto& e : ev_comp) { e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
     for (auto& e : ev_down) { e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
-    struct EvFree { std::vector<hipEvent_t>&a, &b; ~EvFree() { for (auto e : a) if (e) (void)hipEventDestroy(e); for (auto e : b) if (e) (void)hipEventDestroy(e); } } evfree{ev_comp, ev_down};
+    for (auto& e : ev_setup) { e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    struct EvFree { std::vector<hipEvent_t>&a, &b, &c; ~EvFree() { for (auto* v : {&a, &b, &c}) for (auto e : *v) if (e) (void)hipEventDestroy(e); } } evfree{ev_comp, ev_down, ev_setup};
     hipEvent_t ev_up_last = nullptr;
     HIP_TRY(hipEventCreateWithFlags(&ev_up_last, hipEventDisableTiming));
     struct OneEv { hipEvent_t e; ~OneEv() { if (e) (void)hipEventDestroy(e); } } onefree{ev_up_last};
@@ -648,6 +649,31 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     });
     struct Joiner { std::thread& t; std::atomic<bool>& ab; ~Joiner() { ab.store(true); if (t.joinable()) t.join(); } } joiner{downloader, abort_flag};
 
+    // D2H of chunk c's outputs into its pinned slot (the slot must have been unpacked: two chunks ago)
+    auto enqueue_download = [&](uint64_t c, hipEvent_t also_after) -> int {
+        uint64_t r0, m;
+        chunk_range(c, r0, m);
+        const int oslot = (int)(c % Staging::OUT_SLOTS);
+        while (slot_busy[oslot].load(std::memory_order_acquire)) {
+            if (down_rc.load() != RTGR_OK) return fail(RTGR_ERR_HIP, "download thread failed");
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        slot_busy[oslot].store(1);
+        HIP_TRY(hipStreamWaitEvent(S->s_down, ev_comp[c], 0));
+        if (also_after) HIP_TRY(hipStreamWaitEvent(S->s_down, also_after, 0));
+        char* dst = (char*)S->pin_out[oslot].p;
+        size_t off = 0;
+        for (auto& o : outs) {
+            for (int pl = 0; pl < o.planes; pl++)
+                HIP_TRY(hipMemcpyAsync(dst + off + (size_t)pl * m * o.elem, dob + o.dev_off + ((size_t)pl * n + r0) * o.elem,
+                                       (size_t)m * o.elem, hipMemcpyDeviceToHost, S->s_down));
+            off += align256((size_t)m * o.elem * o.planes);
+        }
+        HIP_TRY(hipEventRecord(ev_down[c], S->s_down));
+        chunks_enqueued.store(c + 1, std::memory_order_release);
+        return RTGR_OK;
+    };
+
     // ---- upload + compute, chunk by chunk ---------------------------------------------------------------------------------
     uint64_t piece_no = 0;
     for (uint64_t c = 0; c < nchunks; c++) {
@@ -680,31 +706,19 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
         }
         Window win;
         win.plane_stride = n; win.out_offset = r0; win.nan_flag = have_in ? d_nan : nullptr;
+        win.after_setup = ev_setup[c];
         const uint64_t row0 = chunks[c].row0, rows = chunks[c].rows;
         if (D.knobs.tile) { win.plane_stride = 0; win.out_offset = 0; }
         rc = trace_device<R>(D, scene, opt, have_in ? d_in + r0 * 8 : nullptr, cam, ni, nj, j0 + row0, j0 + row0 + rows, d_rgb,
                              &dout, d_ctr, S->s_comp, 1, 0, &win);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev_comp[c], S->s_comp));
-        // D2H of this chunk's outputs (the slot must have been unpacked: two chunks ago)
-        const int oslot = (int)(c % Staging::OUT_SLOTS);
-        while (slot_busy[oslot].load(std::memory_order_acquire)) {
-            if (down_rc.load() != RTGR_OK) return fail(RTGR_ERR_HIP, "download thread failed");
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
-        }
-        slot_busy[oslot].store(1);
-        HIP_TRY(hipStreamWaitEvent(S->s_down, ev_comp[c], 0));
-        char* dst = (char*)S->pin_out[oslot].p;
-        size_t off = 0;
-        for (auto& o : outs) {
-            for (int pl = 0; pl < o.planes; pl++)
-                HIP_TRY(hipMemcpyAsync(dst + off + (size_t)pl * m * o.elem, dob + o.dev_off + ((size_t)pl * n + r0) * o.elem,
-                                       (size_t)m * o.elem, hipMemcpyDeviceToHost, S->s_down));
-            off += align256((size_t)m * o.elem * o.planes);
-        }
-        HIP_TRY(hipEventRecord(ev_down[c], S->s_down));
-        chunks_enqueued.store(c + 1, std::memory_order_release);
+        // The D2H of chunk c-1 goes out only now, behind the SET-UP kernels of chunk c: the runtime copies device -> host
+        // with blit kernels, and the memory-bound set-up kernels crawl next to them (rocprofv3 timeline at 4096²: prepare of a
+        // 4 M-ray chunk 1.9 ms beside the copies, 0.3 ms alone); beside the VALU-bound integrate pass they cost nothing.
+        if (c > 0 && (rc = enqueue_download(c - 1, ev_setup[c]))) return rc;
     }
+    if ((rc = enqueue_download(nchunks - 1, nullptr))) return rc;
     // counters + NaN flag ride the compute stream
     HIP_TRY(hipMemcpyAsync(S->pin_small.p, dsmall, 256, hipMemcpyDeviceToHost, S->s_comp));
     HIP_TRY(hipStreamSynchronize(S->s_comp));

@@ -131,6 +131,7 @@ struct LaunchEnv {
     DeviceCtx& d;
     StreamState& ss;
     const UserModule* user;  // resolved from the scene's user_metric id (RTGR_USER) or null
+    hipEvent_t after_setup = nullptr;  // optional: recorded on the launch stream behind the ray set-up / queue-order kernels
 };
 
 size_t align256(size_t b);

@@ -174,6 +174,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     if constexpr (METRIC < RTGR_GENERIC_BASE) if (K.tile) {
         const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
         const uint64_t blocks = (tiles + 3) / 4;
+        if (E.after_setup) HIP_TRY(hipEventRecord(E.after_setup, st));
         KernelTimer tm(D, st, 1);
         hipLaunchKernelGGL((trace_kernel<R, METRIC, SPIN>), dim3((unsigned)blocks), dim3(256), 0, st, A);
         return RTGR_OK;
@@ -239,6 +240,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
                 hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys, m, hist + 256, order);
             }
         }
+        if (E.after_setup && off == 0) HIP_TRY(hipEventRecord(E.after_setup, st));
         rc = launch_integrate<R, METRIC, SPIN>(E, IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
         if (rc) return rc;
         ResolveArgs<R> RA;
