@@ -517,7 +517,8 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     // is small so that integration starts after one piece has been packed and uploaded instead of four (the pipeline's
     // fill), the LAST so that only a small unpack follows the last kernel (its drain); in between the chunks are big
     // enough (4 M rays) that the persistent kernels lose nothing to their tails.  Measured at 4096² through
-    // rtgr_trace_pixels_f64: 119 ms with equal 4 M-ray chunks, 106-112 ms with the ramp (device-resident: 86-88 ms;
+    // rtgr_trace_pixels_f64: 119 ms with equal 4 M-ray chunks, 106-112 ms with the ramp, 101-103 ms with the D2H ordered behind the
+    // next chunk's set-up (device-resident: 86-88 ms;
     // measured split of a 106 ms call: chunked compute 95, fill 5, drain 3, the rest host noise).  Measured and rejected:
     // alternating the chunks between TWO compute streams so that their tails overlap — the persistent kernels of two
     // pipelines in flight slow each other down more than the tails cost (pixels 109 -> 123 ms, host 91 -> 98 ms; re-measured
