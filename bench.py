@@ -389,8 +389,10 @@ def main():
             roof["note"] = ("kernel durations overlap between the frames in flight: kernel_ms_per_pass is a sum of stretched "
                             "durations and `achieved` an underestimate; the N = 1 line carries the clean figure")
         # order-independent bit-level checksum of the delivered frame: equal at every N iff the frames are bit-identical
-        frame = image["rgb"] if (multi and not a.no_gather) else (outs[0]["rgb"] if ws == 1 else None)
-        if frame is not None and a.entry == "device":
+        frame = None
+        if a.entry == "device":
+            frame = image["rgb"] if (multi and not a.no_gather) else (outs[0]["rgb"] if ws == 1 else None)
+        if frame is not None:
             bits = frame.contiguous().view(torch.int64 if a.dtype == "f64" else torch.int32).to(torch.int64)
             line["frame_checksum"] = int(bits.sum().item())
         print(json.dumps(line), flush=True)

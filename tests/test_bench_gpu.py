@@ -46,3 +46,12 @@ def test_bench_line_schema_and_one_rank_exchange_path():
     assert ex["cpu_baseline"] is None                                  # the CPU leg is N = 1 only
     serial = _bench("--size", "512", "--steps", "2", "--warmup", "1", "--exchange-at-n1", "--no-overlap")
     assert serial["frame_checksum"] == base["frame_checksum"] and serial["exchange"] == "in turn"
+
+
+def test_bench_host_entry_points():
+    """--entry host / pixels: the timed passes go through rtgr_trace_f64 / rtgr_trace_pixels_f64 (PCIe-inclusive)."""
+    base = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0")
+    for entry in ("host", "pixels"):
+        d = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0", "--entry", entry)
+        assert d["config"]["entry"] == entry and d["step_attempts_per_pass"] == base["step_attempts_per_pass"]
+        assert d["value"] > 0 and d["roofline"]["launches"] >= 2
