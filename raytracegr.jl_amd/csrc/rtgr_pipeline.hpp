@@ -224,10 +224,18 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
         IA.n_simd = (uint32_t)D.num_cu * 4u;
         const uint64_t lanes3 = (uint64_t)D.num_cu * 12 * 64;
         IA.fair_shift = (uint32_t)(K.fair >= 0 ? K.fair : ((m >= 4 * lanes3 && m < 9 * lanes3) ? 13 : 0));
-        {   // ids per queue atomic: ~1/16 of a wave's share of the job, within [8, RTGR_QUEUE_CHUNK]
+        {   // ids per queue atomic, FAR / FULL pass: 1/16 of a wave's share of the job within [8, 16].  These rays last ~200
+            // steps, so even 16.8 M rays in pops of 16 are 1 M atomics in 80 ms (the queue word takes ~90 M/s), and small
+            // pops keep the end of the pass balanced: a wave never sits on ids another, idle wave could run.  Sweep of
+            // 8..256 at 1 / 2.1 / 4.2 / 8.4 / 16.8 M rays (ms per frame, 256-capped rule before -> 16): a = 0 6.71 -> 6.66,
+            // 12.26 -> 12.18, 23.17 -> 22.87, 45.40 -> 44.64, 88.45 -> 88.13; a = 0.8 10.61 -> 10.63, 19.00 -> 18.39,
+            // 34.26 -> 33.03, 66.44 -> 64.06, 127.1 -> 125.0.
+            // Float32 rays last ~22 steps (tol = eps^(3/4) = 6.4e-6): 4.2 M of them in pops of 16 ARE the atomic limit
+            // (2048²: 3.5 -> 4.75 ms), so Float32 keeps the wide rule, up to RTGR_QUEUE_CHUNK ids per pop.
             const uint64_t per_wave = m / ((uint64_t)D.num_cu * 12 + 1);
+            const uint64_t cap = sizeof(R) == 8 ? 16 : RTGR_QUEUE_CHUNK;
             uint64_t qc = per_wave / 16;
-            qc = qc < 8 ? 8 : (qc > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : qc);
+            qc = qc < 8 ? 8 : (qc > cap ? cap : qc);
             IA.queue_chunk = (uint32_t)(K.qchunk > 0 ? K.qchunk : (long)qc);
         }
         {   // ray set-up: camera ray (or the caller's state), ordering key, u̇(y0), initial dt, event sign -> start records
