@@ -48,7 +48,7 @@ int fail(int code, const std::string& msg);  // records the calling thread's las
 // schedule-invariance tests only: no knob changes a result bit.
 struct Knobs {
     long waves_per_cu = -1;       // resident waves per CU of the integrate kernels (auto: 4 x waves/SIMD of the instantiation)
-    long waves_per_cu_near = -1;  // ... of the NEAR pass (auto: 4 below 1.6 M rays)
+    long waves_per_cu_near = -1;  // ... of the NEAR pass (auto: 4 below 2.4 M rays, 6.3 M with spin)
     long chunk = -1;              // rays per pipeline chunk (auto: 2^26, less if memory is short)
     long split = -1;              // 0: one FULL pass instead of FAR + NEAR (auto: on for f64, off for f32)
     long order = -1;              // 0: natural ray order (auto: longest-expected-first from 4096 rays)

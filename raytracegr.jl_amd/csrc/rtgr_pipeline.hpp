@@ -11,7 +11,7 @@
 //   order = 0          keep the natural ray order (auto: longest-expected-first, see rtgr_persistent.hpp)
 //   fair = s           time slice 2^s clocks of the priority rotation (0 = off; auto 13 for 0.8-1.8 M rays, else off)
 //   near_early = n     accepted steps at hand-over below which a ray is put on the NEAR pass's early list (64)
-//   waves_per_cu_near  resident waves per CU of the NEAR pass (auto 4 below 1.6 M rays, else all)
+//   waves_per_cu_near  resident waves per CU of the NEAR pass (auto 4 below 2.4 M rays — 6.3 M with spin —, else all)
 //   far4 = 0/1         force the 3- / 4-waves-per-SIMD instantiation of the a = 0 FAR pass (auto: by launch size)
 #pragma once
 #include "rtgr_host.hpp"
@@ -140,10 +140,13 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
             { KernelTimer tm(D, st, 3);
               // A small launch's NEAR pass ends on its longest-staying rays (one lane each, up to 370 steps in the
               // a = 0.8 scene), and such a wave steps faster alone on its SIMD than next to a second wave: ONE wave per
-              // SIMD below 1.6 M rays (1024²: a = 0.8 NEAR 2.17 -> 1.43 ms, a = 0 0.87 -> 0.64 ms; from 2 M rays on
-              // the second wave's throughput is worth more).
+              // SIMD below 2.4 M rays, below 6.3 M with spin (1024²: a = 0.8 NEAR 2.17 -> 1.43 ms, a = 0 0.87 -> 0.64 ms;
+              // same-run A/B of the frame time, tools/ab_options.py: a = 0.8 at 2.1 M rays 18.64 -> 17.87 ms, 4.2 M
+              // 33.67 -> 33.25, 8.4 M 63.85 -> 64.25; a = 0 at 2.1 M 12.43 -> 12.37, 4.2 M 23.31 -> 23.48: beyond these
+              // sizes the second wave's throughput is worth more).
               dim3 gn = grid(waves_per_simd_of<R, METRIC>(MODE_NEAR));
-              const long wn = K.waves_per_cu_near >= 0 ? K.waves_per_cu_near : (P.n < (uint64_t)D.num_cu * 12 * 64 * 8 ? 4 : 0);
+              const uint64_t one_wave_below = (uint64_t)D.num_cu * 12 * 64 * (SPIN ? 32 : 12);
+              const long wn = K.waves_per_cu_near >= 0 ? K.waves_per_cu_near : (P.n < one_wave_below ? 4 : 0);
               if (wn > 0 && (uint64_t)D.num_cu * (uint64_t)wn < gn.x) gn.x = (unsigned)((uint64_t)D.num_cu * (uint64_t)wn);
               if constexpr (USER) HIP_TRY(launch_module(E.user->near, gn.x, 64, st, P));
               else hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), gn, dim3(64), 0, st, P);
