@@ -40,7 +40,8 @@ def cam_lookat(pos, target=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0), width=1.0):
 CAMS = {"example2": rt.example2_scene()[2], "far20": cam_lookat((14.0, -14.0, 3.0)),
         "inside": cam_lookat((2.6, 0.0, 0.0), target=(2.6, 5.0, 0.0))}
 SETTINGS = [("auto", {}), ("order=0", {"order": 0}), ("fair=0", {"fair": 0}), ("fair=13", {"fair": 13}), ("far4=0", {"far4": 0}),
-            ("far4=1", {"far4": 1}), ("near_early=0", {"near_early": 0}), ("waves_per_cu_near=8", {"waves_per_cu_near": 8})]
+            ("far4=1", {"far4": 1}), ("near_early=0", {"near_early": 0}), ("waves_per_cu_near=8", {"waves_per_cu_near": 8}),
+            ("waves_per_cu_near=4", {"waves_per_cu_near": 4}), ("qchunk=64", {"qchunk": 64}), ("qchunk=256", {"qchunk": 256})]
 
 
 def run(sc, opt, cam, n, reps=3):
