@@ -37,8 +37,9 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(d, "summary.txt"), dst)
     shutil.copy(ej, dst)
-    for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
-        shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if stats:   # (gpurun MERGES result directories: an earlier collection's file may still lie beside the new one)
+        shutil.copy(stats[-1], os.path.join(dst, "kernel_stats.csv"))
     json.dump(line, open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
     print(key, "flop/attempt %.1f" % e["flop_per_step_attempt"], "->", dst)
 json.dump(out, open(os.path.join(ROOT, "profiles", rnd, "flops.json"), "w"), indent=1)
