@@ -19,7 +19,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk"]
+VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk", "schw_iso"]
 N, GRID = 200, 8
 
 
@@ -30,11 +30,22 @@ def pixels():
     return np.array(ij, dtype=np.int64)
 
 
+def truth_scene(name):
+    """scene_variant(name), or — 'schw_iso' — example2's objects and camera around an isotropic-coordinates Schwarzschild hole
+    (the user-metric example; only kind / M enter here, no module is compiled or loaded)."""
+    from scenes import scene_variant, rt
+    if name != "schw_iso":
+        return scene_variant(name)
+    sc, cam = scene_variant("ks_true0")
+    sc.metric = rt._abi.USER
+    return sc, cam
+
+
 def one(job):
     import truth
     from scenes import scene_variant, rt
     name, i, j = job
-    sc, cam = scene_variant(name)
+    sc, cam = truth_scene(name)
     opt = rt.solver_defaults()
     s0 = truth.pixel_state(sc, cam, N, N, i, j)
     r = truth.trace_ray(sc, opt, s0)
@@ -45,8 +56,9 @@ def one(job):
 
 if __name__ == "__main__":
     ij = pixels()
+    only = sys.argv[1:]          # e.g. `make_truth.py schw_iso`: regenerate just these
     with Pool(min(8, os.cpu_count() or 1)) as pool:
-        for name in VARIANTS:
+        for name in (only or VARIANTS):
             res = pool.map(one, [(name, int(i), int(j)) for i, j in ij], chunksize=2)
             out = os.path.join(HERE, f"truth_{name}.npz")
             np.savez_compressed(out, n=N, ij=ij, state0=np.array([r[0] for r in res]),

@@ -24,13 +24,17 @@ import numpy as np
 
 @functools.lru_cache(maxsize=None)
 def _metric_fn(kind):
-    """kind: 'mink' | 'ks_ref' (r as written, :284) | 'ks_true' (textbook r).  Returns f(x, y, z, M, a) ->
+    """kind: 'mink' | 'ks_ref' (r as written, :284) | 'ks_true' (textbook r) | 'schw_iso' (the user-metric example; a scene
+    of kind RTGR_USER is taken to be that one).  Returns f(x, y, z, M, a) ->
     (g[4][4], dg[3][4][4]) with dg[j] = ∂g/∂x_j, j = x,y,z (every metric here is stationary: ∂_t g = 0)."""
     import sympy as sp
     x, y, z, M, a = sp.symbols("x y z M a", real=True)
     eta = sp.diag(-1, 1, 1, 1)
     if kind == "mink":
         g = eta
+    elif kind == "schw_iso":   # Schwarzschild in isotropic coordinates (examples/user_metrics.py: a run-time compiled metric)
+        m = M / (2 * sp.sqrt(x * x + y * y + z * z))
+        g = sp.diag(-((1 - m) / (1 + m)) ** 2, (1 + m) ** 4, (1 + m) ** 4, (1 + m) ** 4) + 0 * a * eta
     else:
         rho2 = x * x + y * y + z * z
         q = rho2 - a * a
@@ -54,7 +58,7 @@ def _kind(scene):
     from conftest import load_package
     abi = load_package()._abi
     k = scene.metric & ~abi.METRIC_GENERIC
-    return {abi.MINKOWSKI: "mink", abi.KS_REF: "ks_ref", abi.KS_TRUE: "ks_true"}[k]
+    return {abi.MINKOWSKI: "mink", abi.KS_REF: "ks_ref", abi.KS_TRUE: "ks_true", abi.USER: "schw_iso"}[k]
 
 
 def metric(scene, pos):
