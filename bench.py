@@ -355,6 +355,10 @@ def main():
             roof["executed_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
             roof["traffic"] = prof["hbm_bytes_per_ray"] * my_rays / a.steps if prof.get("hbm_bytes_per_ray") else None
             roof["profile"] = prof
+            ic = prof.get("issue_ceiling")
+            if ic:   # what the machine can issue for THIS kernel's instruction mix with no operand ever waited for (measured)
+                roof["issue_ceiling_frac"] = ic["frac_of_peak_this_mix_can_issue"]
+                roof["frac_of_issue_ceiling"] = roof["frac"] / ic["frac_of_peak_this_mix_can_issue"]
         else:
             roof["stale_profile"] = why
         name = C_name(lib)
