@@ -42,23 +42,31 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
         shutil.copy(stats[-1], os.path.join(dst, "kernel_stats.csv"))
     json.dump(line, open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
     print(key, "flop/attempt %.1f" % e["flop_per_step_attempt"], "->", dst)
-# the measured issue ceiling of the a = 0 FAR pass's instruction mix (tools/micro/mix_replay.hip; profiles/<round>/mix_replay.log)
+# the measured issue ceiling of a kernel's instruction mix (tools/micro/mix_replay.hip; profiles/<round>/mix_replay.log), taken
+# at the waves-per-SIMD the kernel runs with
 replay = os.path.join(ROOT, "profiles", rnd, "mix_replay.log")
-key0 = "ks_ref0/f64/closed"
-if os.path.exists(replay) and key0 in out["entries"]:
+OCCUPANCY = {"ks_ref0/f64/closed": 4, "ks_true08/f64/closed": 3, "ks_ref0/f64/generic": 2}
+if os.path.exists(replay):
     import re
-    best = {}
-    section = None
+    table, key, pure = {}, None, False
     for l in open(replay):
         if l.startswith("--"):
-            section = "pure_fma" if "v_fma_f64 per iteration" in l else "mix"
-        m = re.search(r"([0-9.]+) TFLOP/s f64 \(([0-9.]+) of 78.6\)", l)
-        if m and section:
-            best[section] = max(best.get(section, 0.0), float(m.group(2)))
-    if "mix" in best:
-        out["entries"][key0]["issue_ceiling"] = {
-            "frac_of_peak_this_mix_can_issue": best["mix"], "frac_of_peak_pure_fma_attains": best.get("pure_fma"),
-            "how": "tools/micro/mix_replay.hip: the per-wave-step instruction counts of this entry as INDEPENDENT instructions, "
-                   "chip-wide, 4 waves/SIMD, wall clock; " + os.path.relpath(replay, ROOT)}
+            m = re.search(r"instruction mix of (\S+)", l)
+            pure = "v_fma_f64 per iteration" in l
+            if m:
+                key = m.group(1)
+            elif not pure:
+                key = "ks_ref0/f64/closed"          # (the first run's header did not name its mix)
+        m = re.match(r"(\d) wave\(s\)/SIMD:.* \(([0-9.]+) of 78.6\)", l)
+        if m and key:
+            table.setdefault(key, {}).setdefault("pure_fma" if pure else "mix", {})[int(m.group(1))] = float(m.group(2))
+    for key, t in table.items():
+        if key in out["entries"] and "mix" in t:
+            w = OCCUPANCY.get(key, 4)
+            out["entries"][key]["issue_ceiling"] = {
+                "waves_per_simd": w, "frac_of_peak_this_mix_can_issue": t["mix"].get(w), "by_waves_per_simd": t["mix"],
+                "frac_of_peak_pure_fma_attains": t.get("pure_fma", {}).get(w),
+                "how": "tools/micro/mix_replay.hip: the per-wave-step instruction counts of this entry as INDEPENDENT "
+                       "instructions, chip-wide, wall clock; " + os.path.relpath(replay, ROOT)}
 json.dump(out, open(os.path.join(ROOT, "profiles", rnd, "flops.json"), "w"), indent=1)
 print("wrote profiles/%s/flops.json for kernel sources %s" % (rnd, out["kernel_source_hash"]))

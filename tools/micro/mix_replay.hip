@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include "mix_replay_counts.inc"
 
 template <bool PURE_FMA>
 __global__ __launch_bounds__(64) void replay(unsigned long long* out, double seed, int iters) {
@@ -36,12 +37,12 @@ int main() {
     printf("%s  %d CUs\n", p.gcnArchName, ncu);
     for (int pure = 0; pure < 2; pure++) {
         auto kern = pure ? replay<true> : replay<false>;
-        const double flop_per_lane = pure ? 2.0 * 812 : 1087.0;
-        printf(pure ? "-- 812 independent v_fma_f64 per iteration: the attainable FMA peak under this chip's power limit\n"
-                    : "-- the FAR pass's mix (812 VALU: 429 FMA / 208 MUL / 21 ADD f64 + 154 others)\n");
+        const double flop_per_lane = pure ? 2.0 * MIX_TOTAL : (double)MIX_FLOP;
+        if (pure) printf("-- %d independent v_fma_f64 per iteration: the attainable FMA peak under this chip's power limit\n", MIX_TOTAL);
+        else printf("-- the instruction mix of %s (%d VALU per wave-step, %d f64 flop per lane)\n", MIX_NAME, MIX_TOTAL, MIX_FLOP);
         for (int wps = 1; wps <= 4; wps++) {
             const int blocks = ncu * 4 * wps;
-            const int iters = 36000 / wps;       // ~50-60 ms per launch
+            const int iters = (int)(36000.0 * 812 / MIX_TOTAL) / wps;       // ~50-60 ms per launch
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, d, 1.25, 2000);   // warm
             (void)hipDeviceSynchronize();
             double best = 1e30;
