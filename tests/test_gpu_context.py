@@ -332,6 +332,30 @@ def test_pixels_entry_point_is_pipelined_in_pieces(lib):
     assert rc == abi.ERR_NAN_INPUT   # `@assert !any(isnan, …)` (src/RayTraceGR.jl:279), evaluated on the device
 
 
+@pytest.mark.parametrize("ni,nj,piece", [(37, 53, 64), (64, 40, 200), (19, 120, 100)])
+def test_host_pipeline_with_many_chunks_and_every_output(lib, ni, nj, piece):
+    """The blocking host entry points cut a job into compute chunks whose D2H is ordered behind the NEXT chunk's set-up
+    kernels and lands in two alternating pinned slots: with tiny pieces (9-25 chunks here) and every per-ray output asked
+    for, camera rays or caller-supplied states, the result must equal the single-launch device path bit for bit."""
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_true08")
+    opt = rt.solver_defaults()
+    ref = hip_trace(lib, sc, opt, ni, nj, cam=cam)        # host_chunk automatic: one chunk at this size
+    st0 = np.zeros((ni * nj, 8))
+    abi.check(lib, lib.rtgr_make_canvas_f64(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, st0.ctypes.data))
+    with abi.options(lib, host_chunk=piece):
+        for state0 in (None, st0):
+            got = hip_trace(lib, sc, opt, ni, nj, cam=cam if state0 is None else None, state0=state0)
+            for k in OUT_KEYS:
+                assert np.array_equal(got[k], ref[k], equal_nan=True), (k, state0 is None)
+            assert got["counters"] == ref["counters"]
+        # a slab of rows, states supplied
+        j0, j1 = nj // 3, nj - 2
+        part = hip_trace(lib, sc, opt, ni, nj, j0=j0, j1=j1, state0=st0[j0 * ni:j1 * ni])
+        assert np.array_equal(part["rgb"], ref["rgb"].reshape(3, nj, ni)[:, j0:j1].reshape(3, -1))
+        assert np.array_equal(part["state_end"], ref["state_end"][j0 * ni:j1 * ni])
+
+
 def test_float32_canvas_through_the_pixel_entry_points(lib):
     """`Canvas{T}` is generic in T (src/RayTraceGR.jl:452-455; the reference's own tests instantiate T = Float32,
     test/runtests.jl:37): trace_rays on a Canvas{Float32} goes through rtgr_trace_pixels_f32 with 44-byte pixels.  It must
