@@ -356,7 +356,7 @@ def main():
             roof["traffic"] = prof["hbm_bytes_per_ray"] * my_rays / a.steps if prof.get("hbm_bytes_per_ray") else None
             roof["profile"] = prof
             ic = prof.get("issue_ceiling")
-            if ic:   # what the machine can issue for THIS kernel's instruction mix with no operand ever waited for (measured)
+            if ic and ic.get("frac_of_peak_this_mix_can_issue"):   # what the machine can issue for THIS kernel's instruction mix with no operand ever waited for (measured)
                 roof["issue_ceiling_frac"] = ic["frac_of_peak_this_mix_can_issue"]
                 roof["frac_of_issue_ceiling"] = roof["frac"] / ic["frac_of_peak_this_mix_can_issue"]
         else:
