@@ -1122,8 +1122,6 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
     return RTGR_OK;
 }
 
-extern "C" {
-}  // extern "C"
 template <class R>
 static int trace_sharded_host(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
                               uint64_t nj, R* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
