@@ -59,3 +59,36 @@ template <class S> __device__ void rtgr_user_metric(const S x[4], double M, doub
     g[0][3] = g[3][0] = (0.02 * M) * cth / rho;
 }
 '''
+
+# Kerr in Boyer–Lindquist coordinates (t, r, θ, φ), drawn on the tracer's Cartesian-like coordinates by the plain
+# spherical map x = r sinθ cosφ, y = r sinθ sinφ, z = r cosθ — the metric a user reaches for first, and one that needs the
+# inverse trigonometric helpers (macos, matan2) the reference's Dual carries (src/RayTraceGR.jl:154-169):
+#   Σ = r² + a² cos²θ,  Δ = r² − 2Mr + a²
+#   ds² = −(1 − 2Mr/Σ) dt² − (4Mar sin²θ/Σ) dt dφ + (Σ/Δ) dr² + Σ dθ² + (r² + a² + 2Ma²r sin²θ/Σ) sin²θ dφ²
+# g_ab = Σ_μν (∂q^μ/∂x^a)(∂q^ν/∂x^b) g_μν with the rows dr = (sθcφ, sθsφ, cθ), dθ = (cθcφ, cθsφ, −sθ)/r, dφ = (−sφ, cφ, 0)/(r sθ).
+# Stationary; singular on the axis of the spherical map and at the horizon Δ = 0 (where captured rays hover, as in isotropic
+# Schwarzschild).  No oracle twin: checked against an independent sympy + DOP853 solution (tests/truth.py 'kerr_bl').
+KERR_BOYER_LINDQUIST = r"""
+template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) {
+    const S X = x[1], Y = x[2], Z = x[3];
+    const S r = msqrt(X * X + Y * Y + Z * Z);
+    const S th = macos(Z / r), ph = matan2(Y, X);
+    const S st = msin(th), ct = mcos(th), sp = msin(ph), cp = mcos(ph);
+    const double a2 = a * a;
+    const S r2 = r * r, s2 = st * st;
+    const S Sig = r2 + a2 * (ct * ct);
+    const S Del = r2 - (2.0 * M) * r + a2;
+    const S w = ((2.0 * M) * r) / Sig;                       // 2Mr/Σ
+    const S gtt = w - 1.0, gtp = -(a * w) * s2, grr = Sig / Del, gthth = Sig;
+    const S gpp = (r2 + a2 + (a2 * w) * s2) * s2;
+    const S zero = mconst<S>(0.0);
+    const S ir = 1.0 / r, irs = ir / st;
+    const S dr[4] = {zero, st * cp, st * sp, ct};
+    const S dth[4] = {zero, ct * cp * ir, ct * sp * ir, -(st * ir)};
+    const S dph[4] = {zero, -(sp * irs), cp * irs, zero};
+    for (int p = 1; p < 4; p++)
+        for (int c = 1; c < 4; c++) g[p][c] = grr * dr[p] * dr[c] + gthth * dth[p] * dth[c] + gpp * dph[p] * dph[c];
+    g[0][0] = gtt;
+    for (int p = 1; p < 4; p++) g[0][p] = g[p][0] = gtp * dph[p];
+}
+"""

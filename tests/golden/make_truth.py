@@ -19,7 +19,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk", "schw_iso"]
+VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk", "schw_iso", "kerr_bl"]
 N, GRID = 200, 8
 
 
@@ -34,10 +34,16 @@ def truth_scene(name):
     """scene_variant(name), or — 'schw_iso' — example2's objects and camera around an isotropic-coordinates Schwarzschild hole
     (the user-metric example; only kind / M enter here, no module is compiled or loaded)."""
     from scenes import scene_variant, rt
-    if name != "schw_iso":
+    if name not in ("schw_iso", "kerr_bl"):
         return scene_variant(name)
-    sc, cam = scene_variant("ks_true0")
+    sc, cam = scene_variant("ks_true0" if name == "schw_iso" else "ks_true08")
     sc.metric = rt._abi.USER
+    if name == "kerr_bl":          # Kerr a = 0.8 in Boyer–Lindquist coordinates (examples/user_metrics.py)
+        import truth
+        sc.user_metric = truth.KERR_BL_MARKER
+        assert sc.obj[0].kind == rt._abi.SPHERE and sc.obj[0].p[8] == -10.0
+        sc.obj[0].p[8] = -8.0      # sky sphere at r = 8: Boyer–Lindquist time runs ~1.5 x faster along these rays than
+        #                            Kerr–Schild time, and example2's plane (t = −20) would cut most rays to r = 10 short
     return sc, cam
 
 
@@ -61,7 +67,17 @@ if __name__ == "__main__":
         for name in (only or VARIANTS):
             res = pool.map(one, [(name, int(i), int(j)) for i, j in ij], chunksize=2)
             out = os.path.join(HERE, f"truth_{name}.npz")
-            np.savez_compressed(out, n=N, ij=ij, state0=np.array([r[0] for r in res]),
+            extra = {}
+            if name == "kerr_bl":   # no oracle twin exists for this metric: the pointwise g(x) and RHS vectors come from here too
+                import truth
+                sc, _ = truth_scene(name)
+                rng = np.random.default_rng(9)
+                s = np.concatenate([rng.uniform(-6, 6, (400, 4)), rng.uniform(-1, 1, (400, 4))], axis=1)
+                s = s[(np.linalg.norm(s[:, 1:4], axis=1) > 2.5) & (np.hypot(s[:, 1], s[:, 2]) > 0.5)][:128]
+                f = truth.rhs(sc)
+                extra = dict(rhs_states=s, rhs_values=np.array([f(0.0, v) for v in s]),
+                             metric_values=np.array([truth.metric(sc, v[:4]) for v in s]))
+            np.savez_compressed(out, n=N, ij=ij, **extra, state0=np.array([r[0] for r in res]),
                                 state_end=np.array([r[1] for r in res]), lambda_end=np.array([r[2] for r in res]),
                                 hit=np.array([r[3] for r in res], dtype=np.uint8), rgb=np.array([r[4] for r in res]),
                                 clearance=np.array([r[5] for r in res]), self_err=np.array([r[6] for r in res]),

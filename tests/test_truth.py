@@ -205,3 +205,61 @@ def test_user_metric_global_error_against_true_geodesics(jit):
     n = int(f["n"])
     r = hip_trace(lib, sc, rt.solver_defaults(), n, n, cam=camera)
     _check_against_truth(USER, r, f, min_sphere_rays=25)
+
+
+KERR_BL = "kerr_bl"   # Kerr a = 0.8 in Boyer–Lindquist coordinates on the spherical map: typed with macos / matan2 / msin / mcos
+
+
+def _kerr_bl_scene(user):
+    _, objs, cam = rt.example2_scene()
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -8.0)] + objs[1:]      # (sky at r = 8: see tests/golden/make_truth.py)
+    return rt.make_scene(user, objs), rt.make_camera(**cam)
+
+
+def test_kerr_bl_fixture_is_what_truth_computes():
+    """One pixel and the pointwise vectors of the Boyer–Lindquist fixture regenerated (sympy + scipy, ≈ 10 s)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import truth
+    from make_truth import truth_scene
+    f = _truth(KERR_BL)
+    sc, cam = truth_scene(KERR_BL)
+    rhs = truth.rhs(sc)
+    for k in (0, 17, 90):
+        assert np.abs(rhs(0.0, f["rhs_states"][k]) - f["rhs_values"][k]).max() < 1e-13
+    k = int(np.where(f["hit"] == 3)[0][0])
+    i, j = (int(v) for v in f["ij"][k])
+    n = int(f["n"])
+    r = truth.trace_ray(sc, rt.solver_defaults(), truth.pixel_state(sc, cam, n, n, i, j))
+    assert r["hit"] == 3 and np.abs(r["state_end"] - f["state_end"][k]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [False, True])
+def test_kerr_in_boyer_lindquist_coordinates_as_user_source(jit):
+    """The metric the round-1 review said "cannot be typed in": Kerr in Boyer–Lindquist coordinates, written with the inverse
+    trigonometric helpers (macos, matan2) and msin / mcos, compiled at run time, against the independent sympy + DOP853
+    solution of the same metric (written there WITHOUT inverse trigonometric functions): g(x) and the geodesic RHS
+    pointwise — which puts the dual derivative rules of the helpers under test where they matter —, then rays."""
+    import sys
+    ex = os.path.join(ROOT, "examples")
+    if ex not in sys.path:
+        sys.path.insert(0, ex)
+    import user_metrics
+    from test_gpu_parity import hip_trace
+    abi = rt._abi
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(-1))
+    f = _truth(KERR_BL)
+    user = rt.UserMetric(user_metrics.KERR_BOYER_LINDQUIST, M=1.0, a=0.8, stationary=True, jit=jit)
+    s = f["rhs_states"]
+    g = user(s[:, :4])
+    assert np.abs(g - f["metric_values"]).max() < 1e-13
+    got = rt.geodesic(s, user, path=1)
+    scale = np.abs(f["rhs_values"]).max(axis=1, keepdims=True)
+    assert (np.abs(got - f["rhs_values"]) / scale).max() < 5e-12
+    sc, cam = _kerr_bl_scene(user)
+    n = int(f["n"])
+    r = hip_trace(lib, sc, rt.solver_defaults(), n, n, cam=cam)
+    # captured rays hover at the Boyer–Lindquist horizon (r -> r+ = 1.6, where g_rr diverges): colour exact, λ_end to 1e-7
+    _check_against_truth(KERR_BL, r, f, min_sphere_rays=18, tol_cap_lambda=1e-7, tol_cap_state=None)

@@ -21,6 +21,8 @@ import functools
 
 import numpy as np
 
+KERR_BL_MARKER = 0x300   # rtgr_scene.user_metric of a test scene that means "the Boyer–Lindquist example" to this module
+
 
 @functools.lru_cache(maxsize=None)
 def _metric_fn(kind):
@@ -35,6 +37,21 @@ def _metric_fn(kind):
     elif kind == "schw_iso":   # Schwarzschild in isotropic coordinates (examples/user_metrics.py: a run-time compiled metric)
         m = M / (2 * sp.sqrt(x * x + y * y + z * z))
         g = sp.diag(-((1 - m) / (1 + m)) ** 2, (1 + m) ** 4, (1 + m) ** 4, (1 + m) ** 4) + 0 * a * eta
+    elif kind == "kerr_bl":    # Kerr in Boyer–Lindquist coordinates on the plain spherical map (examples/user_metrics.py
+        # KERR_BOYER_LINDQUIST); written here WITHOUT inverse trigonometric functions: cosθ = z/r, sinθ = ϖ/r, …
+        r = sp.sqrt(x * x + y * y + z * z)
+        pw = sp.sqrt(x * x + y * y)
+        ct, st, cp, sphi = z / r, pw / r, x / pw, y / pw
+        Sig = r * r + a * a * ct * ct
+        Del = r * r - 2 * M * r + a * a
+        w = 2 * M * r / Sig
+        gBL = {"tt": w - 1, "tp": -a * w * st ** 2, "rr": Sig / Del, "hh": Sig, "pp": (r * r + a * a + a * a * w * st ** 2) * st ** 2}
+        dr = sp.Matrix([0, st * cp, st * sphi, ct])
+        dth = sp.Matrix([0, ct * cp / r, ct * sphi / r, -st / r])
+        dph = sp.Matrix([0, -sphi / (r * st), cp / (r * st), 0])
+        dt = sp.Matrix([1, 0, 0, 0])
+        g = (gBL["tt"] * dt * dt.T + gBL["tp"] * (dt * dph.T + dph * dt.T) + gBL["rr"] * dr * dr.T + gBL["hh"] * dth * dth.T
+             + gBL["pp"] * dph * dph.T)
     else:
         rho2 = x * x + y * y + z * z
         q = rho2 - a * a
@@ -58,6 +75,8 @@ def _kind(scene):
     from conftest import load_package
     abi = load_package()._abi
     k = scene.metric & ~abi.METRIC_GENERIC
+    if k == abi.USER and scene.user_metric == KERR_BL_MARKER:
+        return "kerr_bl"
     return {abi.MINKOWSKI: "mink", abi.KS_REF: "ks_ref", abi.KS_TRUE: "ks_true", abi.USER: "schw_iso"}[k]
 
 
