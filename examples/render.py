@@ -5,6 +5,8 @@
     python examples/render.py 1             # writes scenes/sphere.png  (example1: flat space)
     python examples/render.py 3             # writes scenes/sphere3.png (example2's scene around a Schwarzschild hole
                                             #   in isotropic coordinates: a metric compiled at run time, UserMetric)
+    python examples/render.py 4             # writes scenes/sphere4.png (the same scene around a Kerr hole, a = 0.8, in
+                                            #   Boyer–Lindquist coordinates — user source with macos / matan2)
 
 The code below is what a user of RayTraceGR.jl writes, with `RayTraceGR.` replaced by the host mirror `rt.`.
 """
@@ -22,10 +24,11 @@ def main():
     ni = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     nj = int(sys.argv[3]) if len(sys.argv) > 3 else ni
     metric = rt.minkowski if which == 1 else rt.kerr_schild
-    if which == 3:  # a metric function of the user's own (the reference: any Julia callable, src/RayTraceGR.jl:302-309)
+    if which in (3, 4):  # a metric function of the user's own (the reference: any Julia callable, src/RayTraceGR.jl:302-309)
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import user_metrics
-        metric = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0, name="schwarzschild_isotropic")
+        metric = (rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, M=1.0, name="schwarzschild_isotropic") if which == 3 else
+                  rt.UserMetric(user_metrics.KERR_BOYER_LINDQUIST, M=1.0, a=0.8, stationary=True, name="kerr_boyer_lindquist"))
     caelum = rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10)                       # background sky, inside-out
     frustum = rt.Plane(-20)                                                    # cut-off plane in the past
     sphere = rt.Sphere((0, 0 if which == 1 else 4, 0, 0), (1, 0, 0, 0), 0.5)   # the visible sphere
@@ -35,7 +38,7 @@ def main():
     canvas, info = rt.trace_rays(metric, objs, canvas, return_info=True)
     from raytracegr_jl_amd.png import write_png
     os.makedirs(rt.api.outdir, exist_ok=True)
-    file = os.path.join(rt.api.outdir, {1: "sphere.png", 2: "sphere2.png", 3: "sphere3.png"}[which])
+    file = os.path.join(rt.api.outdir, {1: "sphere.png", 2: "sphere2.png", 3: "sphere3.png", 4: "sphere4.png"}[which])
     write_png(file, canvas.image_u8())
     print(f'Output file is "{file}"  ({info["rays"]} rays, {info["accepted"] + info["rejected"]} RK step attempts)')
 
