@@ -68,6 +68,9 @@ template <class S> __device__ void rtgr_user_metric(const S x[4], double M, doub
 # g_ab = Σ_μν (∂q^μ/∂x^a)(∂q^ν/∂x^b) g_μν with the rows dr = (sθcφ, sθsφ, cθ), dθ = (cθcφ, cθsφ, −sθ)/r, dφ = (−sφ, cφ, 0)/(r sθ).
 # Stationary; singular on the axis of the spherical map and at the horizon Δ = 0 (where captured rays hover, as in isotropic
 # Schwarzschild).  No oracle twin: checked against an independent sympy + DOP853 solution (tests/truth.py 'kerr_bl').
+# Cost (1024², a = 0.8): 1.4e9 step attempts/s against 9.3e9 for KERR_SCHILD above — the four f64 sin/cos and the acos /
+# atan2 of dual numbers are library calls of ~100 instructions each, and Boyer–Lindquist rays need 770 steps (captured rays
+# crawl towards Δ = 0).  Written for clarity; cosθ = z/r, sinθ = ϖ/r, cosφ = x/ϖ, sinφ = y/ϖ is the fast way to type it.
 KERR_BOYER_LINDQUIST = r"""
 template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) {
     const S X = x[1], Y = x[2], Z = x[3];
