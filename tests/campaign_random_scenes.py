@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off differential campaign: the seeded random scenes of tests/test_gpu_parity.py (_random_scene) for MANY seeds,
 through the closed-form path and the generic path, against the oracle with the test's own bounds.  Prints the seeds that
-violate a bound (none expected) and a summary.      python tools/random_campaign.py [first_seed] [last_seed]"""
+violate a bound and a summary.  It lives under tests/ (not collected by pytest) because it calls the oracle, which only test
+code may do.      python tests/campaign_random_scenes.py [first_seed] [last_seed]"""
 import os
 import sys
 import traceback

@@ -77,13 +77,15 @@ def test_no_cpu_fallback_without_a_gpu(lib):
 
 
 def test_product_does_not_reference_the_oracle():
-    """The oracle is test infrastructure: nothing under raytracegr.jl_amd/ or include/ may mention it."""
-    for base in ("raytracegr.jl_amd", "include"):
+    """The oracle is test infrastructure: nothing under raytracegr.jl_amd/, include/, examples/, julia/ or tools/ may load
+    it — directly or through a test module (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do)."""
+    for base in ("raytracegr.jl_amd", "include", "examples", "julia", "tools"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
-                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".sh", ".jl", ".c")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "librtgr_oracle" not in txt and "oracle_lib" not in txt and "rtgr_oracle_" not in txt, f
+                    assert "test_gpu_parity" not in txt and "test_truth" not in txt, f   # (those modules import the oracle)
 
 
 def test_missing_library_fails_loudly(tmp_path):
