@@ -167,6 +167,23 @@ def test_hip_generic_rhs_global_error_against_true_geodesics(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ks_ref0", "ks_true08", "ks_true0998_disk"])
+def test_hip_tile_kernel_global_error_against_true_geodesics(name):
+    """The simple one-lane-per-ray kernel (option tile = 1: IEEE division, f64 controller, inline event finder) — an
+    independent device formulation — against the same true geodesics."""
+    from test_gpu_parity import hip_trace
+    abi = rt._abi
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(-1))
+    f = _truth(name)
+    sc, cam = scene_variant(name)
+    n = int(f["n"])
+    with abi.options(lib, tile=1):
+        r = hip_trace(lib, sc, rt.solver_defaults(), n, n, cam=cam)
+    _check_against_truth(name, r, f)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", VARIANTS)
 def test_hip_float32_global_error_against_true_geodesics(name):
     """BASELINE config 4's arithmetic (Float32, tol = eps(Float32)^(3/4) ≈ 6.4e-6) against the same true geodesics: the
