@@ -193,7 +193,7 @@ int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len
 
 /* Launch-policy options (experiments and schedule-invariance tests; none changes a result bit).  Names: "waves_per_cu",
  * "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early", "far4", "rounds", "qchunk", "qchunk_near",
- * "tile", "host_chunk".  value -1 = automatic.  Initial values come from the environment variables
+ * "tile", "host_chunk", "peer" (multi-device gather: 0 = through the host, 1 = peer copies or fail).  value -1 = automatic.  Initial values come from the environment variables
  * RTGR_<NAME> read ONCE when the context is created. */
 int rtgr_set_option(rtgr_context* ctx, const char* name, long value);
 int rtgr_get_option(rtgr_context* ctx, const char* name, long* value);
@@ -241,9 +241,15 @@ int rtgr_trace_rows_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const
                                const rtgr_ray_outputs* out, rtgr_counters* d_counters, void* stream);
 
 /* ---- the hot path, host buffers (what a Julia ccall passes) ---------------------------------------------------
- * Same semantics with HOST pointers; the library stages through pinned buffers of the context (device 0), pipelines
- * H2D copy / integration / D2H copy of successive pieces on three streams, and blocks until done.
+ * Same semantics with HOST pointers; the library stages through pinned buffers of the context, pipelines H2D copy /
+ * integration / D2H copy of successive pieces on three streams, and blocks until done.
  *   state0 may be NULL (device-side make_canvas from `cam`).  `ctr` (host, optional) is overwritten.
+ * EVERY device of the context takes part (the reference's caller is `trace_rays(metric, objs, canvas)`,
+ * src/RayTraceGR.jl:483-484, :560, :596 — one call, parallel inside): the rows of the slab are dealt cyclically, device k
+ * of N takes slab rows k, k+N, …; each device is driven by a host thread of its own inside the call, uploads ITS rows from
+ * the caller's array and downloads them straight back into it over its own PCIe link (no hop through device 0, no peer
+ * copies); counters are summed.  The results do not depend on the number of devices, bit for bit.  A context of one device
+ * (the default context) runs on the calling thread.
  */
 int rtgr_trace_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* state0,
                    const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, double* rgb,
@@ -267,13 +273,19 @@ int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_so
 int rtgr_trace_one_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float pos[4],
                        const float normal[4], float rgb[3], float state_end[8], uint8_t* status);
 
-/* ---- the hot path over ALL devices of the context -------------------------------------------------
- * One blocking call from one host thread: image rows are dealt cyclically to the context's N devices (device k traces
- * rows k, k+N, …), every device runs the pipeline on a stream of its own, and the rows — RGB planes and, when asked
- * for, status / hit / step counts / end states / lambda_end / redshift — are copied peer-to-peer (hipMemcpyPeerAsync: one
- * xGMI link per peer, no reduction, no halo) to device 0, put back in place there, and (host variant) downloaded.
- * Counters of all devices are summed into `ctr` (host).  The `_device` variant leaves the full frame in device-0
- * memory: d_rgb (3 planes of ni*nj) and the members of `out` are device-0 pointers. */
+/* ---- the hot path over ALL devices of the context, frame assembled in DEVICE memory ---------------------
+ * rtgr_trace_sharded_device_*: one blocking call from one host thread: image rows are dealt cyclically to the context's N
+ * devices (device k traces rows k, k+N, …), every device runs the pipeline on a stream of its own, and the rows — RGB
+ * planes and, when asked for, status / hit / step counts / end states / lambda_end / redshift — are copied peer-to-peer
+ * (hipMemcpyPeerAsync on the source device's stream: one xGMI link per peer, no reduction, no halo) to device 0 and put
+ * back in place there: d_rgb (3 planes of ni*nj) and the members of `out` are device-0 pointers.  Counters of all devices
+ * are summed into `ctr` (host).
+ *   Peer access is established by rtgr_create.  Where it could not be (the reason is kept), the rows of that device travel
+ * device -> pinned host -> device 0 instead; option "peer" = 0 forces that path for every device (also between two entries
+ * of one physical GPU: how it is tested on a one-GPU box), "peer" = 1 makes the call fail with RTGR_ERR_HIP naming the
+ * device pair instead of falling back.  A failing hipMemcpyPeerAsync is RTGR_ERR_HIP with the pair in the message.
+ * rtgr_trace_sharded_f64 / _f32 (host destination) need no gather: they are rtgr_trace_f64 / _f32 with state0 = NULL over
+ * the whole canvas (every device downloads its own rows). */
 int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam,
                            uint64_t ni, uint64_t nj, double* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr);
 int rtgr_trace_sharded_device_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt,

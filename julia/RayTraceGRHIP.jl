@@ -73,14 +73,18 @@ end
     Context(device_ids) / close(ctx)
 
 All devices one Julia process drives (`rtgr_create`).  `trace_rays(...; ctx)` on a context with several devices deals the
-image rows to all of them and collects the frame on the first (one `ccall`, one host thread — no Distributed.jl, which
-the reference tried and abandoned, README.md:129-135).  Without a context the library's default one is used.
+canvas rows cyclically to ALL of them inside the one `ccall` (`rtgr_trace_pixels_f64/_f32`: device k of N takes rows
+k, k+N, …, uploads those rows of `c.pixels` over its own PCIe link and writes them straight back into the output array —
+nothing is routed through the first device; include/rtgr.h "the hot path, host buffers") — no Distributed.jl, which the
+reference tried and abandoned (README.md:129-135).  Without a context the library's default one (ONE device) is used.
+Exercised in this repository by the C caller (`tests/c/abi_layout.c --render … 3`) and `tests/test_gpu_context.py`
+with a context that lists the GPU several times; between physically different GPUs it has not run yet (no node).
 """
 mutable struct Context
     handle::Ctx
-    function Context(device_ids::Vector{<:Integer} = Int[])
+    function Context(device_ids::AbstractVector{<:Integer} = Int[])
         h = Ref{Ctx}(C_NULL)
-        ids = Cint.(device_ids)
+        ids = collect(Cint, device_ids)
         check(ccall((:rtgr_create, librtgr), Cint, (Ptr{Cint}, Cint, Ptr{Ctx}), isempty(ids) ? C_NULL : ids, length(ids), h))
         finalizer(c -> ccall((:rtgr_destroy, librtgr), Cint, (Ctx,), c.handle), new(h[]))
     end
@@ -138,7 +142,8 @@ pack(s::RayTraceGR.Sphere{Float32}) = RtgrObject(RTGR_SPHERE, 0, (Float64.(s.pos
 
 Drop-in for `RayTraceGR.trace_rays` (src/RayTraceGR.jl:483-484).  Passes `pointer(c.pixels)` — the reference's own
 `Pixel{T}` AoS (:446-450; 88 bytes for Float64, 44 for Float32) — across the ABI; returns a new canvas with `rgb`
-filled (:532).  The tolerance is `eps(T)^(3/4)` as in the reference (:485).
+filled (:532).  The tolerance is `eps(T)^(3/4)` as in the reference (:485).  `ctx = Context(0:7)`: all eight GPUs of a
+node work on the canvas (rows dealt cyclically); the result does not depend on the number of devices, bit for bit.
 """
 function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Canvas{T}; ctx = nothing) where {T<:Union{Float64,Float32}}
     scene = scene_of(metric, objs, ctx)

@@ -193,15 +193,15 @@ def _lib():
     return lib
 
 
-def make_canvas(metric, pos, widthx, widthy, normal, ni, nj, dtype=np.float64):
+def make_canvas(metric, pos, widthx, widthy, normal, ni, nj, dtype=np.float64, ctx=None):
     """make_canvas(metric, pos, widthx, widthy, normal, ni, nj)::Canvas{T}  (src/RayTraceGR.jl:457-478), on the GPU.
     `dtype` plays the reference's type parameter T (np.float64 or np.float32)."""
     lib = _lib()
-    sc = make_scene(metric, [])
+    sc = make_scene(metric, [], ctx)
     cam = make_camera(pos, widthx, widthy, normal)
     st = np.empty((ni * nj, 8), dtype=dtype)
     fn = lib.rtgr_make_canvas_f64 if dtype == np.float64 else lib.rtgr_make_canvas_f32
-    _abi.check(lib, fn(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
+    _abi.check(lib, fn(ctx, C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
     px = np.zeros((ni, nj), dtype=pixel_dtype(dtype), order="F")
     flat = px.reshape(-1, order="F")
     flat["pos"] = st[:, :4]
@@ -216,13 +216,15 @@ def _canvas_scalar(px_dtype):
     raise TypeError("Canvas{Float64} or Canvas{Float32} expected")
 
 
-def trace_rays(metric, objs, c, opt=None, return_info=False):
+def trace_rays(metric, objs, c, opt=None, return_info=False, ctx=None):
     """trace_rays(metric, objs, c::Canvas{T})::Canvas{T}  (src/RayTraceGR.jl:482-536), T = Float64 or Float32.
 
     Passes the reference's own AoS pixel array across the ABI (rtgr_trace_pixels_f64 / _f32) and returns a NEW canvas
-    with pos/normal copied and rgb set (:532).  Pure, like the reference.  The tolerance is eps(T)^(3/4) (:485)."""
+    with pos/normal copied and rgb set (:532).  Pure, like the reference.  The tolerance is eps(T)^(3/4) (:485).
+    `ctx`: an rtgr_context handle (_abi.create_context); on a context of several devices the image rows are dealt
+    cyclically to ALL of them inside this one call (the reference's `Threads.@threads` loop, across GPUs)."""
     lib = _lib()
-    sc = make_scene(metric, objs)
+    sc = make_scene(metric, objs, ctx)
     ni, nj = c.pixels.shape
     pin = np.asfortranarray(c.pixels)
     t = _canvas_scalar(pin.dtype)
@@ -230,17 +232,17 @@ def trace_rays(metric, objs, c, opt=None, return_info=False):
     pout = np.empty_like(pin, order="F")
     ctr = rtgr_counters()
     fn = lib.rtgr_trace_pixels_f64 if t == np.float64 else lib.rtgr_trace_pixels_f32
-    _abi.check(lib, fn(None, C.byref(sc), C.byref(opt), pin.ctypes.data, ni, nj, pout.ctypes.data, C.byref(ctr)))
+    _abi.check(lib, fn(ctx, C.byref(sc), C.byref(opt), pin.ctypes.data, ni, nj, pout.ctypes.data, C.byref(ctr)))
     out = Canvas(pout)
     return (out, ctr.as_dict()) if return_info else out
 
 
-def trace_ray(metric, objs, cb, p, opt=None):
+def trace_ray(metric, objs, cb, p, opt=None, ctx=None):
     """Legacy single-pixel shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:65-79).
     `cb` is accepted for signature parity and ignored: the callback is always
     ContinuousCallback(min_distance(objs, ·), terminate!) (src/RayTraceGR.jl:488-490)."""
     lib = _lib()
-    sc = make_scene(metric, objs)
+    sc = make_scene(metric, objs, ctx)
     t = _canvas_scalar(p.dtype)
     opt = opt or solver_defaults(t)
     pos = np.ascontiguousarray(p["pos"], dtype=t)
@@ -249,7 +251,7 @@ def trace_ray(metric, objs, cb, p, opt=None):
     se = np.zeros(8, t)
     st = C.c_uint8(0)
     fn = lib.rtgr_trace_one_f64 if t == np.float64 else lib.rtgr_trace_one_f32
-    _abi.check(lib, fn(None, C.byref(sc), C.byref(opt), pos.ctypes.data, nrm.ctypes.data, rgb.ctypes.data, se.ctypes.data,
+    _abi.check(lib, fn(ctx, C.byref(sc), C.byref(opt), pos.ctypes.data, nrm.ctypes.data, rgb.ctypes.data, se.ctypes.data,
                        C.addressof(st)))
     return Pixel(pos, nrm, rgb, dtype=t)
 
@@ -317,11 +319,11 @@ def example2_scene(metric=None):
     return (metric or kerr_schild), [caelum, frustum, sphere], cam
 
 
-def _run_example(scene, ni, nj, fname, save):
+def _run_example(scene, ni, nj, fname, save, ctx=None):
     from .png import write_png
     metric, objs, cam = scene
-    canvas = make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], ni, nj)
-    canvas = trace_rays(metric, objs, canvas)
+    canvas = make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], ni, nj, ctx=ctx)
+    canvas = trace_rays(metric, objs, canvas, ctx=ctx)
     if save:
         os.makedirs(outdir, exist_ok=True)
         file = os.path.join(outdir, fname)
@@ -332,14 +334,14 @@ def _run_example(scene, ni, nj, fname, save):
     return canvas
 
 
-def example1(ni=200, nj=200, save=True):
+def example1(ni=200, nj=200, save=True, ctx=None):
     """example1()  src/RayTraceGR.jl:542-576"""
-    return _run_example(example1_scene(), ni, nj, "sphere.png", save)
+    return _run_example(example1_scene(), ni, nj, "sphere.png", save, ctx)
 
 
-def example2(ni=200, nj=200, save=True):
+def example2(ni=200, nj=200, save=True, ctx=None):
     """example2()  src/RayTraceGR.jl:578-612"""
-    return _run_example(example2_scene(), ni, nj, "sphere2.png", save)
+    return _run_example(example2_scene(), ni, nj, "sphere2.png", save, ctx)
 
 
 __all__ = ["D", "Metric", "UserMetric", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",

@@ -31,12 +31,12 @@ int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------------------
 static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
                                          "far4", "rounds", "qchunk", "qchunk_near", "tile", "host_chunk",
-                                         "dbg_pass_far", nullptr};
+                                         "dbg_pass_far", "peer", nullptr};
 const char* const* knob_names() { return KNOB_NAMES; }
 long* knob_slot(Knobs& k, const char* name) {
     if (!name) return nullptr;
     long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
-                     &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far};
+                     &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far, &k.peer};
     for (int i = 0; KNOB_NAMES[i]; i++)
         if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
     return nullptr;
@@ -173,6 +173,12 @@ using namespace rtgr;
 
 struct rtgr_context {
     std::vector<std::unique_ptr<DeviceCtx>> devs;
+    // peer access device 0 <-> device k, established by rtgr_create: 1 = enabled both ways (or the same physical device),
+    // 0 = not available, with the reason (the multi-device gather then stages through pinned host memory, or fails when the
+    // option peer = 1 requires peer copies)
+    std::vector<char> peer_ok;
+    std::vector<std::string> peer_why;
+    std::mutex modules_mu;   // run-time metric modules are loaded / unloaded on all devices under ONE lock
 };
 
 namespace {
@@ -214,7 +220,7 @@ void free_device_state(DeviceCtx& d, bool all) {
             if (kv.second.queue) (void)hipFree(kv.second.queue);
         }
     }
-    d.staging.reset();
+    if (all) d.staging.reset();   // (rtgr_trim releases the staging BUFFERS separately, under the staging's own mutex)
     if (all) {
         d.streams.clear();
         for (auto& m : d.modules) if (m.module && m.owned) (void)hipModuleUnload(m.module);
@@ -248,17 +254,32 @@ int create_context(const int* ids, int n, rtgr_context** out) {
         d->knobs = k;
         c->devs.push_back(std::move(d));
     }
-    // peer access device 0 <-> every other physical device (the multi-device gather); failures are not fatal —
-    // hipMemcpyPeerAsync then stages through the host
+    // peer access device 0 <-> every other physical device (the gather of rtgr_trace_sharded_device_*).  A failure is not
+    // fatal for the context — it is RECORDED per device with its reason, and the gather then stages that device's rows
+    // through pinned host memory (or returns RTGR_ERR_HIP naming the pair when the option peer = 1 insists on peer copies).
+    c->peer_ok.assign((size_t)n, 1);
+    c->peer_why.assign((size_t)n, std::string());
     for (int i = 1; i < n; i++) {
         const int a = c->devs[0]->dev, b = c->devs[i]->dev;
         if (a == b) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
-            { DeviceGuard g(a); (void)hipDeviceEnablePeerAccess(b, 0); }
-            { DeviceGuard g(b); (void)hipDeviceEnablePeerAccess(a, 0); }
-            (void)hipGetLastError();  // "already enabled" is fine
-        }
+        auto enable = [&](int from, int to) -> bool {
+            int can = 0;
+            hipError_t e = hipDeviceCanAccessPeer(&can, from, to);
+            if (e != hipSuccess || !can) {
+                c->peer_why[i] = "hipDeviceCanAccessPeer(" + std::to_string(from) + " -> " + std::to_string(to) + "): " +
+                                 (e != hipSuccess ? hipGetErrorString(e) : "no peer access between these devices");
+                return false;
+            }
+            DeviceGuard g(from);
+            e = hipDeviceEnablePeerAccess(to, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                c->peer_why[i] = "hipDeviceEnablePeerAccess(" + std::to_string(from) + " -> " + std::to_string(to) + "): " + hipGetErrorString(e);
+                return false;
+            }
+            return true;
+        };
+        if (!enable(a, b) || !enable(b, a)) c->peer_ok[i] = 0;
+        (void)hipGetLastError();  // "already enabled" leaves a sticky error behind
     }
     *out = c.release();
     return RTGR_OK;
@@ -471,10 +492,16 @@ struct OutArray { void* host; size_t elem; int planes; size_t dev_off; };
 // when the camera generates them on the device) and 24 B/ray out (+ what `out` asks for) — never the 88-byte pixels.
 // `px_in` != NULL: the input is the reference's Pixel{T} array (11 scalars per pixel, pos + normal are packed
 // out of it on the way up) and `px_out` receives Pixel(p.pos, p.normal, rgb) (:532).
+// `rows` (multi-device contexts): this device's share of the slab — local row k is slab row rows.first + k * rows.stride
+// (cyclic rows).  The device buffers hold the LOCAL rays contiguously; the row map is applied where rays are
+// packed out of / unpacked into the caller's arrays, so every device reads its rows from, and writes them straight back
+// into, the caller's host memory over its own PCIe link — no hop through device 0.
+struct RowShare { uint64_t first = 0, stride = 1; };
+
 template <class R>
 int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const R* state0, const R* px_in,
                          R* px_out, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* rgb,
-                         const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+                         const rtgr_ray_outputs* out, rtgr_counters* ctr, RowShare share = RowShare()) {
     DeviceGuard guard(D.dev);
     if (!guard.ok) return fail(RTGR_ERR_HIP, "hipSetDevice failed");
     Staging* S = nullptr;
@@ -485,8 +512,23 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     HIP_TRY(hipStreamSynchronize(S->s_up));
     HIP_TRY(hipStreamSynchronize(S->s_comp));
     HIP_TRY(hipStreamSynchronize(S->s_down));
-    const uint64_t nrows = j1 - j0, n = ni * nrows;
+    const uint64_t nrows_slab = j1 - j0, n_slab = ni * nrows_slab;   // the caller's arrays
+    const uint64_t nrows = nrows_slab > share.first ? (nrows_slab - share.first + share.stride - 1) / share.stride : 0;
+    const uint64_t n = ni * nrows;                                     // this device's rays
+    if (ctr) std::memset(ctr, 0, sizeof *ctr);
+    if (n == 0) return RTGR_OK;
     const bool have_in = state0 != nullptr || px_in != nullptr;
+    const bool strided = share.stride != 1;
+    // local rays [a, a + cnt) as runs of consecutive rays of the caller's arrays: body(local_first, global_first, length)
+    auto for_runs = [ni, share, strided](uint64_t a, uint64_t cnt, auto&& body) {
+        if (!strided) { body(a, share.first * ni + a, cnt); return; }
+        while (cnt > 0) {
+            const uint64_t k = a / ni, i = a % ni;
+            const uint64_t len = (ni - i) < cnt ? (ni - i) : cnt;
+            body(a, (share.first + k * share.stride) * ni + i, len);
+            a += len; cnt -= len;
+        }
+    };
 
     // ---- output arrays ---------------------------------------------------------------------------------------------
     std::vector<OutArray> outs;
@@ -629,18 +671,25 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
                 if (k == 0 && px_in) {  // Pixel(p.pos, p.normal, col)  (:532)
                     const R* pr = (const R*)(src + off);
                     parallel_rows(m, 11 * sizeof(R), [&](uint64_t a, uint64_t cnt) {
-                        for (uint64_t w = a; w < a + cnt; w++) {
-                            R* po = px_out + (r0 + w) * 11;
-                            const R* pi = px_in + (r0 + w) * 11;
-                            if (po != pi) for (int q = 0; q < 8; q++) po[q] = pi[q];
-                            po[8] = pr[w]; po[9] = pr[m + w]; po[10] = pr[2 * m + w];
-                        }
+                        for_runs(r0 + a, cnt, [&](uint64_t l0, uint64_t g0, uint64_t len) {
+                            for (uint64_t e = 0; e < len; e++) {
+                                const uint64_t w = l0 - r0 + e;
+                                R* po = px_out + (g0 + e) * 11;
+                                const R* pi = px_in + (g0 + e) * 11;
+                                if (po != pi) for (int q = 0; q < 8; q++) po[q] = pi[q];
+                                po[8] = pr[w]; po[9] = pr[m + w]; po[10] = pr[2 * m + w];
+                            }
+                        });
                     });
                 } else {
                     for (int pl = 0; pl < o.planes; pl++) {
-                        char* dst = (char*)o.host + ((size_t)pl * n + r0) * o.elem;
+                        char* dst = (char*)o.host + (size_t)pl * n_slab * o.elem;
                         const char* s2 = src + off + (size_t)pl * m * o.elem;
-                        parallel_rows(m, o.elem, [&](uint64_t a, uint64_t cnt) { std::memcpy(dst + a * o.elem, s2 + a * o.elem, cnt * o.elem); });
+                        parallel_rows(m, o.elem, [&](uint64_t a, uint64_t cnt) {
+                            for_runs(r0 + a, cnt, [&](uint64_t l0, uint64_t g0, uint64_t len) {
+                                std::memcpy(dst + g0 * o.elem, s2 + (l0 - r0) * o.elem, len * o.elem);
+                            });
+                        });
                     }
                 }
                 off += align256((size_t)m * o.elem * o.planes);
@@ -686,20 +735,25 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
                 const int slot = (int)(piece_no % Staging::IN_SLOTS);
                 if (piece_no >= (uint64_t)Staging::IN_SLOTS) HIP_TRY(hipEventSynchronize(S->ev_in[slot]));  // slot's last H2D done
                 R* pin = (R*)S->pin_in[slot].p;
-                const uint64_t g0 = r0 + p0;
+                const uint64_t l00 = r0 + p0;   // first local ray of the piece
                 if (px_in) {
                     parallel_rows(pm, 8 * sizeof(R), [&](uint64_t a, uint64_t cnt) {
-                        for (uint64_t w = a; w < a + cnt; w++) {
-                            const R* pi = px_in + (g0 + w) * 11;
-                            R* d = pin + w * 8;
-                            for (int q = 0; q < 8; q++) d[q] = pi[q];
-                        }
+                        for_runs(l00 + a, cnt, [&](uint64_t l0, uint64_t g0, uint64_t len) {
+                            for (uint64_t e = 0; e < len; e++) {
+                                const R* pi = px_in + (g0 + e) * 11;
+                                R* d = pin + (l0 - l00 + e) * 8;
+                                for (int q = 0; q < 8; q++) d[q] = pi[q];
+                            }
+                        });
                     });
                 } else {
-                    const R* src = state0 + g0 * 8;
-                    parallel_rows(pm, 8 * sizeof(R), [&](uint64_t a, uint64_t cnt) { std::memcpy(pin + a * 8, src + a * 8, cnt * 8 * sizeof(R)); });
+                    parallel_rows(pm, 8 * sizeof(R), [&](uint64_t a, uint64_t cnt) {
+                        for_runs(l00 + a, cnt, [&](uint64_t l0, uint64_t g0, uint64_t len) {
+                            std::memcpy(pin + (l0 - l00) * 8, state0 + g0 * 8, len * 8 * sizeof(R));
+                        });
+                    });
                 }
-                HIP_TRY(hipMemcpyAsync(d_in + g0 * 8, pin, (size_t)pm * 8 * sizeof(R), hipMemcpyHostToDevice, S->s_up));
+                HIP_TRY(hipMemcpyAsync(d_in + l00 * 8, pin, (size_t)pm * 8 * sizeof(R), hipMemcpyHostToDevice, S->s_up));
                 HIP_TRY(hipEventRecord(S->ev_in[slot], S->s_up));
             }
             HIP_TRY(hipEventRecord(ev_up_last, S->s_up));
@@ -710,8 +764,14 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
         win.after_setup = ev_setup[c];
         const uint64_t row0 = chunks[c].row0, rows = chunks[c].rows;
         if (D.knobs.tile) { win.plane_stride = 0; win.out_offset = 0; }
-        rc = trace_device<R>(D, scene, opt, have_in ? d_in + r0 * 8 : nullptr, cam, ni, nj, j0 + row0, j0 + row0 + rows, d_rgb,
-                             &dout, d_ctr, S->s_comp, 1, 0, &win);
+        if (!strided)
+            rc = trace_device<R>(D, scene, opt, have_in ? d_in + r0 * 8 : nullptr, cam, ni, nj, j0 + share.first + row0,
+                                 j0 + share.first + row0 + rows, d_rgb, &dout, d_ctr, S->s_comp, 1, 0, &win);
+        else {  // local rows row0 … of a cyclic share: image rows j0 + first + (row0 + k) * stride
+            const uint64_t jf = j0 + share.first + row0 * share.stride;
+            rc = trace_device<R>(D, scene, opt, have_in ? d_in + r0 * 8 : nullptr, cam, ni, nj, jf, jf + 1, d_rgb, &dout, d_ctr,
+                                 S->s_comp, share.stride, rows, &win);
+        }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev_comp[c], S->s_comp));
         // The D2H of chunk c-1 goes out only now, behind the SET-UP kernels of chunk c: the runtime copies device -> host
@@ -733,6 +793,47 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     return RTGR_OK;
 }
 
+// The host-pointer hot path over EVERY device of the context — what `trace_rays(metric, objs, canvas)` binds
+// (src/RayTraceGR.jl:483-536; call sites :560, :596).  Rows of the slab are dealt cyclically: device k of N takes slab rows
+// k, k+N, …, runs the three-stream pipeline above on them from a host thread of its own, reads ITS rows from the caller's
+// array and writes them straight back (H2D and D2H over the device's own PCIe link; nothing is routed through device 0);
+// counters are summed.  One device (or a one-row slab): the plain single-device call on the calling thread.
+template <class R>
+int trace_host_all_devices(rtgr_context* c, const rtgr_scene* scene, const rtgr_solver* opt, const R* state0, const R* px_in,
+                           R* px_out, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* rgb,
+                           const rtgr_ray_outputs* out, rtgr_counters* ctr) {
+    const uint64_t nrows = j1 - j0;
+    const uint64_t N = c->devs.size() < nrows ? c->devs.size() : nrows;
+    if (N <= 1) return trace_host_pipelined<R>(*c->devs[0], scene, opt, state0, px_in, px_out, cam, ni, nj, j0, j1, rgb, out, ctr);
+    if (c->devs[0]->knobs.tile) return fail(RTGR_ERR_BAD_ARG, "the multi-device path needs the persistent pipeline (option tile = 0)");
+    std::vector<int> rcs(N, RTGR_OK);
+    std::vector<std::string> errs(N);
+    std::vector<rtgr_counters> ctrs(N);
+    auto work = [&](uint64_t k) {
+        RowShare sh;
+        sh.first = k; sh.stride = N;
+        rcs[k] = trace_host_pipelined<R>(*c->devs[k], scene, opt, state0, px_in, px_out, cam, ni, nj, j0, j1, rgb, out, &ctrs[k], sh);
+        if (rcs[k]) errs[k] = g_err;   // the message is per thread: carry it to the caller's
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint64_t k = 1; k < N; k++) th.emplace_back(work, k);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    for (uint64_t k = 0; k < N; k++)
+        if (rcs[k]) return fail(rcs[k], "device " + std::to_string(c->devs[k]->dev) + " (entry " + std::to_string(k) + " of the context): " + errs[k]);
+    if (ctr) {
+        std::memset(ctr, 0, sizeof *ctr);
+        for (uint64_t k = 0; k < N; k++) {
+            const uint64_t* p = (const uint64_t*)&ctrs[k];
+            uint64_t* q = (uint64_t*)ctr;
+            for (int w = 0; w < 8; w++) q[w] = (w == 7) ? (q[w] > p[w] ? q[w] : p[w]) : q[w] + p[w];   // [7] is a maximum (diagnostics)
+        }
+    }
+    return RTGR_OK;
+}
+
 template <class R>
 int trace_host(rtgr_context* ctx_in, const rtgr_scene* scene, const rtgr_solver* opt, const R* state0, const rtgr_camera* cam,
                uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, R* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
@@ -743,7 +844,7 @@ int trace_host(rtgr_context* ctx_in, const rtgr_scene* scene, const rtgr_solver*
     if (ni == 0 || nj == 0 || j1 <= j0 || j1 > nj) return fail(RTGR_ERR_BAD_ARG, "bad canvas range: need 0 <= j0 < j1 <= nj, ni > 0");
     if (!state0 && !cam) return fail(RTGR_ERR_BAD_ARG, "need state0 or a camera");
     if (!scene) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
-    return trace_host_pipelined<R>(*c->devs[0], scene, opt, state0, nullptr, nullptr, cam, ni, nj, j0, j1, rgb, out, ctr);
+    return trace_host_all_devices<R>(c, scene, opt, state0, nullptr, nullptr, cam, ni, nj, j0, j1, rgb, out, ctr);
 }
 
 // scratch device buffers of the small host-pointer hooks (eval_*, make_canvas): RAII, synchronous
@@ -801,7 +902,24 @@ int rtgr_trim(rtgr_context* ctx) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
     if (rc) return rc;
-    for (auto& d : c->devs) { std::lock_guard<std::mutex> lk(d->mu); free_device_state(*d, false); }
+    for (auto& d : c->devs) {
+        // Host-pointer calls hold Staging::mu for their whole duration and take D.mu inside it (to enqueue), so the staging
+        // is trimmed FIRST and under its own mutex only (a call in flight finishes first, the next one re-allocates); the
+        // struct itself — mutex, streams, events — goes with the context, never here.
+        Staging* s = nullptr;
+        { std::lock_guard<std::mutex> lk(d->mu); s = d->staging.get(); }
+        if (s) {
+            DeviceGuard g(d->dev);
+            std::lock_guard<std::mutex> ls(s->mu);
+            (void)hipStreamSynchronize(s->s_up); (void)hipStreamSynchronize(s->s_comp); (void)hipStreamSynchronize(s->s_down);
+            for (auto& b : s->pin_in) b.release();
+            for (auto& b : s->pin_out) b.release();
+            s->pin_small.release();
+            s->d_in.release(); s->d_out.release(); s->d_small.release(); s->d_recv.release();
+        }
+        std::lock_guard<std::mutex> lk(d->mu);
+        free_device_state(*d, false);
+    }
     return RTGR_OK;
 }
 int rtgr_init(int device) {
@@ -977,8 +1095,7 @@ static int trace_pixels(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_s
     if (!pixels_in || !pixels_out) return fail(RTGR_ERR_BAD_ARG, "pixels is NULL");
     if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
     if (!scene) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
-    return trace_host_pipelined<R>(*c->devs[0], scene, opt, nullptr, pixels_in, pixels_out, nullptr, ni, nj, 0, nj, nullptr,
-                                   nullptr, ctr);
+    return trace_host_all_devices<R>(c, scene, opt, nullptr, pixels_in, pixels_out, nullptr, ni, nj, 0, nj, nullptr, nullptr, ctr);
 }
 template <class R>
 static int trace_one(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const R pos[4], const R normal[4],
@@ -1041,6 +1158,7 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
     std::vector<Staging*> S(N, nullptr);
     std::vector<uint64_t> nrows(N, 0);
     std::vector<hipEvent_t> ev(N, nullptr);
+    std::vector<char> via_host(N, 0);
     struct EvFree { std::vector<hipEvent_t>& e; ~EvFree() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } evfree{ev};
     int rc;
     // the part / counter / receive buffers are shared by consecutive sharded calls: one such call at a time per context
@@ -1057,6 +1175,20 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         if ((rc = S[k]->pin_small.need(256))) return rc;
         if (k == 0 && N > 1 && (rc = S[0]->d_recv.need(part_bytes * (N - 1)))) return rc;
         HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        // how this device's rows reach device 0: peer copy (default), or D2H + H2D through pinned host memory when peer
+        // access could not be enabled at rtgr_create — or when the option peer = 0 forces that path (also between two
+        // entries of the SAME physical device: how the fallback is tested on a one-GPU box)
+        if (k > 0) {
+            const long want = c->devs[0]->knobs.peer;
+            if (want == 0) via_host[k] = 1;
+            else if (!c->peer_ok[k]) {
+                if (want > 0)
+                    return fail(RTGR_ERR_HIP, "option peer = 1 but there is no peer access between device " + std::to_string(c->devs[0]->dev) +
+                                              " and device " + std::to_string(D.dev) + ": " + c->peer_why[k]);
+                via_host[k] = 1;
+            }
+            if (via_host[k] && (rc = S[k]->pin_out[0].need(part_bytes))) return rc;
+        }
     }
     // 1. every device traces its rows on its own stream
     for (uint64_t k = 0; k < N; k++) {
@@ -1085,10 +1217,31 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         if (k > 0) {
             char* rb = (char*)S[0]->d_recv.p + (k - 1) * part_bytes;
             const size_t used = part_bytes;  // padded arrays: a single copy per peer
-            if (c->devs[0]->dev == D.dev) HIP_TRY(hipMemcpyAsync(rb, pb, used, hipMemcpyDeviceToDevice, S[k]->s_comp));
-            else HIP_TRY(hipMemcpyPeerAsync(rb, c->devs[0]->dev, pb, D.dev, used, S[k]->s_comp));
+            if (via_host[k]) HIP_TRY(hipMemcpyAsync(S[k]->pin_out[0].p, pb, used, hipMemcpyDeviceToHost, S[k]->s_comp));
+            else if (c->devs[0]->dev == D.dev) HIP_TRY(hipMemcpyAsync(rb, pb, used, hipMemcpyDeviceToDevice, S[k]->s_comp));
+            else {
+                const hipError_t e = hipMemcpyPeerAsync(rb, c->devs[0]->dev, pb, D.dev, used, S[k]->s_comp);
+                if (e != hipSuccess)
+                    return fail(RTGR_ERR_HIP, "hipMemcpyPeerAsync device " + std::to_string(D.dev) + " -> device " +
+                                              std::to_string(c->devs[0]->dev) + " (" + std::to_string(used) + " bytes): " + hipGetErrorString(e));
+            }
         }
         HIP_TRY(hipEventRecord(ev[k], S[k]->s_comp));
+    }
+    // 2b. rows that travel through the host: wait for the device's D2H (every device has been started by now, so they all
+    // run meanwhile), then upload to device 0 on its upload stream; the placement below is ordered behind it by event
+    for (uint64_t k = 1; k < N; k++) {
+        if (nrows[k] == 0 || !via_host[k]) continue;
+        { DeviceGuard g(c->devs[k]->dev);
+          const hipError_t e = hipEventSynchronize(ev[k]);
+          if (e != hipSuccess) return fail(RTGR_ERR_HIP, "device " + std::to_string(c->devs[k]->dev) + " (rows to the host): " + hipGetErrorString(e)); }
+        DeviceGuard g0(c->devs[0]->dev);
+        char* rb = (char*)S[0]->d_recv.p + (k - 1) * part_bytes;
+        HIP_TRY(hipMemcpyAsync(rb, S[k]->pin_out[0].p, part_bytes, hipMemcpyHostToDevice, S[0]->s_up));
+        // "the rows of device k are on device 0": an event of DEVICE 0 (an event is recorded on streams of its own device)
+        (void)hipEventDestroy(ev[k]); ev[k] = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev[k], S[0]->s_up));
     }
     // 3. device 0 puts every rank's rows back in place
     {
@@ -1116,59 +1269,19 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         HIP_TRY(hipStreamSynchronize(S[k]->s_comp));
         const uint64_t* p = (const uint64_t*)S[k]->pin_small.p;
         uint64_t* q = (uint64_t*)&sum;
-        for (int w = 0; w < 8; w++) q[w] += p[w];
+        for (int w = 0; w < 8; w++) q[w] = (w == 7) ? (q[w] > p[w] ? q[w] : p[w]) : q[w] + p[w];   // [7] is a maximum (diagnostics)
     }
     if (ctr) *ctr = sum;
     return RTGR_OK;
 }
 
+// Host destination: no gather on device 0 is needed — every device downloads its own rows straight into the caller's
+// arrays (trace_host_all_devices), which is what rtgr_trace_f64 does on a multi-device context.
 template <class R>
 static int trace_sharded_host(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
                               uint64_t nj, R* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) {
-    rtgr_context* c = nullptr;
-    int rc = resolve_ctx(ctx, &c);
-    if (rc) return rc;
-    if (!rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
-    if (ni == 0 || nj == 0) return fail(RTGR_ERR_BAD_ARG, "empty canvas");
-    const uint64_t n = ni * nj;
-    DeviceCtx& D0 = *c->devs[0];
-    DeviceGuard g(D0.dev);
-    // the full frame on device 0, then one download per array
-    struct Item { void* host; size_t bytes; void* dev; };
-    std::vector<Item> items;
-    items.push_back({rgb, (size_t)n * 3 * sizeof(R), nullptr});
-    rtgr_ray_outputs dout;
-    std::memset(&dout, 0, sizeof dout);
-    if (out) {
-        if (out->state_end) items.push_back({out->state_end, (size_t)n * 8 * sizeof(R), nullptr});
-        if (out->lambda_end) items.push_back({out->lambda_end, (size_t)n * sizeof(R), nullptr});
-        if (out->status) items.push_back({out->status, (size_t)n, nullptr});
-        if (out->hit) items.push_back({out->hit, (size_t)n, nullptr});
-        if (out->n_accept) items.push_back({out->n_accept, (size_t)n * 4, nullptr});
-        if (out->n_reject) items.push_back({out->n_reject, (size_t)n * 4, nullptr});
-        if (out->redshift) items.push_back({out->redshift, (size_t)n * 8, nullptr});
-    }
-    size_t total = 0;
-    for (auto& it : items) total += align256(it.bytes);
-    DevBuf full;
-    if ((rc = full.alloc(total))) return rc;
-    {
-        size_t off = 0;
-        for (auto& it : items) { it.dev = (char*)full.p + off; off += align256(it.bytes); }
-        size_t k = 1;
-        if (out) {
-            if (out->state_end) dout.state_end = items[k++].dev;
-            if (out->lambda_end) dout.lambda_end = items[k++].dev;
-            if (out->status) dout.status = (uint8_t*)items[k++].dev;
-            if (out->hit) dout.hit = (uint8_t*)items[k++].dev;
-            if (out->n_accept) dout.n_accept = (uint32_t*)items[k++].dev;
-            if (out->n_reject) dout.n_reject = (uint32_t*)items[k++].dev;
-            if (out->redshift) dout.redshift = items[k++].dev;
-        }
-    }
-    if ((rc = trace_sharded<R>(c, scene, opt, cam, ni, nj, (R*)items[0].dev, &dout, ctr))) return rc;
-    for (auto& it : items) HIP_TRY(hipMemcpy(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost));
-    return RTGR_OK;
+    if (!cam) return fail(RTGR_ERR_BAD_ARG, "camera is NULL");
+    return trace_host<R>(ctx, scene, opt, nullptr, cam, ni, nj, 0, nj, rgb, out, ctr);
 }
 template <class R>
 static int trace_sharded_device(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni,
@@ -1366,6 +1479,7 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> load_lock(c->modules_mu);
     for (auto& d : c->devs) {
         DeviceGuard guard(d->dev);
         std::lock_guard<std::mutex> lk(d->mu);
@@ -1388,15 +1502,19 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 // load a gfx950 code object image into every device of the context; its id is a hash of the image
 static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out) {
     const uint64_t id = fnv1a(image);
+    std::lock_guard<std::mutex> load_lock(c->modules_mu);   // one load / unload at a time per context
     for (auto& d : c->devs) {
         DeviceGuard guard(d->dev);
+        bool same_phys = false;  // a logical duplicate of a device shares the module of its twin
+        UserModule twin;
+        for (auto& o : c->devs)
+            if (o.get() != d.get() && o->dev == d->dev) {
+                std::lock_guard<std::mutex> lo(o->mu);   // (the twin's list is read under the twin's lock)
+                if (const UserModule* m = o->find_module(id)) { twin = *m; twin.owned = false; same_phys = true; break; }
+            }
         std::lock_guard<std::mutex> lk(d->mu);
         if (d->find_module(id)) continue;
-        bool same_phys = false;  // a logical duplicate of a device shares the module of its twin
-        for (auto& o : c->devs)
-            if (o.get() != d.get() && o->dev == d->dev)
-                if (const UserModule* m = o->find_module(id)) { d->modules.push_back(*m); d->modules.back().owned = false; same_phys = true; break; }
-        if (same_phys) continue;
+        if (same_phys) { d->modules.push_back(twin); continue; }
         UserModule u;
         u.id = id;
         hipError_t e = hipModuleLoadData(&u.module, image.data());

@@ -61,6 +61,9 @@ struct Knobs {
     long tile = 0;                // 1: the simple tile-per-wave kernel (RTGR_KERNEL=tile), an independent formulation
     long host_chunk = -1;         // host entry points: rays per H2D/compute/D2H pipeline piece (auto: 2^20)
     long dbg_pass_far = 0;        // debug builds: which pass reports its wave timeline
+    long peer = -1;               // multi-device gather (rtgr_trace_sharded_device_*): 0 = always stage the rows through pinned
+                                  // host memory (the no-peer-access fallback, forced), 1 = peer copies or fail, -1 = peer copies
+                                  // where rtgr_create could enable peer access, the fallback elsewhere
 };
 const char* const* knob_names();  // NULL-terminated
 long* knob_slot(Knobs& k, const char* name);
@@ -122,7 +125,15 @@ struct KernelTimer {  // RAII: records start now, stop at scope exit
         if (d.timing) { a = d.take_event(); b = d.take_event(); (void)hipEventRecord(a, st); }
     }
     ~KernelTimer() {
-        if (a) { (void)hipEventRecord(b, st); d.timed.push_back({a, b, which}); }
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        d.timed.push_back({a, b, which});
+        // timing left on and never read: keep the newest launches only (their events go back to the pool)
+        constexpr size_t CAP = 4096;
+        if (d.timed.size() > CAP) {
+            for (size_t i = 0; i < CAP / 2; i++) { d.event_pool.push_back(d.timed[i].a); d.event_pool.push_back(d.timed[i].b); }
+            d.timed.erase(d.timed.begin(), d.timed.begin() + CAP / 2);
+        }
     }
 };
 

@@ -11,6 +11,9 @@
  *                                   88-byte Pixel array exactly as src/RayTraceGR.jl:446-450 lays it out, rtgr_trace_pixels_f64
  *                                   — and write the N0f8 image[j][i][c] bytes (compared with sphere2.png by the test);
  *                                   also rtgr_trace_one_f64 on the centre pixel (legacy trace_ray shape, test/runtests.jl:76)
+ *   abi_layout --render  <lib> out N the same through an explicit context that lists device 0 N times (rtgr_create): the
+ *                                   drop-in entry deals the canvas rows to every device of the context — what a Julia
+ *                                   `trace_rays(...; ctx = Context(0:7))` does on an 8-GPU node
  */
 #include <dlfcn.h>
 #include <math.h>
@@ -51,7 +54,7 @@ _Static_assert(sizeof(pixel_f64) == 88 && offsetof(pixel_f64, normal) == 32 && o
 typedef struct { float pos[4], normal[4], rgb[3]; } pixel_f32;   /* Pixel{Float32}: what rtgr_trace_pixels_f32 takes */
 _Static_assert(sizeof(pixel_f32) == 44 && offsetof(pixel_f32, normal) == 16 && offsetof(pixel_f32, rgb) == 32, "Pixel{Float32}");
 
-static const char* const BOUND[] = {"rtgr_create", "rtgr_destroy", "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version",
+static const char* const BOUND[] = {"rtgr_create", "rtgr_destroy", "rtgr_context_devices", "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version",
                                     "rtgr_solver_defaults", "rtgr_trace_pixels_f64", "rtgr_trace_pixels_f32", "rtgr_trace_one_f64", "rtgr_trace_one_f32", "rtgr_trace_f64",
                                     "rtgr_trace_sharded_f64", "rtgr_make_canvas_f64", "rtgr_user_metric_load", "rtgr_user_metric_compile",
                                     "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", NULL};
@@ -61,6 +64,9 @@ typedef int (*fn_canvas)(rtgr_context*, const rtgr_scene*, const rtgr_camera*, u
 typedef int (*fn_pixels)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const double*, uint64_t, uint64_t, double*, rtgr_counters*);
 typedef int (*fn_one)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const double*, const double*, double*, double*, uint8_t*);
 typedef const char* (*fn_err)(void);
+typedef int (*fn_create)(const int*, int, rtgr_context**);
+typedef int (*fn_destroy)(rtgr_context*);
+typedef int (*fn_ndev)(rtgr_context*);
 
 int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render <lib> [out]\n"); return 2; }
@@ -79,6 +85,14 @@ int main(int argc, char** argv) {
     fn_pixels pixels = (fn_pixels)dlsym(h, "rtgr_trace_pixels_f64");
     fn_one one = (fn_one)dlsym(h, "rtgr_trace_one_f64");
     fn_err err = (fn_err)dlsym(h, "rtgr_last_error");
+    rtgr_context* ctx = NULL;   /* NULL = the process's default context (one device) */
+    const int ndev = argc > 4 ? atoi(argv[4]) : 0;
+    if (ndev > 0) {
+        int ids[RTGR_MAX_DEVICES] = {0};
+        if (ndev > RTGR_MAX_DEVICES) return 2;
+        if (((fn_create)dlsym(h, "rtgr_create"))(ids, ndev, &ctx)) { fprintf(stderr, "rtgr_create: %s\n", err()); return 14; }
+        if (((fn_ndev)dlsym(h, "rtgr_context_devices"))(ctx) != ndev) return 15;
+    }
     /* example2(): src/RayTraceGR.jl:581-593 */
     rtgr_scene sc;
     memset(&sc, 0, sizeof sc);
@@ -95,13 +109,13 @@ int main(int argc, char** argv) {
     double* st = (double*)malloc(n * 8 * sizeof(double));
     pixel_f64* px = (pixel_f64*)calloc(n, sizeof(pixel_f64));
     pixel_f64* out = (pixel_f64*)calloc(n, sizeof(pixel_f64));
-    if (canvas(NULL, &sc, &cam, ni, nj, 0, nj, st)) { fprintf(stderr, "make_canvas: %s\n", err()); return 6; }
+    if (canvas(ctx, &sc, &cam, ni, nj, 0, nj, st)) { fprintf(stderr, "make_canvas: %s\n", err()); return 6; }
     for (uint64_t k = 0; k < n; k++) {   /* Pixel(pos, normal, zeros)  (:475) at pixels[i,j], linear index i + j*ni */
         memcpy(px[k].pos, st + 8 * k, 32);
         memcpy(px[k].normal, st + 8 * k + 4, 32);
     }
     rtgr_counters ctr;
-    if (pixels(NULL, &sc, &opt, (const double*)px, ni, nj, (double*)out, &ctr)) { fprintf(stderr, "trace_pixels: %s\n", err()); return 7; }
+    if (pixels(ctx, &sc, &opt, (const double*)px, ni, nj, (double*)out, &ctr)) { fprintf(stderr, "trace_pixels: %s\n", err()); return 7; }
     if (ctr.rays != n || ctr.events != n) { fprintf(stderr, "counters: %llu rays %llu events\n", (unsigned long long)ctr.rays, (unsigned long long)ctr.events); return 8; }
     FILE* f = fopen(argv[3], "wb");
     if (!f) return 9;
@@ -118,10 +132,11 @@ int main(int argc, char** argv) {
     const uint64_t kc = 99 + 99 * ni;
     double rgb1[3], se[8];
     uint8_t status = 255;
-    if (one(NULL, &sc, &opt, px[kc].pos, px[kc].normal, rgb1, se, &status)) { fprintf(stderr, "trace_one: %s\n", err()); return 11; }
+    if (one(ctx, &sc, &opt, px[kc].pos, px[kc].normal, rgb1, se, &status)) { fprintf(stderr, "trace_one: %s\n", err()); return 11; }
     for (int c = 0; c < 3; c++)
         if (rgb1[c] != out[kc].rgb[c]) { fprintf(stderr, "trace_one differs from trace_pixels\n"); return 12; }
     if (status != RTGR_RAY_EVENT) return 13;
+    if (ctx && ((fn_destroy)dlsym(h, "rtgr_destroy"))(ctx)) return 16;
     printf("ok %llu rays\n", (unsigned long long)ctr.rays);
     return 0;
 }

@@ -125,14 +125,17 @@ def test_c_caller_layout_and_symbols(lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_caller_renders_example2(lib, tmp_path):
+@pytest.mark.parametrize("ndev", [0, 3])
+def test_c_caller_renders_example2(lib, tmp_path, ndev):
     """The same C program, on the GPU: example2() through rtgr_make_canvas_f64 -> an 88-byte Pixel array laid out as
-    src/RayTraceGR.jl:446-450 -> rtgr_trace_pixels_f64 (+ rtgr_trace_one_f64), image bytes == the reference's sphere2.png."""
+    src/RayTraceGR.jl:446-450 -> rtgr_trace_pixels_f64 (+ rtgr_trace_one_f64), image bytes == the reference's sphere2.png.
+    ndev = 3: through an explicit context that lists the GPU three times — the drop-in entry then deals the rows to all
+    three (logical) devices, as it does to the 8 GPUs of a node."""
     import subprocess
     from raytracegr_jl_amd.png import read_png
     exe = _build_c_caller(tmp_path)
     out = str(tmp_path / "img.bin")
-    res = subprocess.run([exe, "--render", abi.LIB_PATH, out], capture_output=True, text=True)
+    res = subprocess.run([exe, "--render", abi.LIB_PATH, out] + ([str(ndev)] if ndev else []), capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     img = np.fromfile(out, np.uint8).reshape(200, 200, 3)
     gold = read_png(os.path.join(ROOT, "tests", "golden", "sphere2.png"))

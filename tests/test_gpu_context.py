@@ -438,3 +438,142 @@ def test_workspace_growth_and_stream_capture(lib):
     torch.cuda.synchronize()
     assert torch.equal(out["rgb"], eager) and bool(torch.isfinite(big).all())
     abi.check(lib, lib.rtgr_trim(None))   # frees retired buffers (graph `g` must not be replayed afterwards)
+
+
+# ---- the reference's OWN call shape over every device of a context (src/RayTraceGR.jl:483-536, :596) -------
+def _golden(name):
+    from raytracegr_jl_amd.png import read_png
+    return read_png(os.path.join(ROOT, "tests", "golden", name))
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_trace_rays_drop_in_entry_uses_every_device_of_the_context(lib, ndev):
+    """`trace_rays(metric, objs, canvas)` binds rtgr_trace_pixels_f64: on a context of N devices the call deals the
+    canvas rows cyclically to ALL of them (each device uploads its own rows from the caller's Pixel array and downloads
+    them straight back into it), and example2()'s image is still the reference's sphere2.png, 40000/40000 — and the
+    Pixel array equals the single-device one bit for bit.  The per-device kernel timers prove that every device
+    integrated something."""
+    import torch
+    metric, objs, cam = rt.example2_scene()
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * ndev)
+    try:
+        canvas = rt.make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], 200, 200, ctx=ctx)
+        single, info1 = rt.trace_rays(metric, objs, canvas, return_info=True)                 # default context: one device
+        for k in range(ndev):
+            abi.check(lib, lib.rtgr_timing_enable(ctx, k, 1))
+        multi, infoN = rt.trace_rays(metric, objs, canvas, return_info=True, ctx=ctx)
+        assert int((multi.image_u8() != _golden("sphere2.png")).any(axis=2).sum()) == 0
+        assert multi.pixels.tobytes() == single.pixels.tobytes()
+        assert infoN == info1 and info1["rays"] == 40000
+        ms, launches = (C.c_double * 4)(), (C.c_uint64 * 4)()
+        for k in range(ndev):
+            abi.check(lib, lib.rtgr_timing_read(ctx, k, C.byref(ms), C.byref(launches)))
+            assert launches[1] >= 1 and ms[1] > 0.0, f"device entry {k} of the context ran no integrate pass"
+            abi.check(lib, lib.rtgr_timing_enable(ctx, k, 0))
+        # in place (pixels_out aliases pixels_in) and Float32, ragged shares (77 rows over ndev devices)
+        sc = rt.make_scene(metric, objs)
+        c32 = rt.make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], 96, 77, dtype=np.float32)
+        one32 = rt.trace_rays(metric, objs, c32)
+        opt32 = rt.solver_defaults(np.float32)
+        px = np.asfortranarray(c32.pixels).copy(order="F")
+        ctr = abi.rtgr_counters()
+        abi.check(lib, lib.rtgr_trace_pixels_f32(ctx, C.byref(sc), C.byref(opt32), px.ctypes.data, 96, 77, px.ctypes.data, C.byref(ctr)))
+        assert px.tobytes() == np.asfortranarray(one32.pixels).tobytes() and ctr.rays == 96 * 77
+        # legacy single-ray shape on a multi-device context: one row, one device
+        p = canvas.pixels[99, 99]
+        assert rt.trace_ray(metric, objs, None, p, ctx=ctx)["rgb"].tobytes() == single.pixels[99, 99]["rgb"].tobytes()
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+@pytest.mark.parametrize("ndev", [2, 4])
+def test_host_entry_with_caller_rays_and_every_output_over_all_devices(lib, ndev):
+    """rtgr_trace_f64 with caller-supplied states (`input_func(i)`, :492-496) and a row slab [j0, j1), every per-ray
+    output requested, on an N-device context == the single-device call, bit for bit; likewise from a camera."""
+    import torch
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_true08")
+    opt = rt.solver_defaults()
+    ni, nj, j0, j1 = 80, 61, 5, 58
+    st = np.zeros((ni * nj, 8))
+    abi.check(lib, lib.rtgr_make_canvas_f64(None, C.byref(sc), C.byref(cam), ni, nj, 0, nj, st.ctypes.data))
+    slab = np.ascontiguousarray(st[j0 * ni:j1 * ni])
+    ref_s = hip_trace(lib, sc, opt, ni, nj, j0, j1, state0=slab)
+    ref_c = hip_trace(lib, sc, opt, ni, nj, j0, j1, cam=cam)
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * ndev)
+    try:
+        n = ni * (j1 - j0)
+        for ref, s0, cm in ((ref_s, slab.ctypes.data, None), (ref_c, None, C.byref(cam))):
+            rgb = np.zeros((3, n))
+            o, arrs = O._outs(n, np.float64, True)
+            ctr = abi.rtgr_counters()
+            abi.check(lib, lib.rtgr_trace_f64(ctx, C.byref(sc), C.byref(opt), s0, cm, ni, nj, j0, j1, rgb.ctypes.data,
+                                              C.byref(o), C.byref(ctr)))
+            assert np.array_equal(rgb, ref["rgb"])
+            for k in OUT_KEYS[1:]:
+                assert np.array_equal(arrs[k], ref[k]), k
+            assert ctr.as_dict() == ref["counters"]
+        # a NaN in ONE device's rows is the whole call's error, with the device named (the reference asserts, :279)
+        bad = slab.copy()
+        bad[3 * ni + 7, 2] = np.nan       # slab row 3 -> device entry 3 % ndev
+        rgb = np.zeros((3, n))
+        rc = lib.rtgr_trace_f64(ctx, C.byref(sc), C.byref(opt), bad.ctypes.data, None, ni, nj, j0, j1, rgb.ctypes.data, None, None)
+        assert rc == abi.ERR_NAN_INPUT and b"entry %d of the context" % (3 % ndev) in lib.rtgr_last_error()
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+def test_gather_without_peer_access_and_peer_option(lib):
+    """rtgr_trace_sharded_device_*: option peer = 0 forces the no-peer-access fallback (rows travel device -> pinned host
+    -> device 0) — also between entries of one physical device, which is how it is exercised on a one-GPU box; peer = 1
+    insists on peer copies.  Same frame, bit for bit, either way."""
+    import torch
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_ref0")
+    opt = rt.solver_defaults()
+    ni, nj = 72, 50
+    n = ni * nj
+    ref = hip_trace(lib, sc, opt, ni, nj, cam=cam)
+    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 3)
+    try:
+        for peer in (0, 1, -1):
+            abi.check(lib, lib.rtgr_set_option(ctx, b"peer", peer))
+            d_rgb = torch.zeros((3, n), dtype=torch.float64, device="cuda")
+            d_se = torch.zeros((n, 8), dtype=torch.float64, device="cuda")
+            d_hit = torch.full((n,), 255, dtype=torch.uint8, device="cuda")
+            od = abi.rtgr_ray_outputs()
+            od.state_end, od.hit = d_se.data_ptr(), d_hit.data_ptr()
+            ctr = abi.rtgr_counters()
+            abi.check(lib, lib.rtgr_trace_sharded_device_f64(ctx, C.byref(sc), C.byref(opt), C.byref(cam), ni, nj,
+                                                             d_rgb.data_ptr(), C.byref(od), C.byref(ctr)))
+            assert np.array_equal(d_rgb.cpu().numpy(), ref["rgb"]), peer
+            assert np.array_equal(d_se.cpu().numpy(), ref["state_end"]) and np.array_equal(d_hit.cpu().numpy(), ref["hit"])
+            assert ctr.as_dict() == ref["counters"]
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+def test_trim_while_host_calls_are_in_flight(lib):
+    """rtgr_trim frees retired workspaces and the staging BUFFERS; a host-pointer call in flight on another thread holds
+    the staging for its whole duration, so trimming must wait for it, not free under it."""
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_ref0")
+    opt = rt.solver_defaults()
+    ref = hip_trace(lib, sc, opt, 160, 120, cam=cam)
+    stop, errors = threading.Event(), []
+
+    def trimmer():
+        while not stop.is_set():
+            if lib.rtgr_trim(None) != 0:
+                errors.append(lib.rtgr_last_error())
+
+    th = threading.Thread(target=trimmer)
+    th.start()
+    try:
+        for _ in range(6):
+            got = hip_trace(lib, sc, opt, 160, 120, cam=cam)
+            assert np.array_equal(got["rgb"], ref["rgb"]) and got["counters"] == ref["counters"]
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
