@@ -43,12 +43,12 @@ __global__ __launch_bounds__(256) void eval_metric_kernel(DevScene<R> sc, const 
 // path 0: the Kerr–Schild-form contraction with IEEE division / sqrt (ks_field + ksform_accel: what the tile kernel runs)
 // path 1: the generic dual-number RHS (what RTGR_METRIC_GENERIC and user metrics run)
 // path 2: EXACTLY the function the production integrate loop calls — accel<R, METRIC, SPIN, FAST = true>
-//         (accel_radial / accel_spin with the 4/6-instruction frcp / frsq, the KS_TRUE null-congruence shortcuts)
+//         (accel_radial / accel_spin_true / accel_spin_ref with the 4/6-instruction frcp / frsq, the KS_TRUE null-congruence shortcuts)
 template <class R, int METRIC, bool SPIN>
 RTGR_DEV void rhs_paths(const R* si, R M, R a, int path, R* so) {
     if (path == 2) {
         so[0] = si[4]; so[1] = si[5]; so[2] = si[6]; so[3] = si[7];
-        accel<R, METRIC, SPIN, true>(si + 1, si + 4, M, a, so + 4);
+        accel<R, METRIC, SPIN, true>(si + 1, si + 4, metric_consts<R>(M, a), so + 4);
     } else {
         rhs<R, METRIC, SPIN>(si, M, a, so);
     }

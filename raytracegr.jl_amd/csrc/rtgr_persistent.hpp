@@ -63,23 +63,17 @@
 namespace rtgr {
 
 // fast f32 helpers for the step-size machinery
-// A wave-uniform value computed with vector instructions (there is no scalar f64 ALU) lives in a VGPR — and, in a kernel
-// squeezed to 127 registers, gets spilled to scratch and reloaded in the loop.  Through readfirstlane it lives in SGPRs.
-RTGR_DEV double uniform_(double v) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned long long u = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                                 (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)b);
-    return __builtin_bit_cast(double, u);
-}
-RTGR_DEV float uniform_(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v)));
-}
+// (uniform_(), rtgr_physics.hpp: a wave-uniform value computed with vector instructions — there is no scalar f64 ALU —
+//  lives in a VGPR and, in a kernel squeezed to 127 registers, gets spilled to scratch and reloaded in the loop; through
+//  readfirstlane it lives in SGPRs.)
 // one-instruction f32 max / min / clamp (fmaxf / fminf spend a second v_max x, x on canonicalising each computed operand)
 RTGR_DEV float fmax1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RTGR_DEV float fmin1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RTGR_DEV float fclamp1(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }  // v_med3_f32
 RTGR_DEV float flog2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 RTGR_DEV float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // lanes below `lane` set in mask
 RTGR_DEV uint32_t mask_rank(unsigned long long mask, uint32_t lane) {
@@ -155,7 +149,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     }
     const uint64_t total = A.n + n_early;
     unsigned long long* const queue = (MODE == MODE_NEAR) ? A.ctrl + 1 : A.ctrl;
-    const R M = A.sc.M, aspin = A.sc.a;
+    const MetricK<R> MK = metric_consts<R>(A.sc.M, A.sc.a);
     const R reltol = A.opt.reltol, abstol = A.opt.abstol;
     const R t0 = A.opt.lambda0, t1 = A.opt.lambda1, dtmax = uniform_(A.opt.lambda1 - A.opt.lambda0);
     const float igamma = 1.0f / 0.9f, qmin_inv = 5.0f, qmax_inv = 0.1f;
@@ -346,7 +340,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(hc, u[1 + q], x[1 + q]);
             }
-            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[1]);
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[1]);
             KSTORE(1);
             // ---- stage 3 -------------------------------------------------------------------------------------
             {
@@ -356,7 +350,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(h2a, k[0][1 + q], rfma(hc, u[1 + q], x[1 + q]));
             }
-            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[2]);
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[2]);
             KSTORE(2);
             // ---- stages 4, 5, 6 ----------------------------------------------------------------------------------
 #pragma unroll
@@ -366,7 +360,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma(h2, rfma(N::A2[3][1], KL(1, 1 + q), N::A2[3][0] * k[0][1 + q]),
                             rfma(h * N::c[3], u[1 + q], x[1 + q]));
-            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[3]);
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[3]);
             KSTORE(3);
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -376,7 +370,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma(h2, rfma(N::A2[4][2], KL(2, 1 + q), rfma(N::A2[4][1], KL(1, 1 + q), N::A2[4][0] * k[0][1 + q])),
                             rfma(h * N::c[4], u[1 + q], x[1 + q]));
-            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[4]);
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[4]);
             KSTORE(4);
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -386,7 +380,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma(h2, rfma(N::A2[5][3], KL(3, 1 + q), rfma(N::A2[5][2], KL(2, 1 + q), rfma(N::A2[5][1], KL(1, 1 + q),
                             N::A2[5][0] * k[0][1 + q]))), rfma(h * N::c[5], u[1 + q], x[1 + q]));
-            accel<R, METRIC, SPIN, true>(X, U, M, aspin, k[5]);
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[5]);
             KSTORE(5);
             // ---- stage 7 = the step result (FSAL) ----------------------------------------------------------------
 #pragma unroll
@@ -396,25 +390,30 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 xn[q] = rfma(h2, rfma(N::A2[6][4], KL(4, q), rfma(N::A2[6][3], KL(3, q), rfma(N::A2[6][2], KL(2, q),
                              rfma(N::A2[6][1], KL(1, q), N::A2[6][0] * k[0][q])))), rfma(h * N::c[6], u[q], x[q]));
             }
-            accel<R, METRIC, SPIN, true>(xn + 1, un, M, aspin, k[6]);
+            accel<R, METRIC, SPIN, true>(xn + 1, un, MK, k[6]);
 
             if (run) {
                 // ---- embedded error, residual norm in f32 ----------------------------------------
-                float acc = 0.0f;
+                // ũ_q = h e_q with e = (Σ b̃_l k_l, h Σ BT2_l k_l + Σb̃ u): the common factor h is applied ONCE, to the f32 sum
+                // of squares (eight f64 products less per step), and the (u, x) pair of a component goes through the
+                // residual arithmetic as one packed f32 operand (v_pk_mul_f32 / v_pk_fma_f32).
+                float2_t acc2 = {0.0f, 0.0f};
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const R eu = h * rfma(N::bt[6], k[6][q], rfma(N::bt[5], KL(5, q), rfma(N::bt[4], KL(4, q),
+                    const R eu = rfma(N::bt[6], k[6][q], rfma(N::bt[5], KL(5, q), rfma(N::bt[4], KL(4, q),
                                      rfma(N::bt[3], KL(3, q), rfma(N::bt[2], KL(2, q), rfma(N::bt[1], KL(1, q), N::bt[0] * k[0][q]))))));
-                    const R ex = h * rfma(h, rfma(N::BT2[5], KL(5, q), rfma(N::BT2[4], KL(4, q), rfma(N::BT2[3], KL(3, q),
+                    const R ex = rfma(h, rfma(N::BT2[5], KL(5, q), rfma(N::BT2[4], KL(4, q), rfma(N::BT2[3], KL(3, q),
                                      rfma(N::BT2[2], KL(2, q), rfma(N::BT2[1], KL(1, q), N::BT2[0] * k[0][q]))))), N::sbt * u[q]);
-                    const float isku = __builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(u[q], un[q]), reltol, abstol));
-                    const float iskx = __builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(x[q], xn[q]), reltol, abstol));
-                    const float ru = (float)eu * isku, rx = (float)ex * iskx;
-                    acc = __builtin_fmaf(ru, ru, __builtin_fmaf(rx, rx, acc));
+                    const float2_t isk = {__builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(u[q], un[q]), reltol, abstol)),
+                                          __builtin_amdgcn_rcpf((float)rfma(rmaxabs<R>(x[q], xn[q]), reltol, abstol))};
+                    const float2_t e = {(float)eu, (float)ex};
+                    const float2_t r2 = e * isk;
+                    acc2 = __builtin_elementwise_fma(r2, r2, acc2);
                 }
                 // EEst² — the square root is never taken: the tests are EEst <= 1 <=> EEst² <= 1, and the controller works with
                 // log2 EEst = ½ log2 EEst² (sqrtf's IEEE expansion was ~15 instructions per step)
-                const float EEst2 = acc * 0.125f;
+                const float hf32 = (float)h;
+                const float EEst2 = (acc2.x + acc2.y) * (0.125f * hf32 * hf32);
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
                 bool is_event = false, is_interior = false, handed = false, hand_back = false;
                 R top = R(0);
@@ -678,6 +677,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             }
         }
         // ---- commit the accepted step: the only place (besides the refill) where the ray state is assigned ------------
+        // (the compiler emits this as 12 v_mov_b64 under the lanes' EXEC mask — not as 24 v_cndmask_b32 selects; checked
+        //  in the ISA, tools/isa_mix.py --list mov)
         if (commit) {
 #pragma unroll
             for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k0[q] = k[6][q]; }
@@ -754,7 +755,7 @@ template <class R, int METRIC, bool SPIN>
 RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = w < A.n;
-    const R M = A.sc.M, aspin = A.sc.a;
+    const MetricK<R> MK = metric_consts<R>(A.sc.M, A.sc.a);
     const R reltol = A.opt.reltol, abstol = A.opt.abstol, dtmax = A.opt.lambda1 - A.opt.lambda0;
     R x[4] = {R(0), R(1), R(0), R(0)}, u[4] = {R(-1), R(0), R(1), R(0)}, k1[4], k2[4];
     if (valid) {
@@ -776,7 +777,7 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     }
     if (A.keys) order_key<R>(x, u, valid, w, A.keys, A.hist);  // block-wide (LDS histogram): before any early exit
     if (!valid) return;
-    accel<R, METRIC, SPIN, true>(x + 1, u, M, aspin, k1);      // f0 = (u, k1)
+    accel<R, METRIC, SPIN, true>(x + 1, u, MK, k1);      // f0 = (u, k1)
     float acc0 = 0.0f, acc1 = 0.0f;
     float iskx[4], isku[4];
 #pragma unroll
@@ -796,7 +797,7 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     for (int q = 0; q < 4; q++) U[q] = rfma(dt0, k1[q], u[q]);
 #pragma unroll
     for (int q = 0; q < 3; q++) X[q] = rfma(dt0, u[1 + q], x[1 + q]);
-    accel<R, METRIC, SPIN, true>(X, U, M, aspin, k2);          // f1 − f0 = (dt0·k1, k2 − k1)
+    accel<R, METRIC, SPIN, true>(X, U, MK, k2);          // f1 − f0 = (dt0·k1, k2 − k1)
     float acc2 = 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {

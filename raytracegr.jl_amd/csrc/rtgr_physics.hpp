@@ -219,10 +219,38 @@ RTGR_DEV void ksform_accel(const KSField<R>& F, const R u[4], R ud[4]) {
     for (int i = 0; i < 3; i++) ud[1 + i] = rfma(F.k[i], SkL, -L[i]);
 }
 
+// Wave-uniform constants of the metric, formed ONCE per kernel (there is no scalar f64 ALU: a product of two kernel
+// arguments is a VALU instruction and a VGPR pair unless it is pinned into SGPRs with readfirstlane, see uniform_()).
+template <class R>
+struct MetricK {
+    R M, a;
+    R M2;    // 2M
+    R a2;    // a²
+    R a2x2;  // 2a
+};
+RTGR_DEV double uniform_(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned long long u = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                                 (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    return __builtin_bit_cast(double, u);
+}
+RTGR_DEV float uniform_(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v)));
+}
+template <class R>
+RTGR_DEV MetricK<R> metric_consts(R M, R a) {
+    MetricK<R> k;
+    k.M = M; k.a = a;
+    k.M2 = uniform_(R(2) * M);
+    k.a2 = uniform_(a * a);
+    k.a2x2 = uniform_(R(2) * a);
+    return k;
+}
+
 // a = 0 (the reference's configuration, :276): k_i = x_i/r, every gradient is radial, and the whole contraction
 // collapses to u̇^i = x_i·g, u̇^t = P − S·kL (derivation in DESIGN.md §RHS).  xs = (x,y,z), u = (u^t,u^x,u^y,u^z).
 template <class R, int METRIC, bool FAST>
-RTGR_DEV void accel_radial(const R xs[3], const R u[4], R M, R ud[4]) {
+RTGR_DEV void accel_radial(const R xs[3], const R u[4], const MetricK<R>& C, R ud[4]) {
     const R rho2 = rfma(xs[0], xs[0], rfma(xs[1], xs[1], xs[2] * xs[2]));
     const R ir = FAST ? frsq<R>(rho2) : R(1) / rsqrt_(rho2);           // 1/ρ
     R invr, rq2;                                                         // 1/r ; ∇r = rq2·x
@@ -234,7 +262,7 @@ RTGR_DEV void accel_radial(const R xs[3], const R u[4], R M, R ud[4]) {
         invr = ir;                                                       // r = ρ
         rq2 = ir;
     }
-    const R f = R(2) * M * invr;                                         // f = 2M r³/r⁴  (:285)
+    const R f = C.M2 * invr;                                             // f = 2M r³/r⁴  (:285)
     const R xu = rfma(xs[0], u[1], rfma(xs[1], u[2], xs[2] * u[3]));
     const R uu = rfma(u[1], u[1], rfma(u[2], u[2], u[3] * u[3]));
     const R D = rq2 * xu;                                                // u·∇r
@@ -259,54 +287,37 @@ RTGR_DEV void accel_radial(const R xs[3], const R u[4], R M, R ud[4]) {
     ud[1] = xs[0] * g; ud[2] = xs[1] * g; ud[3] = xs[2] * g;
 }
 
-// a != 0: fused field + contraction.  ∂_j k_i = kr_i ∂_j r + E_ij with the sparse explicit part
-// E = [[r w, a w, 0], [−a w, r w, 0], [0, 0, 1/r]] (w = 1/(r²+a²)), and ∇f = f_r ∇r + f_z ẑ, so the two contractions
-// Dk_i = u^j ∂_j k_i and W_d = u^i ∂_d k_i come from D = u·∇r, kr·u, E u and Eᵀu without forming the 3x3 Jacobian.
-template <class R, int METRIC, bool FAST>
-RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
+// a != 0, the reference's as-written radius (:284): fused field + contraction.  ∂_j k_i = kr_i ∂_j r + E_ij with the sparse
+// explicit part E = [[r w, a w, 0], [−a w, r w, 0], [0, 0, 1/r]] (w = 1/(r²+a²)), and ∇f = f_r ∇r + f_z ẑ, so the two
+// contractions Dk_i = u^j ∂_j k_i and W_d = u^i ∂_d k_i come from D = u·∇r, kr·u, E u and Eᵀu without forming the 3x3
+// Jacobian.  (Not a benchmark configuration: kept in the general form.)
+template <class R, bool FAST>
+RTGR_DEV void accel_spin_ref(const R xs[3], const R u[4], const MetricK<R>& C, R ud[4]) {
     const R x = xs[0], y = xs[1], z = xs[2];
-    const R a2 = a * a;
+    const R a = C.a, a2 = C.a2;
     const R rho2 = rfma(x, x, rfma(y, y, z * z));
     const R q = rho2 - a2;
-    // With the TEXTBOOK radius r is a root of r⁴ − q r² − a²z² = 0 and k is the principal null congruence, which buys
-    // (checked to 40 digits): r⁴ + a²z² = r²·sqrt(q²+4a²z²);  |k|² = 1;  k^j ∂_j k_i = 0;  k^i ∂_d k_i = 0;  k·∇r = 1.
-    // Hence 1/den needs no reciprocal of its own, S = f/(1 + f(|k|²−1)) = f, and k♯^d L_d = −½K²(f_r + f_z k_z).
-    // The as-written radius (:284) is not that root for a ≠ 0, so KS_REF keeps the general expressions.
-    R r, ir, rq2, rz;  // r, 1/r, ∇r = rq2 (x,y,z) + rz ẑ
-    R iden, rid;       // 1/(r⁴ + a² z²), r³/(r⁴ + a² z²)
     const R a2z = a2 * z;
-    if constexpr (METRIC == RTGR_KS_REF) {
-        R s1, is1, s2, is2;                                   // r = sqrt(q)/2 + sqrt(a² z² + (q/2)²)            :284
-        sqrt_inv<FAST>(q, s1, is1);
-        const R hq = R(0.5) * q;
-        sqrt_inv<FAST>(rfma(a2 * z, z, hq * hq), s2, is2);
-        r = rfma(R(0.5), s1, s2);
-        ir = rcp_<FAST>(r);
-        rq2 = R(0.5) * rfma(q, is2, is1);
-        rz = a2 * z * is2;
-        const R r2 = r * r;
-        iden = rcp_<FAST>(rfma(r2, r2, a2z * z));
-        rid = r2 * r * iden;
-    } else {
-        R sq, is;                                             // r² = (q + sqrt(q² + 4a²z²))/2
-        sqrt_inv<FAST>(rfma(q, q, R(4) * a2 * z * z), sq, is);
-        sqrt_inv<FAST>(R(0.5) * (q + sq), r, ir);
-        const R hir = R(0.5) * ir;
-        rq2 = rfma(q * is, hir, hir);
-        rz = a2 * z * is * ir;
-        iden = ir * ir * is;                                  // den = r² sqrt(q²+4a²z²)
-        rid = r * is;
-    }
-    const R dr0 = rq2 * x, dr1 = rq2 * y, dr2 = rfma(rq2, z, rz);
+    R s1, is1, s2, is2;                                   // r = sqrt(q)/2 + sqrt(a² z² + (q/2)²)            :284
+    sqrt_inv<FAST>(q, s1, is1);
+    const R hq = R(0.5) * q;
+    sqrt_inv<FAST>(rfma(a2z, z, hq * hq), s2, is2);
+    const R r = rfma(R(0.5), s1, s2);
+    const R ir = rcp_<FAST>(r);
+    const R rq2 = R(0.5) * rfma(q, is2, is1);             // ∇r = rq2 (x,y,z) + rz ẑ
+    const R rz = a2z * is2;
     const R r2 = r * r;
-    const R f = (R(2) * M) * rid;                               // f = 2M r³/(r⁴+a²z²)                             :285
+    const R iden = rcp_<FAST>(rfma(r2, r2, a2z * z));     // 1/(r⁴ + a² z²)
+    const R rid = r2 * r * iden;
+    const R dr0 = rq2 * x, dr1 = rq2 * y, dr2 = rfma(rq2, z, rz);
+    const R f = C.M2 * rid;                                     // f = 2M r³/(r⁴+a²z²)                             :285
     const R f_r = f * rfma(R(-4), rid, R(3) * ir);              // ∂f/∂r = f (3/r − 4r³/den)
     const R f_z = R(-2) * f * a2z * iden;                       // ∂f/∂z at fixed r
     const R w = rcp_<FAST>(r2 + a2);
     const R k0 = rfma(r, x, a * y) * w, k1 = rfma(r, y, -a * x) * w, k2 = z * ir;            // :286-289
     const R m2r = R(-2) * r;
     const R kr0 = w * rfma(m2r, k0, x), kr1 = w * rfma(m2r, k1, y), kr2 = -k2 * ir;          // ∂k_i/∂r
-    const R rw = r * w, aw2 = (R(2) * a) * w;
+    const R rw = r * w, aw2 = C.a2x2 * w;
     const R ut = u[0], ux = u[1], uy = u[2], uz = u[3];
     const R D = rfma(dr0, ux, rfma(dr1, uy, dr2 * uz));        // u·∇r
     const R Df = rfma(f_r, D, f_z * uz);                        // u·∇f
@@ -321,23 +332,79 @@ RTGR_DEV void accel_spin(const R xs[3], const R u[4], R M, R a, R ud[4]) {
     const R V1 = rfma(kr1, D, rfma(-kru, dr1, -aw2 * ux));
     const R V2 = rfma(kr2, D, -kru * dr2);
     const R P = rfma(K, Df, f * A);                             // L_t
-    const R fK = f * K, g2 = R(-0.5) * K * K * f_r, g3 = R(-0.5) * K * K * f_z;
+    const R hK2 = R(-0.5) * K * K;
+    const R fK = f * K, g2 = hK2 * f_r, g3 = hK2 * f_z;
     const R L0 = rfma(k0, P, rfma(fK, V0, g2 * dr0));
     const R L1 = rfma(k1, P, rfma(fK, V1, g2 * dr1));
     const R L2 = rfma(k2, P, rfma(fK, V2, rfma(g2, dr2, g3)));
-    R SkL;
-    if constexpr (METRIC == RTGR_KS_REF) {
-        const R kk = rfma(k0, k0, rfma(k1, k1, k2 * k2));
-        const R S = f * rcp_<FAST>(rfma(f, kk - R(1), R(1)));
-        const R kL = rfma(k0, L0, rfma(k1, L1, rfma(k2, L2, -P)));
-        SkL = S * kL;
-    } else {
-        SkL = f * rfma(g3, k2, g2);                             // S = f,  k♯^d L_d = −½K²(f_r + f_z k_z)
-    }
+    const R kk = rfma(k0, k0, rfma(k1, k1, k2 * k2));
+    const R S = f * rcp_<FAST>(rfma(f, kk - R(1), R(1)));
+    const R kL = rfma(k0, L0, rfma(k1, L1, rfma(k2, L2, -P)));
+    const R SkL = S * kL;
     ud[0] = P - SkL;
     ud[1] = rfma(k0, SkL, -L0);
     ud[2] = rfma(k1, SkL, -L1);
     ud[3] = rfma(k2, SkL, -L2);
+}
+
+// a != 0, TEXTBOOK radius — the configuration BASELINE.json words (a = 0.8, a = 0.998): 44 MUL + 42 FMA + 3 ADD + 3
+// transcendental seeds per evaluation (round 2's form of the same contraction: 58 + 46 + 5 + 3).
+//
+// r is a root of r⁴ − q r² − a²z² = 0 (q = ρ² − a²) and k is the principal null congruence, which buys (checked to 40
+// digits, tools/check_identities.py): with Σ = sqrt(q² + 4a²z²) = 2r² − q,
+//     r⁴ + a²z² = r² Σ;   |k|² = 1;   k^j ∂_j k_i = 0;   k^i ∂_d k_i = 0;   k·∇r = 1;
+//     ∇r = (r/Σ)(x,y,z) + (a²z/(rΣ)) ẑ        — the SAME r/Σ that makes f = 2M r/Σ (one product, no reciprocal of its own);
+//     ∂f/∂r = f ψ, ψ = 3/r − 4r/Σ;   ∂f/∂z|_r = f φ, φ = −2a²z/(r²Σ);   S = f/(1 + f(|k|²−1)) = f.
+// With the general contraction written out (accel_spin_ref: A, V_i = Dk_i − W_i, L_i, P) and regrouped by WHAT MULTIPLIES
+// x_i, k_i and the rotation (uy, −ux, 0) — neither ∂_i r, nor ∂k_i/∂r, nor V_i, nor L_i is ever formed —
+//     u̇^t = f [ K (ψ D + φ u^z) + A ] + ½K² f² (ψ + φ k_z)
+//     u̇^i = −k_i u̇^t − fK V_i + ½K² ∂_i f
+//         = k_i (2 r w E − u̇^t) + x_i (c_r r/Σ − E w) − 2 a w fK (uy, −ux)_i                         (i = x, y)
+//     u̇^z = z [ (E/r − u̇^t)/r + c_r r/Σ ] + c_r a²z/(rΣ) + ½K² f φ
+// where D = u·∇r, K = k_a u^a, E = fK D, c_r = fK (∂k/∂r · u) + ½K² f ψ, A = u^b u^c ∂_b k_c.
+template <class R, bool FAST>
+RTGR_DEV void accel_spin_true(const R xs[3], const R u[4], const MetricK<R>& C, R ud[4]) {
+    const R x = xs[0], y = xs[1], z = xs[2];
+    const R ut = u[0], ux = u[1], uy = u[2], uz = u[3];
+    const R q = rfma(x, x, rfma(y, y, rfma(z, z, -C.a2)));         // ρ² − a²
+    const R a2z = C.a2 * z;
+    const R sig2 = rfma(R(4), a2z * z, q * q);                      // Σ² = q² + 4a²z²
+    R sig, is;                                                      // Σ, 1/Σ
+    sqrt_inv<FAST>(sig2, sig, is);
+    const R r2 = R(0.5) * (q + sig);                                // r² = (q + Σ)/2
+    R r, ir;
+    sqrt_inv<FAST>(r2, r, ir);
+    const R rid = r * is;                                           // r/Σ: ∇r's isotropic part AND r³/(r⁴+a²z²)
+    const R rz = a2z * (is * ir);                                   // a²z/(rΣ): ∇r's extra z part
+    const R phi = -(rz * ir) * R(2);                                // (∂f/∂z)/f
+    const R psi = rfma(R(-4), rid, R(3) * ir);                      // (∂f/∂r)/f
+    const R w = rcp_<FAST>(r2 + C.a2);
+    const R rw = r * w, aw = C.a * w;
+    const R k0 = rfma(rw, x, aw * y), k1 = rfma(rw, y, -(aw * x)), k2 = z * ir;                 // :286-289
+    const R xu2 = rfma(x, ux, y * uy), xu = rfma(z, uz, xu2);
+    const R Ku2 = rfma(k0, ux, k1 * uy);
+    const R K = ut + rfma(k2, uz, Ku2);                             // k_a u^a
+    const R D = rfma(rid, xu, rz * uz);                             // u·∇r
+    const R rw2m = R(-2) * rw;
+    const R iruz = ir * uz;
+    // ∂k/∂r · u with ∂k_i/∂r = w (x_i − 2 r k_i) (i = x, y), −k_z/r (z)
+    const R kru = rfma(w, xu2, rfma(rw2m, Ku2, -(k2 * iruz)));
+    // A = u^b u^c ∂_b k_c = kru D + uᵀE u,  uᵀE u = r w (ux² + uy²) + uz²/r  (the ±a w parts of E cancel)
+    const R A = rfma(kru, D, rfma(rw, rfma(ux, ux, uy * uy), iruz * uz));
+    const R inner = rfma(psi, D, phi * uz);                         // (u·∇f)/f
+    const R f = C.M2 * rid;                                         // f = 2M r³/(r⁴+a²z²) = 2M r/Σ                  :285
+    const R Kf = f * K, hf = (R(0.5) * K) * Kf;                     // fK, ½K² f
+    const R udt = rfma(hf * f, rfma(phi, k2, psi), rfma(Kf, inner, f * A));
+    const R E = Kf * D;
+    const R cr = rfma(Kf, kru, hf * psi);
+    const R nck = rfma(rw2m, E, udt);                               // −(2 r w E − u̇^t)
+    const R crr = cr * rid;
+    const R cx = rfma(-E, w, crr);
+    const R rot = (C.a2x2 * w) * Kf;                                // 2 a w fK
+    ud[0] = udt;
+    ud[1] = rfma(-k0, nck, rfma(x, cx, -(rot * uy)));
+    ud[2] = rfma(-k1, nck, rfma(y, cx, rot * ux));
+    ud[3] = rfma(z, rfma(ir, rfma(E, ir, -udt), crr), rfma(cr, rz, hf * phi));
 }
 
 // acceleration only (the ẋ = u half is handled by the caller):  u̇ = accel(x_spatial, u)
@@ -345,15 +412,17 @@ template <class R> RTGR_DEV void accel_generic(uint32_t metric, const R xs[3], c
 constexpr int RTGR_GENERIC_BASE = 100;  // METRIC template value 100 + kind selects the generic dual-number RHS
 
 template <class R, int METRIC, bool SPIN, bool FAST>
-RTGR_DEV void accel(const R xs[3], const R u[4], R M, R a, R ud[4]) {
+RTGR_DEV void accel(const R xs[3], const R u[4], const MetricK<R>& C, R ud[4]) {
     if constexpr (METRIC >= RTGR_GENERIC_BASE) {
-        accel_generic<R>((uint32_t)(METRIC - RTGR_GENERIC_BASE), xs, u, M, a, ud);
+        accel_generic<R>((uint32_t)(METRIC - RTGR_GENERIC_BASE), xs, u, C.M, C.a, ud);
     } else if constexpr (METRIC == RTGR_MINKOWSKI) {
         ud[0] = ud[1] = ud[2] = ud[3] = R(0);
     } else if constexpr (!SPIN) {
-        accel_radial<R, METRIC, FAST>(xs, u, M, ud);
+        accel_radial<R, METRIC, FAST>(xs, u, C, ud);
+    } else if constexpr (METRIC == RTGR_KS_REF) {
+        accel_spin_ref<R, FAST>(xs, u, C, ud);
     } else {
-        accel_spin<R, METRIC, FAST>(xs, u, M, a, ud);
+        accel_spin_true<R, FAST>(xs, u, C, ud);
     }
 }
 
