@@ -40,6 +40,24 @@ template <class S> __device__ void rtgr_user_metric(const S x[4], double M, doub
 }
 '''
 
+# A TIME-DEPENDENT metric: isotropic Schwarzschild whose spatial part expands, g_ij = e^{2Ht} psi^4 delta_ij, H = the metric's
+# `a` parameter.  Not a solution of anything — a checker (oracle/rtgr_oracle.cpp expanding_isotropic): a metric that depends on
+# t must be traced with d_t g != 0 evaluated at the ray's own t, as the reference does (src/RayTraceGR.jl:302-313, :358-363);
+# UserMetric(..., stationary=False) (the default) carries the stage time through the integrate kernels for it.
+EXPANDING_ISOTROPIC = r'''
+template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) {
+    const S rho = msqrt(x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    const S m = (0.5 * M) / rho;
+    const S lapse = (1.0 - m) / (1.0 + m);
+    const S psi2 = (1.0 + m) * (1.0 + m);
+    const S s = mexp(a * x[0]);
+    for (int p = 0; p < 4; p++)
+        for (int c = 0; c < 4; c++) g[p][c] = mconst<S>(0.0);
+    g[0][0] = -(lapse * lapse);
+    g[1][1] = g[2][2] = g[3][3] = (s * s) * (psi2 * psi2);
+}
+'''
+
 # A smooth, static, non-diagonal perturbation of flat space written with EVERY elementary function the reference's Dual
 # carries (src/RayTraceGR.jl:132-196) — not physics, a checker: the oracle has the same function (oracle/rtgr_oracle.cpp
 # helper_zoo) and tests compare g, dg, Christoffels and the RHS point by point.

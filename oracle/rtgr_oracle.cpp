@@ -256,11 +256,31 @@ inline void helper_zoo(const S xx[D], T M, S g[D][D]) {
     g[0][3] = g[3][0] = T(0.02) * m * cth / rho;
 }
 
+// A third stand-in, TIME DEPENDENT: isotropic Schwarzschild whose spatial part expands, g_ij = e^{2Ht} ψ⁴ δ_ij with H = the
+// scene's `a` — the checker of examples/user_metrics.py:EXPANDING_ISOTROPIC.  The reference differentiates the metric
+// in all four coordinates and evaluates it at the ray's full 4-position (src/RayTraceGR.jl:302-313, :358-363), so a metric
+// that depends on t must be traced with ∂_t g ≠ 0 at the ray's own t.  Selected by rtgr_scene.user_metric == RTGR_ORACLE_EXPANDING.
+constexpr uint64_t RTGR_ORACLE_EXPANDING = 0x201;
+template <class T, class S>
+inline void expanding_isotropic(const S xx[D], T M, T H, S g[D][D]) {
+    S rho = sqrt(pow2(xx[1]) + pow2(xx[2]) + pow2(xx[3]));
+    S m = cst<T, S>(T(0.5) * M) / rho;
+    S one = cst<T, S>(T(1));
+    S lapse = (one - m) / (one + m);
+    S psi2 = pow2(one + m);
+    S s = exp(H * xx[0]);
+    for (int p = 0; p < D; p++)
+        for (int q = 0; q < D; q++) g[p][q] = cst<T, S>(T(0));
+    g[0][0] = cst<T, S>(T(0)) - pow2(lapse);
+    g[1][1] = g[2][2] = g[3][3] = pow2(s) * pow2(psi2);
+}
+
 template <class T, class S>
 inline void metric_eval(const rtgr_scene& sc, const S x[D], S g[D][D]) {
     const uint32_t kind = sc.metric & ~RTGR_METRIC_GENERIC;  // the flag picks a product code path, not a metric
     if (kind == RTGR_MINKOWSKI) minkowski<T, S>(x, g);
     else if (kind == RTGR_USER && sc.user_metric == RTGR_ORACLE_ZOO) helper_zoo<T, S>(x, T(sc.M), g);
+    else if (kind == RTGR_USER && sc.user_metric == RTGR_ORACLE_EXPANDING) expanding_isotropic<T, S>(x, T(sc.M), T(sc.a), g);
     else if (kind == RTGR_USER) schwarzschild_isotropic<T, S>(x, T(sc.M), g);
     else kerr_schild<T, S>(x, T(sc.M), T(sc.a), (int)kind, g);
 }

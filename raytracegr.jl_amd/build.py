@@ -68,12 +68,27 @@ def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ):
                     if os.path.exists(obj):
                         os.unlink(obj)
                     raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
-    if jobs or force or _stale(out, objs):
+    # Which flag set the existing library was linked from is recorded next to it: after an experiment build
+    # (`build.py -DRTGR_ROOT_STATS`, --save-temps, …) a plain build finds its own objects fresh and OLDER than the library,
+    # and must still relink — or tests and bench would silently run the experiment binary.
+    tag_file = out + ".tag"
+    linked_tag = open(tag_file).read().strip() if os.path.exists(tag_file) else None
+    if jobs or force or _stale(out, objs) or linked_tag != tag:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs + ["-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=HERE)
+        with open(tag_file, "w") as fh:
+            fh.write(tag + "\n")
     return out
+
+
+def linked_tag(out=OUT):
+    """'std' for the production flag set, a hash for an experiment build, None when unknown."""
+    try:
+        return open(out + ".tag").read().strip()
+    except OSError:
+        return None
 
 
 if __name__ == "__main__":
@@ -82,4 +97,5 @@ if __name__ == "__main__":
         extra.append("-Rpass-analysis=kernel-resource-usage")
     if "--save-temps" in sys.argv:
         extra += ["-save-temps=obj"]
-    build(force=("--force" in sys.argv), extra=extra)
+    # (--resource-usage / --save-temps only print or write something when the units are actually compiled)
+    build(force=("--force" in sys.argv or "--resource-usage" in sys.argv or "--save-temps" in sys.argv), extra=extra)

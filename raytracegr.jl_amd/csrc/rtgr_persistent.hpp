@@ -123,8 +123,7 @@ template <class R>
 RTGR_DEV void flush_early(const IntegrateArgs<R>& A, const uint32_t* buf, uint32_t cnt, uint32_t lane) {
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(A.ctrl + 6, (unsigned long long)cnt);
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-           (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
+    base = uniform64(base);
     for (uint32_t i = lane; i < cnt; i += 64) A.early[base + i] = buf[i];
 }
 
@@ -145,7 +144,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     uint64_t n_early = 0;
     if (MODE == MODE_NEAR && A.early) {  // (wave-uniform for the compiler too: it sets the loop's exit)
         const unsigned long long c = A.ctrl[6];
-        n_early = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)c);
+        n_early = uniform64(c);
     }
     const uint64_t total = A.n + n_early;
     unsigned long long* const queue = (MODE == MODE_NEAR) ? A.ctrl + 1 : A.ctrl;
@@ -235,8 +234,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                     if (first_early) eb = echunk * blockIdx.x;
                     else if (lane == 0) eb = atomicAdd(A.ctrl + 7, echunk) + echunk * gridDim.x;
                     first_early = false;
-                    eb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(eb >> 32)) << 32) |
-                         (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)eb);
+                    eb = uniform64(eb);
                     if (eb >= n_early) { early_done = true; continue; }
                     q_next = eb;
                     q_end = (eb + echunk) < n_early ? (eb + echunk) : n_early;
@@ -251,8 +249,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 // exhausted then live in SGPRs and the loop's exits are scalar branches.  (With a __shfl the compiler
                 // had to treat the loop exit as divergent and copied all 12 loop-carried f64 state registers to
                 // shadow registers and back at the latch: 41 v_mov per iteration, 4.7 % of the kernel's instructions.)
-                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-                       (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
+                base = uniform64(base);
                 base += n_early;  // positions [0, n_early) are the early list's
                 q_next = base < total ? base : total;
                 q_end = (base + amount) < total ? (base + amount) : total;
@@ -332,6 +329,10 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             const R h = run ? dt : R(0);
             const R h2 = h * h;
             R X[3], U[4];
+            // x^t at the stage: formed only for a user metric that was not declared stationary (such a metric was
+            // traced frozen at t = 0 — the reference evaluates christoffel(metric, x) at the full 4-position, :358-363)
+            constexpr bool TDEP = needs_stage_time<METRIC>();
+            R Xt = R(0);
             // ---- stage 2 -------------------------------------------------------------------------------------
             {
                 const R ha = h * N::a[1][0], hc = h * N::c[1];
@@ -339,8 +340,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 for (int q = 0; q < 4; q++) U[q] = rfma(ha, k[0][q], u[q]);
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(hc, u[1 + q], x[1 + q]);
+                if constexpr (TDEP) Xt = rfma(hc, u[0], x[0]);
             }
-            accel<R, METRIC, SPIN, true>(X, U, MK, k[1]);
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[1], Xt);
             KSTORE(1);
             // ---- stage 3 -------------------------------------------------------------------------------------
             {
@@ -349,8 +351,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 for (int q = 0; q < 4; q++) U[q] = rfma(w1, KL(1, q), rfma(w0, k[0][q], u[q]));
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma(h2a, k[0][1 + q], rfma(hc, u[1 + q], x[1 + q]));
+                if constexpr (TDEP) Xt = rfma(h2a, k[0][0], rfma(hc, u[0], x[0]));
             }
-            accel<R, METRIC, SPIN, true>(X, U, MK, k[2]);
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[2], Xt);
             KSTORE(2);
             // ---- stages 4, 5, 6 ----------------------------------------------------------------------------------
 #pragma unroll
@@ -360,7 +363,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma(h2, rfma(N::A2[3][1], KL(1, 1 + q), N::A2[3][0] * k[0][1 + q]),
                             rfma(h * N::c[3], u[1 + q], x[1 + q]));
-            accel<R, METRIC, SPIN, true>(X, U, MK, k[3]);
+            if constexpr (TDEP) Xt = rfma(h2, rfma(N::A2[3][1], KL(1, 0), N::A2[3][0] * k[0][0]), rfma(h * N::c[3], u[0], x[0]));
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[3], Xt);
             KSTORE(3);
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -370,7 +374,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma(h2, rfma(N::A2[4][2], KL(2, 1 + q), rfma(N::A2[4][1], KL(1, 1 + q), N::A2[4][0] * k[0][1 + q])),
                             rfma(h * N::c[4], u[1 + q], x[1 + q]));
-            accel<R, METRIC, SPIN, true>(X, U, MK, k[4]);
+            if constexpr (TDEP) Xt = rfma(h2, rfma(N::A2[4][2], KL(2, 0), rfma(N::A2[4][1], KL(1, 0), N::A2[4][0] * k[0][0])),
+                                          rfma(h * N::c[4], u[0], x[0]));
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[4], Xt);
             KSTORE(4);
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -380,7 +386,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma(h2, rfma(N::A2[5][3], KL(3, 1 + q), rfma(N::A2[5][2], KL(2, 1 + q), rfma(N::A2[5][1], KL(1, 1 + q),
                             N::A2[5][0] * k[0][1 + q]))), rfma(h * N::c[5], u[1 + q], x[1 + q]));
-            accel<R, METRIC, SPIN, true>(X, U, MK, k[5]);
+            if constexpr (TDEP) Xt = rfma(h2, rfma(N::A2[5][3], KL(3, 0), rfma(N::A2[5][2], KL(2, 0), rfma(N::A2[5][1], KL(1, 0),
+                                          N::A2[5][0] * k[0][0]))), rfma(h * N::c[5], u[0], x[0]));
+            accel<R, METRIC, SPIN, true>(X, U, MK, k[5], Xt);
             KSTORE(5);
             // ---- stage 7 = the step result (FSAL) ----------------------------------------------------------------
 #pragma unroll
@@ -390,7 +398,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 xn[q] = rfma(h2, rfma(N::A2[6][4], KL(4, q), rfma(N::A2[6][3], KL(3, q), rfma(N::A2[6][2], KL(2, q),
                              rfma(N::A2[6][1], KL(1, q), N::A2[6][0] * k[0][q])))), rfma(h * N::c[6], u[q], x[q]));
             }
-            accel<R, METRIC, SPIN, true>(xn + 1, un, MK, k[6]);
+            accel<R, METRIC, SPIN, true>(xn + 1, un, MK, k[6], xn[0]);
 
             if (run) {
                 // ---- embedded error, residual norm in f32 ----------------------------------------
@@ -777,7 +785,7 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     }
     if (A.keys) order_key<R>(x, u, valid, w, A.keys, A.hist);  // block-wide (LDS histogram): before any early exit
     if (!valid) return;
-    accel<R, METRIC, SPIN, true>(x + 1, u, MK, k1);      // f0 = (u, k1)
+    accel<R, METRIC, SPIN, true>(x + 1, u, MK, k1, x[0]);      // f0 = (u, k1)
     float acc0 = 0.0f, acc1 = 0.0f;
     float iskx[4], isku[4];
 #pragma unroll
@@ -797,7 +805,7 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     for (int q = 0; q < 4; q++) U[q] = rfma(dt0, k1[q], u[q]);
 #pragma unroll
     for (int q = 0; q < 3; q++) X[q] = rfma(dt0, u[1 + q], x[1 + q]);
-    accel<R, METRIC, SPIN, true>(X, U, MK, k2);          // f1 − f0 = (dt0·k1, k2 − k1)
+    accel<R, METRIC, SPIN, true>(X, U, MK, k2, rfma(dt0, u[0], x[0]));          // f1 − f0 = (dt0·k1, k2 − k1)
     float acc2 = 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {

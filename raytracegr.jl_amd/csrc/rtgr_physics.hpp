@@ -228,11 +228,15 @@ struct MetricK {
     R a2;    // a²
     R a2x2;  // 2a
 };
+// A 64-bit value every lane holds, made wave-uniform FOR THE COMPILER (SGPR pair).  __builtin_amdgcn_readfirstlane
+// returns a signed int: each half goes through uint32_t, or a low word with bit 31 set sign-extends over the high word
+// (round 2's spelling did exactly that — harmless for its operands, 100.0 and queue positions below 2^31, fatal for a² = 0.64).
+RTGR_DEV unsigned long long uniform64(unsigned long long b) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+           (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+}
 RTGR_DEV double uniform_(double v) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned long long u = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                                 (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)b);
-    return __builtin_bit_cast(double, u);
+    return __builtin_bit_cast(double, uniform64(__builtin_bit_cast(unsigned long long, v)));
 }
 RTGR_DEV float uniform_(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v)));
@@ -408,13 +412,28 @@ RTGR_DEV void accel_spin_true(const R xs[3], const R u[4], const MetricK<R>& C, 
 }
 
 // acceleration only (the ẋ = u half is handled by the caller):  u̇ = accel(x_spatial, u)
-template <class R> RTGR_DEV void accel_generic(uint32_t metric, const R xs[3], const R u[4], R M, R a, R ud[4]);
+template <class R> RTGR_DEV void accel_generic(uint32_t metric, R xt, const R xs[3], const R u[4], R M, R a, R ud[4]);
 constexpr int RTGR_GENERIC_BASE = 100;  // METRIC template value 100 + kind selects the generic dual-number RHS
+#ifndef RTGR_USER_NE
+#define RTGR_USER_NE 4   // a user unit built with -DRTGR_USER_NE=3 declares its metric stationary (api.UserMetric(stationary=True))
+#endif
 
+// Does the integrate loop have to carry the stage's TIME coordinate for this metric?  The reference evaluates
+// christoffel(metric, x) at the full 4-position (src/RayTraceGR.jl:358-363); every built-in metric is stationary, so only
+// a user metric that was NOT declared stationary needs x^t at the stages (the other instantiations never form it).
+template <int METRIC> constexpr bool needs_stage_time() {
+#ifdef RTGR_USER_METRIC
+    return METRIC == RTGR_GENERIC_BASE + RTGR_USER && RTGR_USER_NE == 4;
+#else
+    return false;
+#endif
+}
+
+// xt: the time coordinate of the evaluation point (read only when needs_stage_time<METRIC>())
 template <class R, int METRIC, bool SPIN, bool FAST>
-RTGR_DEV void accel(const R xs[3], const R u[4], const MetricK<R>& C, R ud[4]) {
+RTGR_DEV void accel(const R xs[3], const R u[4], const MetricK<R>& C, R ud[4], R xt = R(0)) {
     if constexpr (METRIC >= RTGR_GENERIC_BASE) {
-        accel_generic<R>((uint32_t)(METRIC - RTGR_GENERIC_BASE), xs, u, C.M, C.a, ud);
+        accel_generic<R>((uint32_t)(METRIC - RTGR_GENERIC_BASE), xt, xs, u, C.M, C.a, ud);
     } else if constexpr (METRIC == RTGR_MINKOWSKI) {
         ud[0] = ud[1] = ud[2] = ud[3] = R(0);
     } else if constexpr (!SPIN) {
@@ -720,12 +739,9 @@ RTGR_DEV void generic_rhs(uint32_t metric, R M, R a, const R s[8], R ds[8]) {
 
 // acceleration through the GENERIC dual-number path (what the reference does for any metric callable): used by the
 // integrate kernels when the scene asks for it (RTGR_METRIC_GENERIC flag) and for every user metric.
-#ifndef RTGR_USER_NE
-#define RTGR_USER_NE 4   // a user unit built with -DRTGR_USER_NE=3 declares its metric stationary (api.UserMetric(stationary=True))
-#endif
 template <class R>
-RTGR_DEV void accel_generic(uint32_t metric, const R xs[3], const R u[4], R M, R a, R ud[4]) {
-    const R x[4] = {R(0), xs[0], xs[1], xs[2]};
+RTGR_DEV void accel_generic(uint32_t metric, R xt, const R xs[3], const R u[4], R M, R a, R ud[4]) {
+    const R x[4] = {xt, xs[0], xs[1], xs[2]};   // (xt = 0 for every stationary metric: it is never read)
 #ifdef RTGR_USER_METRIC
     if (metric == (uint32_t)RTGR_USER) { generic_accel<R, RTGR_USER_NE, true>(metric, M, a, x, u, ud); return; }
 #endif

@@ -170,6 +170,46 @@ def test_user_helper_functions_match_oracle_twins(lib):
 
 
 @pytest.mark.gpu
+def test_time_dependent_user_metric_is_traced_at_the_rays_own_time(lib):
+    """A metric that depends on t (examples/user_metrics.py:EXPANDING_ISOTROPIC, H = 0.03; the rays run from t = 0 back to
+    t = −20, over which the spatial scale changes by e^0.6).  The reference evaluates christoffel(metric, x) at the ray's
+    full 4-position (src/RayTraceGR.jl:358-363); round 2's integrate kernels carried only the spatial stage positions and
+    traced such a metric frozen at t = 0.  Against the oracle's twin: ∂_t g pointwise, the RHS, the traced frame
+    to the bars of the stationary metrics — and the same metric WRONGLY declared stationary must NOT pass, which is what
+    makes this test sensitive to the defect."""
+    H = 0.03
+    user = rt.UserMetric(user_metrics.EXPANDING_ISOTROPIC, M=1.0, a=H)                 # stationary=False: four partials
+    sc_o = rt.make_scene(user, [])
+    sc_o.user_metric = 0x201          # the oracle's marker for its copy of this function
+    x, rng = _points(1024, 31, rmin=0.9)
+    g, dg = rt.dmetric(user, x)
+    go, dgo, Go = O.eval_metric(sc_o, x)
+    assert np.abs(g - go).max() <= 1e-13 * np.abs(go).max() and np.abs(dg - dgo).max() <= 2e-13 * np.abs(dgo).max()
+    assert np.abs(dg[..., 0]).max() > 1e-2                                              # ∂_t g is really there
+    s = np.concatenate([x, rng.normal(size=(len(x), 4))], axis=1)
+    got, ref = rt.geodesic(s, user, path=1), O.geodesic(sc_o, s)
+    scale = np.abs(ref[:, 4:]).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(got[:, 4:] - ref[:, 4:]) / scale).max() < 5e-12
+    _, objs, cam = rt.example2_scene()
+    from test_gpu_parity import compare, hip_trace
+    camera, opt = rt.make_camera(**cam), rt.solver_defaults()
+    scn, sco = rt.make_scene(user, objs), rt.make_scene(user, objs)
+    sco.user_metric = 0x201
+    ref = O.trace(sco, opt, 48, 48, cam=camera)
+    gpu = hip_trace(lib, scn, opt, 48, 48, cam=camera)
+    compare(gpu, ref, max_class_flips=2, max_step_diff=2)
+    same = (gpu["hit"] == ref["hit"]) & (ref["hit"] != 2)       # (captured rays end with |u| ~ 1e4: relative bars only)
+    assert np.abs(gpu["state_end"][same] - ref["state_end"][same]).max() < 1e-8
+    with abi.options(lib, split=0):                                                     # the single FULL pass too
+        compare(hip_trace(lib, scn, opt, 32, 32, cam=camera), O.trace(sco, opt, 32, 32, cam=camera), max_class_flips=2, max_step_diff=2)
+    # declared stationary (three partials, stage time not carried): a different — wrong — image
+    frozen = rt.UserMetric(user_metrics.EXPANDING_ISOTROPIC, M=1.0, a=H, stationary=True)
+    bad = hip_trace(lib, rt.make_scene(frozen, objs), opt, 48, 48, cam=camera)
+    ok = (bad["hit"] == ref["hit"]) & (ref["hit"] != 2) & (ref["hit"] > 0)
+    assert np.abs(bad["state_end"][ok] - ref["state_end"][ok]).max() > 1e-3
+
+
+@pytest.mark.gpu
 def test_metric_from_source_text_in_one_call(lib):
     """rtgr_user_metric_compile: the metric as SOURCE TEXT, compiled in-process with hiprtc and loaded — what a Julia host
     does in one ccall instead of shelling out to hipcc.  Same kernels as the hipcc-built unit: the traced frame must agree
