@@ -60,11 +60,18 @@ def parse():
                     help="closed = Kerr-Schild-form contraction (production); generic = reference-style dual-number RHS "
                          "(RTGR_METRIC_GENERIC): its executed flops are the reference formulation's; "
                          "user = the same metric typed as run-time compiled source (api.UserMetric; ks_true* variants)")
-    ap.add_argument("--entry", default="device", choices=["device", "host", "pixels"],
+    ap.add_argument("--ctx-devices", type=int, default=0,
+                    help="entries host / pixels / sharded: run on an explicit rtgr_context of this many devices (device k of the "
+                         "context = visible GPU k mod #visible, so on a one-GPU box the same GPU is listed N times: a rehearsal "
+                         "of the code path, not of the speed).  0 = the default context (host, pixels) / every visible GPU (sharded)")
+    ap.add_argument("--entry", default="device", choices=["device", "host", "pixels", "sharded"],
                     help="which C-ABI entry point the timed passes go through: device = rtgr_trace_rows_device (inputs and "
                          "outputs resident in HBM: the headline), host = rtgr_trace (camera on the device, RGB planes to "
                          "host memory), pixels = rtgr_trace_pixels_f64 (the reference's Array{Pixel} in and out over "
-                         "PCIe — what a Julia ccall binds).  N = 1 only for host / pixels")
+                         "PCIe — what a Julia ccall binds; with --ctx-devices N the call deals the rows to N devices), "
+                         "sharded = rtgr_trace_sharded_device_f64: ONE process drives every device of the context, rows "
+                         "gathered on device 0 by peer copies — the single-process twin of the torchrun form, same "
+                         "frame_checksum.  host / pixels / sharded: one process (--gpus 1 under no launcher)")
     ap.add_argument("--extras", type=int, default=1,
                     help="1: after the timed region (rank 0, N = 1, default workload) also time the host and pixels entry "
                          "points and the Kerr a = 0.8 variant, reported in entry_points / variants; 0: skip")
@@ -111,20 +118,47 @@ def cpu_baseline(rt, scene, cam, opt, sample):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     nthreads = int(O.lib().rtgr_oracle_num_threads())
+    O.trace(scene, opt, 64, 64, cam=cam, details=False, nthreads=nthreads)  # warm (thread pool, page faults)
     t0 = time.perf_counter()
-    O.trace(scene, opt, 64, 64, cam=cam, details=False, nthreads=nthreads)  # warm + pilot
+    O.trace(scene, opt, 256, 256, cam=cam, details=False, nthreads=nthreads)  # pilot: big enough to keep every thread busy
     pilot = time.perf_counter() - t0
-    if sample <= 0:  # auto: about 15 s of CPU work, bounded
-        sample = int(min(1536, max(64, 64 * (15.0 / max(pilot, 1e-3)) ** 0.5)))
+    if sample <= 0:  # auto: about 8 s of CPU work (the whole leg, with the pilot, stays near 10 s), bounded
+        sample = int(min(1024, max(128, 256 * (8.0 / max(pilot, 1e-3)) ** 0.5)))
     t0 = time.perf_counter()
     r = O.trace(scene, opt, sample, sample, cam=cam, details=False, nthreads=nthreads)
     dt = time.perf_counter() - t0
     c = r["counters"]
     attempts = c["accepted"] + c["rejected"]
-    return {"value": attempts / dt, "unit": "RK step attempts/s", "cores": nthreads, "kind": "port",
+    phys, logical = physical_cores()
+    return {"value": attempts / dt, "unit": "RK step attempts/s", "cores": nthreads, "threads": nthreads,
+            "physical_cores": phys, "logical_cpus": logical, "kind": "port",
             "sample": f"{sample}x{sample} screen of the same scene ({c['rays']} rays, {attempts} step attempts) "
-                      f"in {dt:.2f} s; C++/OpenMP restatement of the reference algorithm (Julia absent)",
+                      f"in {dt:.2f} s on {nthreads} OpenMP threads ({phys} physical cores, {logical} logical CPUs visible); "
+                      f"C++/OpenMP restatement of the reference algorithm (Julia absent)",
             "rays_per_s": c["rays"] / dt, "seconds": dt}
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) this process may run on — `cores` of cpu_baseline is the THREAD count the oracle used
+    (omp_get_max_threads), which on an SMT host is the logical count, not the cores."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cur = set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur:
+                    if int(cur.get("processor", -1)) in allowed:
+                        seen.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    cur = {}
+                continue
+            k, v = line.split(":", 1)
+            cur[k.strip()] = v.strip()
+        if cur and int(cur.get("processor", -1)) in allowed:
+            seen.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+        return (len(seen) or logical), logical
+    except Exception:  # noqa: BLE001
+        return logical, logical
 
 
 def kernel_source_hash():
@@ -190,10 +224,23 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
-    assert a.entry == "device" or ws == 1, "--entry host/pixels: N = 1 only"
+    assert a.entry == "device" or ws == 1, "--entry host / pixels / sharded: ONE process (it drives the devices itself)"
+    if a.entry == "device":
+        assert ws == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+        if multi:   # the collective's own idea of the job must agree with the launcher's
+            assert dist.get_world_size() == ws and dist.get_rank() == rank, (dist.get_world_size(), ws, dist.get_rank(), rank)
     lib = abi.load()
     abi.check(lib, lib.rtgr_init(local))
+    # host / pixels / sharded on an explicit context (--ctx-devices N; sharded: every visible GPU by default)
+    ctx, ctx_ids = None, [local]
+    if a.entry != "device" and (a.ctx_devices > 0 or a.entry == "sharded"):
+        nctx = a.ctx_devices if a.ctx_devices > 0 else max(ndev, 1)
+        ctx_ids = [k % max(ndev, 1) for k in range(nctx)]
+        ctx = abi.create_context(lib, ctx_ids)
+        assert lib.rtgr_context_devices(ctx) == nctx
+    n_physical = len(set(ctx_ids))
+    if a.entry != "device":
+        assert a.gpus in (1, n_physical), f"--gpus {a.gpus} but the context spans {n_physical} physical GPU(s)"
 
     if ws > 1:
         os.environ["RTGR_NO_COMPILE"] = "1"   # --rhs user on a cold cache: fail fast instead of N ranks starting hipcc
@@ -251,19 +298,32 @@ def main():
             host["rgb"] = np.empty((3, ni * nj), npdt)
         c = abi.rtgr_counters()
         fn = lib.rtgr_trace_f64 if a.dtype == "f64" else lib.rtgr_trace_f32
-        abi.check(lib, fn(None, ctypes.byref(scene), ctypes.byref(opt), None, ctypes.byref(cam), ni, nj, 0, nj,
+        abi.check(lib, fn(ctx, ctypes.byref(scene), ctypes.byref(opt), None, ctypes.byref(cam), ni, nj, 0, nj,
                           host["rgb"].ctypes.data, None, ctypes.byref(c)))
+        return c
+
+    def sharded_pass():   # rtgr_trace_sharded_device_*: one call, every device of the context, frame assembled on device 0
+        if "d_rgb" not in host:
+            d0 = torch.device("cuda", ctx_ids[0])
+            host["d_rgb"] = torch.empty((3, ni * nj), dtype=torch.float64 if a.dtype == "f64" else torch.float32, device=d0)
+            host["d_status"] = torch.empty(ni * nj, dtype=torch.uint8, device=d0)
+        c = abi.rtgr_counters()
+        o = abi.rtgr_ray_outputs()
+        o.status = host["d_status"].data_ptr()
+        fn = lib.rtgr_trace_sharded_device_f64 if a.dtype == "f64" else lib.rtgr_trace_sharded_device_f32
+        abi.check(lib, fn(ctx, ctypes.byref(scene), ctypes.byref(opt), ctypes.byref(cam), ni, nj, host["d_rgb"].data_ptr(),
+                          ctypes.byref(o), ctypes.byref(c)))
         return c
 
     def pixels_pass():  # rtgr_trace_pixels_f64: the reference's Array{Pixel{Float64},2} in, a new one out
         if "px" not in host:
             st = np.empty((ni * nj, 8))
-            abi.check(lib, lib.rtgr_make_canvas_f64(None, ctypes.byref(scene), ctypes.byref(cam), ni, nj, 0, nj, st.ctypes.data))
+            abi.check(lib, lib.rtgr_make_canvas_f64(ctx, ctypes.byref(scene), ctypes.byref(cam), ni, nj, 0, nj, st.ctypes.data))
             px = np.zeros(ni * nj, dtype=rt.pixel_dtype())
             px["pos"], px["normal"] = st[:, :4], st[:, 4:]
             host["px"], host["px_out"] = px, np.empty_like(px)
         c = abi.rtgr_counters()
-        abi.check(lib, lib.rtgr_trace_pixels_f64(None, ctypes.byref(scene), ctypes.byref(opt), host["px"].ctypes.data, ni, nj,
+        abi.check(lib, lib.rtgr_trace_pixels_f64(ctx, ctypes.byref(scene), ctypes.byref(opt), host["px"].ctypes.data, ni, nj,
                                                  host["px_out"].ctypes.data, ctypes.byref(c)))
         return c
 
@@ -287,7 +347,7 @@ def main():
             image["rgb"] = sharded.assemble_rows(parts["rgb"], ni, nj, ws, a.layout)  # the gathered frame, rows back in place
             image["status"] = sharded.assemble_rows([p[None] for p in parts["status"]], ni, nj, ws, a.layout)[0]
 
-    one_pass = {"device": device_pass, "host": host_pass, "pixels": pixels_pass}[a.entry]
+    one_pass = {"device": device_pass, "host": host_pass, "pixels": pixels_pass, "sharded": sharded_pass}[a.entry]
     # untimed: W warm-up passes, and at least one pass through every stream / output buffer of the frames in flight, so that
     # no workspace is allocated inside the timed region whatever W is
     extra_warm = max(0, nbuf - a.warmup) if a.entry == "device" else 0
@@ -295,7 +355,8 @@ def main():
         one_pass()
     torch.cuda.synchronize()
     ctr.zero_()
-    abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
+    for k in range(len(ctx_ids) if ctx else 1):
+        abi.check(lib, lib.rtgr_timing_enable(ctx, k, 1))
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -325,14 +386,27 @@ def main():
     # per-kernel HIP-event timing recorded by the library on the launch stream (rtgr_timing_*)
     kms = (ctypes.c_double * 4)()
     kln = (ctypes.c_uint64 * 4)()
-    abi.check(lib, lib.rtgr_timing_read(None, 0, ctypes.byref(kms), ctypes.byref(kln)))
-    abi.check(lib, lib.rtgr_timing_enable(None, 0, 0))
+    abi.check(lib, lib.rtgr_timing_read(ctx, 0, ctypes.byref(kms), ctypes.byref(kln)))
+    abi.check(lib, lib.rtgr_timing_enable(ctx, 0, 0))
+    per_device_ms = None
+    if ctx:   # a multi-device context: every device has its timers; the roofline below uses the BUSIEST device's
+        per_device_ms = [[float(kms[w]) for w in range(4)]]
+        for k in range(1, len(ctx_ids)):
+            m2, l2 = (ctypes.c_double * 4)(), (ctypes.c_uint64 * 4)()
+            abi.check(lib, lib.rtgr_timing_read(ctx, k, ctypes.byref(m2), ctypes.byref(l2)))
+            abi.check(lib, lib.rtgr_timing_enable(ctx, k, 0))
+            per_device_ms.append([float(m2[w]) for w in range(4)])
+        busiest = max(per_device_ms, key=lambda v: v[1] + v[3])
+        for w in range(4):
+            kms[w] = busiest[w]
     if rank == 0:
         # roofline of the dominant kernels — integrate_kernel's FAR pass (~93 % of device time) and NEAR pass, the two
         # launches of the same template that together perform the counted step attempts — over this rank's launches
         my = ctr.cpu().numpy()
         n_launch = max(int(kln[1]), 1)   # (host entry points launch once per pipeline chunk)
         my_attempts, my_rays = int(my[1] + my[2]), int(my[0])
+        if ctx and len(ctx_ids) > 1:   # the call returns the counters summed over the context's devices: an even share
+            my_attempts, my_rays = my_attempts // len(ctx_ids), my_rays // len(ctx_ids)
         k_s = (float(kms[1]) + float(kms[3])) * 1e-3   # seconds in the integrate kernels, all launches of this rank
         prof, why = load_profile(a)
         peak = FP64_VALU_PEAK_TFLOPS if a.dtype == "f64" else F32_SCALAR_VALU_PEAK_TFLOPS
@@ -348,12 +422,21 @@ def main():
                                               f"reference's dual-number formulation would execute for the same steps; NOT "
                                               f"a utilisation — the closed Kerr-Schild contraction executes fewer)",
                 "hbm_algorithmic_GBps": (my_rays * (132 + 2 * 140 + 204 + 25)) / k_s / 1e9}
+        # SURVEY §8(d)'s own fraction, for the record: the reference FORMULATION's flops for the steps taken, over the time the
+        # closed contraction needed for them.  It exceeds 1 on the closed-form kernels BECAUSE they do not execute the
+        # dual-number work (parity-checked pointwise instead); `frac` is the executed-flop figure and the one to read.
+        roof["contract_8d_frac"] = roof["reference_equivalent_tflops"] / peak
+        roof["contract_8d_note"] = ("SURVEY 8d formula: (attempts x 5404 + 2 x rays x 814) / kernel time / peak; > 1 on the "
+                                    "closed Kerr-Schild contraction because it elides the dual-number chain; not a utilisation")
+        ALGORITHMIC_BYTES_PER_RAY = 89    # <= 64 B in + 24 B out + 1 status byte
         if prof is not None:
             flop = prof["flop_per_step_attempt"] * my_attempts
             roof["achieved"] = flop / k_s / 1e12
             roof["frac"] = roof["achieved"] / peak
             roof["executed_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
             roof["traffic"] = prof["hbm_bytes_per_ray"] * my_rays / a.steps if prof.get("hbm_bytes_per_ray") else None
+            if prof.get("hbm_bytes_per_ray"):   # what the pipeline's hand-over records cost over the algorithm's own bytes
+                roof["traffic_over_algorithmic"] = prof["hbm_bytes_per_ray"] / ALGORITHMIC_BYTES_PER_RAY
             roof["profile"] = prof
             ic = prof.get("issue_ceiling")
             if ic and ic.get("frac_of_peak_this_mix_can_issue"):   # what the machine can issue for THIS kernel's instruction mix with no operand ever waited for (measured)
@@ -371,13 +454,15 @@ def main():
         cpu = cpu_baseline(rt, scene, cam, opt, a.cpu_sample) if (a.cpu_sample != 0 and not multi) else None  # N=1 only
         line = {
             "metric": "geodesic RK step attempts/s (Tsit5, 6 RHS each), Kerr-Schild screen, whole job",
-            "value": attempts / dt, "unit": "RK step attempts/s", "n_gpus": ws, "steps": a.steps,
+            "value": attempts / dt, "unit": "RK step attempts/s", "n_gpus": ws if a.entry == "device" else n_physical, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"example2 scene (Kerr-Schild {a.variant}, 3 objects) {ni}x{nj} screen, "
-                                   f"tol=eps^(3/4), lambda in [0,100]; rows dealt {a.layout} over {ws} GPU(s)"
+                                   f"tol=eps^(3/4), lambda in [0,100]; rows dealt {a.layout} over "
+                                   f"{ws if a.entry == 'device' else str(len(ctx_ids)) + ' context device(s) on ' + str(n_physical)} GPU(s)"
                                    f"{'' if ws == 1 or a.no_gather else ' + ' + ('RCCL' if a.backend == 'nccl' else 'gloo') + ' gather of RGB + status to rank 0'}",
-                       "size": a.size, "variant": a.variant, "rhs": a.rhs, "entry": a.entry, "parallelism": f"rows/{ws}"},
+                       "size": a.size, "variant": a.variant, "rhs": a.rhs, "entry": a.entry,
+                       "parallelism": f"rows/{ws if a.entry == 'device' else len(ctx_ids)}"},
             "rays_per_s": rays / dt, "rays": rays // a.steps, "step_attempts_per_pass": attempts // a.steps,
             "accepted": acc // a.steps, "rejected": rej // a.steps, "rhs_evals_per_pass": nrhs // a.steps,
             "device": name, "roofline": roof, "cpu_baseline": cpu,
@@ -386,6 +471,14 @@ def main():
         if multi and not a.no_gather:
             line["gathered_status_not_event"] = int((image["status"] != 0).sum())
             line["exchange"] = "overlapped with the next pass" if overlap else "in turn"
+        if multi:
+            line["world_size_checked"] = dist.get_world_size()
+        if ctx:
+            line["ctx_devices"] = ctx_ids
+            line["per_device_kernel_ms"] = [{"setup_and_order": v[0], "far": v[1], "resolve": v[2], "near": v[3]} for v in per_device_ms]
+            if n_physical < len(ctx_ids):
+                line["ctx_note"] = (f"{len(ctx_ids)} context devices on {n_physical} physical GPU(s): a rehearsal of the "
+                                    "multi-device code path — the logical devices share one GPU, so this is not a scaling figure")
         line["frames_in_flight"] = nflight
         if extra_warm:
             line["allocation_passes"] = extra_warm   # untimed passes beyond `warmup` (one per stream / output buffer)
@@ -396,10 +489,18 @@ def main():
         frame = None
         if a.entry == "device":
             frame = image["rgb"] if (multi and not a.no_gather) else (outs[0]["rgb"] if ws == 1 else None)
+        elif a.entry == "sharded":
+            frame = host["d_rgb"]
+        elif a.entry == "host":
+            frame = torch.from_numpy(host["rgb"])
+        elif a.entry == "pixels":
+            frame = torch.from_numpy(np.ascontiguousarray(host["px_out"]["rgb"].T))   # planes, like the other entries
         if frame is not None:
             bits = frame.contiguous().view(torch.int64 if a.dtype == "f64" else torch.int32).to(torch.int64)
             line["frame_checksum"] = int(bits.sum().item())
         print(json.dumps(line), flush=True)
+    if ctx:
+        abi.check(lib, lib.rtgr_destroy(ctx))
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -434,16 +535,43 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
     sharded.trace_rows_torch(sc8, opt, cam8, n, n, 0, 1, n, counters=ctr, out=o)
     torch.cuda.synchronize()
     ctr.zero_()
+    import ctypes
+    lib = rt._abi.load()
+    rt._abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
     t0 = time.perf_counter()
-    reps = 2
+    reps = 3
     for _ in range(reps):
         sharded.trace_rows_torch(sc8, opt, cam8, n, n, 0, 1, n, counters=ctr, out=o)
     torch.cuda.synchronize()
     d8 = (time.perf_counter() - t0) / reps
+    kms, kln = (ctypes.c_double * 4)(), (ctypes.c_uint64 * 4)()
+    rt._abi.check(lib, lib.rtgr_timing_read(None, 0, ctypes.byref(kms), ctypes.byref(kln)))
+    rt._abi.check(lib, lib.rtgr_timing_enable(None, 0, 0))
     att = (int(ctr[1]) + int(ctr[2])) / reps
-    ex["variants"] = {"ks_true08": {"workload": f"Kerr-Schild a=0.8 (textbook radius), same scene and camera, {n}x{n}",
-                                    "ms_per_pass": d8 * 1e3, "step_attempts_per_s": att / d8, "rays_per_s": n * n / d8,
-                                    "step_attempts_per_ray": att / (n * n)}}
+    v = {"workload": f"Kerr-Schild a=0.8 (textbook radius), same scene and camera, {n}x{n}",
+         "ms_per_pass": d8 * 1e3, "step_attempts_per_s": att / d8, "rays_per_s": n * n / d8,
+         "step_attempts_per_ray": att / (n * n)}
+    # the same executed-flop roofline as the headline's, from THIS variant's profile entry (hash-keyed like the headline's)
+    k_s = (float(kms[1]) + float(kms[3])) * 1e-3 / reps
+    class _A:  # noqa: E701
+        variant, dtype, rhs = "ks_true08", "f64", "closed"
+    prof, why = load_profile(_A)
+    r8 = {"bound": "valu_f64", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms_per_pass": k_s * 1e3,
+          "far_pass_ms_per_pass": float(kms[1]) / reps, "near_pass_ms_per_pass": float(kms[3]) / reps,
+          "achieved": None, "frac": None}
+    if prof is not None:
+        r8["achieved"] = prof["flop_per_step_attempt"] * att / k_s / 1e12
+        r8["frac"] = r8["achieved"] / FP64_VALU_PEAK_TFLOPS
+        r8["executed_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
+        r8["valu_per_wave_step"] = prof.get("per_wave_step", {}).get("valu")
+        r8["source"] = prof.get("source")
+        ic = prof.get("issue_ceiling")
+        if ic and ic.get("frac_of_peak_this_mix_can_issue"):
+            r8["issue_ceiling_frac"] = ic["frac_of_peak_this_mix_can_issue"]
+    else:
+        r8["stale_profile"] = why
+    v["roofline"] = r8
+    ex["variants"] = {"ks_true08": v}
     return ex
 
 

@@ -785,6 +785,12 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     }
     if (A.keys) order_key<R>(x, u, valid, w, A.keys, A.hist);  // block-wide (LDS histogram): before any early exit
     if (!valid) return;
+    // The ray's state is a VALUE from here on, whichever way it was obtained: without this barrier the compiler contracts
+    // the last product of make_pixel (u = (…)·1/√2) into the first sum of the RHS (k_a u^a = u^t + …) when the camera ray
+    // is generated in this kernel, and cannot when the same ray is loaded from the caller's array — camera and state0
+    // frames then differ in the last bit of u̇(y0) (found by test_host_pipeline_with_many_chunks_and_every_output).
+#pragma unroll
+    for (int q = 0; q < 4; q++) { asm volatile("" : "+v"(x[q])); asm volatile("" : "+v"(u[q])); }
     accel<R, METRIC, SPIN, true>(x + 1, u, MK, k1, x[0]);      // f0 = (u, k1)
     float acc0 = 0.0f, acc1 = 0.0f;
     float iskx[4], isku[4];

@@ -55,3 +55,22 @@ def test_bench_host_entry_points():
         d = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0", "--entry", entry)
         assert d["config"]["entry"] == entry and d["step_attempts_per_pass"] == base["step_attempts_per_pass"]
         assert d["value"] > 0 and d["roofline"]["launches"] >= 2
+
+
+def test_bench_single_process_multi_device_entries():
+    """--entry sharded (rtgr_trace_sharded_device_f64, frame gathered on device 0) and --entry pixels / host with
+    --ctx-devices N (the drop-in host entries dealing rows to every device of the context): the delivered frame is the
+    single-device frame bit for bit (frame_checksum) and the counters are the same job's.  One GPU: the context lists it N
+    times, which the line says (ctx_note) — a rehearsal of the code path, not a scaling figure."""
+    base = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0")
+    for args in (("--entry", "sharded", "--ctx-devices", "3"), ("--entry", "pixels", "--ctx-devices", "2"),
+                 ("--entry", "host", "--ctx-devices", "4"), ("--entry", "host")):
+        d = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0", *args)
+        assert d["frame_checksum"] == base["frame_checksum"], args
+        assert d["step_attempts_per_pass"] == base["step_attempts_per_pass"] and d["n_gpus"] == 1
+        if "--ctx-devices" in args:
+            n = int(args[-1])
+            assert d["ctx_devices"] == [0] * n and "rehearsal" in d["ctx_note"]
+            assert len(d["per_device_kernel_ms"]) == n and all(v["far"] > 0 for v in d["per_device_kernel_ms"])
+    for k in ("contract_8d_frac", "contract_8d_note"):
+        assert k in base["roofline"]

@@ -206,7 +206,7 @@ def test_time_dependent_user_metric_is_traced_at_the_rays_own_time(lib):
     frozen = rt.UserMetric(user_metrics.EXPANDING_ISOTROPIC, M=1.0, a=H, stationary=True)
     bad = hip_trace(lib, rt.make_scene(frozen, objs), opt, 48, 48, cam=camera)
     ok = (bad["hit"] == ref["hit"]) & (ref["hit"] != 2) & (ref["hit"] > 0)
-    assert np.abs(bad["state_end"][ok] - ref["state_end"][ok]).max() > 1e-3
+    assert (bad["hit"] != ref["hit"]).mean() > 0.05 or np.abs(bad["state_end"][ok] - ref["state_end"][ok]).max() > 1e-3
 
 
 @pytest.mark.gpu
