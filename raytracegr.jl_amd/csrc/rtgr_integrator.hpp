@@ -317,6 +317,7 @@ RTGR_DEV uint8_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, co
 // metric(x) with plain scalars (no duals): what make_canvas calls (:469)
 template <class R>
 RTGR_DEV void metric_plain(const DevScene<R>& sc, const R x[4], R g[4][4]) {
+#pragma clang fp contract(off)   // see make_pixel
 #ifdef RTGR_USER_METRIC
     if (sc.metric == (uint32_t)RTGR_USER) {
         rtgr_user_metric<R>(x, (double)sc.M, (double)sc.a, g);
@@ -341,6 +342,12 @@ RTGR_DEV void metric_plain(const DevScene<R>& sc, const R x[4], R g[4][4]) {
 template <class R>
 RTGR_DEV void make_pixel(const DevScene<R>& sc, const DevCamera<R>& cam, uint64_t ni, uint64_t nj, uint64_t i0,
                          uint64_t j0, R s[8]) {
+    // No implicit contraction in the camera (here, metric_plain, ks_field, inv4sym): this function is inlined into
+    // prepare_kernel — next to the RHS of the same point — AND into canvas_kernel, and -ffp-contract=fast decides fusions by
+    // use counts after inlining and CSE: a product shared with the neighbouring code (a², ρ²) fused in one kernel and not in
+    // the other, and the camera ray generated inside the pipeline differed from rtgr_make_canvas' in the last bit (round 3:
+    // found by test_host_pipeline_with_many_chunks_and_every_output when the spin RHS changed).  Explicit rfma() stay FMAs.
+#pragma clang fp contract(off)
     const R dx = (R(i0 + 1) - R(0.5)) / R(ni) - R(0.5);                               // :465
     const R dy = (R(j0 + 1) - R(0.5)) / R(nj) - R(0.5);                               // :466
     R x[4], n[4];

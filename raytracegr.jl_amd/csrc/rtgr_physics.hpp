@@ -114,6 +114,7 @@ struct KSField {
 // SPIN = false is the reference's actual configuration (a = 0 hard-wired, :276) and drops the a-terms statically.
 template <class R, int METRIC, bool SPIN, bool FAST = false>
 RTGR_DEV void ks_field(R x, R y, R z, R M, R a, KSField<R>& F) {
+#pragma clang fp contract(off)   // (part of the camera: see make_pixel, rtgr_integrator.hpp)
     const R a2 = SPIN ? a * a : R(0);
     const R rho2 = rfma(x, x, rfma(y, y, z * z));
     R r, rq2, rz;  // r, 2*∂r/∂q (so that ∇r = rq2*(x,y,z) + rz*ẑ), explicit ∂r/∂z
@@ -351,7 +352,7 @@ RTGR_DEV void accel_spin_ref(const R xs[3], const R u[4], const MetricK<R>& C, R
     ud[3] = rfma(k2, SkL, -L2);
 }
 
-// a != 0, TEXTBOOK radius — the configuration BASELINE.json words (a = 0.8, a = 0.998): 44 MUL + 42 FMA + 3 ADD + 3
+// a != 0, TEXTBOOK radius — the configuration BASELINE.json words (a = 0.8, a = 0.998): 48 MUL + 41 FMA + 3 ADD + 2
 // transcendental seeds per evaluation (round 2's form of the same contraction: 58 + 46 + 5 + 3).
 //
 // r is a root of r⁴ − q r² − a²z² = 0 (q = ρ² − a²) and k is the principal null congruence, which buys (checked to 40
@@ -376,13 +377,24 @@ RTGR_DEV void accel_spin_true(const R xs[3], const R u[4], const MetricK<R>& C, 
     R sig, is;                                                      // Σ, 1/Σ
     sqrt_inv<FAST>(sig2, sig, is);
     const R r2 = R(0.5) * (q + sig);                                // r² = (q + Σ)/2
-    R r, ir;
-    sqrt_inv<FAST>(r2, r, ir);
+    // 1/r AND w = 1/(r²+a²) from ONE reciprocal square root, t = 1/sqrt(r² (r²+a²)²) = 1/(r (r²+a²)):
+    //     1/r = t (r²+a²),   r = r²/r,   w = t r
+    // (a transcendental seed costs 3.6 issue slots: one less per evaluation for one product more)
+    R r, ir, w;
+    if constexpr (FAST) {
+        const R r2a = r2 + C.a2;
+        const R t = frsq<R>(r2 * (r2a * r2a));
+        ir = t * r2a;
+        r = r2 * ir;
+        w = t * r;
+    } else {
+        sqrt_inv<false>(r2, r, ir);
+        w = R(1) / (r2 + C.a2);
+    }
     const R rid = r * is;                                           // r/Σ: ∇r's isotropic part AND r³/(r⁴+a²z²)
     const R rz = a2z * (is * ir);                                   // a²z/(rΣ): ∇r's extra z part
     const R phi = -(rz * ir) * R(2);                                // (∂f/∂z)/f
     const R psi = rfma(R(-4), rid, R(3) * ir);                      // (∂f/∂r)/f
-    const R w = rcp_<FAST>(r2 + C.a2);
     const R rw = r * w, aw = C.a * w;
     const R k0 = rfma(rw, x, aw * y), k1 = rfma(rw, y, -(aw * x)), k2 = z * ir;                 // :286-289
     const R xu2 = rfma(x, ux, y * uy), xu = rfma(z, uz, xu2);
@@ -613,6 +625,7 @@ RTGR_DT RTGR_DEV void metric_dual(uint32_t metric, R M, R a, const RTGR_DD xx[4]
 
 template <class R>
 RTGR_DEV void inv4sym(const R m[4][4], R o[4][4]) {  // cofactor inverse (StaticArrays closed form)
+#pragma clang fp contract(off)   // (part of the camera: see make_pixel, rtgr_integrator.hpp)
     const R s0 = m[0][0] * m[1][1] - m[1][0] * m[0][1], s1 = m[0][0] * m[1][2] - m[1][0] * m[0][2];
     const R s2 = m[0][0] * m[1][3] - m[1][0] * m[0][3], s3 = m[0][1] * m[1][2] - m[1][1] * m[0][2];
     const R s4 = m[0][1] * m[1][3] - m[1][1] * m[0][3], s5 = m[0][2] * m[1][3] - m[1][2] * m[0][3];

@@ -1,0 +1,66 @@
+"""The random-scene differential campaign (DESIGN §2 "where the bounds stop holding") under pytest: the seeded scene
+generator of tests/test_gpu_parity.py for seeds 15-214, through the closed-form path AND the generic dual-number path,
+against the oracle with the random-scene test's own bounds.
+
+193 of the 200 seeds are inside every bound on both paths.  The 7 others are listed here by name.  The claim about them
+(round 2: a script's printout, now an assertion) is that they are properties of the ALGORITHM — error estimates that are
+rounding noise of the particular RHS formulation — not device errors:
+
+  * five Minkowski scenes with several small spheres (seeds 25, 40, 90, 140, 170): Γ ≡ 0 makes the embedded error estimate
+    pure rounding noise, steps grow to dt ≈ 2-10, and whether a ray "hits" a sphere narrower than the 10-sample spacing is
+    decided by where the samples fall;
+  * two Kerr–Schild scenes (56, 171) with a late plane and reltol 1e-9: captured rays reach |u^t| ~ 1e7 before they end,
+    where the estimate is dominated by the rounding noise of the RHS formulation.
+
+What is asserted for each of them: an INDEPENDENT device formulation of the same algorithm — the tile kernel (option
+tile = 1: f64 controller, IEEE division, inline event finder; shares no integrate code with the production pipeline) —
+is at least as far from the oracle, on the same bounds, as the production kernels are (up to the factor 2 one expects
+between two draws of the same noise), AND the two device formulations differ from EACH OTHER as much as either differs
+from the oracle.  A production-kernel defect would show as production alone being far out."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from scenes import rt
+from test_gpu_parity import _random_scene, hip_trace, lib, random_scene_violations  # noqa: F401  (lib: fixture)
+
+pytestmark = pytest.mark.gpu
+abi = rt._abi
+KNOWN_NOISE_DOMINATED = {25, 40, 56, 90, 140, 170, 171}
+SEEDS = range(15, 215)
+
+
+def _traces(lib, seed, generic):
+    sc, cam, opt, nobj = _random_scene(seed)
+    if generic and sc.metric != abi.MINKOWSKI:
+        sc.metric |= abi.METRIC_GENERIC
+    gpu = hip_trace(lib, sc, opt, 40, 32, cam=cam)
+    sc0, _, _, _ = _random_scene(seed)
+    ref = O.trace(sc0, opt, 40, 32, cam=cam)
+    return sc0, cam, opt, nobj, gpu, ref
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["closed", "generic"])
+@pytest.mark.parametrize("seed", [s for s in SEEDS if s not in KNOWN_NOISE_DOMINATED])
+def test_campaign_seed_is_inside_every_bound(lib, seed, generic):
+    sc, cam, opt, nobj, gpu, ref = _traces(lib, seed, generic)
+    v = random_scene_violations(gpu, ref, sc, nobj)
+    assert not v, v
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["closed", "generic"])
+@pytest.mark.parametrize("seed", sorted(KNOWN_NOISE_DOMINATED))
+def test_campaign_outlier_is_formulation_noise_not_a_device_error(lib, seed, generic):
+    sc, cam, opt, nobj, prod, ref = _traces(lib, seed, generic)
+    with abi.options(lib, tile=1):
+        tile = hip_trace(lib, sc, opt, 40, 32, cam=cam)
+    v_prod = random_scene_violations(prod, ref, sc, nobj)
+    v_tile = random_scene_violations(tile, ref, sc, nobj)
+    v_pair = random_scene_violations(prod, tile, sc, nobj)       # device formulation against device formulation
+    print(f"seed {seed} {'generic' if generic else 'closed'}: production vs oracle {v_prod}; tile kernel vs oracle {v_tile}; "
+          f"production vs tile kernel {v_pair}")
+    assert v_prod, "this seed is listed as noise-dominated but the production path is inside every bound: unlist it"
+    worst = max(v_prod, key=v_prod.get)
+    assert worst in v_tile, (worst, v_prod, v_tile)                 # the independent formulation breaks the SAME bound ...
+    assert v_tile[worst] >= 0.5 * v_prod[worst], (v_prod, v_tile)   # ... by at least as much (two draws of one noise: factor 2)
+    assert worst in v_pair and v_pair[worst] >= 0.5 * min(v_prod[worst], v_tile[worst]), (v_prod, v_tile, v_pair)

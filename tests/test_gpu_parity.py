@@ -791,13 +791,27 @@ def test_random_scenes_match_oracle(lib, seed):
     sc, cam, opt, nobj = _random_scene(seed)
     gpu = hip_trace(lib, sc, opt, 40, 32, cam=cam)
     ref = O.trace(sc, opt, 40, 32, cam=cam)
+    v = random_scene_violations(gpu, ref, sc, nobj)
+    assert not v, v
+
+
+def random_scene_violations(gpu, ref, sc, nobj):
+    """The stated bounds of the random-scene comparison as MEASUREMENTS: {bound name: measured / allowed} for every bound
+    that is exceeded (empty = inside every bound).  tests/test_campaign_random_scenes.py uses the ratios to compare HOW FAR
+    two device formulations are from the oracle on the seeds where the algorithm itself is noise-dominated."""
+    out = {}
+
+    def check(name, measured, allowed):
+        if measured > allowed:
+            out[name] = float(measured) / max(float(allowed), 1e-300)
+
     unfin_g, unfin_r = gpu["status"] >= 2, ref["status"] >= 2
-    assert abs(int(unfin_g.sum()) - int(unfin_r.sum())) <= 0.05 * unfin_r.sum() + 3
+    check("unfinished_count", abs(int(unfin_g.sum()) - int(unfin_r.sum())), 0.05 * unfin_r.sum() + 3)
     ok = ~unfin_g & ~unfin_r
     flips = (gpu["hit"] != ref["hit"]) & ok
     nflip_max = 0.03 * 1280 if sc.metric == abi.MINKOWSKI else 6
-    assert int(flips.sum()) <= nflip_max, int(flips.sum())
-    assert int(((gpu["status"] != ref["status"]) & ok).sum()) <= nflip_max  # event <-> λ1 is the same coin toss
+    check("class_flips", int(flips.sum()), nflip_max)
+    check("status_flips", int(((gpu["status"] != ref["status"]) & ok).sum()), nflip_max)  # event <-> λ1 is the same coin toss
     same = ok & ~flips & (gpu["status"] == ref["status"])
     d = np.abs(gpu["rgb"][:, same] - ref["rgb"][:, same])
     per = gpu["hit"][same].astype(np.float64) / max(nobj, 1)   # sawtooth period of a coloured hit (:427, :530)
@@ -807,10 +821,12 @@ def test_random_scenes_match_oracle(lib, seed):
     # rays that orbit the hole many times before they hit something (>= 500 step attempts) amplify rounding differences
     # exponentially (unstable photon orbit); they are the only ones allowed over the bound, and only a few
     long_orbit = (ref["n_accept"][same] + ref["n_reject"][same]) >= 500
-    assert int((bad & ~long_orbit).sum()) <= 2, np.sort(e[~long_orbit])[-4:]
-    assert int(bad.sum()) <= 0.02 * 1280 and (e[bad] < 1e-2).all()
+    check("rgb_over_1e-6", int((bad & ~long_orbit).sum()), 2)
+    check("rgb_over_1e-6_long_orbits", int(bad.sum()), 0.02 * 1280)
+    check("rgb_worst", float(e[bad].max()) if bad.any() else 0.0, 1e-2)
     sd = np.abs((gpu["n_accept"] + gpu["n_reject"]).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))
-    assert np.percentile(sd[same], 99) <= 3 if same.any() else True
+    check("step_count_p99", float(np.percentile(sd[same], 99)) if same.any() else 0.0, 3)
+    return out
 
 
 @pytest.mark.parametrize("name", ["ks_ref0", "ks_true08"])
