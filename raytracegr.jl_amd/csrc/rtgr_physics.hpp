@@ -379,17 +379,19 @@ RTGR_DEV void accel_spin_true(const R xs[3], const R u[4], const MetricK<R>& C, 
     const R r2 = R(0.5) * (q + sig);                                // r² = (q + Σ)/2
     // 1/r AND w = 1/(r²+a²) from ONE reciprocal square root, t = 1/sqrt(r² (r²+a²)²) = 1/(r (r²+a²)):
     //     1/r = t (r²+a²),   r = r²/r,   w = t r
-    // (a transcendental seed costs 3.6 issue slots: one less per evaluation for one product more)
+    // (an f64 transcendental seed costs 3.6 issue slots: one less per evaluation for three products more.  Float64 only:
+    //  the chain t -> 1/r -> r -> w compounds three roundings, +10 % on the RHS's rounding noise, which Float32 — whose
+    //  error estimate sits close to that noise, and whose seeds cost half — cannot afford)
     R r, ir, w;
-    if constexpr (FAST) {
+    if constexpr (FAST && sizeof(R) == 8) {
         const R r2a = r2 + C.a2;
         const R t = frsq<R>(r2 * (r2a * r2a));
         ir = t * r2a;
         r = r2 * ir;
         w = t * r;
     } else {
-        sqrt_inv<false>(r2, r, ir);
-        w = R(1) / (r2 + C.a2);
+        sqrt_inv<FAST>(r2, r, ir);
+        w = rcp_<FAST>(r2 + C.a2);
     }
     const R rid = r * is;                                           // r/Σ: ∇r's isotropic part AND r³/(r⁴+a²z²)
     const R rz = a2z * (is * ir);                                   // a²z/(rΣ): ∇r's extra z part

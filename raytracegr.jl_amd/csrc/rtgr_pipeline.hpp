@@ -141,7 +141,7 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
               // A small launch's NEAR pass ends on its longest-staying rays (one lane each, up to 370 steps in the
               // a = 0.8 scene), and such a wave steps faster alone on its SIMD than next to a second wave: ONE wave per
               // SIMD below 2.4 M rays, below 6.3 M with spin (1024²: a = 0.8 NEAR 2.17 -> 1.43 ms, a = 0 0.87 -> 0.64 ms;
-              // same-run A/B of the frame time, tools/ab_options.py: a = 0.8 at 2.1 M rays 18.64 -> 17.87 ms, 4.2 M
+              // same-run A/B of the frame time, tools/launch_ab.py ab: a = 0.8 at 2.1 M rays 18.64 -> 17.87 ms, 4.2 M
               // 33.67 -> 33.25, 8.4 M 63.85 -> 64.25; a = 0 at 2.1 M 12.43 -> 12.37, 4.2 M 23.31 -> 23.48: beyond these
               // sizes the second wave's throughput is worth more).
               dim3 gn = grid(waves_per_simd_of<R, METRIC>(MODE_NEAR));

@@ -27,9 +27,11 @@ def scene_variant(name):
 
 def wrap_aware_rgb_err(a, b, hit, nobj=3):
     """L∞ distance between RGB planes a, b [3, n], evaluated modulo the sawtooth of objcolor (src/RayTraceGR.jl:427):
-    channels R,G of a sphere hit are mod(·,1)*omin/nobj, so the circular distance has period omin/nobj."""
+    channels R,G of a sphere hit are mod(·,1)*omin/nobj, so the circular distance has period omin/nobj.  The thin disk (no
+    reference counterpart) puts its sawtooths on G and B (rtgr_integrator.hpp colour_pixel), so all three channels are
+    compared circularly; on a channel that is constant for the object hit the circular distance IS the distance."""
     d = np.abs(a - b)
     per = (hit.astype(np.float64) / nobj)[None, :]
     per = np.where(per > 0, per, 1.0)
-    dc = np.minimum(d[:2], np.abs(per - d[:2]))
-    return max(dc.max(initial=0.0), d[2].max(initial=0.0))
+    dc = np.minimum(d, np.abs(per - d))
+    return dc.max(initial=0.0)
