@@ -56,10 +56,11 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="CPU baseline renders a sample x sample screen; -1 = auto (~15 s of CPU work), 0 = off")
-    ap.add_argument("--rhs", default="closed", choices=["closed", "generic", "user"],
+    ap.add_argument("--rhs", default="closed", choices=["closed", "generic", "user", "user_ks"],
                     help="closed = Kerr-Schild-form contraction (production); generic = reference-style dual-number RHS "
                          "(RTGR_METRIC_GENERIC): its executed flops are the reference formulation's; "
-                         "user = the same metric typed as run-time compiled source (api.UserMetric; ks_true* variants)")
+                         "user = the same metric typed as run-time compiled source (api.UserMetric; ks_true* variants); "
+                         "user_ks = typed in Kerr-Schild form (f and k only: rtgr_user_ks)")
     ap.add_argument("--ctx-devices", type=int, default=0,
                     help="entries host / pixels / sharded: run on an explicit rtgr_context of this many devices (device k of the "
                          "context = visible GPU k mod #visible, so on a one-GPU box the same GPU is listed N times: a rehearsal "
@@ -99,11 +100,12 @@ def build_scene(rt, variant, generic=False):
                   "ks_true0998": rt.KerrSchild(1, 0.998), "ks_true0998_disk": rt.KerrSchild(1, 0.998)}[variant]
         if variant == "ks_true0998_disk":  # BASELINE config 5: thin accretion disk instead of the small sphere
             objs = objs[:2] + [rt.Disk(0.05, 2.0, 4.0)]  # camera (cylindrical radius 4.5) stays outside the disk
-    if generic == "user":
+    if generic in ("user", "user_ks"):
         assert variant.startswith("ks_true"), "--rhs user: the example source is the textbook Kerr-Schild metric"
         sys.path.insert(0, os.path.join(ROOT, "examples"))
         import user_metrics
-        metric = rt.UserMetric(user_metrics.KERR_SCHILD, M=metric.M, a=metric.a, stationary=True)
+        src = user_metrics.KERR_SCHILD if generic == "user" else user_metrics.KERR_SCHILD_KS
+        metric = rt.UserMetric(src, M=metric.M, a=metric.a, stationary=True)
         generic = False
     sc = rt.make_scene(metric, objs)
     if generic and variant != "mink":
@@ -245,7 +247,7 @@ def main():
     if ws > 1:
         os.environ["RTGR_NO_COMPILE"] = "1"   # --rhs user on a cold cache: fail fast instead of N ranks starting hipcc
     npdt = np.float64 if a.dtype == "f64" else np.float32
-    scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user"}[a.rhs])
+    scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user", "user_ks": "user_ks"}[a.rhs])
     opt = rt.solver_defaults(npdt)
     ni = nj = a.size
     # rows are dealt cyclically (rank r: rows r, r+N, …): contiguous slabs of a black-hole image are unbalanced

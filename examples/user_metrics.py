@@ -25,6 +25,26 @@ template <class S> __device__ void rtgr_user_metric(const S x[4], double M, doub
 }
 '''
 
+# The same metric given in KERR–SCHILD FORM (rtgr_user_ks): only f and k — what is different between one Kerr–Schild metric
+# and another.  The library derives g = eta + f k k for the camera and the evaluation hooks, and the integrate kernels
+# differentiate these four scalars (instead of ten metric entries) and use the closed contraction of the built-ins.
+# Contract: k_t = 1, k null with respect to eta (|k| = 1), no t-dependence.
+KERR_SCHILD_KS = r'''
+template <class S> __device__ void rtgr_user_ks(const S x[4], double M, double a, S& f, S k[3]) {
+    const S X = x[1], Y = x[2], Z = x[3];
+    const double a2 = a * a;
+    const S ZZ = Z * Z;
+    const S q = X * X + Y * Y + ZZ - a2;
+    const S r2 = 0.5 * (q + msqrt(q * q + (4.0 * a2) * ZZ));
+    const S r = msqrt(r2);
+    f = ((2.0 * M) * (r2 * r)) / (r2 * r2 + a2 * ZZ);
+    const S den = r2 + a2;
+    k[0] = (r * X + a * Y) / den;
+    k[1] = (r * Y - a * X) / den;
+    k[2] = Z / r;
+}
+'''
+
 # Schwarzschild in isotropic coordinates — NOT of Kerr–Schild form, so no built-in covers it:
 #   ds² = −((1−m)/(1+m))² dt² + (1+m)⁴ (dx²+dy²+dz²),  m = M / (2ρ)
 SCHWARZSCHILD_ISOTROPIC = r'''

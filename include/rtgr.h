@@ -343,7 +343,15 @@ int rtgr_eval_fastmath_f64(rtgr_context* ctx, const double* x, uint64_t n, doubl
  * of the code object: loading the same file twice yields the same id and one resident copy).  A scene selects it with
  * metric = RTGR_USER and user_metric = id, in every entry point that takes a scene (trace, make_canvas, eval_metric,
  * eval_geodesic path 1); M and a of the scene are passed through to the function.  Several metrics may be resident at
- * once.  The Python mirror automates the steps (api.UserMetric). */
+ * once.  The Python mirror automates the steps (api.UserMetric).
+ *
+ * A metric OF KERR–SCHILD FORM, g = eta + f k (x) k with k_t = 1, k null with respect to eta and no t-dependence, may be given
+ * by its two ingredients instead of its 16 entries:
+ *     template <class S> __device__ void rtgr_user_ks(const S x[4], double M, double a, S& f, S k[3]);
+ * (unit built with -DRTGR_USER_KS=1 -DRTGR_USER_NE=3; rtgr_user_metric_compile detects the name in the source text).  The
+ * unit derives the 16 entries for make_canvas and the evaluation hooks; its integrate kernels differentiate the four scalars
+ * (f, k_x, k_y, k_z) and use the closed contraction of the built-in metrics — no 4x4 solve.
+ * rtgr_eval_geodesic_f64(path = 2) on a user scene evaluates exactly that loop RHS. */
 int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out);
 /* The same in ONE call from source text: `source` (the definition of rtgr_user_metric<S>, as above) is pasted into the
  * unit template, compiled IN-PROCESS with hiprtc (libhiprtc is resolved with dlopen at first use; ~3 s; no hipcc needed on

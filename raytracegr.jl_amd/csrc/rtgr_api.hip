@@ -1436,9 +1436,11 @@ static int eval_geodesic_host(rtgr_context* ctx, const rtgr_scene* scene, const 
     if ((rc = bi.alloc(n * 8 * sizeof(R)))) return rc;
     if ((rc = bo.alloc(n * 8 * sizeof(R)))) return rc;
     HIP_TRY(hipMemcpy(bi.p, s, n * 8 * sizeof(R), hipMemcpyHostToDevice));
-    if (sc.metric == RTGR_USER) {  // a user metric has the generic path only
+    if (sc.metric == RTGR_USER) {  // paths 0 / 1: the reference formulation (4-wide duals through g); path 2: the unit's own loop RHS
         if (sizeof(R) != 8) return fail(RTGR_ERR_BAD_ARG, "user metrics are evaluated in Float64");
-        HIP_TRY(launch_module(user->eval_geodesic, (unsigned)((n + 255) / 256), 256, (hipStream_t) nullptr, sc, (const R*)bi.p, n, (R*)bo.p));
+        if (path == 2 && !user->eval_accel) return fail(RTGR_ERR_BAD_ARG, "this user-metric code object carries no rtgr_user_eval_accel");
+        HIP_TRY(launch_module(path == 2 ? user->eval_accel : user->eval_geodesic, (unsigned)((n + 255) / 256), 256,
+                              (hipStream_t) nullptr, sc, (const R*)bi.p, n, (R*)bo.p));
     } else if constexpr (sizeof(R) == 8) {
         if ((rc = misc_eval_geodesic_f64(sc, (const double*)bi.p, n, path, (double*)bo.p, nullptr))) return rc;
     } else {
@@ -1539,7 +1541,8 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
             {&u.canvas, "rtgr_user_canvas", true},           {&u.eval_metric, "rtgr_user_eval_metric", true},
             {&u.eval_geodesic, "rtgr_user_eval_geodesic", true}, {&u.prepare, "rtgr_user_prepare", true},
             {&u.full10_f32, "rtgr_user_integrate_full10_f32", false}, {&u.fulln_f32, "rtgr_user_integrate_fulln_f32", false},
-            {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false}};
+            {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false},
+            {&u.eval_accel, "rtgr_user_eval_accel", false}};
         for (auto& w : want)
             if (hipModuleGetFunction(w.f, u.module, w.name) != hipSuccess) {
                 (void)hipGetLastError();
@@ -1627,9 +1630,11 @@ int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationa
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
     if (rc) return rc;
-    if (!source || !std::strstr(source, "rtgr_user_metric"))
+    const bool ks_form = source && std::strstr(source, "rtgr_user_ks") != nullptr;
+    if (!source || (!ks_form && !std::strstr(source, "rtgr_user_metric")))
         return fail(RTGR_ERR_BAD_ARG, "the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
-                                      "double M, double a, S g[4][4])`");
+                                      "double M, double a, S g[4][4])` (or, for a metric of Kerr-Schild form, rtgr_user_ks(const S "
+                                      "x[4], double M, double a, S& f, S k[3]))");
     Hiprtc& R = hiprtc();
     if (!R.ok()) return fail(RTGR_ERR_BAD_ARG, "libhiprtc not found: build the unit with hipcc --genco and use rtgr_user_metric_load");
     const std::string dir = csrc_dir();
@@ -1650,7 +1655,8 @@ int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationa
     if (R.create(&prog, unit.c_str(), "rtgr_user_unit.hip", 2, hdr_src, hdr_name) != 0) return fail(RTGR_ERR_HIP, "hiprtcCreateProgram failed");
     const std::string inc = "-I" + dir;
     std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
-    if (stationary) opts.push_back("-DRTGR_USER_NE=3");
+    if (stationary || ks_form) opts.push_back("-DRTGR_USER_NE=3");   // (Kerr–Schild form: stationary by contract)
+    if (ks_form) opts.push_back("-DRTGR_USER_KS=1");
     const int cr = R.compile(prog, (int)opts.size(), opts.data());
     if (cr != 0) {
         size_t ls = 0;

@@ -74,7 +74,7 @@ struct UserModule {
     hipModule_t module = nullptr;
     bool owned = true;   // false: a logical duplicate of a device shares its twin's module and must not unload it
     hipFunction_t far = nullptr, near = nullptr, full10 = nullptr, fulln = nullptr, canvas = nullptr, prepare = nullptr,
-                  eval_metric = nullptr, eval_geodesic = nullptr;
+                  eval_metric = nullptr, eval_geodesic = nullptr, eval_accel = nullptr;
     // Float32 twins (absent in units built without them)
     hipFunction_t full10_f32 = nullptr, fulln_f32 = nullptr, prepare_f32 = nullptr, canvas_f32 = nullptr;
 };

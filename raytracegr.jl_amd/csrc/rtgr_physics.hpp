@@ -580,6 +580,14 @@ RTGR_DT struct MConst<RTGR_DD> { static RTGR_DEV RTGR_DD make(double c) { return
 template <class S> RTGR_DEV S mconst(double c) { return MConst<S>::make(c); }
 #ifdef RTGR_USER_METRIC
 template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]);
+#ifdef RTGR_USER_KS
+// A user metric OF KERR–SCHILD FORM, g = η + f k⊗k with k_t = 1, k null with respect to η (|k⃗|² = 1: what makes it a
+// Kerr–Schild metric and g⁻¹ = η⁻¹ − f k♯k♯) and no t-dependence, may be given by its two ingredients instead of its 16
+// entries: the unit then defines rtgr_user_ks (and the unit template derives rtgr_user_metric from it for the camera and the
+// evaluation hooks).  The integrate kernels push 3-wide duals through FOUR scalars (f, k_x, k_y, k_z) instead of ten
+// metric entries and contract with ksform_accel — no 4x4 solve, no per-direction matrix–vector products.
+template <class S> __device__ void rtgr_user_ks(const S x[4], double M, double a, S& f, S k[3]);
+#endif
 #endif
 
 // metric(x::SVector{4,Dual}) for the built-ins; the UPPER triangle g[a][b], a <= b, is filled (and mirrored).
@@ -754,10 +762,43 @@ RTGR_DEV void generic_rhs(uint32_t metric, R M, R a, const R s[8], R ds[8]) {
 
 // acceleration through the GENERIC dual-number path (what the reference does for any metric callable): used by the
 // integrate kernels when the scene asks for it (RTGR_METRIC_GENERIC flag) and for every user metric.
+#if defined(RTGR_USER_METRIC) && defined(RTGR_USER_KS)
+// u̇ for a user metric given in Kerr–Schild form (rtgr_user_ks): (f, ∇f, k_i, ∂_j k_i) from 3-wide forward duals through the
+// user's function, then the closed contraction of the built-ins' IEEE path with S = f (k null).
+template <class R>
+RTGR_DEV void user_ks_accel(const R x[4], const R u[4], R M, R a, R ud[4]) {
+    using Dd = DDual<R, 3, true>;
+    Dd xd[4], f, k[3];
+    for (int p = 0; p < 4; p++) {
+        xd[p] = dconst_<R, 3, true>(x[p]);
+        if (p >= 1) xd[p].e[p - 1] = R(1);
+    }
+    rtgr_user_ks<Dd>(xd, (double)M, (double)a, f, k);
+    const R ut = u[0], ux = u[1], uy = u[2], uz = u[3];
+    const R K = rfma(k[0].v, ux, rfma(k[1].v, uy, rfma(k[2].v, uz, ut)));                       // k_a u^a
+    const R Df = rfma(f.e[0], ux, rfma(f.e[1], uy, f.e[2] * uz));                               // u·∇f
+    R Dk[3], W[3];
+    for (int i = 0; i < 3; i++) Dk[i] = rfma(k[i].e[0], ux, rfma(k[i].e[1], uy, k[i].e[2] * uz));        // u^j ∂_j k_i
+    for (int d = 0; d < 3; d++) W[d] = rfma(k[0].e[d], ux, rfma(k[1].e[d], uy, k[2].e[d] * uz));         // u^i ∂_d k_i
+    const R A = rfma(ux, Dk[0], rfma(uy, Dk[1], uz * Dk[2]));                                   // u^b u^c ∂_b k_c
+    const R P = rfma(K, Df, f.v * A);                                                           // L_t
+    const R fK = f.v * K, hK2 = R(-0.5) * K * K;
+    R L[3];
+    for (int i = 0; i < 3; i++) L[i] = rfma(k[i].v, P, rfma(fK, Dk[i] - W[i], hK2 * f.e[i]));
+    const R kL = rfma(k[0].v, L[0], rfma(k[1].v, L[1], rfma(k[2].v, L[2], -P)));                // k♯^d L_d, k♯ = (−1, k_i)
+    const R SkL = f.v * kL;                                                                     // S = f/(1 + f(|k|²−1)) = f
+    ud[0] = P - SkL;
+    for (int i = 0; i < 3; i++) ud[1 + i] = rfma(k[i].v, SkL, -L[i]);
+}
+#endif
+
 template <class R>
 RTGR_DEV void accel_generic(uint32_t metric, R xt, const R xs[3], const R u[4], R M, R a, R ud[4]) {
     const R x[4] = {xt, xs[0], xs[1], xs[2]};   // (xt = 0 for every stationary metric: it is never read)
 #ifdef RTGR_USER_METRIC
+#ifdef RTGR_USER_KS
+    if (metric == (uint32_t)RTGR_USER) { user_ks_accel<R>(x, u, M, a, ud); return; }
+#endif
     if (metric == (uint32_t)RTGR_USER) { generic_accel<R, RTGR_USER_NE, true>(metric, M, a, x, u, ud); return; }
 #endif
     generic_accel<R, 3, true>(metric, M, a, x, u, ud);   // the built-in metrics are stationary

@@ -53,11 +53,15 @@ def compile_user_metric(source, verbose=False, stationary=False):
     """Build (or fetch from the cache) the code object of a user metric; returns its path.  Needs hipcc, no GPU.
     stationary=True declares that the metric does not depend on t: the integrate kernels then carry the three spatial
     partials only (-DRTGR_USER_NE=3), a quarter less dual arithmetic."""
-    if "rtgr_user_metric" not in source:
+    ks_form = "rtgr_user_ks" in source    # the metric given in Kerr–Schild form: f and k instead of the 16 entries
+    if "rtgr_user_metric" not in source and not ks_form:
         raise ValueError("the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
-                         "double M, double a, S g[4][4])`")
+                         "double M, double a, S g[4][4])` (or rtgr_user_ks(const S x[4], double M, double a, S& f, S k[3]) "
+                         "for a metric of Kerr-Schild form)")
     d = cache_dir()
-    extra = ["-DRTGR_USER_NE=3"] if stationary else []
+    extra = ["-DRTGR_USER_NE=3"] if (stationary or ks_form) else []
+    if ks_form:
+        extra.append("-DRTGR_USER_KS=1")
     tag = _digest(source, extra)
     out = os.path.join(d, f"metric_{tag}.hsaco")
     if os.path.exists(out):

@@ -23,7 +23,8 @@ import user_metrics  # noqa: E402
 abi = rt._abi
 um = sys.modules[rt.__name__ + ".user_metric"]
 KERNELS = ["rtgr_user_integrate_far", "rtgr_user_integrate_near", "rtgr_user_integrate_full10",
-           "rtgr_user_integrate_fulln", "rtgr_user_canvas", "rtgr_user_prepare", "rtgr_user_eval_metric", "rtgr_user_eval_geodesic"]
+           "rtgr_user_integrate_fulln", "rtgr_user_canvas", "rtgr_user_prepare", "rtgr_user_eval_metric", "rtgr_user_eval_geodesic",
+           "rtgr_user_eval_accel"]
 
 
 def test_code_object_builds_on_cpu_and_has_every_kernel():
@@ -207,6 +208,53 @@ def test_time_dependent_user_metric_is_traced_at_the_rays_own_time(lib):
     bad = hip_trace(lib, rt.make_scene(frozen, objs), opt, 48, 48, cam=camera)
     ok = (bad["hit"] == ref["hit"]) & (ref["hit"] != 2) & (ref["hit"] > 0)
     assert (bad["hit"] != ref["hit"]).mean() > 0.05 or np.abs(bad["state_end"][ok] - ref["state_end"][ok]).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_user_metric_given_in_kerr_schild_form(lib):
+    """rtgr_user_ks: a user metric of Kerr–Schild form given by f and k alone (examples/user_metrics.py:KERR_SCHILD_KS).
+    The unit derives its 16 entries for the camera and the hooks (== the 16-entry source, == the oracle's kerr_schild),
+    and its integrate kernels use the closed contraction on the user's (f, k): the loop's own RHS (rtgr_eval_geodesic path 2
+    on a user scene) against the oracle pointwise, the traced frame against the oracle to the built-in metrics' bars, the
+    hiprtc route (the library detects rtgr_user_ks in the source text) against the hipcc-built unit."""
+    M, a = 1.0, 0.8
+    ks = rt.UserMetric(user_metrics.KERR_SCHILD_KS, M=M, a=a)
+    full = rt.UserMetric(user_metrics.KERR_SCHILD, M=M, a=a, stationary=True)
+    builtin = rt.KerrSchild(M, a)
+    sc_o = rt.make_scene(builtin, [])
+    x, rng = _points(2048, 41)
+    for got, ref in zip(rt.dmetric(ks, x), rt.dmetric(full, x)):
+        assert np.abs(got - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+    go, dgo, Go = O.eval_metric(sc_o, x)
+    g, dg = rt.dmetric(ks, x)
+    assert np.abs(g - go).max() <= 1e-13 and np.abs(dg - dgo).max() <= 1e-12 and np.abs(rt.christoffel(ks, x) - Go).max() <= 1e-11
+    s = np.concatenate([x, rng.normal(size=(len(x), 4))], axis=1)
+    ref = O.geodesic(sc_o, s)
+    scale = np.abs(ref[:, 4:]).max(axis=1, keepdims=True) + 1e-300
+    for m, path in ((ks, 2), (ks, 1), (full, 2), (builtin, 2)):
+        got = rt.geodesic(s, m, path=path)
+        assert (np.abs(got[:, 4:] - ref[:, 4:]) / scale).max() < 5e-12, (m, path)
+    _, objs, cam = rt.example2_scene()
+    from test_gpu_parity import compare, hip_trace
+    camera, opt = rt.make_camera(**cam), rt.solver_defaults()
+    oracle = O.trace(rt.make_scene(builtin, objs), opt, 64, 64, cam=camera)
+    gpu = hip_trace(lib, rt.make_scene(ks, objs), opt, 64, 64, cam=camera)
+    compare(gpu, oracle, max_class_flips=2, max_step_diff=2)
+    with abi.options(lib, split=0):
+        compare(hip_trace(lib, rt.make_scene(ks, objs), opt, 32, 32, cam=camera), O.trace(rt.make_scene(builtin, objs), opt, 32, 32, cam=camera),
+                max_class_flips=2, max_step_diff=2)
+    opt32 = rt.solver_defaults(np.float32)
+    g32 = hip_trace(lib, rt.make_scene(ks, objs), opt32, 32, 32, cam=camera, dtype=np.float32)
+    r32 = O.trace(rt.make_scene(builtin, objs), opt32, 32, 32, cam=camera, dtype=np.float32)
+    flips = g32["hit"] != r32["hit"]
+    assert flips.mean() <= 0.02
+    assert wrap_aware_rgb_err(g32["rgb"][:, ~flips].astype(float), r32["rgb"][:, ~flips].astype(float), g32["hit"][~flips], 3) < 2e-2
+    jit = rt.UserMetric(user_metrics.KERR_SCHILD_KS, M=M, a=a, jit=True)        # source text -> hiprtc inside the library
+    j = hip_trace(lib, rt.make_scene(jit, objs), opt, 40, 40, cam=camera)
+    h = hip_trace(lib, rt.make_scene(ks, objs), opt, 40, 40, cam=camera)
+    same = j["hit"] == h["hit"]
+    assert (~same).sum() <= 1 and wrap_aware_rgb_err(j["rgb"][:, same], h["rgb"][:, same], j["hit"][same], 3) <= 1e-6
+    assert np.abs(j["n_accept"].astype(int) - h["n_accept"].astype(int)).max() <= 1
 
 
 @pytest.mark.gpu
