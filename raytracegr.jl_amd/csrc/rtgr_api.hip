@@ -1534,6 +1534,10 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
                 return bail("not a user-metric code object (no rtgr_user_abi_version)");
             if (hipMemcpyDtoH(&ver, dptr, sizeof ver) != hipSuccess) return bail("cannot read rtgr_user_abi_version");
             if (ver != RTGR_ABI_VERSION) return bail("built against another ABI version");
+            unsigned fw = 0;   // optional: occupancy the unit's FAR pass was built for
+            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_far_waves") == hipSuccess && bytes == sizeof fw &&
+                hipMemcpyDtoH(&fw, dptr, sizeof fw) == hipSuccess && fw >= 1 && fw <= 8) u.far_waves = fw;
+            (void)hipGetLastError();
         }
         struct { hipFunction_t* f; const char* name; bool required; } want[] = {
             {&u.far, "rtgr_user_integrate_far", true},       {&u.near, "rtgr_user_integrate_near", true},

@@ -73,6 +73,7 @@ struct UserModule {
     uint64_t id = 0;
     hipModule_t module = nullptr;
     bool owned = true;   // false: a logical duplicate of a device shares its twin's module and must not unload it
+    unsigned far_waves = 0;  // waves per SIMD the unit's FAR pass is built for (0: the generic default)
     hipFunction_t far = nullptr, near = nullptr, full10 = nullptr, fulln = nullptr, canvas = nullptr, prepare = nullptr,
                   eval_metric = nullptr, eval_geodesic = nullptr, eval_accel = nullptr;
     // Float32 twins (absent in units built without them)

@@ -111,7 +111,8 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
 #endif
             { KernelTimer tm(D, st, 1);
               if constexpr (USER) {
-                  HIP_TRY(launch_module(E.user->far, grid(waves_per_simd_of<R, METRIC>(MODE_FAR)).x, 64, st, P));
+                  const int fw = E.user->far_waves ? (int)E.user->far_waves : waves_per_simd_of<R, METRIC>(MODE_FAR);
+                  HIP_TRY(launch_module(E.user->far, grid(fw).x, 64, st, P));
               } else {
                   bool four = false;
                   if constexpr (sizeof(R) == 8 && !SPIN && METRIC < RTGR_GENERIC_BASE && METRIC != RTGR_MINKOWSKI) {
