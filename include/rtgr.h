@@ -164,8 +164,9 @@ typedef struct rtgr_ray_outputs {
                              (:411; a future-directed coordinate 4-velocity such as the examples' (1,0,0,0)) normalised
                              at the end point, or the static observer there for planes / disks; NaN where the ray hits
                              nothing or u_emit is not timelike.
-                             No reference counterpart (`vel` is stored and never used, :411, :416).  Float64 entry
-                             points of the built-in metrics only. */
+                             No reference counterpart (`vel` is stored and never used, :411, :416).  Every metric
+                             (built-in, run-time compiled) and both scalar types, like `Sphere{T}` and the metric
+                             argument of the reference (:409-413, :302-309); n scalars of the entry point's type. */
 } rtgr_ray_outputs;
 
 /* ---- lifecycle --------------------------------------------------------------------------------------------- */

@@ -430,8 +430,8 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
         A.n_accept = out->n_accept;
         A.n_reject = out->n_reject;
         if (out->redshift) {
-            if (sizeof(R) != 8 || A.sc.metric == RTGR_USER)
-                return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift: Float64 entry points of the built-in metrics only");
+            if (A.sc.metric == RTGR_USER && !(sizeof(R) == 8 ? user->redshift : user->redshift_f32))
+                return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift: this user-metric code object carries no rtgr_user_redshift kernel (rebuild the unit)");
             if (!out->state_end || !out->hit)
                 return fail(RTGR_ERR_BAD_ARG, "rtgr_ray_outputs.redshift needs state_end and hit in the same call");
         }
@@ -449,12 +449,20 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
     LaunchEnv E{D, *ss, user, win ? win->after_setup : nullptr};
     rc = dispatch(E, A, generic, spin, st);
     if (rc) return rc;
-    if constexpr (sizeof(R) == 8) {
-        if (out && out->redshift) {   // one more kernel behind the pipeline: needs the end states and the hit map it wrote
-            rc = misc_redshift_f64(A.sc, A.cam, (const double*)A.state0, ni, nj, j0, jstride, ni * nrows, A.out_offset,
+    if (out && out->redshift) {   // one more kernel behind the pipeline: needs the end states and the hit map it wrote
+        const uint64_t nr = ni * nrows;
+        if (A.sc.metric == RTGR_USER) {
+            HIP_TRY(launch_module(sizeof(R) == 8 ? user->redshift : user->redshift_f32, (unsigned)((nr + 255) / 256), 256, st, A.sc, A.cam,
+                                  A.state0, ni, nj, j0, jstride, nr, A.out_offset, (const R*)A.state_end, (const uint8_t*)A.hit,
+                                  (R*)out->redshift));
+        } else if constexpr (sizeof(R) == 8) {
+            rc = misc_redshift_f64(A.sc, A.cam, (const double*)A.state0, ni, nj, j0, jstride, nr, A.out_offset,
                                    (const double*)A.state_end, A.hit, (double*)out->redshift, st);
-            if (rc) return rc;
+        } else {
+            rc = misc_redshift_f32(A.sc, A.cam, (const float*)A.state0, ni, nj, j0, jstride, nr, A.out_offset,
+                                   (const float*)A.state_end, A.hit, (float*)out->redshift, st);
         }
+        if (rc) return rc;
     }
     HIP_TRY(hipGetLastError());
     return RTGR_OK;
@@ -1150,7 +1158,7 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         if (out0->hit) arrs.push_back({1, 1, out0->hit, 0});
         if (out0->n_accept) arrs.push_back({4, 1, out0->n_accept, 0});
         if (out0->n_reject) arrs.push_back({4, 1, out0->n_reject, 0});
-        if (out0->redshift) arrs.push_back({8, 1, out0->redshift, 0});
+        if (out0->redshift) arrs.push_back({sizeof(R), 1, out0->redshift, 0});
     }
     const uint64_t nrows_max = (nj + N - 1) / N, nmax = ni * nrows_max;
     size_t part_bytes = 0;
@@ -1546,7 +1554,8 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
             {&u.eval_geodesic, "rtgr_user_eval_geodesic", true}, {&u.prepare, "rtgr_user_prepare", true},
             {&u.full10_f32, "rtgr_user_integrate_full10_f32", false}, {&u.fulln_f32, "rtgr_user_integrate_fulln_f32", false},
             {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false},
-            {&u.eval_accel, "rtgr_user_eval_accel", false}};
+            {&u.eval_accel, "rtgr_user_eval_accel", false}, {&u.redshift, "rtgr_user_redshift", false},
+            {&u.redshift_f32, "rtgr_user_redshift_f32", false}};
         for (auto& w : want)
             if (hipModuleGetFunction(w.f, u.module, w.name) != hipSuccess) {
                 (void)hipGetLastError();

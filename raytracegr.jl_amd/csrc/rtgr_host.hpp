@@ -78,6 +78,7 @@ struct UserModule {
                   eval_metric = nullptr, eval_geodesic = nullptr, eval_accel = nullptr;
     // Float32 twins (absent in units built without them)
     hipFunction_t full10_f32 = nullptr, fulln_f32 = nullptr, prepare_f32 = nullptr, canvas_f32 = nullptr;
+    hipFunction_t redshift = nullptr, redshift_f32 = nullptr;   // optional (units built before round 3 have none)
 };
 
 struct TimedLaunch { hipEvent_t a, b; int which; };
@@ -179,6 +180,9 @@ int misc_eval_fastmath_f64(const double* d_x, uint64_t n, double* d_rcp, double*
 int misc_redshift_f64(const DevScene<double>& sc, const DevCamera<double>& cam, const double* d_state0, uint64_t ni, uint64_t nj,
                       uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const double* d_state_end,
                       const uint8_t* d_hit, double* d_red, hipStream_t st);
+int misc_redshift_f32(const DevScene<float>& sc, const DevCamera<float>& cam, const float* d_state0, uint64_t ni, uint64_t nj,
+                      uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const float* d_state_end,
+                      const uint8_t* d_hit, float* d_red, hipStream_t st);
 int misc_quantize(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, hipStream_t st);
 // multi-device gather on device 0: rows of rank r (cyclic over nranks) back into place
 int misc_place_rows_f64(const double* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,

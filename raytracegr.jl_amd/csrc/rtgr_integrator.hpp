@@ -379,4 +379,67 @@ RTGR_DEV void make_pixel(const DevScene<R>& sc, const DevCamera<R>& cam, uint64_
     }
 }
 
+// ---- redshift (rtgr_ray_outputs.redshift; SURVEY §8 f4: "Doppler/redshift via the unused Sphere.vel", :411, :416) --------
+// g = (k·u_obs) / (k·u_emit): the ratio observed / emitted frequency of the light that reaches a pixel.
+//   k      = tangent of the traced ray (an affinely parametrised null geodesic, so k is parallel-transported and the
+//            ratio does not depend on its normalisation or on the direction the ray was traced in)
+//   u_obs  = the static observer make_canvas builds every ray from, future-directed: −g^{-1} e_t / sqrt(−g(t,t)) at the
+//            pixel (:471-472; the reference uses the past-directed sign because it traces rays backwards in time)
+//   u_emit = Sphere: its `vel` (coordinate 4-velocity as stored in the reference's struct) normalised with the metric at
+//            the hit point; Plane / Disk: the static observer t̂ there
+//   ·      = the metric at the respective end of the ray — ANY metric: built-in or run-time compiled, Float64 or Float32
+// NaN where nothing is hit, or where u_emit is not timelike (a static emitter inside the ergoregion, vel = 0, …).
+template <class R>
+RTGR_DEV void static_observer(const R g[4][4], R t[4], bool& ok) {
+    R gu[4][4];
+    inv4sym<R>(g, gu);
+    R t2 = R(0);
+    for (int p = 0; p < 4; p++) t[p] = gu[p][0];
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; q < 4; q++) t2 += t[p] * g[p][q] * t[q];
+    ok = t2 < R(0);
+    const R s = R(-1) / rsqrt_(-t2);   // g^{-1} e_t points to the past (make_canvas builds past-directed rays from it); −: future
+    for (int p = 0; p < 4; p++) t[p] *= s;
+}
+template <class R>
+RTGR_DEV R inner(const R g[4][4], const R a[4], const R b[4]) {
+    R acc = R(0);
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; q < 4; q++) acc += a[p] * g[p][q] * b[q];
+    return acc;
+}
+// one thread per ray; a body function so that run-time compiled metric units wrap it in kernels of their own (metric_plain
+// dispatches to the unit's rtgr_user_metric there)
+template <class R>
+RTGR_DEV void redshift_body(const DevScene<R>& sc, const DevCamera<R>& cam, const R* state0, uint64_t ni, uint64_t nj, uint64_t j0,
+                            uint64_t jstride, uint64_t n, uint64_t out_offset, const R* state_end, const uint8_t* hit, R* red) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const uint64_t idx = out_offset + w;
+    const R nan = R(__builtin_nan(""));
+    const uint32_t h = hit[idx];
+    if (h == 0 || h > sc.nobj) { red[idx] = nan; return; }
+    R s0[8], se[8];
+    if (state0) for (int c = 0; c < 8; c++) s0[c] = state0[w * 8 + c];
+    else make_pixel<R>(sc, cam, ni, nj, w % ni, j0 + (w / ni) * jstride, s0);
+    for (int c = 0; c < 8; c++) se[c] = state_end[idx * 8 + c];
+    R g0[4][4], ge[4][4], tobs[4], uem[4];
+    bool ok0, oke;
+    metric_plain<R>(sc, s0, g0);
+    static_observer<R>(g0, tobs, ok0);
+    metric_plain<R>(sc, se, ge);
+    const DevObject<R>& ob = sc.obj[h - 1];
+    if (ob.kind == RTGR_SPHERE) {
+        const R v[4] = {ob.p[4], ob.p[5], ob.p[6], ob.p[7]};
+        const R v2 = inner<R>(ge, v, v);
+        oke = v2 < R(0);
+        const R s = R(1) / rsqrt_(-v2);
+        for (int p = 0; p < 4; p++) uem[p] = v[p] * s;
+    } else {
+        static_observer<R>(ge, uem, oke);
+    }
+    const R num = inner<R>(g0, s0 + 4, tobs), den = inner<R>(ge, se + 4, uem);
+    red[idx] = (ok0 && oke) ? num / den : nan;
+}
+
 }  // namespace rtgr

@@ -729,6 +729,42 @@ def test_redshift_output_matches_its_definition(lib):
                               C.byref(o2), None) == abi.ERR_BAD_ARG
 
 
+def test_redshift_output_for_float32_and_run_time_compiled_metrics(lib):
+    """`Sphere{T}` and the metric argument are generic in the reference (src/RayTraceGR.jl:409-413, :302-309), so the redshift
+    output is too: (1) a user-typed Kerr–Schild metric (16-entry source and Kerr–Schild-form source) gives the built-in
+    metric's redshift plane to rounding — the definition evaluated with the USER's metric function at both ends of the ray;
+    (2) the Float32 entry point agrees with the Float64 plane at a Float32 bar on the rays whose end point is well
+    conditioned (sphere and sky hits)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import user_metrics
+    _, objs, cam = rt.example2_scene()
+    objs[2] = rt.Sphere((0, 4, 0, 0), (1.1, 0.2, -0.1, 0.3), 0.5)
+    camera, opt = rt.make_camera(**cam), rt.solver_defaults()
+    ref = _trace_with_redshift(lib, rt.make_scene(rt.KerrSchild(1, 0.8), objs), opt, 48, 48, camera)
+    fin = np.isfinite(ref["redshift"])
+    assert fin.sum() > 1500
+    for src in (user_metrics.KERR_SCHILD, user_metrics.KERR_SCHILD_KS):
+        um = rt.UserMetric(src, M=1.0, a=0.8, stationary=True)
+        got = _trace_with_redshift(lib, rt.make_scene(um, objs), opt, 48, 48, camera)
+        same = (got["hit"] == ref["hit"]) & fin & (ref["hit"] != 2)
+        assert same.sum() > 1000 and np.array_equal(np.isfinite(got["redshift"]), fin)
+        assert np.abs(got["redshift"][same] / ref["redshift"][same] - 1).max() < 1e-8
+    # Float32
+    n = 48 * 48
+    opt32 = rt.solver_defaults(np.float32)
+    rgb = np.zeros((3, n), np.float32)
+    o, arrs = O._outs(n, np.float32, True)
+    red = np.zeros(n, np.float32)
+    o.redshift = red.ctypes.data
+    sc = rt.make_scene(rt.KerrSchild(1, 0.8), objs)
+    abi.check(lib, lib.rtgr_trace_f32(None, C.byref(sc), C.byref(opt32), None, C.byref(camera), 48, 48, 0, 48, rgb.ctypes.data,
+                                      C.byref(o), None))
+    same = (arrs["hit"] == ref["hit"]) & fin & (ref["hit"] != 2)
+    assert same.sum() > 1000 and np.isnan(red[arrs["hit"] == 0]).all()
+    assert np.abs(red[same].astype(float) / ref["redshift"][same] - 1).max() < 2e-3
+
+
 def test_nan_states_end_rays_cleanly_on_every_pass(lib):
     """kerr_schild as written with a != 0 takes sqrt(rho² - a²) (src/RayTraceGR.jl:284): NaN for rho < a, where the
     reference would throw (`@assert !any(isnan, …)`, :279).  Here the ray ends with status RTGR_RAY_NAN — in the FAR

@@ -34,9 +34,16 @@ def classify(op):
         return "cmp_f64"
     if TRANS.match(op):
         return "trans_" + op.rsplit("_", 1)[1][:3]
-    if op.startswith(("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_pk_", "v_max_f32", "v_min_f32",
-                      "v_med3_f32", "v_mac_f32")):
-        return "f32_arith"
+    if op.startswith(("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")):
+        return "pk_f32"      # two f32 operations per lane in ONE issue slot (the PMC counters count such an instruction once)
+    if op.startswith(("v_fma_f32", "v_fmac_f32", "v_mac_f32")):
+        return "fma_f32"
+    if op.startswith("v_mul_f32"):
+        return "mul_f32"
+    if op.startswith(("v_add_f32", "v_sub_f32")):
+        return "add_f32"
+    if op.startswith(("v_pk_", "v_max_f32", "v_min_f32", "v_med3_f32")):
+        return "f32_other"
     if op.startswith("v_cmp"):
         return "cmp_other"
     if op.startswith("v_cvt"):
@@ -100,6 +107,14 @@ def main():
         flop = 2 * c["fma_f64"] + c["mul_f64"] + c["add_f64"]
         print(f"== {title}: {len(seq)} instructions, {valu} VALU, {f64} f64 FMA/MUL/ADD ({c['fma_f64']}/{c['mul_f64']}/{c['add_f64']}), "
               f"{flop} f64 flop per lane, flop per VALU slot {flop / max(valu, 1):.3f} of 2")
+        pk = collections.Counter(op.split("_e")[0] for op, _ in seq if classify(op) == "pk_f32")
+        if pk or c["fma_f32"] + c["mul_f32"] + c["add_f32"] > 50:
+            f32 = c["fma_f32"] + c["mul_f32"] + c["add_f32"]
+            flop32 = 2 * c["fma_f32"] + c["mul_f32"] + c["add_f32"] + 4 * pk["v_pk_fma_f32"] + 2 * (pk["v_pk_mul_f32"] + pk["v_pk_add_f32"])
+            print(f"   f32: {f32} scalar FMA/MUL/ADD ({c['fma_f32']}/{c['mul_f32']}/{c['add_f32']}) + {sum(pk.values())} PACKED "
+                  f"({pk['v_pk_fma_f32']} pk_fma / {pk['v_pk_mul_f32']} pk_mul / {pk['v_pk_add_f32']} pk_add) = {flop32} f32 flop per lane; "
+                  f"{(sum(pk.values())) / max(f32 + sum(pk.values()), 1):.2f} of the arithmetic instructions are packed, "
+                  f"flop per VALU slot {flop32 / max(valu, 1):.3f} of 4")
         for k, v in sorted(c.items(), key=lambda kv: -kv[1]):
             print(f"   {k:12s} {v:6d}")
         return c
