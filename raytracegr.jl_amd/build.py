@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 UNITS = ["tu_f64_ksref.hip", "tu_f64_kstrue.hip", "tu_f64_generic.hip", "tu_f64_mink.hip", "tu_f32_closed.hip",
          "tu_f32_generic.hip", "rtgr_misc.hip", "rtgr_api.hip"]
 # the device-side headers: what the KERNELS are made of (bench.py keys its roofline profile on their hash)
-KERNEL_HEADERS = ["rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_tsit5_tables.hpp"]
+KERNEL_HEADERS = ["rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_packed_f32.hpp",
+                  "rtgr_tsit5_tables.hpp"]
 HEADERS = KERNEL_HEADERS + ["rtgr_host.hpp", "rtgr_pipeline.hpp"]
 DEPS = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(HERE, "..", "include", "rtgr.h")]
 OUT = os.path.join(HERE, "librtgr_hip.so")

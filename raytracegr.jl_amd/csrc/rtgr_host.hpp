@@ -61,6 +61,8 @@ struct Knobs {
     long tile = 0;                // 1: the simple tile-per-wave kernel (RTGR_KERNEL=tile), an independent formulation
     long host_chunk = -1;         // host entry points: rays per H2D/compute/D2H pipeline piece (auto: 2^20)
     long dbg_pass_far = 0;        // debug builds: which pass reports its wave timeline
+    long pack = -1;               // Float32 closed-form FULL pass: 0 = scalar kernel (one ray per lane), 1 = packed two-rays-per-lane
+                                  // kernel, -1 = packed where it pays (a != 0)
     long peer = -1;               // multi-device gather (rtgr_trace_sharded_device_*): 0 = always stage the rows through pinned
                                   // host memory (the no-peer-access fallback, forced), 1 = peer copies or fail, -1 = peer copies
                                   // where rtgr_create could enable peer access, the fallback elsewhere

@@ -25,6 +25,9 @@ namespace rtgr {
 
 #define RTGR_DEV __device__ __forceinline__
 
+template <class T> struct IsF64 { static constexpr bool v = false; };   // (no <type_traits>: the user units are also built by hiprtc)
+template <> struct IsF64<double> { static constexpr bool v = true; };
+
 // ---- small math helpers -------------------------------------------------------------------------------------------
 template <class R> RTGR_DEV R rfma(R a, R b, R c);
 template <> RTGR_DEV double rfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -383,7 +386,7 @@ RTGR_DEV void accel_spin_true(const R xs[3], const R u[4], const MetricK<R>& C, 
     //  the chain t -> 1/r -> r -> w compounds three roundings, +10 % on the RHS's rounding noise, which Float32 — whose
     //  error estimate sits close to that noise, and whose seeds cost half — cannot afford)
     R r, ir, w;
-    if constexpr (FAST && sizeof(R) == 8) {
+    if constexpr (FAST && IsF64<R>::v) {
         const R r2a = r2 + C.a2;
         const R t = frsq<R>(r2 * (r2a * r2a));
         ir = t * r2a;

@@ -13,9 +13,11 @@
 //   near_early = n     accepted steps at hand-over below which a ray is put on the NEAR pass's early list (64)
 //   waves_per_cu_near  resident waves per CU of the NEAR pass (auto 4 below 2.4 M rays — 6.3 M with spin —, else all)
 //   far4 = 0/1         force the 3- / 4-waves-per-SIMD instantiation of the a = 0 FAR pass (auto: by launch size)
+//   pack = 0           Float32: the scalar one-ray-per-lane kernel instead of the packed two-rays-per-lane one
 #pragma once
 #include "rtgr_host.hpp"
 #include "rtgr_persistent.hpp"
+#include "rtgr_packed_f32.hpp"
 
 namespace rtgr {
 
@@ -160,6 +162,21 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
 #endif
         KernelTimer tm(D, st, 1);
         const dim3 g = grid(waves_per_simd_of<R, METRIC>(MODE_FULL));
+        // Float32, closed-form RHS, the reference's 10 sample points: the two-rays-per-lane kernel (rtgr_packed_f32.hpp); a wave is a
+        // pool of 128 ray slots there.  It executes 1.55x fewer instructions per ray-step (PMC) but needs 205 registers — two waves
+        // per SIMD, where a wave issues at most 83 % of the slots (tools/micro/valu_rates.hip: 3.75 vs 3.13 ticks per instruction at 2
+        // vs 3 waves) — and v_pk_fma_f32 issues at 0.88 of a scalar v_fma_f32's rate: measured at 2048², +8 % with spin (the RHS, all
+        // of which packs, is 40 % of the step), -5 % at a = 0 (a 50-flop RHS).  Hence automatic for a != 0 only; option pack = 0 / 1
+        // forces the scalar / the packed kernel (A/B, tests).
+        if constexpr (sizeof(R) == 4 && METRIC < RTGR_GENERIC_BASE) {
+            if (npts10 && (K.pack >= 0 ? K.pack != 0 : SPIN)) {
+                const uint64_t waves2 = (IA.n + 127) / 128;
+                const uint64_t per_cu = K.waves_per_cu > 0 ? (uint64_t)K.waves_per_cu : (uint64_t)(4 * RTGR_WAVES_PER_SIMD_PACKED);
+                const uint64_t resident = (uint64_t)D.num_cu * per_cu;
+                hipLaunchKernelGGL((integrate2_kernel<METRIC, SPIN>), dim3((unsigned)(waves2 < resident ? waves2 : resident)), dim3(64), 0, st, P);
+                return RTGR_OK;
+            }
+        }
         if constexpr (USER) {
             hipFunction_t f = sizeof(R) == 8 ? (npts10 ? E.user->full10 : E.user->fulln)
                                              : (npts10 ? E.user->full10_f32 : E.user->fulln_f32);

@@ -551,6 +551,57 @@ def test_f32_crops_of_the_spinning_variants_match_f32_oracle(lib, name):
     assert gpu["counters"]["rays"] == 64 * 64 and gpu["counters"]["events"] >= 0.99 * ref["counters"]["events"]
 
 
+@pytest.mark.parametrize("name", ["mink", "ks_ref0", "ks_ref08", "ks_true08", "ks_true0998_disk"])
+def test_f32_packed_two_rays_per_lane_kernel_equals_the_scalar_kernel(lib, name):
+    """The Float32 FULL pass exists twice: one ray per lane (integrate_body<float>) and two rays per lane in packed f32
+    arithmetic (rtgr_packed_f32.hpp; automatic for a != 0, option pack = 0 / 1 forces either).  Same algorithm, same
+    operations per ray: every ray accounted for in both, Minkowski frames bit-identical (no RHS: nothing for the compiler
+    to contract differently), Kerr–Schild frames equal up to the last-bit differences of FMA contraction — identical hit
+    maps up to a few silhouette pixels, step attempts within 0.2 %, RGB within 1e-4 — with and without end states (the
+    packed kernel writes the velocity polynomial of every step when they are asked for), ragged sizes (odd ray counts
+    leave half-empty lanes), and against the Float32 oracle to the scalar kernel's bars."""
+    sc, cam = scene_variant(name)
+    opt = rt.solver_defaults(np.float32)
+    for ni, nj in ((96, 64), (33, 7), (1, 1)):
+        with abi.options(lib, pack=0):
+            one = hip_trace(lib, sc, opt, ni, nj, cam=cam, dtype=np.float32)
+        with abi.options(lib, pack=1):
+            two = hip_trace(lib, sc, opt, ni, nj, cam=cam, dtype=np.float32)
+        n = ni * nj
+        assert two["counters"]["rays"] == n and two["counters"]["events"] + two["counters"]["not_finished"] <= n
+        assert np.array_equal(two["status"], one["status"]) or (two["status"] != one["status"]).sum() <= max(1, n // 500)
+        if name == "mink":
+            for k in ("rgb", "state_end", "lambda_end", "n_accept", "n_reject", "status", "hit"):
+                assert np.array_equal(two[k], one[k], equal_nan=True), k
+            assert two["counters"] == one["counters"]
+            continue
+        flips = two["hit"] != one["hit"]
+        assert flips.sum() <= max(1, n // 500), flips.sum()
+        same = ~flips
+        assert wrap_aware_rgb_err(two["rgb"][:, same].astype(float), one["rgb"][:, same].astype(float), two["hit"][same]) < 1e-4
+        a2, a1 = (two["counters"][k] for k in ("accepted", "rejected")), (one["counters"][k] for k in ("accepted", "rejected"))
+        assert abs(sum(a2) - sum(a1)) <= 0.002 * sum(one["counters"][k] for k in ("accepted", "rejected")) + 2
+        ok = same & (one["hit"] != 2)      # (captured rays end with |u| ~ 1e4: relative bars only)
+        if ok.any():
+            assert np.abs(two["state_end"][ok] - one["state_end"][ok]).max() < 2e-3
+    # RGB only (no end states requested: the record layout without the velocity polynomial)
+    rgb1, rgb2 = np.zeros((3, 96 * 64), np.float32), np.zeros((3, 96 * 64), np.float32)
+    for pk, rgb in ((0, rgb1), (1, rgb2)):
+        with abi.options(lib, pack=pk):
+            abi.check(lib, lib.rtgr_trace_f32(None, C.byref(sc), C.byref(opt), None, C.byref(cam), 96, 64, 0, 64, rgb.ctypes.data, None, None))
+    assert (np.abs(rgb1 - rgb2).max(axis=0) > 1e-4).sum() <= 12
+    # the packed kernel against the Float32 oracle, the scalar kernel's bars
+    with abi.options(lib, pack=1):
+        gpu = hip_trace(lib, sc, opt, 64, 64, cam=cam, dtype=np.float32)
+    ref = O.trace(sc, opt, 64, 64, cam=cam, dtype=np.float32)
+    flips = gpu["hit"] != ref["hit"]
+    assert flips.mean() <= (0.03 if name == "mink" else 0.01), flips.mean()
+    assert wrap_aware_rgb_err(gpu["rgb"][:, ~flips].astype(float), ref["rgb"][:, ~flips].astype(float), gpu["hit"][~flips]) < 2e-2
+    g = gpu["counters"]["accepted"] + gpu["counters"]["rejected"]
+    r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
+    assert 0.7 * r <= g <= 1.1 * r
+
+
 @pytest.mark.parametrize("name", ["ks_ref0", "ks_true08"])
 def test_f32_generic_path_bounds_the_step_count_gap(lib, name):
     """The Float32 closed contraction takes 15-20 % fewer steps than the Float32 oracle (above).  Explanation under

@@ -17,7 +17,7 @@ import sys
 
 d = sys.argv[1]
 entry_out = sys.argv[sys.argv.index("--entry-out") + 1] if "--entry-out" in sys.argv else None
-WANT = ("integrate_kernel", "integrate_far4_kernel", "prepare_kernel", "resolve_kernel", "trace_kernel", "canvas_kernel",
+WANT = ("integrate_kernel", "integrate2_kernel", "integrate_far4_kernel", "prepare_kernel", "resolve_kernel", "trace_kernel", "canvas_kernel",
         "rtgr_user_integrate", "rtgr_user_prepare", "order_scatter")
 stats = {}
 for f in glob.glob(d + "/trace/*/*_kernel_stats.csv"):
