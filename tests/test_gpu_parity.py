@@ -367,17 +367,25 @@ def test_max_steps_status(lib):
     assert gpu["counters"]["not_finished"] == int((gpu["status"] >= 2).sum())
 
 
+# Float32 against the Float32 oracle, the bars ("tighten the crop tests to what was measured").  Measured on 64²
+# crops of six scene variants, scalar and packed kernel (round 3): 0 hit-class flips; wrap-aware RGB difference <= 3.1e-4 on
+# the small sphere, <= 2.6e-5 on the sky, 0 on the plane; step attempts 0.86-0.96 x the oracle's.  Both are Float32
+# solutions whose own distance from the TRUE geodesic is ~1.6e-4 in state / 5.5e-5 in RGB (tests/test_truth.py, bar 5e-4),
+# so two of them may differ by twice that: RGB bar 1e-3 (round 2: 2e-2), flips <= 0.25 % (round 2: 1 %), step attempts
+# within [0.8, 1.0] x the oracle's (round 2: [0.7, 1.1]).
+F32_RGB_TOL, F32_FLIP_FRAC, F32_STEPS = 1e-3, 0.0025, (0.8, 1.0)
+
+
 def test_f32_path_matches_f32_oracle_statistically(lib):
-    """Config C4 (Float32, tol = eps(Float32)^(3/4)): compared with the Float32 oracle; bound relaxed (stated:
-    hit classes may flip on ≤1 % of pixels, RGB of the rest within 2e-2 wrap-aware)."""
+    """Config C4 (Float32, tol = eps(Float32)^(3/4)): compared with the Float32 oracle at the Float32 bars above."""
     sc, cam = example(2)
     opt = rt.solver_defaults(np.float32)
     gpu = hip_trace(lib, sc, opt, 64, 64, cam=cam, dtype=np.float32)
     ref = O.trace(sc, opt, 64, 64, cam=cam, dtype=np.float32)
     flips = gpu["hit"] != ref["hit"]
-    assert flips.mean() <= 0.01
+    assert flips.mean() <= F32_FLIP_FRAC
     same = ~flips
-    assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same]) < 2e-2
+    assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same]) < F32_RGB_TOL
 
 
 def test_quantize_and_device_pointers(lib):
@@ -521,14 +529,14 @@ def test_f32_step_statistics_match_f32_oracle(lib):
     """Float32 path (config C4).  In Float32 the embedded error estimate sits close to the rounding noise of the RHS
     (tol = 6.4e-6 vs eps = 1.2e-7), and the oracle's as-written formulation (duals through every metric entry, 64
     Christoffel symbols) is noisier than the device's closed contraction, so it accepts ~15-20 % more, smaller steps.
-    Stated bound: device step attempts within [0.7, 1.1] x the Float32 oracle's; every ray still ends by an event."""
+    Stated bound: device step attempts within [0.8, 1.0] x the Float32 oracle's (measured 0.86); every ray still ends by an event."""
     sc, cam = example(2)
     opt = rt.solver_defaults(np.float32)
     gpu = hip_trace(lib, sc, opt, 96, 96, cam=cam, dtype=np.float32)
     ref = O.trace(sc, opt, 96, 96, cam=cam, dtype=np.float32)
     g = gpu["counters"]["accepted"] + gpu["counters"]["rejected"]
     r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
-    assert 0.7 * r <= g <= 1.1 * r, (gpu["counters"], ref["counters"])
+    assert F32_STEPS[0] * r <= g <= F32_STEPS[1] * r, (gpu["counters"], ref["counters"])
     assert gpu["counters"]["events"] == ref["counters"]["events"] == 96 * 96
 
 
@@ -536,18 +544,19 @@ def test_f32_step_statistics_match_f32_oracle(lib):
 def test_f32_crops_of_the_spinning_variants_match_f32_oracle(lib, name):
     """Config C4 runs Kerr–Schild a = 0.8 in Float32: accel_spin<float> (as-written and textbook radius, with the
     null-congruence shortcuts) against the Float32 oracle.  Stated bounds as for a = 0: <= 1 % hit-class flips, RGB of
-    the rest within 2e-2 wrap-aware, every ray accounted for, step attempts within [0.7, 1.1] x the oracle's."""
+    the rest within 1e-3 wrap-aware, every ray accounted for, step attempts within [0.8, 1.0] x the oracle's (the Float32
+    bars stated above test_f32_path_matches_f32_oracle_statistically)."""
     sc, cam = scene_variant(name)
     opt = rt.solver_defaults(np.float32)
     gpu = hip_trace(lib, sc, opt, 64, 64, cam=cam, dtype=np.float32)
     ref = O.trace(sc, opt, 64, 64, cam=cam, dtype=np.float32)
     flips = gpu["hit"] != ref["hit"]
-    assert flips.mean() <= 0.01, flips.mean()
+    assert flips.mean() <= F32_FLIP_FRAC, flips.mean()
     same = ~flips
-    assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same]) < 2e-2
+    assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same]) < F32_RGB_TOL
     g = gpu["counters"]["accepted"] + gpu["counters"]["rejected"]
     r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
-    assert 0.7 * r <= g <= 1.1 * r, (gpu["counters"], ref["counters"])
+    assert F32_STEPS[0] * r <= g <= F32_STEPS[1] * r, (gpu["counters"], ref["counters"])
     assert gpu["counters"]["rays"] == 64 * 64 and gpu["counters"]["events"] >= 0.99 * ref["counters"]["events"]
 
 
@@ -596,11 +605,11 @@ def test_f32_packed_two_rays_per_lane_kernel_equals_the_scalar_kernel(lib, name)
         gpu = hip_trace(lib, sc, opt, 64, 64, cam=cam, dtype=np.float32)
     ref = O.trace(sc, opt, 64, 64, cam=cam, dtype=np.float32)
     flips = gpu["hit"] != ref["hit"]
-    assert flips.mean() <= (0.03 if name == "mink" else 0.01), flips.mean()
-    assert wrap_aware_rgb_err(gpu["rgb"][:, ~flips].astype(float), ref["rgb"][:, ~flips].astype(float), gpu["hit"][~flips]) < 2e-2
+    assert flips.mean() <= (0.03 if name == "mink" else F32_FLIP_FRAC), flips.mean()
+    assert wrap_aware_rgb_err(gpu["rgb"][:, ~flips].astype(float), ref["rgb"][:, ~flips].astype(float), gpu["hit"][~flips]) < F32_RGB_TOL
     g = gpu["counters"]["accepted"] + gpu["counters"]["rejected"]
     r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
-    assert name == "mink" or 0.7 * r <= g <= 1.1 * r      # (Minkowski: the step sequence is rounding noise)
+    assert name == "mink" or F32_STEPS[0] * r <= g <= F32_STEPS[1] * r      # (Minkowski: the step sequence is rounding noise)
 
 
 @pytest.mark.parametrize("name", ["ks_ref0", "ks_true08"])
@@ -626,9 +635,9 @@ def test_f32_generic_path_bounds_the_step_count_gap(lib, name):
     r, g, c = att(ref["counters"]), att(gen["counters"]), att(closed["counters"])
     assert c <= 1.02 * g and g <= 1.03 * r and r - g <= 0.10 * r, (g, r, c)
     flips = gen["hit"] != ref["hit"]
-    assert flips.mean() <= 0.01
+    assert flips.mean() <= F32_FLIP_FRAC
     same = ~flips
-    assert wrap_aware_rgb_err(gen["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gen["hit"][same]) < 2e-2
+    assert wrap_aware_rgb_err(gen["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gen["hit"][same]) < F32_RGB_TOL
     assert gen["counters"]["events"] >= 0.99 * ref["counters"]["events"]
 
 
