@@ -13,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))
 b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
@@ -31,6 +31,8 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
             line = json.loads(l)
     e = json.load(open(ej))
     key = f'{line["config"]["variant"]}/{line["dtype"]}/{line["config"]["rhs"]}'
+    if cfg.endswith("_scalar"):   # the same configuration through the scalar Float32 kernel (RTGR_PACK=0): kept beside, never used by bench.py
+        key += "/scalar_kernel"
     e["config_dir"] = f"profiles/{rnd}/{cfg}"
     out["entries"][key] = e
     dst = os.path.join(ROOT, "profiles", rnd, cfg)
