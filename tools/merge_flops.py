@@ -47,7 +47,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
 # the measured issue ceiling of a kernel's instruction mix (tools/micro/mix_replay.hip; profiles/<round>/mix_replay.log), taken
 # at the waves-per-SIMD the kernel runs with
 replay = os.path.join(ROOT, "profiles", rnd, "mix_replay.log")
-OCCUPANCY = {"ks_ref0/f64/closed": 4, "ks_true08/f64/closed": 3, "ks_ref0/f64/generic": 2}
+OCCUPANCY = {"ks_ref0/f64/closed": 4, "ks_true08/f64/closed": 3, "ks_ref0/f64/generic": 2, "ks_true08/f64/user_ks": 3}
 if os.path.exists(replay):
     import re
     table, key, pure = {}, None, False
