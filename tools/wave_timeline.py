@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--share", type=int, default=1)
     ap.add_argument("--variant", default="ks_ref0")
     ap.add_argument("--set", default="")
+    ap.add_argument("--pass", dest="which", default="far", choices=["far", "near"], help="which pass reports its waves")
     a = ap.parse_args()
     spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
@@ -52,7 +53,7 @@ def main():
     buf = torch.zeros(4 * 8192 + n + 16, dtype=torch.int64, device="cuda")
     abi.check(lib, lib.rtgr_debug_set_buffer(buf.data_ptr()))
     kw = dict((k, int(v)) for k, v in (kv.split("=") for kv in a.set.split(",") if kv))
-    kw["dbg_pass_far"] = 1
+    kw["dbg_pass_far"] = 1 if a.which == "far" else 0
     ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
     out = {}
     with abi.options(lib, **kw):
@@ -78,8 +79,8 @@ def main():
     n_simd = 1024
     cls = np.arange(nw) // n_simd
     print(f"{a.variant} {a.size}² share 1/{a.share}: {n / 1e6:.2f} M rays, {attempts / 1e6:.1f} M step attempts, options {kw}")
-    print(f"FAR pass: {kms[1]:.3f} ms by HIP events, {T:.3f} ms first wave start -> last wave end, {nw} waves ({nw // n_simd} per SIMD); "
-          f"NEAR {kms[3]:.3f} ms, set-up {kms[0]:.3f}, resolve {kms[2]:.3f}")
+    print(f"{a.which.upper()} pass timeline: {T:.3f} ms first wave start -> last wave end, {nw} waves ({max(nw // n_simd, 1)} per SIMD); by HIP events: "
+          f"FAR {kms[1]:.3f} ms, NEAR {kms[3]:.3f} ms, set-up {kms[0]:.3f}, resolve {kms[2]:.3f}")
     far_attempts = None
     print("waves still running at t/T =  " + "  ".join(f"{f:4.1f}" for f in np.arange(0.1, 1.01, 0.1)))
     for c in range(cls.max() + 1):
@@ -90,8 +91,15 @@ def main():
         print(f"  class {c}: iterations/wave {iters[m].mean():7.0f} (max {iters[m].max()}), us/iteration {((end[m] - start[m]) / iters[m]).mean() * 1e3:5.2f}, "
               f"rays/wave {rays[m].mean():6.1f}, first wave out {end[m].min():.3f} ms, median {np.median(end[m]):.3f}, last {end[m].max():.3f}")
     lane_steps = 64.0 * iters.sum()
-    print(f"wave-iterations {iters.sum()}, lane utilisation <= {attempts / lane_steps:.3f} (all step attempts of the frame / 64 x FAR iterations; "
-          f"the NEAR pass's few are included in the numerator)")
+    if a.which == "far":
+        print(f"wave-iterations {iters.sum()}, lane utilisation <= {attempts / lane_steps:.3f} (all step attempts of the frame / 64 x FAR iterations; "
+              f"the NEAR pass's few are included in the numerator)")
+    else:   # per-ray stays of the NEAR pass follow the per-wave block: (accepted steps at hand-over, accepted steps in this pass)
+        pr = buf[4 * 8192:4 * 8192 + n].cpu().numpy().view(np.uint32).reshape(-1, 2)[:n]
+        stay = pr[:, 1].astype(np.int64)
+        print(f"wave-iterations {iters.sum()}; rays that went through the NEAR pass {int((stay > 0).sum())} of {n}, accepted steps taken there "
+              f"{int(stay.sum())} ({stay.sum() / max(attempts, 1) * 100:.1f} % of the frame's), mean stay {stay[stay > 0].mean():.1f} steps, "
+              f"p99 {np.percentile(stay[stay > 0], 99):.0f}, max {stay.max()}; lane utilisation of the pass {stay.sum() / lane_steps:.3f}")
     # throughput while everybody is busy: iterations per ms in the first half of the pass ~ (sum over waves of iterations done by T/2)
     half = sum(min(1.0, (0.5 * T - s) / max(e - s, 1e-9)) * it for s, e, it in zip(start, end, iters) if s < 0.5 * T)
     rate = half / (0.5 * T)
