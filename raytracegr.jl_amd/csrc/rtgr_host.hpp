@@ -51,7 +51,7 @@ struct Knobs {
     long waves_per_cu_near = -1;  // ... of the NEAR pass (auto: 4 below 2.4 M rays, 6.3 M with spin)
     long chunk = -1;              // rays per pipeline chunk (auto: 2^26, less if memory is short)
     long split = -1;              // 0: one FULL pass instead of FAR + NEAR (auto: on for f64, off for f32)
-    long order = -1;              // 0: natural ray order (auto: longest-expected-first from 4096 rays)
+    long order = -1;              // 0: natural ray order, 1: longest-expected-first (auto: ordered from 4096 rays; Float32 only up to 2 M)
     long fair = -1;               // log2 of the priority-rotation time slice in clocks, 0 = off (auto: by launch size)
     long near_early = 64;         // accepted steps at hand-over below which a ray goes on the NEAR pass's early list (0: no list)
     long far4 = -1;               // 0/1: force the 3- / 4-waves-per-SIMD a = 0 FAR instantiation (auto: by launch size)

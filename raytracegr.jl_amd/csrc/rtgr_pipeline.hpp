@@ -8,7 +8,7 @@
 //   waves_per_cu       resident waves per CU of the integrate kernel (auto = 4 x the instantiation's waves/SIMD)
 //   chunk              rays per pipeline chunk (auto 2^26, less if memory is short); bounds the workspace
 //   split = 0          one FULL integrate pass instead of the FAR + NEAR pair
-//   order = 0          keep the natural ray order (auto: longest-expected-first, see rtgr_persistent.hpp)
+//   order = 0 / 1      natural ray order / longest-expected-first (rtgr_persistent.hpp); auto: ordered, except Float32 above 2 M rays
 //   fair = s           time slice 2^s clocks of the priority rotation (0 = off; auto 13 for 0.8-1.8 M rays, else off)
 //   near_early = n     accepted steps at hand-over below which a ray is put on the NEAR pass's early list (64)
 //   waves_per_cu_near  resident waves per CU of the NEAR pass (auto 4 below 2.4 M rays — 6.3 M with spin —, else all)
@@ -227,8 +227,11 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
         const R* s0 = A.state0 ? A.state0 + off * 8 : nullptr;  // null: prepare_kernel generates the camera rays
-        // longest-expected-first queue order: pays off when a lane gets few rays (see rtgr_persistent.hpp)
-        const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 && K.order != 0;
+        // longest-expected-first queue order: pays off when a lane gets few rays (see rtgr_persistent.hpp).  Float32 rays
+        // last ~20 steps, so above 2 M rays the order's own kernels and the scattered record traffic cost more than the
+        // shorter tail returns (measured: 2048² a = 0.8 3.21 -> 2.98 ms, 4096² 12.4 -> 10.8 ms; 1024² a = 0 0.98 <- 1.56)
+        const bool order_auto = sizeof(R) == 8 || m <= (1ull << 21);
+        const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 && (K.order >= 0 ? K.order != 0 : order_auto);
         unsigned long long* q = E.ss.queue;  // one slot per stream: the stream orders this chunk behind the previous one
         hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, st, q, use_order ? hist : (uint32_t*)nullptr);
         IntegrateArgs<R> IA;

@@ -502,6 +502,22 @@ def test_scheduling_knobs_do_not_change_results(lib):
         assert ref["counters"] == got["counters"], knobs
 
 
+def test_scheduling_knobs_do_not_change_float32_results(lib):
+    """The same for the Float32 kernels (packed two-rays-per-lane and scalar, each against itself): natural or
+    longest-first order (the auto rule switches at 2 M rays), queue chunk, resident waves."""
+    sc, cam = scene_variant("ks_true0998_disk")
+    opt = rt.solver_defaults(np.float32)
+    for pack in (1, 0):
+        with abi.options(lib, pack=pack):
+            ref = hip_trace(lib, sc, opt, 192, 128, cam=cam, dtype=np.float32)
+            for knobs in ({"order": 0}, {"order": 1, "qchunk": 8}, {"waves_per_cu": 4, "order": 0}, {"fair": 12}):
+                with abi.options(lib, pack=pack, **knobs):
+                    got = hip_trace(lib, sc, opt, 192, 128, cam=cam, dtype=np.float32)
+                for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+                    assert np.array_equal(ref[k], got[k], equal_nan=ref[k].dtype.kind == "f"), (pack, knobs, k)
+                assert ref["counters"] == got["counters"], (pack, knobs)
+
+
 def test_interp_points_other_than_10_use_the_generic_scan(lib):
     """interp_points != 10 takes the runtime-θ scan (FULL pass only); compare with the oracle at 4 and 25 points."""
     sc, cam = example(2)
