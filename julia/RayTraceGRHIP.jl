@@ -5,7 +5,10 @@
 #   * tests/c/abi_layout.c — a compiled C caller that passes the same bytes this file would (structs by pointer, an
 #     88-byte Pixel array) and whose _Static_asserts pin the table below; tests/test_abi.py runs it on the CPU (layout,
 #     symbols) and on the GPU (example2() == sphere2.png through rtgr_trace_pixels_f64 + rtgr_trace_one_f64);
-#   * raytracegr.jl_amd/api.py — the same calls through Python ctypes, which every GPU test uses.
+#   * raytracegr.jl_amd/api.py — the same calls through Python ctypes, which every GPU test uses;
+#   * tests/test_julia_stub.py — every `ccall` below against the prototypes of include/rtgr.h (symbol declared and exported,
+#     as many argument types and arguments as C parameters, pointer / Cint / UInt64 kinds, return type), the structs' field
+#     order against the header's, and the block structure of this file.
 #
 # fieldoffset table (bytes; Julia lays isbits structs out by the C rules, so `fieldoffset(T, i)` must print exactly this —
 # a maintainer can check with `[(fieldname(T,i), fieldoffset(T,i)) for i in 1:fieldcount(T)]`):
