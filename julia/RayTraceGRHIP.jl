@@ -89,8 +89,14 @@ mutable struct Context
         h = Ref{Ctx}(C_NULL)
         ids = collect(Cint, device_ids)
         check(ccall((:rtgr_create, librtgr), Cint, (Ptr{Cint}, Cint, Ptr{Ctx}), isempty(ids) ? C_NULL : ids, length(ids), h))
-        finalizer(c -> ccall((:rtgr_destroy, librtgr), Cint, (Ctx,), c.handle), new(h[]))
+        finalizer(close, new(h[]))
     end
+end
+function Base.close(c::Context)     # idempotent; also the finalizer
+    c.handle == C_NULL && return nothing
+    ccall((:rtgr_destroy, librtgr), Cint, (Ctx,), c.handle)
+    c.handle = C_NULL
+    nothing
 end
 handle(::Nothing) = C_NULL
 handle(c::Context) = c.handle
