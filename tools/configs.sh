@@ -2,7 +2,8 @@
 # The five BASELINE.json configurations on one GPU (config 1 is the CPU-runnable 200² Minkowski case; config 3 is the
 # bench default).  usage: tools/configs.sh <outfile>
 OUT=${1:-gpurun_out/configs.log}
-run() { echo "### $1" | tee -a $OUT; shift; python bench.py --cpu-sample 0 --extras 0 --steps 2 --warmup 1 "$@" 2>/dev/null | python -c "
+# (small frames get enough passes for the clocks to settle: 2 passes of a 3 ms frame measure the ramp, not the kernel)
+run() { echo "### $1" | tee -a $OUT; shift; S=2; W=1; case "$*" in *"--size 200"*|*"--size 1024"*|*"--dtype f32"*) S=30; W=6;; esac; python bench.py --cpu-sample 0 --extras 0 --steps $S --warmup $W "$@" 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -22,3 +23,4 @@ run "C3 through rtgr_trace_f64 (camera on device, RGB to host)" --variant ks_ref
 run "C5 through rtgr_trace_pixels_f64 (5.9 GB of pixels each way)" --variant ks_true0998_disk --size 8192 --entry pixels
 run "generic dual-number RHS 2048x2048 (reference formulation)" --variant ks_ref0 --size 2048 --rhs generic
 run "user metric (textbook Kerr-Schild as run-time compiled source) 2048x2048" --variant ks_true08 --size 2048 --rhs user
+run "user metric typed in Kerr-Schild form (rtgr_user_ks: f and k only) 2048x2048" --variant ks_true08 --size 2048 --rhs user_ks
