@@ -516,6 +516,15 @@ def test_scheduling_knobs_do_not_change_float32_results(lib):
                 for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
                     assert np.array_equal(ref[k], got[k], equal_nan=ref[k].dtype.kind == "f"), (pack, knobs, k)
                 assert ref["counters"] == got["counters"], (pack, knobs)
+    # the automatic rule itself: above 2^21 Float32 rays the launch keeps the natural order (ragged size: 1459 x 1447 rays,
+    # not a multiple of the packed kernel's 128-ray pool) — same frame as with the order forced on
+    sc, cam = scene_variant("ks_true08")
+    auto = hip_trace(lib, sc, opt, 1459, 1447, cam=cam, dtype=np.float32)
+    with abi.options(lib, order=1):
+        forced = hip_trace(lib, sc, opt, 1459, 1447, cam=cam, dtype=np.float32)
+    for k in ("rgb", "status", "hit", "n_accept", "n_reject"):
+        assert np.array_equal(auto[k], forced[k], equal_nan=auto[k].dtype.kind == "f"), k
+    assert auto["counters"] == forced["counters"] and auto["counters"]["rays"] == 1459 * 1447 > (1 << 21)
 
 
 def test_interp_points_other_than_10_use_the_generic_scan(lib):
