@@ -32,6 +32,9 @@
 #include "rtgr_integrator.hpp"
 #include "rtgr_tsit5_tables.hpp"
 
+#ifndef RTGR_GHOST_LANES
+#define RTGR_GHOST_LANES 1  // lanes without a ray run the step's control block too (few-lane VALU instructions are 2.4 x dearer)
+#endif
 #ifndef RTGR_ROOT_SHORTCUT
 #define RTGR_ROOT_SHORTCUT 1
 #endif
@@ -400,7 +403,15 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             }
             accel<R, METRIC, SPIN, true>(xn + 1, un, MK, k[6], xn[0]);
 
-            if (run) {
+            // The error estimate, the controller, the reach bound and (NEAR) the sample-point scan ALSO run in uniform control
+            // flow: a wave64 VALU instruction with few lanes enabled is not cheaper on this chip, it is 2.4 x DEARER — f64
+            // arithmetic with <= 8 lanes in EXEC issues at 12.4 instead of 5.25 clocks, f32 with <= 16 lanes likewise
+            // (tools/micro/exec_mask_rates.hip, profiles/r03/exec_mask_rates.log) — and the waves that decide when a small
+            // launch ends (the last rays of the FAR pass, the long stayers of the NEAR pass) are exactly the ones with a
+            // handful of live lanes.  So lanes without a ray ("ghosts") walk through this block too, on whatever state they
+            // hold and h = 0; every side effect below is gated by `run`, and their decisions are wiped at the end of the block.
+            // (-DRTGR_GHOST_LANES=0: the block under the running lanes' EXEC mask, for A/B.)
+            if (RTGR_GHOST_LANES ? true : run) {
                 // ---- embedded error, residual norm in f32 ----------------------------------------
                 // ũ_q = h e_q with e = (Σ b̃_l k_l, h Σ BT2_l k_l + Σb̃ u): the common factor h is applied ONCE, to the f32 sum
                 // of squares (eight f64 products less per step), and the (u, x) pair of a component goes through the
@@ -471,7 +482,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     safe = safe && (rabs(obj_distance<R>(ob, xs)) > guard * (dl[1] + dl[2] + dl[3]));
                                 }
                             }
-                            if constexpr (MODE == MODE_FAR) hand_over = !safe || (ps == R(0));
+                            if constexpr (MODE == MODE_FAR) hand_over = run && (!safe || (ps == R(0)));
                             else {
                                 need_scan = !safe || (ps == R(0));
                                 safe_streak = need_scan ? 0u : safe_streak + 1u;
@@ -480,7 +491,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         // NEAR pass: a ray stays here until it ends, also after it has left every object's reach; its
                         // wave then runs with few lanes (the longest stays are 150-370 steps), so the scan is skipped
                         // whenever NO active lane needs it — a wave-uniform decision, same results by the same bound.
-                        if constexpr (MODE == MODE_NEAR) need_scan = __ballot((EEst2 <= 1.0f) && need_scan) != 0ull;
+                        if constexpr (MODE == MODE_NEAR) need_scan = __ballot(run && (EEst2 <= 1.0f) && need_scan) != 0ull;
                     }
                     if (hand_over) {
                         // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
@@ -599,6 +610,10 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         if (nacc + nrej >= A.opt.max_steps) done = RTGR_RAY_MAXSTEPS;
                         else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
                     }
+                }
+                if (!run) {  // a ghost lane decides nothing
+                    done = 0xffu; is_event = false; is_interior = false; handed = false; hand_back = false; commit = false;
+                    list_it = false;
                 }
                 // ---- an event: hand the step's position polynomial to the resolve kernel (built from the step-START state,
                 // so it has to happen before the commit below) -----------------------------------------------------------------

@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--flags", default="")
+    ap.add_argument("--bench-steps", type=int, default=0, help="builds: timed passes per run (default 3, 30 up to 2048²)")
     a = ap.parse_args()
     variants = a.variants.split(",")
     if a.mode == "builds":
@@ -109,7 +110,8 @@ def main():
                 env.pop("RTGR_LIB", None)
                 if path:
                     env["RTGR_LIB"] = path
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-sample", "0",
+                steps = a.bench_steps or (30 if a.size <= 2048 else 3)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(max(1, steps // 5)), "--cpu-sample", "0",
                                     "--extras", "0", "--size", str(a.size), "--variant", variant, "--dtype", a.dtype],
                                    capture_output=True, text=True, env=env)
                 line = next((json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")), None)
