@@ -186,7 +186,8 @@ def check(lib, code):
 
 class options:
     """`with options(lib, split=0, near_early=8): ...` — set launch-policy options of a context (default: the
-    process's default context) for the duration of the block (rtgr_set_option; they never change a result bit)."""
+    process's default context) for the duration of the block (rtgr_set_option).  Scheduling options never change a result
+    bit; `tile` and `pack` select another formulation of the same algorithm (equal up to rounding): include/rtgr.h."""
 
     def __init__(self, lib, ctx=None, **kw):
         self.lib, self.ctx, self.kw, self.old = lib, ctx, kw, {}

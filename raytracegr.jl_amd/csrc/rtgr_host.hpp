@@ -45,7 +45,8 @@ int fail(int code, const std::string& msg);  // records the calling thread's las
 // ---- launch policy knobs ------------------------------------------------------------------------------------------------
 // Parsed ONCE from the environment when a context is created (RTGR_<NAME>), changeable per context with
 // rtgr_set_option(ctx, "name", value).  -1 = "auto" (the library decides from the launch size).  Experiments and
-// schedule-invariance tests only: no knob changes a result bit.
+// schedule-invariance tests only: no knob changes a result bit, except `tile` and `pack`, which select another formulation of
+// the same algorithm (results equal up to rounding).
 struct Knobs {
     long waves_per_cu = -1;       // resident waves per CU of the integrate kernels (auto: 4 x waves/SIMD of the instantiation)
     long waves_per_cu_near = -1;  // ... of the NEAR pass (auto: 4 below 2.4 M rays, 6.3 M with spin)
