@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <limits>
 #include <thread>
 
 #include <dlfcn.h>
@@ -62,14 +63,15 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 template <class R>
 size_t workspace_bytes(uint64_t rays, bool with_state) {
     const int recw = with_state ? REC_W_STATE : REC_W;
+    static_assert(HAND_W <= REC_W, "the hand-over record shares the ray's record slot");
     return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
-           align256(rays * HAND_W * sizeof(R)) + 2 * align256(rays * sizeof(uint32_t)) + align256(rays) + 4096;
+           2 * align256(rays * sizeof(uint32_t)) + align256(rays) + 4096;
 }
 template size_t workspace_bytes<double>(uint64_t, bool);
 template size_t workspace_bytes<float>(uint64_t, bool);
 
 // Rays per pipeline chunk.  Every chunk pays the tails of its passes once, so bigger is better (8192² in one chunk instead
-// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (33.7 GB of workspace at 501 B/ray), halved
+// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (14.3 GB of workspace at 213 B/ray; 25.0 GB at the 373 B/ray of a call that asks for end states), halved
 // until the workspace fits into a quarter of the memory that is free when it has to be (re)allocated.
 template <class R>
 uint64_t pick_chunk(const DeviceCtx& d, const StreamState& ss, uint64_t n, bool with_state) {
@@ -320,6 +322,23 @@ int device_of(rtgr_context* c, const void* d_ptr, DeviceCtx** out) {
 // ---------------------------------------------------------------------------------------------------------------------
 // argument conversion
 // ---------------------------------------------------------------------------------------------------------------------
+// The band of s whose correctly rounded square root (in R) EQUALS r: lo = min{s : sqrt(s) >= r}, hi = min{s : sqrt(s) > r}.
+// disk_sign_distance (rtgr_physics.hpp) reads sign(r − RN(sqrt(s))) off these two thresholds, exactly as the IEEE square root
+// of obj_distance would give it.  A few nextafter steps around r² (the root maps 1–3 neighbouring s onto one value).
+template <class R>
+void disk_sqrt_band(R r, R& lo, R& hi) {
+    const R inf = std::numeric_limits<R>::infinity();
+    if (!(r >= R(0))) { lo = hi = R(0); return; }      // negative (or NaN) radius: sqrt(s) > r for every s >= 0
+    if (r == inf) { lo = hi = inf; return; }
+    R c = r * r;
+    if (!(c < inf)) c = std::numeric_limits<R>::max();
+    for (int it = 0; it < 4096 && c > R(0) && std::sqrt(c) >= r; it++) c = std::nextafter(c, -inf);
+    for (int it = 0; it < 4096 && std::sqrt(c) < r; it++) c = std::nextafter(c, inf);
+    lo = c;
+    for (int it = 0; it < 4096 && std::sqrt(c) <= r; it++) c = std::nextafter(c, inf);
+    hi = c;
+}
+
 template <class R>
 int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserModule** user) {
     if (!s) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
@@ -345,6 +364,10 @@ int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const
             return fail(RTGR_ERR_BAD_ARG, "unknown object kind (abstract Object has no distance)");
         d.obj[o].kind = s->obj[o].kind;
         for (int q = 0; q < 9; q++) d.obj[o].p[q] = (R)s->obj[o].p[q];
+        if (s->obj[o].kind == RTGR_DISK) {   // p[3..6]: the scan's sign thresholds on x² + y² (device-side only; the ABI's disk is p[0..2])
+            disk_sqrt_band<R>(d.obj[o].p[1], d.obj[o].p[3], d.obj[o].p[4]);
+            disk_sqrt_band<R>(d.obj[o].p[2], d.obj[o].p[5], d.obj[o].p[6]);
+        }
     }
     return RTGR_OK;
 }
@@ -1701,7 +1724,7 @@ int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id) {
 
 #ifdef RTGR_ROOT_STATS
 // debug builds only: a device buffer the NEAR pass writes per-wave {start, end, iterations, rays} and per-ray stays into
-// (tools/debug_near_waves.py)
+// (tools/wave_timeline.py)
 int rtgr_debug_set_buffer(void* d_buf) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(nullptr, &c);
@@ -1709,7 +1732,7 @@ int rtgr_debug_set_buffer(void* d_buf) {
     c->devs[0]->dbg = (unsigned long long*)d_buf;
     return RTGR_OK;
 }
-// debug builds only (tools/debug_root_iters.py): copy the head of the default stream's workspace (the event records) to the host
+// debug builds only: copy the head of the default stream's workspace (the event records) to the host
 int rtgr_debug_workspace(void* stream, void* dst, uint64_t bytes) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(nullptr, &c);

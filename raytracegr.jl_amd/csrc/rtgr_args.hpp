@@ -82,7 +82,7 @@ struct IntegrateArgs {
     R* rec;                 // n x recw
     uint32_t* meta;         // n x 3: accepted, rejected, status | interior << 8
     int recw;               // REC_W or REC_W_STATE
-    R* hand;                // n x HAND_W: rays handed from the FAR pass to the NEAR pass
+    R* hand;                // the rays' start / hand-over records: HAND_W scalars at the head of each ray's record slot (== rec, stride recw)
     unsigned long long* ctrl;  // [0] ray queue head of the FULL / FAR pass, [1] queue head of the NEAR pass (per round)
     uint32_t pick_flag;     // passes that resume rays (NEAR, FAR of round >= 1): meta flag of the rays to pick up; 0 = camera rays
     uint32_t allow_handback;  // NEAR: hand a ray back to the next round's FAR pass once it has left every object's reach
@@ -112,6 +112,9 @@ struct IntegrateArgs {
 // hand-over record instead of a camera ray.  Results are identical to FULL by construction (the scan is skipped only
 // where it provably finds nothing); rays spend >90 % of their steps in the FAR pass, which is ~30 % cheaper per step.
 enum IntegrateMode : int { MODE_FULL = 0, MODE_FAR = 1, MODE_NEAR = 2 };
+// A ray's start / hand-over record and its event record are never alive at the same time (prepare -> FAR -> [hand-over ->] NEAR
+// -> event record -> resolve: each writer holds the ray in registers when it writes), so they share ONE slot of recw scalars
+// per ray: the hand-over record is its first HAND_W scalars.  (Round 3 kept them apart: 128 B per ray more.)
 constexpr int HAND_W = 16;  // x[4] u[4] k0[4] t dt ps lq
 constexpr uint32_t META_HANDED = 0xffff0000u;    // meta[3*idx+2] of a ray waiting for a NEAR pass
 constexpr uint32_t META_HANDBACK = 0xffff0001u;  // … of a ray a NEAR pass handed back to the next round's FAR pass

@@ -69,13 +69,13 @@ RTGR_DEV void fold_distances2(const DevObject<float>& o, const V2 (&pos)[P][4], 
                 dmin[p] = rmin<V2>(dmin[p], rfma<V2>(dx, dx, rfma<V2>(dy, dy, rfma<V2>(dz, dz, nR2))));
             }
         }
-    } else {   // RTGR_DISK: per half through the scalar distance (the asm barrier keeps its sqrt inside this branch)
+    } else {   // RTGR_DISK: per half through the scalar sign-exact surrogate (fold_distances; the asm barrier keeps it inside this branch)
 #pragma unroll
         for (int p = 0; p < P; p++) {
             V2 px = pos[p][1], py = pos[p][2];
             asm volatile("" : "+v"(px), "+v"(py));
-            const float xa[4] = {pos[p][0].x, px.x, py.x, pos[p][3].x}, xb[4] = {pos[p][0].y, px.y, py.y, pos[p][3].y};
-            dmin[p] = rmin<V2>(dmin[p], V2{obj_distance<float>(o, xa), obj_distance<float>(o, xb)});
+            dmin[p] = rmin<V2>(dmin[p], V2{disk_sign_distance<float>(o, px.x, py.x, pos[p][3].x),
+                                           disk_sign_distance<float>(o, px.y, py.y, pos[p][3].y)});
         }
     }
 }
@@ -145,7 +145,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 m_need = __ballot(state[hh] == L_FREE);
             }
             if (state[hh] == L_TAKEN) {
-                const float* hd = A.hand + idx[hh] * HAND_W;
+                const float* hd = A.hand + idx[hh] * (uint64_t)A.recw;
 #pragma unroll
                 for (int q = 0; q < 4; q++) { x[q][hh] = hd[q]; u[q][hh] = hd[4 + q]; k0[q][hh] = hd[8 + q]; }
                 t[hh] = hd[12]; dt[hh] = hd[13]; ps[hh] = hd[14]; lq[hh] = hd[15];
@@ -231,7 +231,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
             const V2 rx = ex * rcp_seed2(rfma<V2>(rmaxabs<V2>(x[q], xn[q]), V2(reltol), V2(abstol)));
             acc2 = rfma<V2>(ru, ru, rfma<V2>(rx, rx, acc2));
         }
-        const V2 EE2 = acc2 * (V2(0.125f) * h2);
+        const V2 EE2 = (acc2 * h) * (V2(0.125f) * h);   // (h twice, not h²: see integrate_body)
         // ---- ContinuousCallback scan, packed for both rays; used by the halves that accept their step ----
         // x(θ) = x + θ c1 + θ² c2 + θ³ c3 + θ⁴ c4 ;  c1 = h u,  c_m = h² Σ_l R2[l][m] k_l
         V2 cc[4][4];

@@ -1,8 +1,8 @@
 // rtgr_persistent.hpp — the production trace pipeline:
 //     prepare (camera ray, queue key, u̇(y0), initial dt) -> [order scan/scatter] -> integrate<FAR> -> integrate<NEAR>
-//     -> resolve                                                                   (rtgr_hip.hip: launch_trace)
+//     -> resolve                                                              (rtgr_pipeline.hpp: launch_trace)
 //
-// Why a pipeline instead of one loop per ray (the simple tile kernel in rtgr_hip.hip keeps that shape):
+// Why a pipeline instead of one loop per ray (the simple tile kernel, trace_kernel in rtgr_pipeline.hpp, keeps that shape):
 //   * rays need 27…991 Tsit5 step attempts inside one image; a wave that owns 64 fixed rays idles until
 //     its longest ray ends, and each ray's end-of-life episode (bracketed root-find on the dense output, colouring,
 //     next ray's camera set-up) would run with one lane active;
@@ -107,15 +107,14 @@ RTGR_DEV void fold_distances(const DevObject<R>& o, const R (&pos)[P][4], R (&dm
             }
         }
     } else {
-        // RTGR_DISK.  The asm barrier pins the operands inside this branch: without it LLVM hoists the (loop-invariant)
-        // sqrt(x²+y²) of every sample point out of the object loop and executes P IEEE square roots per step for
-        // scenes that contain no disk at all.
+        // RTGR_DISK: the scan needs the distance's SIGN only — disk_sign_distance reads it off x² + y² without a square
+        // root, exactly (rtgr_physics.hpp).  The asm barrier pins the operands inside this branch: without it LLVM hoists
+        // the (loop-invariant) x² + y² of every sample point out of the object loop, for scenes that contain no disk at all.
 #pragma unroll
         for (int p = 0; p < P; p++) {
             R px = pos[p][1], py = pos[p][2];
             asm volatile("" : "+v"(px), "+v"(py));
-            const R xs[4] = {pos[p][0], px, py, pos[p][3]};
-            dmin[p] = rmin(dmin[p], obj_distance<R>(o, xs));
+            dmin[p] = rmin(dmin[p], disk_sign_distance<R>(o, px, py, pos[p][3]));
         }
     }
 }
@@ -133,7 +132,7 @@ RTGR_DEV void flush_early(const IntegrateArgs<R>& A, const uint32_t* buf, uint32
 // ---------------------------------------------------------------------------------------------------------------------
 // integrate kernel
 // ---------------------------------------------------------------------------------------------------------------------
-// The kernel body is a device function so that run-time generated units (user metrics, rtgr_user_template.hip) can
+// The kernel body is a device function so that run-time generated units (user metrics, rtgr_user_unit.hip.in) can
 // wrap it in extern "C" kernels of their own.
 template <class R, int METRIC, bool SPIN, bool NPTS10, int MODE, bool LDSK = false>
 RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
@@ -188,7 +187,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #endif
     const unsigned long long qchunk = A.queue_chunk;
     // Wave ages.  A SIMD's arbiter issues from its OLDEST ready wave first, and a persistent grid never renews its
-    // waves: measured (tools/debug_near_waves.py, RTGR_DBG_PASS=far) 2.9 us per iteration for the first-launched
+    // waves: measured (round 1; its successor is tools/wave_timeline.py on a -DRTGR_ROOT_STATS build) 2.9 us per iteration for the first-launched
     // third of the FAR pass's workgroups, 5-7 us for the second, 14 us for the youngest (40 us on the 4-wave grid).
     // Throughput does not care, the tail of a small launch does: a young wave that holds rays of 950 steps needs
     // the whole pass for them.  So (a) the head of the longest-first queue goes to the low workgroup indices (first
@@ -293,7 +292,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         dbg_rays += __builtin_popcountll(__ballot(state == L_TAKEN));
 #endif
         if (state == L_TAKEN) {
-            const R* hd = A.hand + idx * HAND_W;
+            const R* hd = A.hand + idx * (uint64_t)A.recw;
 #pragma unroll
             for (int q = 0; q < 4; q++) { x[q] = hd[q]; u[q] = hd[4 + q]; k0[q] = hd[8 + q]; }
             t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
@@ -431,8 +430,11 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 }
                 // EEst² — the square root is never taken: the tests are EEst <= 1 <=> EEst² <= 1, and the controller works with
                 // log2 EEst = ½ log2 EEst² (sqrtf's IEEE expansion was ~15 instructions per step)
+                // (the two factors of h one after the other, not as h²: (float)h squared underflows below |h| ~ 1e-19 while the sum may
+                //  already be huge — 0 · inf = NaN would end the ray as RTGR_RAY_NAN instead of DTMIN, a flushed h² would ACCEPT the
+                //  step with maximum growth; same three multiplies.  ADVICE r3.)
                 const float hf32 = (float)h;
-                const float EEst2 = (acc2.x + acc2.y) * (0.125f * hf32 * hf32);
+                const float EEst2 = ((acc2.x + acc2.y) * hf32) * (0.125f * hf32);
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
                 bool is_event = false, is_interior = false, handed = false, hand_back = false;
                 R top = R(0);
@@ -477,9 +479,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     safe = safe && (rabs(D0) > rfma(guard, B, R(256) * eps * mag));
                                 } else {
                                     R px = x[1], py = x[2];
-                                    asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's sqrt inside this branch
-                                    const R xs[4] = {x[0], px, py, x[3]};
-                                    safe = safe && (rabs(obj_distance<R>(ob, xs)) > guard * (dl[1] + dl[2] + dl[3]));
+                                    asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's root inside this branch
+                                    safe = safe && (rabs(disk_distance_fast<R>(ob, px, py, x[3])) > guard * (dl[1] + dl[2] + dl[3]));
                                 }
                             }
                             if constexpr (MODE == MODE_FAR) hand_over = run && (!safe || (ps == R(0)));
@@ -495,7 +496,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                     }
                     if (hand_over) {
                         // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
-                        R* hd = A.hand + idx * HAND_W;
+                        R* hd = A.hand + idx * (uint64_t)A.recw;
 #pragma unroll
                         for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k[0][q]; }
                         hd[12] = t; hd[13] = dt; hd[14] = ps; hd[15] = (R)lq;
@@ -647,7 +648,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 if (hand_back) {
                     // NEAR -> next round's FAR pass: the ray has been out of every object's reach for two steps; its
                     // committed state goes back into the hand-over record and the cheaper pass carries it on
-                    R* hd = A.hand + idx * HAND_W;
+                    R* hd = A.hand + idx * (uint64_t)A.recw;
 #pragma unroll
                     for (int q = 0; q < 4; q++) { hd[q] = xn[q]; hd[4 + q] = un[q]; hd[8 + q] = k[6][q]; }
                     hd[12] = t; hd[13] = dt; hd[14] = ps; hd[15] = (R)lq;
@@ -838,7 +839,7 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     // dt1 = 10^(-(2 + log10 md)/5) = 2^(-(2 log2 10 + log2 md)/5)
     const float dt1f = (md <= 1e-15f) ? fmaxf(1e-6f, (float)dt0 * 1e-3f) : fexp2(-0.2f * (6.643856189774724f + flog2(md)));
     const R dt_init = rmin(rmin(R(100) * dt0, (R)dt1f), dtmax);
-    R* hd = A.hand + w * HAND_W;
+    R* hd = A.hand + w * (uint64_t)A.recw;
 #pragma unroll
     for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k1[q]; }
     hd[12] = A.opt.lambda0;
@@ -953,8 +954,7 @@ RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th
 // the result is a point with g >= 0 within ~32 ulp of it — the reference's prevfloat(find_zero(...))
 // up to a few ulp (a 512-ulp window, 1e-13 in θ, for the rays whose distance is too noisy for that).  If the probes fail
 // (estimate was off) the loop simply continues on the tightened bracket; the bisection point `mid` guarantees progress.
-// (tools/debug_root_dump.py replays the finder on the host, with exact FMA emulation, from a dumped event record.)
-// -DRTGR_ROOT_STATS builds report the iteration count through lambda_end (tools/debug_root_iters.py).
+// -DRTGR_ROOT_STATS builds report the iteration count of every ray through lambda_end.
 template <class R>
 RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R ps, R top, int* iters = nullptr) {
     R lo = R(0), hi = top;

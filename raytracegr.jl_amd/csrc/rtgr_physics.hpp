@@ -61,7 +61,8 @@ template <class R> RTGR_DEV R rmin(R a, R b);
 template <> RTGR_DEV double rmin<double>(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <> RTGR_DEV float rmin<float>(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // ---- fast reciprocal / reciprocal square root: hardware seed + ONE third-order correction on the FMA pipe.
-// Measured on gfx950 (tools/micro/rcp_accuracy.hip): v_rcp_f64 / v_rsq_f64 seeds are good to 2^-24.4 / 2^-24.2, so a
+// Measured on gfx950 (rtgr_eval_fastmath_f64, tests/test_gpu_parity.py::test_fast_reciprocal_and_rsqrt_accuracy; the seeds
+// themselves in round 1 with a stand-alone microbenchmark): v_rcp_f64 / v_rsq_f64 seeds are good to 2^-24.4 / 2^-24.2, so a
 // cubically convergent step (error e³ ≈ 2^-73) lands on full double precision: max relative error 1.1e-16 / 1.4e-16
 // over 2^20 operands in [2^-10, 2^10].  No denormal / inf fix-up (operands here are O(1e-3 … 1e3)).  The IEEE
 // expansions hipcc emits for `1.0/x` and `sqrt(x)` cost 11 and ~14 instructions; these cost 4 and 6.
@@ -359,7 +360,7 @@ RTGR_DEV void accel_spin_ref(const R xs[3], const R u[4], const MetricK<R>& C, R
 // transcendental seeds per evaluation (round 2's form of the same contraction: 58 + 46 + 5 + 3).
 //
 // r is a root of r⁴ − q r² − a²z² = 0 (q = ρ² − a²) and k is the principal null congruence, which buys (checked to 40
-// digits, tools/check_identities.py): with Σ = sqrt(q² + 4a²z²) = 2r² − q,
+// digits by tools/check_identities.py, which tests/test_identities.py runs): with Σ = sqrt(q² + 4a²z²) = 2r² − q,
 //     r⁴ + a²z² = r² Σ;   |k|² = 1;   k^j ∂_j k_i = 0;   k^i ∂_d k_i = 0;   k·∇r = 1;
 //     ∇r = (r/Σ)(x,y,z) + (a²z/(rΣ)) ẑ        — the SAME r/Σ that makes f = 2M r/Σ (one product, no reciprocal of its own);
 //     ∂f/∂r = f ψ, ψ = 3/r − 4r/Σ;   ∂f/∂z|_r = f φ, φ = −2a²z/(r²Σ);   S = f/(1 + f(|k|²−1)) = f.
@@ -837,6 +838,32 @@ RTGR_DEV R obj_distance(const DevObject<R>& o, const R pos[4]) {
     d = rmax(d, o.p[1] - rc);
     d = rmax(d, rc - o.p[2]);
     return d;
+}
+
+// The disk's distance as the ContinuousCallback SCAN needs it: its sign only (the scan multiplies the minimum over the
+// objects by the sign at the step start and tests < 0 / <= 0; the minimum's sign is fixed by its members' signs).  The two
+// radial terms r_in − ϱ and ϱ − r_out are replaced by THEIR SIGNS, read off s = x² + y² without taking the root: the host
+// precomputes, in the device's scalar type, the band of s whose correctly rounded square root equals the radius
+// (p[3] = min{s : √s >= r_in}, p[4] = min{s : √s > r_in}, p[5], p[6] likewise for r_out; disk_sqrt_bands, rtgr_api.hip), so
+//     sign(r_in − RN(√s)) = +1 for s < p[3], 0 for p[3] <= s < p[4], −1 otherwise
+// EXACTLY — same sign, zero included, as obj_distance computes with its IEEE square root, for every s (√ is monotone and
+// correctly rounded).  Nine IEEE roots (~16 instructions each) per accepted NEAR step become compares and selects; the true
+// distance is still what the event root-finder (resolve_kernel) and the colouring see.
+template <class R>
+RTGR_DEV R disk_sign_distance(const DevObject<R>& o, R px, R py, R pz) {
+    const R s = rfma(px, px, py * py);
+    const R e_in = s < o.p[3] ? R(1) : (s < o.p[4] ? R(0) : R(-1));     // sign(r_in − ϱ)
+    const R e_out = s < o.p[5] ? R(-1) : (s < o.p[6] ? R(0) : R(1));    // sign(ϱ − r_out)
+    return rmax(rmax(rabs(pz) - o.p[0], e_in), e_out);
+}
+
+// … and as the FAR pass's reach bound needs it: its magnitude, to ~1e-16 relative (the bound carries a 1e-6 guard), from
+// the 6-instruction reciprocal square root instead of the IEEE expansion.
+template <class R>
+RTGR_DEV R disk_distance_fast(const DevObject<R>& o, R px, R py, R pz) {
+    const R s = rfma(px, px, py * py);
+    const R rc = s > R(0) ? s * frsq<R>(s) : R(0);
+    return rmax(rmax(rabs(pz) - o.p[0], o.p[1] - rc), rc - o.p[2]);
 }
 
 template <class R>

@@ -211,8 +211,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     char* cur = base + align256(chunk * recw * sizeof(R));
     uint32_t* meta = (uint32_t*)cur;
     cur += align256(chunk * 3 * sizeof(uint32_t));
-    R* hand = (R*)cur;
-    cur += align256(chunk * HAND_W * sizeof(R));
+    R* hand = rec;  // start / hand-over records live at the head of the rays' record slots (rtgr_args.hpp: HAND_W)
     uint32_t* order = (uint32_t*)cur;
     cur += align256(chunk * sizeof(uint32_t));
     uint32_t* early = (uint32_t*)cur;
