@@ -214,6 +214,14 @@ int rtgr_reserve_workspace(rtgr_context* ctx, const void* d_any, void* stream, u
  * NEAR pass.  Not for use during hipGraph capture. */
 int rtgr_timing_enable(rtgr_context* ctx, int index, int on);
 int rtgr_timing_read(rtgr_context* ctx, int index, double ms[4], uint64_t launches[4]);
+/* … and of the multi-device exchange of rtgr_trace_sharded_device_* on device `index`, since the previous read: [0] this device's
+ * rows leaving it for device 0 (the peer copy, or the device -> pinned host leg of the fallback), measured on the source device's
+ * stream behind its trace; [1] device 0 only: the placement kernels that put the ranks' rows back into the frame. */
+int rtgr_timing_read_exchange(rtgr_context* ctx, int index, double ms[2], uint64_t launches[2]);
+/* Peer access between device 0 and device `index` of the context as rtgr_create established it: 1 = peer copies (or the same
+ * physical device, or index 0), 0 = not available — the gather then stages that device's rows through pinned host memory — with
+ * the reason copied into `why` (may be NULL).  Negative rtgr_status on error. */
+int rtgr_peer_access(rtgr_context* ctx, int index, char* why, uint64_t why_len);
 
 /* ---- the hot path, device-resident buffers ------------------------------------------------------------------
  * Replaces the body of trace_rays (src/RayTraceGR.jl:482-536) for rows j in [j0, j1) of an ni x nj canvas.

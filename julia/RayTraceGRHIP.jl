@@ -4,24 +4,37 @@
 # NOT EXECUTED IN THIS REPOSITORY: the build image has no Julia.  What stands in for running it:
 #   * tests/c/abi_layout.c — a compiled C caller that passes the same bytes this file would (structs by pointer, an
 #     88-byte Pixel array) and whose _Static_asserts pin the table below; tests/test_abi.py runs it on the CPU (layout,
-#     symbols) and on the GPU (example2() == sphere2.png through rtgr_trace_pixels_f64 + rtgr_trace_one_f64);
+#     symbols) and on the GPU (example2() == sphere2.png through rtgr_trace_pixels_f64 + rtgr_trace_one_f64; a
+#     KerrSchild(1, 0.998) + Disk frame through rtgr_trace_f64 with per-ray outputs, against the oracle);
 #   * raytracegr.jl_amd/api.py — the same calls through Python ctypes, which every GPU test uses;
 #   * tests/test_julia_stub.py — every `ccall` below against the prototypes of include/rtgr.h (symbol declared and exported,
 #     as many argument types and arguments as C parameters, pointer / Cint / UInt64 kinds, return type), the structs' field
-#     order against the header's, and the block structure of this file.
+#     order and the enum constants against the header's, the block structure of this file and of julia/runtests_hip.jl, and
+#     that every name runtests_hip.jl uses is defined here.
+#   * julia/runtests_hip.jl — the reference's test/runtests.jl:12-79 (incl. the commented-out "rays" test) restated over
+#     this module, plus example1() / example2() against the committed goldens: what a maintainer runs first.
 #
 # fieldoffset table (bytes; Julia lays isbits structs out by the C rules, so `fieldoffset(T, i)` must print exactly this —
-# a maintainer can check with `[(fieldname(T,i), fieldoffset(T,i)) for i in 1:fieldcount(T)]`):
+# a maintainer can check with `[(fieldname(T,i), fieldoffset(T,i)) for i in 1:fieldcount(T)]`; runtests_hip.jl does):
 #
 #   RtgrObject       80   kind 0, reserved 4, p 8
-#   RtgrScene     1312   metric 0, nobj 4, M 8, a 16, user_metric 24, obj 32
-#   RtgrSolver      72   reltol 0, abstol 8, lambda0 16, lambda1 24, hit_threshold 32, miss_rgb 40, max_steps 64, interp_points 68
-#   RtgrCounters    64   rays 0, accepted 8, rejected 16, rhs_evals 24, events 32, events_interior 40, not_finished 48, reserved 56
-#   Pixel{Float64}  88   pos 0, normal 32, rgb 64          (the reference's own type, src/RayTraceGR.jl:446-450)
-#   Pixel{Float32}  44   pos 0, normal 16, rgb 32
+#   RtgrScene      1312   metric 0, nobj 4, M 8, a 16, user_metric 24, obj 32
+#   RtgrSolver       72   reltol 0, abstol 8, lambda0 16, lambda1 24, hit_threshold 32, miss_rgb 40, max_steps 64, interp_points 68
+#   RtgrCamera      128   pos 0, widthx 32, widthy 64, normal 96
+#   RtgrCounters     64   rays 0, accepted 8, rejected 16, rhs_evals 24, events 32, events_interior 40, not_finished 48, reserved 56
+#   RtgrRayOutputs   56   state_end 0, lambda_end 8, status 16, hit 24, n_accept 32, n_reject 40, redshift 48
+#   Pixel{Float64}   88   pos 0, normal 32, rgb 64          (the reference's own type, src/RayTraceGR.jl:446-450)
+#   Pixel{Float32}   44   pos 0, normal 16, rgb 32
 #
 # It is a thin `ccall` layer; host code stays Julia, the metric/object/Pixel signatures of the reference are preserved,
 # and anything that cannot cross the C ABI (an arbitrary metric callable) falls back to the reference's own CPU path.
+#
+# Every BASELINE.json configuration from Julia (INTEGRATION.md "Julia" has them spelled out):
+#   C1  example1()                                                      minkowski, 200², == scenes/sphere.png
+#   C2  example2(ni = 1024, nj = 1024, metric = KerrSchild(1.0, 0.8))   Kerr–Schild a = 0.8, 3 objects
+#   C3  render(kerr_schild, objs, cam..., 4096, 4096; ctx = Context(0:7))   rows dealt to 8 GPUs, RGB planes back
+#   C4  example2(T = Float32, ni = 2048, nj = 2048, metric = KerrSchild(1.0, 0.8))
+#   C5  example_disk(ni = 8192, nj = 8192)                              KerrSchild(1, 0.998) + Disk(0.05, 2, 4)
 module RayTraceGRHIP
 
 using RayTraceGR
@@ -30,6 +43,7 @@ using StaticArrays
 const librtgr = get(ENV, "RTGR_LIB", "librtgr_hip.so")
 const RTGR_MAX_OBJECTS = 16
 const Ctx = Ptr{Cvoid}          # rtgr_context*; C_NULL = the process's default context
+const D = RayTraceGR.D          # 4 (src/RayTraceGR.jl:253-254)
 
 # ---- PODs of include/rtgr.h ------------------------------------------------------------------------------------------
 struct RtgrObject
@@ -55,22 +69,115 @@ struct RtgrSolver
     max_steps::UInt32
     interp_points::UInt32
 end
+struct RtgrCamera
+    pos::NTuple{4,Float64}
+    widthx::NTuple{4,Float64}
+    widthy::NTuple{4,Float64}
+    normal::NTuple{4,Float64}
+end
 struct RtgrCounters
     rays::UInt64; accepted::UInt64; rejected::UInt64; rhs_evals::UInt64
     events::UInt64; events_interior::UInt64; not_finished::UInt64; reserved::UInt64
 end
+struct RtgrRayOutputs          # optional per-ray outputs; C_NULL = not wanted
+    state_end::Ptr{Cvoid}
+    lambda_end::Ptr{Cvoid}
+    status::Ptr{UInt8}
+    hit::Ptr{UInt8}
+    n_accept::Ptr{UInt32}
+    n_reject::Ptr{UInt32}
+    redshift::Ptr{Cvoid}
+end
 
-const RTGR_MINKOWSKI, RTGR_KS_REF, RTGR_KS_TRUE, RTGR_USER = UInt32(0), UInt32(1), UInt32(2), UInt32(3)
-const RTGR_PLANE, RTGR_SPHERE = UInt32(1), UInt32(2)
-
-pack(pl::RayTraceGR.Plane{Float64}) = RtgrObject(RTGR_PLANE, 0, (pl.time, 0, 0, 0, 0, 0, 0, 0, 0))
-pack(s::RayTraceGR.Sphere{Float64}) = RtgrObject(RTGR_SPHERE, 0, (s.pos..., s.vel..., s.radius))
-const NOOBJ = RtgrObject(0, 0, ntuple(_ -> 0.0, 9))
+# enum rtgr_metric / rtgr_object_kind / rtgr_ray_status of the header (tests/test_julia_stub.py compares the values)
+const RTGR_MINKOWSKI = UInt32(0)
+const RTGR_KS_REF = UInt32(1)
+const RTGR_KS_TRUE = UInt32(2)
+const RTGR_USER = UInt32(3)
+const RTGR_METRIC_GENERIC = UInt32(0x100)
+const RTGR_PLANE = UInt32(1)
+const RTGR_SPHERE = UInt32(2)
+const RTGR_DISK = UInt32(3)
+const RTGR_RAY_EVENT = UInt8(0)
+const RTGR_RAY_LAMBDA1 = UInt8(1)
+const RTGR_RAY_MAXSTEPS = UInt8(2)
+const RTGR_RAY_DTMIN = UInt8(3)
+const RTGR_RAY_NAN = UInt8(4)
 
 function check(rc)
     rc < 0 && error("librtgr_hip: ", unsafe_string(ccall((:rtgr_last_error, librtgr), Cstring, ())))
     rc
 end
+
+# ---- new scene vocabulary (SURVEY §8 f4): what BASELINE configs 2, 4 and 5 need and the reference does not have -------
+"""
+    KerrSchild(M, a; textbook = true, generic = false)
+
+The parameterised Kerr–Schild metric the reference's `kerr_schild` hard-wires to `M = 1`, `a = 0  # T(0.8)`
+(src/RayTraceGR.jl:275-276).  A callable like every metric of the reference — `KerrSchild(1.0, 0.8)(x)` is the 4x4 `g_ab`
+in plain Julia, accepts `Dual`s, works with `RayTraceGR.dmetric / christoffel / make_canvas / trace_rays` on the CPU — and
+the C ABI carries it as an enum plus `(M, a)`:
+`textbook = true`  → `RTGR_KS_TRUE`, the radius `r² = (q + sqrt(q² + 4a²z²))/2`, `q = ρ² − a²` (a true Kerr black hole);
+`textbook = false` → `RTGR_KS_REF`, the radius exactly as written at :284 (not a solution of the field equations for a ≠ 0;
+identical for a = 0).  `generic = true` traces with the reference's own formulation of the RHS (4-wide duals, 4x4 inverse,
+Christoffel contraction) instead of the closed Kerr–Schild contraction: same results to rounding, ~2.6 x the time.
+"""
+struct KerrSchild
+    M::Float64
+    a::Float64
+    textbook::Bool
+    generic::Bool
+end
+KerrSchild(M::Real = 1.0, a::Real = 0.0; textbook::Bool = true, generic::Bool = false) =
+    KerrSchild(Float64(M), Float64(a), textbook, generic)
+
+basereal(::Type{T}) where {T<:AbstractFloat} = T
+basereal(::Type{RayTraceGR.Dual{T,DT}}) where {T,DT} = T             # the reference's Dual mixes with its OWN scalar type only (:55-121)
+function (m::KerrSchild)(xx::SVector{4,T}) where {T}             # src/RayTraceGR.jl:274-294 with (M, a) as parameters
+    M, a = basereal(T)(m.M), basereal(T)(m.a)
+    t, x, y, z = xx
+    @assert !any(isnan, (t, x, y, z))                             # :279
+    η = @SMatrix T[p == q ? (p == 1 ? -1 : 1) : 0 for p in 1:4, q in 1:4]
+    ρ2 = x^2 + y^2 + z^2
+    if m.textbook
+        q = ρ2 - a^2
+        r = sqrt((q + sqrt(q^2 + 4 * a^2 * z^2)) / 2)
+    else
+        r = sqrt(ρ2 - a^2) / 2 + sqrt(a^2 * z^2 + ((ρ2 - a^2) / 2)^2)   # :284 as written
+    end
+    f = 2 * M * r^3 / (r^4 + a^2 * z^2)                           # :285
+    k = SVector{4,T}(1, (r * x + a * y) / (r^2 + a^2), (r * y - a * x) / (r^2 + a^2), z / r)   # :286-289
+    @SMatrix T[η[p, q] + f * k[p] * k[q] for p in 1:4, q in 1:4]   # :291
+end
+
+"""
+    Disk{T}(half_thickness, r_in, r_out) <: RayTraceGR.Object{T}
+
+Thin accretion disk `|z| <= h`, `r_in <= sqrt(x² + y²) <= r_out` in the equatorial plane (BASELINE config 5; no reference
+counterpart).  Obeys the reference's distance contract (:377-383: zero on the surface, positive outside, negative inside),
+so the reference's CPU `trace_rays` handles it too through the two methods below; `RTGR_DISK` across the ABI.
+"""
+struct Disk{T} <: RayTraceGR.Object{T}
+    half_thickness::T
+    r_in::T
+    r_out::T
+end
+function RayTraceGR.distance(d::Disk{T}, pos::SVector{4,T})::T where {T}
+    ϱ = sqrt(pos[2]^2 + pos[3]^2)
+    max(abs(pos[4]) - d.half_thickness, d.r_in - ϱ, ϱ - d.r_out)
+end
+function RayTraceGR.objcolor(d::Disk{T}, pos::SVector{4,T})::SVector{3,T} where {T}   # checkerboard in (radius, azimuth)
+    ϱ = sqrt(pos[2]^2 + pos[3]^2)
+    ϕ = atan(pos[3], pos[2])
+    SVector{3,T}(1, mod(ϱ, 1), mod(12 * ϕ / π, 1))
+end
+
+# the objects' own parameters stay Float64 across the ABI (rtgr_object.p); T selects the arithmetic of the path
+pack(pl::RayTraceGR.Plane) = RtgrObject(RTGR_PLANE, 0, (Float64(pl.time), 0, 0, 0, 0, 0, 0, 0, 0))
+pack(s::RayTraceGR.Sphere) = RtgrObject(RTGR_SPHERE, 0, (Float64.(s.pos)..., Float64.(s.vel)..., Float64(s.radius)))
+pack(d::Disk) = RtgrObject(RTGR_DISK, 0, (Float64(d.half_thickness), Float64(d.r_in), Float64(d.r_out), 0, 0, 0, 0, 0, 0))
+pack(o::RayTraceGR.Object) = nothing            # an object type this library does not know: the CPU path handles it
+const NOOBJ = RtgrObject(0, 0, ntuple(_ -> 0.0, 9))
 
 """
     Context(device_ids) / close(ctx)
@@ -100,6 +207,7 @@ function Base.close(c::Context)     # idempotent; also the finalizer
 end
 handle(::Nothing) = C_NULL
 handle(c::Context) = c.handle
+ndevices(ctx) = Int(check(ccall((:rtgr_context_devices, librtgr), Cint, (Ctx,), handle(ctx))))
 
 """
     DeviceMetric(code_object; M = 1.0, a = 0.0)
@@ -131,6 +239,8 @@ end
 
 # (enum, M, a, user_metric id) of a metric argument, or nothing when it cannot cross the ABI
 metric_desc(m::DeviceMetric, ctx) = (RTGR_USER, m.M, m.a, module_id(m, ctx))
+metric_desc(m::KerrSchild, ctx) = ((m.textbook ? RTGR_KS_TRUE : RTGR_KS_REF) | (m.generic ? RTGR_METRIC_GENERIC : UInt32(0)),
+                                   m.M, m.a, UInt64(0))
 metric_desc(m, ctx) = m === RayTraceGR.minkowski ? (RTGR_MINKOWSKI, 1.0, 0.0, UInt64(0)) :
                       m === RayTraceGR.kerr_schild ? (RTGR_KS_REF, 1.0, 0.0, UInt64(0)) :   # as written: M = 1, a = 0 (:275-276)
                       nothing
@@ -138,13 +248,51 @@ metric_desc(m, ctx) = m === RayTraceGR.minkowski ? (RTGR_MINKOWSKI, 1.0, 0.0, UI
 function scene_of(metric, objs, ctx)
     d = metric_desc(metric, ctx)
     (d === nothing || length(objs) > RTGR_MAX_OBJECTS) && return nothing
-    packed = ntuple(i -> i <= length(objs) ? pack(objs[i]) : NOOBJ, RTGR_MAX_OBJECTS)
+    po = map(pack, objs)
+    any(isnothing, po) && return nothing
+    packed = ntuple(i -> i <= length(po) ? po[i] : NOOBJ, RTGR_MAX_OBJECTS)
     Ref(RtgrScene(d[1], length(objs), d[2], d[3], d[4], packed))
 end
+solver_of(::Type{T}) where {T} = begin
+    opt = Ref{RtgrSolver}()
+    check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, T === Float32 ? 1 : 0))
+    opt
+end
+camera_of(pos, widthx, widthy, normal) =
+    Ref(RtgrCamera(Tuple(Float64.(pos)), Tuple(Float64.(widthx)), Tuple(Float64.(widthy)), Tuple(Float64.(normal))))
 
-# the objects' own parameters stay Float64 across the ABI (rtgr_object.p); T selects the arithmetic of the path
-pack(pl::RayTraceGR.Plane{Float32}) = RtgrObject(RTGR_PLANE, 0, (Float64(pl.time), 0, 0, 0, 0, 0, 0, 0, 0))
-pack(s::RayTraceGR.Sphere{Float32}) = RtgrObject(RTGR_SPHERE, 0, (Float64.(s.pos)..., Float64.(s.vel)..., Float64(s.radius)))
+"""
+    make_canvas(metric, pos, widthx, widthy, normal, ni, nj; ctx = nothing) -> Canvas{T}
+
+`RayTraceGR.make_canvas` (src/RayTraceGR.jl:457-478) on the device (`rtgr_make_canvas_f64/_f32`: metric at the pixel, `g⁻¹e_t`,
+normalisation — one thread per pixel), returned as the reference's own `Canvas{T}` of `Pixel{T}(x, u, zeros)` (:475).
+A metric that cannot cross the ABI falls back to the reference's function.
+"""
+function make_canvas(metric, pos::SVector{4,T}, widthx::SVector{4,T}, widthy::SVector{4,T}, normal::SVector{4,T},
+                     ni::Int, nj::Int; ctx = nothing) where {T<:Union{Float64,Float32}}
+    scene = scene_of(metric, RayTraceGR.Object{T}[], ctx)
+    scene === nothing && return RayTraceGR.make_canvas(metric, pos, widthx, widthy, normal, ni, nj)
+    cam = camera_of(pos, widthx, widthy, normal)
+    st = Array{T}(undef, 8, ni, nj)                 # n x 8 ray states, pixel index i + j*ni (column-major pixels[i,j], :463-464)
+    GC.@preserve st begin
+        if T === Float64
+            check(ccall((:rtgr_make_canvas_f64, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrCamera}, UInt64, UInt64, UInt64, UInt64, Ptr{Float64}),
+                        handle(ctx), scene, cam, ni, nj, 0, nj, pointer(st)))
+        else
+            check(ccall((:rtgr_make_canvas_f32, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrCamera}, UInt64, UInt64, UInt64, UInt64, Ptr{Float32}),
+                        handle(ctx), scene, cam, ni, nj, 0, nj, pointer(st)))
+        end
+    end
+    pixels = Array{RayTraceGR.Pixel{T}}(undef, ni, nj)
+    for j in 1:nj, i in 1:ni
+        pixels[i, j] = RayTraceGR.Pixel{T}(SVector{4,T}(st[1, i, j], st[2, i, j], st[3, i, j], st[4, i, j]),
+                                           SVector{4,T}(st[5, i, j], st[6, i, j], st[7, i, j], st[8, i, j]),
+                                           zeros(SVector{3,T}))
+    end
+    RayTraceGR.Canvas{T}(pixels)
+end
 
 """
     trace_rays(metric, objs, c::Canvas{T}; ctx = nothing) -> Canvas{T},   T = Float64 | Float32
@@ -153,12 +301,13 @@ Drop-in for `RayTraceGR.trace_rays` (src/RayTraceGR.jl:483-484).  Passes `pointe
 `Pixel{T}` AoS (:446-450; 88 bytes for Float64, 44 for Float32) — across the ABI; returns a new canvas with `rgb`
 filled (:532).  The tolerance is `eps(T)^(3/4)` as in the reference (:485).  `ctx = Context(0:7)`: all eight GPUs of a
 node work on the canvas (rows dealt cyclically); the result does not depend on the number of devices, bit for bit.
+`metric`: `minkowski`, `kerr_schild`, `KerrSchild(M, a)`, a `DeviceMetric`; anything else runs the reference's CPU path.
+`objs`: `Plane`, `Sphere`, `Disk`.
 """
 function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Canvas{T}; ctx = nothing) where {T<:Union{Float64,Float32}}
     scene = scene_of(metric, objs, ctx)
     scene === nothing && return RayTraceGR.trace_rays(metric, objs, c)        # arbitrary metric callable: reference CPU path
-    opt = Ref{RtgrSolver}()
-    check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, T === Float32 ? 1 : 0))
+    opt = solver_of(T)
     ni, nj = size(c.pixels)
     out = similar(c.pixels)
     ctr = Ref{RtgrCounters}()
@@ -177,22 +326,218 @@ function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Ca
 end
 
 """
-    trace_ray(metric, objs, cb, p::Pixel{Float64}; ctx = nothing) -> Pixel{Float64}
+    RayDetails{T}
+
+What the reference computes per ray and throws away: `sols.u[i]` (`state_end`, :516), `sol.t[end]` (`lambda_end`, :503), the
+solver's return code (`status`, ignored at :502-505), `omin` of the colouring rule (`hit`, :518-526), the accepted / rejected
+step counts; plus `redshift` (the frequency ratio observed/emitted from `Sphere.vel`, which the reference stores and never
+uses, :411) and the call's `RtgrCounters`.  Arrays are `ni x nj` like `c.pixels` (`state_end`: `8 x ni x nj`).
+"""
+struct RayDetails{T}
+    state_end::Array{T,3}
+    lambda_end::Matrix{T}
+    status::Matrix{UInt8}
+    hit::Matrix{UInt8}
+    n_accept::Matrix{UInt32}
+    n_reject::Matrix{UInt32}
+    redshift::Matrix{T}
+    counters::RtgrCounters
+end
+
+"""
+    render(metric, objs, pos, widthx, widthy, normal, ni, nj; T = Float64, ctx = nothing, details = false)
+        -> (R, G, B)  or  ((R, G, B), RayDetails)
+
+`make_canvas` + `trace_rays` in ONE call with the camera on the device (`rtgr_trace_f64/_f32`, `state0 = NULL`): the 88-byte
+pixels never exist — nothing goes up, three `ni x nj` planes come back (what `colorview(RGB, R', G', B')` consumes, :566-569).
+This is the call for the big screens (4096², 8192²: 5.9 GB of pixels each way otherwise).  All devices of `ctx` take part.
+"""
+function render(metric, objs, pos, widthx, widthy, normal, ni::Integer, nj::Integer;
+                T::Type = Float64, ctx = nothing, details::Bool = false)
+    scene = scene_of(metric, objs, ctx)
+    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric and Plane / Sphere / Disk cross the C ABI")
+    opt = solver_of(T)
+    cam = camera_of(pos, widthx, widthy, normal)
+    rgb = Array{T}(undef, ni, nj, 3)                # plane-major: rgb[:, :, c] is plane c
+    ctr = Ref{RtgrCounters}()
+    det = details ? RayDetails{T}(Array{T}(undef, 8, ni, nj), Matrix{T}(undef, ni, nj), Matrix{UInt8}(undef, ni, nj),
+                                  Matrix{UInt8}(undef, ni, nj), Matrix{UInt32}(undef, ni, nj), Matrix{UInt32}(undef, ni, nj),
+                                  Matrix{T}(undef, ni, nj), RtgrCounters(0, 0, 0, 0, 0, 0, 0, 0)) : nothing
+    GC.@preserve rgb det begin
+        outs = details ? Ref(RtgrRayOutputs(pointer(det.state_end), pointer(det.lambda_end), pointer(det.status), pointer(det.hit),
+                                            pointer(det.n_accept), pointer(det.n_reject), pointer(det.redshift))) :
+                         Ref(RtgrRayOutputs(C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+        if T === Float64
+            check(ccall((:rtgr_trace_f64, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Float64}, Ptr{RtgrCamera}, UInt64, UInt64, UInt64, UInt64,
+                         Ptr{Float64}, Ptr{RtgrRayOutputs}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, C_NULL, cam, ni, nj, 0, nj, pointer(rgb), outs, ctr))
+        else
+            check(ccall((:rtgr_trace_f32, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Float32}, Ptr{RtgrCamera}, UInt64, UInt64, UInt64, UInt64,
+                         Ptr{Float32}, Ptr{RtgrRayOutputs}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, C_NULL, cam, ni, nj, 0, nj, pointer(rgb), outs, ctr))
+        end
+    end
+    planes = (rgb[:, :, 1], rgb[:, :, 2], rgb[:, :, 3])
+    details || return planes
+    planes, RayDetails{T}(det.state_end, det.lambda_end, det.status, det.hit, det.n_accept, det.n_reject, det.redshift, ctr[])
+end
+
+"""
+    trace_ray(metric, objs, cb, p::Pixel{T}; ctx = nothing) -> Pixel{T}
 
 Legacy single-pixel shape (test/runtests.jl:76).  `cb` is ignored: the callback is always
 `ContinuousCallback(min_distance(objs, ·), terminate!)` (src/RayTraceGR.jl:488-490).
 """
-function trace_ray(metric, objs::Vector{RayTraceGR.Object{Float64}}, cb, p::RayTraceGR.Pixel{Float64}; ctx = nothing)
+function trace_ray(metric, objs::Vector{RayTraceGR.Object{T}}, cb, p::RayTraceGR.Pixel{T}; ctx = nothing) where {T<:Union{Float64,Float32}}
     scene = scene_of(metric, objs, ctx)
-    scene === nothing && error("only minkowski / kerr_schild / DeviceMetric cross the C ABI")
-    opt = Ref{RtgrSolver}()
-    check(ccall((:rtgr_solver_defaults, librtgr), Cint, (Ptr{RtgrSolver}, Cint), opt, 0))
+    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric cross the C ABI")
+    opt = solver_of(T)
     pos, nrm = Ref(p.pos), Ref(p.normal)
-    rgb = Ref(zeros(SVector{3,Float64})); se = Ref(zeros(SVector{8,Float64})); st = Ref{UInt8}(0)
-    check(ccall((:rtgr_trace_one_f64, librtgr), Cint,
-                (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
-                handle(ctx), scene, opt, pos, nrm, rgb, se, st))
-    RayTraceGR.Pixel{Float64}(p.pos, p.normal, rgb[])
+    rgb = Ref(zeros(SVector{3,T})); se = Ref(zeros(SVector{8,T})); st = Ref{UInt8}(0)
+    if T === Float64
+        check(ccall((:rtgr_trace_one_f64, librtgr), Cint,
+                    (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
+                    handle(ctx), scene, opt, pos, nrm, rgb, se, st))
+    else
+        check(ccall((:rtgr_trace_one_f32, librtgr), Cint,
+                    (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
+                    handle(ctx), scene, opt, pos, nrm, rgb, se, st))
+    end
+    RayTraceGR.Pixel{T}(p.pos, p.normal, rgb[])
+end
+
+# ---- the reference's unit-test surface on the device (test/runtests.jl:12-61) --------------------------------------------
+"""
+    dmetric(metric, x::SVector{4,T}; ctx = nothing) -> (g::SMatrix{4,4,T}, dg::SArray{Tuple{4,4,4},T})
+    christoffel(metric, x; ctx = nothing) -> Γ::SArray{Tuple{4,4,4},T}
+    metric_at(metric, x; ctx = nothing) -> g
+
+`RayTraceGR.dmetric` (:302-313) and `christoffel` (:321-331) evaluated by the device's dual-number path
+(`rtgr_eval_metric_f64/_f32`) — what test/runtests.jl:12-61 exercises, `T = Float32` at :37.  The C arrays are row-major
+`g[a][b]`, `dg[a][b][c] = ∂_c g_ab`, `Gam[a][b][c] = Γ^a_bc`; Julia's column-major view of the same bytes has the indices
+reversed, hence the `permutedims`.
+"""
+function eval_metric(metric, x::SVector{4,T}, ctx) where {T<:Union{Float64,Float32}}
+    scene = scene_of(metric, RayTraceGR.Object{T}[], ctx)
+    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric cross the C ABI")
+    xs = collect(x)
+    g = Array{T}(undef, 4, 4); dg = Array{T}(undef, 4, 4, 4); Γ = Array{T}(undef, 4, 4, 4)
+    GC.@preserve xs g dg Γ begin
+        if T === Float64
+            check(ccall((:rtgr_eval_metric_f64, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{Float64}, UInt64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                        handle(ctx), scene, pointer(xs), 1, pointer(g), pointer(dg), pointer(Γ)))
+        else
+            check(ccall((:rtgr_eval_metric_f32, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{Float32}, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                        handle(ctx), scene, pointer(xs), 1, pointer(g), pointer(dg), pointer(Γ)))
+        end
+    end
+    SMatrix{4,4,T}(permutedims(g)), SArray{Tuple{4,4,4},T}(permutedims(dg, (3, 2, 1))), SArray{Tuple{4,4,4},T}(permutedims(Γ, (3, 2, 1)))
+end
+metric_at(metric, x; ctx = nothing) = eval_metric(metric, x, ctx)[1]
+dmetric(metric, x; ctx = nothing) = eval_metric(metric, x, ctx)[1:2]
+christoffel(metric, x; ctx = nothing) = eval_metric(metric, x, ctx)[3]
+
+"""
+    geodesic(s::SVector{8,T}, metric; ctx = nothing, path = 2) -> ṡ::SVector{8,T}
+
+`RayTraceGR.geodesic(r, metric, λ)` (:358-370) on the device (`rtgr_eval_geodesic_f64/_f32`): `path = 1` is the reference's own
+formulation (duals → christoffel → contraction), `path = 2` exactly the function the production integrate loop calls.
+"""
+function geodesic(s::SVector{8,T}, metric; ctx = nothing, path::Integer = 2) where {T<:Union{Float64,Float32}}
+    scene = scene_of(metric, RayTraceGR.Object{T}[], ctx)
+    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric cross the C ABI")
+    si = collect(s); so = similar(si)
+    GC.@preserve si so begin
+        if T === Float64
+            check(ccall((:rtgr_eval_geodesic_f64, librtgr), Cint, (Ctx, Ptr{RtgrScene}, Ptr{Float64}, UInt64, Cint, Ptr{Float64}),
+                        handle(ctx), scene, pointer(si), 1, path, pointer(so)))
+        else
+            check(ccall((:rtgr_eval_geodesic_f32, librtgr), Cint, (Ctx, Ptr{RtgrScene}, Ptr{Float32}, UInt64, Cint, Ptr{Float32}),
+                        handle(ctx), scene, pointer(si), 1, path, pointer(so)))
+        end
+    end
+    SVector{8,T}(so)
+end
+
+# ---- example1() / example2() (src/RayTraceGR.jl:540-612): drop-in twins that write the same PNGs ---------------------------
+const outdir = "scenes"
+
+"8-bit image the way `save(file, colorview(RGB, R', G', B'))` quantises it (N0f8: round(clamp(v, 0, 1) * 255), :566-575): `3 x ni x nj`"
+quantize(planes) = UInt8[round(UInt8, clamp(planes[c][i, j], 0, 1) * 255) for c in 1:3, i in 1:size(planes[1], 1), j in 1:size(planes[1], 2)]
+
+function save_scene(file, planes)
+    # Images / ImageIO are the reference's own dependency for this step (:3-6, :575); loaded here so that `using RayTraceGRHIP`
+    # alone does not pull them in
+    Images = Base.require(Base.PkgId(Base.UUID("916415d5-f1e6-5110-898d-aaa5f9f070e0"), "Images"))
+    T = eltype(planes[1])
+    scene = Images.colorview(Images.RGB, T.(planes[1])', T.(planes[2])', T.(planes[3])')     # :566-569
+    mkpath(dirname(file))
+    rm(file, force = true)
+    println("Output file is \"$file\"")
+    Images.save(file, scene)                                                                 # :575
+end
+
+function example_scene(::Type{T}, which::Int) where {T}
+    caelum = RayTraceGR.Sphere{T}(SVector{4,T}(0, 0, 0, 0), SVector{4,T}(1, 0, 0, 0), -10)              # :546, :584
+    frustum = RayTraceGR.Plane{T}(-20)                                                                 # :547, :585
+    centre = which == 1 ? SVector{4,T}(0, 0, 0, 0) : SVector{4,T}(0, 4, 0, 0)                          # :548, :586
+    sphere = RayTraceGR.Sphere{T}(centre, SVector{4,T}(1, 0, 0, 0), T(1) / 2)
+    objs = RayTraceGR.Object{T}[caelum, frustum, sphere]
+    pos = which == 1 ? SVector{4,T}(0, 0, -2, 0) : SVector{4,T}(0, 4, -2, 0)                           # :554, :592
+    objs, pos, SVector{4,T}(0, 1, 0, 0), SVector{4,T}(0, 0, 0, 1), SVector{4,T}(0, 0, 1, 0)            # widthx, widthy, normal
+end
+
+"""
+    example1(; T = Float64, ni = 200, nj = 200, ctx = nothing, file = "scenes/sphere.png") -> Canvas{T}
+
+`RayTraceGR.example1()` (:542-578) with `make_canvas` and `trace_rays` on the device: Minkowski, caelum + frustum + sphere,
+the 200 x 200 screen — BASELINE config 1.  Writes the same PNG (39 855 of 40 000 pixels equal the committed `sphere.png`; the
+rest is the silhouette ring, where the reference's own result depends on the last bit of the root-finder — SURVEY §4.2).
+"""
+function example1(; T::Type = Float64, ni::Int = 200, nj::Int = 200, ctx = nothing, file = joinpath(outdir, "sphere.png"))
+    metric = RayTraceGR.minkowski
+    objs, pos, widthx, widthy, normal = example_scene(T, 1)
+    canvas = make_canvas(metric, pos, widthx, widthy, normal, ni, nj; ctx = ctx)
+    canvas = trace_rays(metric, objs, canvas; ctx = ctx)
+    file === nothing || save_scene(file, ntuple(c -> T[p.rgb[c] for p in canvas.pixels], 3))
+    canvas
+end
+
+"""
+    example2(; T = Float64, ni = 200, nj = 200, metric = kerr_schild, ctx = nothing, file = "scenes/sphere2.png") -> Canvas{T}
+
+`RayTraceGR.example2()` (:580-612): Kerr–Schild, three objects.  Defaults reproduce the committed `sphere2.png` byte for byte.
+BASELINE config 2: `example2(ni = 1024, nj = 1024, metric = KerrSchild(1.0, 0.8))`;
+config 4: `example2(T = Float32, ni = 2048, nj = 2048, metric = KerrSchild(1.0, 0.8))`.
+"""
+function example2(; T::Type = Float64, ni::Int = 200, nj::Int = 200, metric = RayTraceGR.kerr_schild, ctx = nothing,
+                  file = joinpath(outdir, "sphere2.png"))
+    objs, pos, widthx, widthy, normal = example_scene(T, 2)
+    canvas = make_canvas(metric, pos, widthx, widthy, normal, ni, nj; ctx = ctx)
+    canvas = trace_rays(metric, objs, canvas; ctx = ctx)
+    file === nothing || save_scene(file, ntuple(c -> T[p.rgb[c] for p in canvas.pixels], 3))
+    canvas
+end
+
+"""
+    example_disk(; a = 0.998, ni = 8192, nj = 8192, T = Float64, ctx = nothing, file = "scenes/disk.png") -> (R, G, B)
+
+BASELINE config 5: near-extremal Kerr (`KerrSchild(1.0, a)`, textbook radius) with a thin accretion disk
+`Disk(0.05, 2, 4)` in place of example2's small sphere (the camera, at cylindrical radius 4.5, stays outside the disk),
+example2's camera, an 8192² screen — through `render` (camera on the device; an `Array{Pixel{Float64}}` of that size would be
+5.9 GB each way).  The scene of `bench.py --variant ks_true0998_disk`.
+"""
+function example_disk(; a::Real = 0.998, ni::Int = 8192, nj::Int = 8192, T::Type = Float64, ctx = nothing,
+                      file = joinpath(outdir, "disk.png"))
+    objs, pos, widthx, widthy, normal = example_scene(T, 2)
+    objs[3] = Disk{T}(T(0.05), T(2), T(4))
+    planes = render(KerrSchild(1.0, a), objs, pos, widthx, widthy, normal, ni, nj; T = T, ctx = ctx)
+    file === nothing || save_scene(file, planes)
+    planes
 end
 
 end # module

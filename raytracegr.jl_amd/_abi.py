@@ -60,7 +60,7 @@ class rtgr_ray_outputs(C.Structure):
 EXPORTS = [
     "rtgr_create", "rtgr_destroy", "rtgr_context_devices", "rtgr_trim", "rtgr_init", "rtgr_shutdown", "rtgr_last_error",
     "rtgr_abi_version", "rtgr_solver_defaults", "rtgr_device_info", "rtgr_set_option", "rtgr_get_option",
-    "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read",
+    "rtgr_reserve_workspace", "rtgr_timing_enable", "rtgr_timing_read", "rtgr_timing_read_exchange", "rtgr_peer_access",
     "rtgr_trace_device_f64", "rtgr_trace_device_f32", "rtgr_trace_rows_device_f64", "rtgr_trace_rows_device_f32",
     "rtgr_trace_f64", "rtgr_trace_f32", "rtgr_trace_pixels_f64", "rtgr_trace_pixels_f32", "rtgr_trace_one_f64", "rtgr_trace_one_f32",
     "rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64", "rtgr_trace_sharded_f32", "rtgr_trace_sharded_device_f32",
@@ -105,6 +105,8 @@ def _declare(lib):
     lib.rtgr_reserve_workspace.argtypes = [ctx, vp, vp, u64, i32, i32]
     lib.rtgr_timing_enable.argtypes = [ctx, i32, i32]
     lib.rtgr_timing_read.argtypes = [ctx, i32, P(C.c_double * 4), P(C.c_uint64 * 4)]
+    lib.rtgr_timing_read_exchange.argtypes = [ctx, i32, P(C.c_double * 2), P(C.c_uint64 * 2)]
+    lib.rtgr_peer_access.argtypes = [ctx, i32, C.c_char_p, u64]
     for suf in ("f64", "f32"):
         getattr(lib, f"rtgr_trace_device_{suf}").argtypes = [
             ctx, P(rtgr_scene), P(rtgr_solver), vp, P(rtgr_camera), u64, u64, u64, u64, vp, P(rtgr_ray_outputs), vp, vp]

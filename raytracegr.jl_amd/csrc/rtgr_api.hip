@@ -494,11 +494,19 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
 // ---------------------------------------------------------------------------------------------------------------------
 // host <-> pinned copies with a few threads (a single core moves ~8 GB/s; PCIe Gen5 x16 wants ~55)
 // ---------------------------------------------------------------------------------------------------------------------
+// How many host threads of ONE call are packing / unpacking at the same time (trace_host_all_devices: one per device, each with
+// a downloader of its own): the copy threads of a pack are that call's share of the cores, not 8 each — an 8-device context
+// would otherwise start up to 8 x 2 x 8 short-lived threads per piece on the same cores and memory channels.
+static thread_local unsigned tl_copy_sharers = 1;
 template <class F>
 void parallel_rows(uint64_t n, size_t bytes_per_item, F&& body) {  // body(first, count)
     const size_t total = (size_t)n * bytes_per_item;
     unsigned hw = std::thread::hardware_concurrency();
     unsigned nt = total < (4u << 20) ? 1u : (hw >= 16 ? 8u : (hw >= 4 ? hw / 2 : 1u));
+    if (tl_copy_sharers > 1) {   // this call's share of the cores: (cores / 2 sharers), at least one thread
+        const unsigned share = hw / (2 * tl_copy_sharers);
+        nt = nt < (share ? share : 1u) ? nt : (share ? share : 1u);
+    }
     if (nt <= 1) { body((uint64_t)0, n); return; }
     std::vector<std::thread> th;
     const uint64_t per = (n + nt - 1) / nt;
@@ -685,8 +693,10 @@ int trace_host_pipelined(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solve
     for (auto& b : slot_busy) b.store(0);
     auto chunk_range = [&](uint64_t c, uint64_t& r0, uint64_t& m) { r0 = chunks[c].row0 * ni; m = chunks[c].rows * ni; };
     const int dev_ordinal = D.dev;
+    const unsigned copy_sharers = tl_copy_sharers;
     std::thread downloader([&] {
         (void)hipSetDevice(dev_ordinal);
+        tl_copy_sharers = copy_sharers;
         for (uint64_t c = 0; c < nchunks; c++) {
             while (chunks_enqueued.load(std::memory_order_acquire) <= c) {
                 if (abort_flag.load()) return;
@@ -843,6 +853,7 @@ int trace_host_all_devices(rtgr_context* c, const rtgr_scene* scene, const rtgr_
     auto work = [&](uint64_t k) {
         RowShare sh;
         sh.first = k; sh.stride = N;
+        struct Sharers { unsigned prev; explicit Sharers(unsigned n) : prev(tl_copy_sharers) { tl_copy_sharers = n; } ~Sharers() { tl_copy_sharers = prev; } } sharers((unsigned)N);
         rcs[k] = trace_host_pipelined<R>(*c->devs[k], scene, opt, state0, px_in, px_out, cam, ni, nj, j0, j1, rgb, out, &ctrs[k], sh);
         if (rcs[k]) errs[k] = g_err;   // the message is per thread: carry it to the caller's
     };
@@ -894,6 +905,21 @@ int host_has_nan(const R* v, uint64_t count) {
     for (uint64_t q = 0; q < count; q++)
         if (v[q] != v[q]) return 1;
     return 0;
+}
+
+// completed timed launches -> the device's accumulators ([0..3] pipeline kernels, [4..5] the multi-device exchange); D.mu held
+int collect_timed(DeviceCtx& d) {
+    for (auto& t : d.timed) {
+        HIP_TRY(hipEventSynchronize(t.b));
+        float e = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, t.a, t.b));
+        d.acc_ms[t.which] += e;
+        d.acc_n[t.which] += 1;
+        d.event_pool.push_back(t.a);
+        d.event_pool.push_back(t.b);
+    }
+    d.timed.clear();
+    return RTGR_OK;
 }
 
 uint64_t fnv1a(const std::vector<char>& b) {
@@ -1037,19 +1063,32 @@ int rtgr_timing_read(rtgr_context* ctx, int index, double ms[4], uint64_t launch
     if (!ms || !launches) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
     if (index < 0 || index >= (int)c->devs.size()) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
     DeviceCtx& d = *c->devs[index];
+    DeviceGuard guard(d.dev);
     std::lock_guard<std::mutex> lk(d.mu);
-    for (int w = 0; w < 4; w++) { ms[w] = 0.0; launches[w] = 0; }
-    for (auto& t : d.timed) {
-        HIP_TRY(hipEventSynchronize(t.b));
-        float e = 0.f;
-        HIP_TRY(hipEventElapsedTime(&e, t.a, t.b));
-        ms[t.which] += e;
-        launches[t.which] += 1;
-        d.event_pool.push_back(t.a);
-        d.event_pool.push_back(t.b);
-    }
-    d.timed.clear();
+    if ((rc = collect_timed(d))) return rc;
+    for (int w = 0; w < 4; w++) { ms[w] = d.acc_ms[w]; launches[w] = d.acc_n[w]; d.acc_ms[w] = 0.0; d.acc_n[w] = 0; }
     return RTGR_OK;
+}
+int rtgr_timing_read_exchange(rtgr_context* ctx, int index, double ms[2], uint64_t launches[2]) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!ms || !launches) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    if (index < 0 || index >= (int)c->devs.size()) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
+    DeviceCtx& d = *c->devs[index];
+    DeviceGuard guard(d.dev);
+    std::lock_guard<std::mutex> lk(d.mu);
+    if ((rc = collect_timed(d))) return rc;
+    for (int w = 0; w < 2; w++) { ms[w] = d.acc_ms[4 + w]; launches[w] = d.acc_n[4 + w]; d.acc_ms[4 + w] = 0.0; d.acc_n[4 + w] = 0; }
+    return RTGR_OK;
+}
+int rtgr_peer_access(rtgr_context* ctx, int index, char* why, uint64_t why_len) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (index < 0 || index >= (int)c->devs.size()) return fail(RTGR_ERR_BAD_ARG, "device index out of range");
+    if (why && why_len) std::snprintf(why, (size_t)why_len, "%s", c->peer_why[(size_t)index].c_str());
+    return c->peer_ok[(size_t)index] ? 1 : 0;
 }
 
 int rtgr_reserve_workspace(rtgr_context* ctx, const void* d_any, void* stream, uint64_t n_rays, int with_state_end, int is_f32) {
@@ -1195,6 +1234,24 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
     // the part / counter / receive buffers are shared by consecutive sharded calls: one such call at a time per context
     // (lock order: device 0's staging mutex first)
     std::vector<std::unique_lock<std::mutex>> locks;
+    // Any error return below leaves through this guard FIRST (declared after `locks`, so destroyed before them): once step 1 has
+    // started, devices 0..k-1 have kernels and copies in flight on their staging streams that read and write d_out / d_recv /
+    // pin_out; returning would drop the Staging locks and destroy the events under them, and the next sharded or host call could
+    // reuse or reallocate those buffers beneath running kernels.  So: drain every stream that may have been used.
+    struct Drain {
+        rtgr_context* c; std::vector<Staging*>& S; bool armed = true;
+        ~Drain() {
+            if (!armed) return;
+            for (size_t k = 0; k < S.size(); k++) {
+                if (!S[k]) continue;
+                DeviceGuard g(c->devs[k]->dev);
+                (void)hipStreamSynchronize(S[k]->s_comp);
+                (void)hipStreamSynchronize(S[k]->s_up);
+                (void)hipStreamSynchronize(S[k]->s_down);
+            }
+            (void)hipGetLastError();
+        }
+    } drain{c, S};
     for (uint64_t k = 0; k < N; k++) {
         DeviceCtx& D = *c->devs[k];
         DeviceGuard g(D.dev);
@@ -1248,6 +1305,10 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         if (k > 0) {
             char* rb = (char*)S[0]->d_recv.p + (k - 1) * part_bytes;
             const size_t used = part_bytes;  // padded arrays: a single copy per peer
+            std::unique_lock<std::mutex> tl(D.mu);   // (the timing list is the device's)
+            KernelTimer tm(D, S[k]->s_comp, 4);      // rtgr_timing_read_exchange [0]: this device's rows leaving it
+            tl.unlock();
+            struct Relock { std::unique_lock<std::mutex>& l; ~Relock() { l.lock(); } } relock{tl};   // ~KernelTimer runs after this: under D.mu again
             if (via_host[k]) HIP_TRY(hipMemcpyAsync(S[k]->pin_out[0].p, pb, used, hipMemcpyDeviceToHost, S[k]->s_comp));
             else if (c->devs[0]->dev == D.dev) HIP_TRY(hipMemcpyAsync(rb, pb, used, hipMemcpyDeviceToDevice, S[k]->s_comp));
             else {
@@ -1282,6 +1343,8 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         for (uint64_t k = 0; k < N; k++) {
             if (nrows[k] == 0) continue;
             HIP_TRY(hipStreamWaitEvent(s0, ev[k], 0));
+            std::lock_guard<std::mutex> tl(D0.mu);
+            KernelTimer tm(D0, s0, 5);               // rtgr_timing_read_exchange [1]: device 0 putting a rank's rows in place
             const char* src = k == 0 ? (const char*)S[0]->d_out.p : (const char*)S[0]->d_recv.p + (k - 1) * part_bytes;
             for (auto& a : arrs) {
                 if (a.planes == 3) {  // rgb: the part's planes are ni*nrows[k] apart
@@ -1303,6 +1366,7 @@ static int trace_sharded(rtgr_context* c, const rtgr_scene* scene, const rtgr_so
         for (int w = 0; w < 8; w++) q[w] = (w == 7) ? (q[w] > p[w] ? q[w] : p[w]) : q[w] + p[w];   // [7] is a maximum (diagnostics)
     }
     if (ctr) *ctr = sum;
+    drain.armed = false;   // every stream used above has been synchronised
     return RTGR_OK;
 }
 
@@ -1533,7 +1597,9 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 }  // extern "C"
 
 // load a gfx950 code object image into every device of the context; its id is a hash of the image
-static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out) {
+constexpr int RTGR_USER_MAX_SCRATCH = 64;   // bytes per lane above which rtgr_user_metric_compile rebuilds a unit at a lower occupancy
+static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out,
+                             int max_scratch = 1 << 30, int* scratch_out = nullptr) {
     const uint64_t id = fnv1a(image);
     std::lock_guard<std::mutex> load_lock(c->modules_mu);   // one load / unload at a time per context
     for (auto& d : c->devs) {
@@ -1565,9 +1631,14 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
                 return bail("not a user-metric code object (no rtgr_user_abi_version)");
             if (hipMemcpyDtoH(&ver, dptr, sizeof ver) != hipSuccess) return bail("cannot read rtgr_user_abi_version");
             if (ver != RTGR_ABI_VERSION) return bail("built against another ABI version");
-            unsigned fw = 0;   // optional: occupancy the unit's FAR pass was built for
-            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_far_waves") == hipSuccess && bytes == sizeof fw &&
-                hipMemcpyDtoH(&fw, dptr, sizeof fw) == hipSuccess && fw >= 1 && fw <= 8) u.far_waves = fw;
+            // optional: the occupancies the unit's FAR / NEAR+FULL / Float32 passes were built for
+            struct { const char* name; unsigned* dst; } occ[] = {{"rtgr_user_far_waves", &u.far_waves}, {"rtgr_user_near_waves", &u.near_waves},
+                                                                {"rtgr_user_f32_waves", &u.f32_waves}};
+            for (auto& o : occ) {
+                unsigned fw = 0;
+                if (hipModuleGetGlobal(&dptr, &bytes, u.module, o.name) == hipSuccess && bytes == sizeof fw &&
+                    hipMemcpyDtoH(&fw, dptr, sizeof fw) == hipSuccess && fw >= 1 && fw <= 8) *o.dst = fw;
+            }
             (void)hipGetLastError();
         }
         struct { hipFunction_t* f; const char* name; bool required; } want[] = {
@@ -1586,6 +1657,23 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
                 *w.f = nullptr;
             }
         if (!u.prepare_f32 || !u.fulln_f32) u.full10_f32 = nullptr;  // all or nothing
+        // scratch bytes per lane of the unit's integrate kernels: rtgr_user_metric_compile rebuilds a unit that spills at a lower
+        // occupancy (a performance matter: the heavy example metrics spill 200-400 registers per step at two waves per SIMD)
+        {
+            hipFunction_t ik[] = {u.far, u.near, u.full10, u.fulln, u.full10_f32, u.fulln_f32};
+            int worst = 0;
+            for (hipFunction_t f : ik) {
+                int local = 0;
+                if (!f || hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) != hipSuccess) { (void)hipGetLastError(); continue; }
+                worst = local > worst ? local : worst;
+            }
+            if (scratch_out) *scratch_out = worst;
+            if (worst > max_scratch) {
+                (void)hipModuleUnload(u.module);
+                return fail(RTGR_ERR_BAD_ARG, what + ": the integrate kernels spill " + std::to_string(worst) + " B per lane to scratch (limit asked: " +
+                            std::to_string(max_scratch) + ")");
+            }
+        }
         d->modules.push_back(u);
     }
     if (id_out) *id_out = id;
@@ -1687,29 +1775,40 @@ int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationa
         "#pragma once\ntypedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
         "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"};
     static const char* const hdr_name[] = {"hip/hip_runtime.h", "stdint.h"};
-    void* prog = nullptr;
-    if (R.create(&prog, unit.c_str(), "rtgr_user_unit.hip", 2, hdr_src, hdr_name) != 0) return fail(RTGR_ERR_HIP, "hiprtcCreateProgram failed");
     const std::string inc = "-I" + dir;
-    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
-    if (stationary || ks_form) opts.push_back("-DRTGR_USER_NE=3");   // (Kerr–Schild form: stationary by contract)
-    if (ks_form) opts.push_back("-DRTGR_USER_KS=1");
-    const int cr = R.compile(prog, (int)opts.size(), opts.data());
-    if (cr != 0) {
-        size_t ls = 0;
-        std::string log;
-        if (R.log_size(prog, &ls) == 0 && ls > 1) { log.resize(ls); (void)R.log(prog, &log[0]); }
+    // occupancy levels (waves per SIMD of the Float64 / Float32 generic-RHS kernels): the defaults first; a unit whose integrate
+    // kernels spill there is rebuilt with more registers per lane (the last level is taken as it comes)
+    static const char* const LEVELS[][2] = {{nullptr, nullptr},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2"},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1"}};
+    for (int level = 0; level < 3; level++) {
+        void* prog = nullptr;
+        if (R.create(&prog, unit.c_str(), "rtgr_user_unit.hip", 2, hdr_src, hdr_name) != 0) return fail(RTGR_ERR_HIP, "hiprtcCreateProgram failed");
+        std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+        if (stationary || ks_form) opts.push_back("-DRTGR_USER_NE=3");   // (Kerr–Schild form: stationary by contract)
+        if (ks_form) opts.push_back("-DRTGR_USER_KS=1");
+        for (const char* o : LEVELS[level]) if (o) opts.push_back(o);
+        const int cr = R.compile(prog, (int)opts.size(), opts.data());
+        if (cr != 0) {
+            size_t ls = 0;
+            std::string log;
+            if (R.log_size(prog, &ls) == 0 && ls > 1) { log.resize(ls); (void)R.log(prog, &log[0]); }
+            (void)R.destroy(&prog);
+            if (log.size() > 6000) log.resize(6000);
+            return fail(RTGR_ERR_BAD_ARG, "hiprtc failed on the user metric:\n" + log);
+        }
+        size_t cs = 0;
+        std::vector<char> image;
+        if (R.code_size(prog, &cs) != 0 || cs == 0) { (void)R.destroy(&prog); return fail(RTGR_ERR_HIP, "hiprtcGetCodeSize failed"); }
+        image.resize(cs);
+        const int gr = R.code(prog, image.data());
         (void)R.destroy(&prog);
-        if (log.size() > 6000) log.resize(6000);
-        return fail(RTGR_ERR_BAD_ARG, "hiprtc failed on the user metric:\n" + log);
+        if (gr != 0) return fail(RTGR_ERR_HIP, "hiprtcGetCode failed");
+        int spilled = 0;
+        rc = load_module_image(c, image, "compiled user metric", id_out, level < 2 ? RTGR_USER_MAX_SCRATCH : 1 << 30, &spilled);
+        if (rc == RTGR_OK || spilled <= RTGR_USER_MAX_SCRATCH) return rc;   // loaded; or failed for another reason than spilling
     }
-    size_t cs = 0;
-    std::vector<char> image;
-    if (R.code_size(prog, &cs) != 0 || cs == 0) { (void)R.destroy(&prog); return fail(RTGR_ERR_HIP, "hiprtcGetCodeSize failed"); }
-    image.resize(cs);
-    const int gr = R.code(prog, image.data());
-    (void)R.destroy(&prog);
-    if (gr != 0) return fail(RTGR_ERR_HIP, "hiprtcGetCode failed");
-    return load_module_image(c, image, "compiled user metric", id_out);
+    return rc;
 }
 
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id) {

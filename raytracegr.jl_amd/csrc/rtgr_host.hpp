@@ -77,6 +77,7 @@ struct UserModule {
     hipModule_t module = nullptr;
     bool owned = true;   // false: a logical duplicate of a device shares its twin's module and must not unload it
     unsigned far_waves = 0;  // waves per SIMD the unit's FAR pass is built for (0: the generic default)
+    unsigned near_waves = 0, f32_waves = 0;   // … its NEAR / FULL passes, Float64 and Float32 (0: the generic defaults)
     hipFunction_t far = nullptr, near = nullptr, full10 = nullptr, fulln = nullptr, canvas = nullptr, prepare = nullptr,
                   eval_metric = nullptr, eval_geodesic = nullptr, eval_accel = nullptr;
     // Float32 twins (absent in units built without them)
@@ -107,6 +108,8 @@ struct DeviceCtx {
     // optional per-kernel timing (bench.py's roofline leg): hipEvents around each kernel of the pipeline
     bool timing = false;
     std::vector<TimedLaunch> timed;
+    double acc_ms[6] = {0, 0, 0, 0, 0, 0};       // summed durations since the last read: [0..3] rtgr_timing_read, [4..5] rtgr_timing_read_exchange
+    uint64_t acc_n[6] = {0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> event_pool;
     std::unique_ptr<Staging, void (*)(Staging*)> staging{nullptr, nullptr};
 #ifdef RTGR_ROOT_STATS

@@ -434,7 +434,11 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 //  already be huge — 0 · inf = NaN would end the ray as RTGR_RAY_NAN instead of DTMIN, a flushed h² would ACCEPT the
                 //  step with maximum growth; same three multiplies.  ADVICE r3.)
                 const float hf32 = (float)h;
+#ifdef RTGR_OLD_ERRNORM
+                const float EEst2 = (acc2.x + acc2.y) * (0.125f * hf32 * hf32);
+#else
                 const float EEst2 = ((acc2.x + acc2.y) * hf32) * (0.125f * hf32);
+#endif
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
                 bool is_event = false, is_interior = false, handed = false, hand_back = false;
                 R top = R(0);

@@ -61,7 +61,7 @@ template <class R> RTGR_DEV R rmin(R a, R b);
 template <> RTGR_DEV double rmin<double>(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <> RTGR_DEV float rmin<float>(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // ---- fast reciprocal / reciprocal square root: hardware seed + ONE third-order correction on the FMA pipe.
-// Measured on gfx950 (rtgr_eval_fastmath_f64, tests/test_gpu_parity.py::test_fast_reciprocal_and_rsqrt_accuracy; the seeds
+// Measured on gfx950 (rtgr_eval_fastmath_f64 and its GPU test, test_fast_reciprocal_and_rsqrt_accuracy; the seeds
 // themselves in round 1 with a stand-alone microbenchmark): v_rcp_f64 / v_rsq_f64 seeds are good to 2^-24.4 / 2^-24.2, so a
 // cubically convergent step (error e³ ≈ 2^-73) lands on full double precision: max relative error 1.1e-16 / 1.4e-16
 // over 2^20 operands in [2^-10, 2^10].  No denormal / inf fix-up (operands here are O(1e-3 … 1e3)).  The IEEE

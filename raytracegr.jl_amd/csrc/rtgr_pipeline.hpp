@@ -147,7 +147,9 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
               // same-run A/B of the frame time, tools/launch_ab.py ab: a = 0.8 at 2.1 M rays 18.64 -> 17.87 ms, 4.2 M
               // 33.67 -> 33.25, 8.4 M 63.85 -> 64.25; a = 0 at 2.1 M 12.43 -> 12.37, 4.2 M 23.31 -> 23.48: beyond these
               // sizes the second wave's throughput is worth more).
-              dim3 gn = grid(waves_per_simd_of<R, METRIC>(MODE_NEAR));
+              int near_waves = waves_per_simd_of<R, METRIC>(MODE_NEAR);
+              if constexpr (USER) if (E.user->near_waves) near_waves = (int)E.user->near_waves;
+              dim3 gn = grid(near_waves);
               const uint64_t one_wave_below = (uint64_t)D.num_cu * 12 * 64 * (SPIN ? 32 : 12);
               const long wn = K.waves_per_cu_near >= 0 ? K.waves_per_cu_near : (P.n < one_wave_below ? 4 : 0);
               if (wn > 0 && (uint64_t)D.num_cu * (uint64_t)wn < gn.x) gn.x = (unsigned)((uint64_t)D.num_cu * (uint64_t)wn);
@@ -161,7 +163,12 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
         P.dbg = D.dbg;   // debug builds: the FULL pass reports its wave timeline too
 #endif
         KernelTimer tm(D, st, 1);
-        const dim3 g = grid(waves_per_simd_of<R, METRIC>(MODE_FULL));
+        int full_waves = waves_per_simd_of<R, METRIC>(MODE_FULL);
+        if constexpr (USER) {   // the occupancy the unit's FULL passes were built for (rtgr_user_near_waves / _f32_waves)
+            const unsigned uw = sizeof(R) == 8 ? E.user->near_waves : E.user->f32_waves;
+            if (uw) full_waves = (int)uw;
+        }
+        const dim3 g = grid(full_waves);
         // Float32, closed-form RHS, the reference's 10 sample points: the two-rays-per-lane kernel (rtgr_packed_f32.hpp); a wave is a
         // pool of 128 ray slots there.  It executes 1.55x fewer instructions per ray-step (PMC) but needs 205 registers — two waves
         // per SIMD, where a wave issues at most 83 % of the slots (tools/micro/valu_rates.hip: 3.75 vs 3.13 ticks per instruction at 2

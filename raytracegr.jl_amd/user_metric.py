@@ -62,7 +62,7 @@ def compile_user_metric(source, verbose=False, stationary=False):
     extra = ["-DRTGR_USER_NE=3"] if (stationary or ks_form) else []
     if ks_form:
         extra.append("-DRTGR_USER_KS=1")
-    tag = _digest(source, extra)
+    tag = _digest(source, extra + [f"max_scratch={MAX_SCRATCH}"])
     out = os.path.join(d, f"metric_{tag}.hsaco")
     if os.path.exists(out):
         return out
@@ -80,15 +80,60 @@ def compile_user_metric(source, verbose=False, stationary=False):
         fh.write(unit)
     os.replace(tmp_src, src)
     tmp = out + f".tmp{os.getpid()}"
-    cmd = [_build.HIPCC] + FLAGS + extra + ["-I", CSRC, "-o", tmp, src]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        if os.path.exists(tmp):
-            os.unlink(tmp)
-        raise RuntimeError(f"hipcc failed on the user metric ({src}):\n{r.stderr[-4000:]}")
-    os.replace(tmp, out)  # atomic: concurrent ranks may compile the same metric
+    # Occupancy levels: the unit's generic-RHS kernels are built for 2 (Float64) / 3 (Float32) waves per SIMD; a metric whose
+    # integrate kernels SPILL there (more than MAX_SCRATCH bytes per lane) is rebuilt with more registers per lane — 1 / 2, then
+    # 1 / 1 (512 registers), the last level taken as it comes: the heavy example metrics spill 200-400 registers per step at two
+    # waves per SIMD, which costs more than the second wave returns.  rtgr_user_metric_compile does the same in-process.
+    worst = {}
+    for n_level, level in enumerate(LEVELS):
+        cmd = [_build.HIPCC] + FLAGS + extra + level + ["-Rpass-analysis=kernel-resource-usage", "-I", CSRC, "-o", tmp, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+            raise RuntimeError(f"hipcc failed on the user metric ({src}):\n{r.stderr[-4000:]}")
+        worst = integrate_kernel_scratch(r.stderr)
+        if verbose:
+            print("   scratch bytes per lane:", worst, flush=True)
+        if max(worst.values(), default=0) <= MAX_SCRATCH or n_level == len(LEVELS) - 1:
+            os.replace(tmp, out)  # atomic: concurrent ranks may compile the same metric
+            return out
+
+
+MAX_SCRATCH = 64   # bytes per lane; == RTGR_USER_MAX_SCRATCH of rtgr_api.hip
+LEVELS = [[], ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2"],
+          ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1"]]
+
+
+def code_object_scratch(path):
+    """{kernel: private_segment_fixed_size} of a code object's integrate kernels, from its metadata notes (llvm-readelf; tests, tools)"""
+    import re
+    txt = subprocess.run([os.path.join(os.path.dirname(_build.HIPCC), "..", "lib", "llvm", "bin", "llvm-readelf"), "--notes", path],
+                         capture_output=True, text=True, check=True).stdout
+    out, cur = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"\s+\.name:\s+(\S+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+        if m and cur and cur.startswith("rtgr_user_integrate"):
+            out[cur] = int(m.group(1))
+    return out
+
+
+def integrate_kernel_scratch(remarks):
+    """{kernel: scratch bytes per lane} of the unit's integrate kernels, from hipcc's -Rpass-analysis=kernel-resource-usage remarks"""
+    import re
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and cur and cur.startswith("rtgr_user_integrate"):
+            out[cur] = int(m.group(1))
     return out
 
 

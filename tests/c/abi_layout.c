@@ -14,6 +14,12 @@
  *   abi_layout --render  <lib> out N the same through an explicit context that lists device 0 N times (rtgr_create): the
  *                                   drop-in entry deals the canvas rows to every device of the context — what a Julia
  *                                   `trace_rays(...; ctx = Context(0:7))` does on an 8-GPU node
+ *   abi_layout --render-disk <lib> out [N]
+ *                                   BASELINE config 5's scene the way julia/RayTraceGRHIP.jl's `render(KerrSchild(1.0, 0.998),
+ *                                   [caelum, frustum, Disk(0.05, 2, 4)], cam...; details = true)` passes it: RTGR_KS_TRUE with
+ *                                   (M, a) in the scene, an RTGR_DISK object, the camera struct (rays generated on the device),
+ *                                   rtgr_trace_f64 with an rtgr_ray_outputs block — 64 x 64; writes the three f64 RGB planes, then
+ *                                   hit, status, n_accept, n_reject (compared with the oracle by the test)
  */
 #include <dlfcn.h>
 #include <math.h>
@@ -63,13 +69,15 @@ typedef int (*fn_defaults)(rtgr_solver*, int);
 typedef int (*fn_canvas)(rtgr_context*, const rtgr_scene*, const rtgr_camera*, uint64_t, uint64_t, uint64_t, uint64_t, double*);
 typedef int (*fn_pixels)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const double*, uint64_t, uint64_t, double*, rtgr_counters*);
 typedef int (*fn_one)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const double*, const double*, double*, double*, uint8_t*);
+typedef int (*fn_trace)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const double*, const rtgr_camera*, uint64_t, uint64_t,
+                        uint64_t, uint64_t, double*, const rtgr_ray_outputs*, rtgr_counters*);
 typedef const char* (*fn_err)(void);
 typedef int (*fn_create)(const int*, int, rtgr_context**);
 typedef int (*fn_destroy)(rtgr_context*);
 typedef int (*fn_ndev)(rtgr_context*);
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render <lib> [out]\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render|--render-disk <lib> [out [ndev]]\n"); return 2; }
     void* h = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
     for (int i = 0; BOUND[i]; i++)
@@ -92,6 +100,43 @@ int main(int argc, char** argv) {
         if (ndev > RTGR_MAX_DEVICES) return 2;
         if (((fn_create)dlsym(h, "rtgr_create"))(ids, ndev, &ctx)) { fprintf(stderr, "rtgr_create: %s\n", err()); return 14; }
         if (((fn_ndev)dlsym(h, "rtgr_context_devices"))(ctx) != ndev) return 15;
+    }
+    if (strcmp(argv[1], "--render-disk") == 0) {
+        fn_trace trace = (fn_trace)dlsym(h, "rtgr_trace_f64");
+        rtgr_scene sc;
+        memset(&sc, 0, sizeof sc);
+        sc.metric = RTGR_KS_TRUE; sc.M = 1.0; sc.a = 0.998; sc.nobj = 3;                     /* KerrSchild(1.0, 0.998) */
+        sc.obj[0].kind = RTGR_SPHERE; sc.obj[0].p[4] = 1.0; sc.obj[0].p[8] = -10.0;             /* caelum */
+        sc.obj[1].kind = RTGR_PLANE; sc.obj[1].p[0] = -20.0;                                     /* frustum */
+        sc.obj[2].kind = RTGR_DISK; sc.obj[2].p[0] = 0.05; sc.obj[2].p[1] = 2.0; sc.obj[2].p[2] = 4.0;   /* Disk(0.05, 2, 4) */
+        rtgr_camera cam;
+        memset(&cam, 0, sizeof cam);
+        cam.pos[1] = 4.0; cam.pos[2] = -2.0; cam.widthx[1] = 1.0; cam.widthy[3] = 1.0; cam.normal[2] = 1.0;
+        rtgr_solver opt;
+        if (defaults(&opt, 0)) return 5;
+        const uint64_t ni = 64, nj = 64, n = ni * nj;
+        double* rgb = (double*)calloc(3 * n, sizeof(double));
+        uint8_t* hit = (uint8_t*)calloc(n, 1);
+        uint8_t* status = (uint8_t*)calloc(n, 1);
+        uint32_t* nacc = (uint32_t*)calloc(n, 4);
+        uint32_t* nrej = (uint32_t*)calloc(n, 4);
+        rtgr_ray_outputs outs;
+        memset(&outs, 0, sizeof outs);
+        outs.hit = hit; outs.status = status; outs.n_accept = nacc; outs.n_reject = nrej;
+        rtgr_counters ctr;
+        if (trace(ctx, &sc, &opt, NULL, &cam, ni, nj, 0, nj, rgb, &outs, &ctr)) { fprintf(stderr, "rtgr_trace_f64: %s\n", err()); return 7; }
+        if (ctr.rays != n) { fprintf(stderr, "counters: %llu rays\n", (unsigned long long)ctr.rays); return 8; }
+        FILE* f = fopen(argv[3], "wb");
+        if (!f) return 9;
+        fwrite(rgb, sizeof(double), 3 * n, f);
+        fwrite(hit, 1, n, f);
+        fwrite(status, 1, n, f);
+        fwrite(nacc, 4, n, f);
+        fwrite(nrej, 4, n, f);
+        fclose(f);
+        if (ctx && ((fn_destroy)dlsym(h, "rtgr_destroy"))(ctx)) return 16;
+        printf("ok %llu rays %llu events\n", (unsigned long long)ctr.rays, (unsigned long long)ctr.events);
+        return 0;
     }
     /* example2(): src/RayTraceGR.jl:581-593 */
     rtgr_scene sc;

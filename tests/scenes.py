@@ -25,13 +25,33 @@ def scene_variant(name):
     return rt.make_scene(m, objs), rt.make_camera(**cam)
 
 
-def wrap_aware_rgb_err(a, b, hit, nobj=3):
-    """L∞ distance between RGB planes a, b [3, n], evaluated modulo the sawtooth of objcolor (src/RayTraceGR.jl:427):
-    channels R,G of a sphere hit are mod(·,1)*omin/nobj, so the circular distance has period omin/nobj.  The thin disk (no
-    reference counterpart) puts its sawtooths on G and B (rtgr_integrator.hpp colour_pixel), so all three channels are
-    compared circularly; on a channel that is constant for the object hit the circular distance IS the distance."""
+def circular_channels(hit, sc=None):
+    """[3, n] bool: which RGB channels of a pixel carry a SAWTOOTH mod(·, 1)·omin/nobj and are therefore compared circularly.
+    A sphere hit puts it on R and G (objcolor, src/RayTraceGR.jl:420-428: B is the constant 1), the thin disk (no reference
+    counterpart; rtgr_integrator.hpp colour_pixel) on G and B (R is the constant 1); a plane's colour is constant.  Without a
+    scene every hit is taken for a sphere.  (the helper used to wrap B for every object, which scored a real B error
+    close to a multiple of omin/nobj on a sphere as ~0.)"""
+    n = hit.shape[0]
+    circ = np.zeros((3, n), bool)
+    kinds = np.full(n, rt._abi.SPHERE)
+    if sc is not None:
+        table = np.array([0] + [sc.obj[o].kind for o in range(sc.nobj)])
+        kinds = table[np.minimum(hit, sc.nobj)]
+    sph, dsk = (kinds == rt._abi.SPHERE) & (hit > 0), (kinds == rt._abi.DISK) & (hit > 0)
+    circ[0] = sph
+    circ[1] = sph | dsk
+    circ[2] = dsk
+    return circ
+
+
+def wrap_aware_rgb_err(a, b, hit, nobj=3, sc=None):
+    """L∞ distance between RGB planes a, b [3, n], evaluated modulo the sawtooth of objcolor (src/RayTraceGR.jl:427) on the
+    channels that carry one (circular_channels): there the circular distance has period omin/nobj; every other channel is
+    compared plainly.  Pass the scene when it may hold a disk."""
+    if sc is not None:
+        nobj = sc.nobj
     d = np.abs(a - b)
-    per = (hit.astype(np.float64) / nobj)[None, :]
+    per = (hit.astype(np.float64) / max(nobj, 1))[None, :]
     per = np.where(per > 0, per, 1.0)
-    dc = np.minimum(d, np.abs(per - d))
+    dc = np.where(circular_channels(hit, sc), np.minimum(d, np.abs(per - d)), d)
     return dc.max(initial=0.0)

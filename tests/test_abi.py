@@ -120,8 +120,8 @@ def test_c_caller_layout_and_symbols(lib, tmp_path):
     assert abi.rtgr_scene.user_metric.offset == 24 and abi.rtgr_scene.obj.offset == 32
     assert abi.rtgr_solver.max_steps.offset == 64 and abi.rtgr_ray_outputs.redshift.offset == 48
     jl = open(os.path.join(ROOT, "julia", "RayTraceGRHIP.jl")).read()
-    for line in ("RtgrScene     1312", "RtgrSolver      72", "Pixel{Float64}  88"):
-        assert line in jl, line
+    for name, size in (("RtgrScene", 1312), ("RtgrSolver", 72), ("RtgrCamera", 128), ("RtgrRayOutputs", 56), (r"Pixel\{Float64\}", 88)):
+        assert re.search(r"^#\s+" + name + r"\s+" + str(size) + r"\s", jl, re.M), name
 
 
 @pytest.mark.gpu
@@ -140,3 +140,36 @@ def test_c_caller_renders_example2(lib, tmp_path, ndev):
     img = np.fromfile(out, np.uint8).reshape(200, 200, 3)
     gold = read_png(os.path.join(ROOT, "tests", "golden", "sphere2.png"))
     assert int((img != gold).any(axis=2).sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndev", [0, 2])
+def test_c_caller_renders_the_kerr_disk_scene(lib, tmp_path, ndev):
+    """BASELINE config 5's scene through the bytes julia/RayTraceGRHIP.jl's `render(KerrSchild(1.0, 0.998), [caelum, frustum,
+    Disk(0.05, 2, 4)], cam...; details = true)` passes: RTGR_KS_TRUE with (M, a), an RTGR_DISK object, the camera struct, an
+    rtgr_ray_outputs block — compiled C, rtgr_trace_f64, 64 x 64 — against the oracle: hit map, statuses, step counts, RGB at
+    1e-6 (VERDICT r3 #1: the same bytes proven for the configurations the reference's own knob cannot reach)."""
+    import subprocess
+    import oracle_lib as O
+    from scenes import wrap_aware_rgb_err
+    exe = _build_c_caller(tmp_path)
+    out = str(tmp_path / "disk.bin")
+    res = subprocess.run([exe, "--render-disk", abi.LIB_PATH, out] + ([str(ndev)] if ndev else []), capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    n = 64 * 64
+    raw = open(out, "rb").read()
+    rgb = np.frombuffer(raw, np.float64, 3 * n).reshape(3, n)
+    hit = np.frombuffer(raw, np.uint8, n, 24 * n)
+    status = np.frombuffer(raw, np.uint8, n, 25 * n)
+    nacc = np.frombuffer(raw, np.uint32, n, 26 * n)
+    nrej = np.frombuffer(raw, np.uint32, n, 30 * n)
+    _, objs, cam = rt.example2_scene()
+    sc = rt.make_scene(rt.KerrSchild(1.0, 0.998), objs[:2] + [rt.Disk(0.05, 2.0, 4.0)])
+    ref = O.trace(sc, rt.solver_defaults(), 64, 64, cam=rt.make_camera(**cam))
+    flips = hit != ref["hit"]
+    assert int(flips.sum()) <= 2, int(flips.sum())
+    assert (hit == 3).sum() > 50                      # the disk is in the picture
+    same = ~flips
+    assert (status[same] == ref["status"][same]).all()
+    assert np.abs((nacc + nrej).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))[same].max() <= 2
+    assert wrap_aware_rgb_err(rgb[:, same], ref["rgb"][:, same], hit[same], sc=sc) <= 1e-6

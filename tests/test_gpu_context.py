@@ -25,6 +25,16 @@ def lib():
     return lib
 
 
+def _devices(n):
+    """n device ordinals for a context, DISTINCT physical GPUs as far as the box has them (VERDICT r3 #3a: on a node the multi-device
+    tests must touch a second GPU — peer copies, per-device PCIe links, modules loaded per device), the calling thread's current
+    device first (the tests keep their device-0 tensors there); on a one-GPU box the same ordinal n times: logical devices with
+    streams, workspaces and staging of their own."""
+    import torch
+    cur, count = torch.cuda.current_device(), max(torch.cuda.device_count(), 1)
+    return [(cur + k) % count for k in range(n)]
+
+
 def _trace(sc, opt, cam, ni, nj, ctx=None, stream=None):
     import torch
     from raytracegr_jl_amd import sharded
@@ -159,7 +169,7 @@ def test_single_process_multi_device_trace(lib, ndev):
     opt = rt.solver_defaults()
     ni, nj = 96, 77   # 77 rows: unequal shares
     ref = hip_trace(lib, sc, opt, ni, nj, cam=cam)
-    ctx = abi.create_context(lib, [torch.cuda.current_device()] * ndev)
+    ctx = abi.create_context(lib, _devices(ndev))
     try:
         assert lib.rtgr_context_devices(ctx) == ndev
         n = ni * nj
@@ -247,7 +257,7 @@ def test_device_resident_float32_and_support_entry_points(lib):
     assert name.value and cu.value >= 64 and mhz.value > 500 and wf.value == 64
     assert lib.rtgr_device_info(None, 5, name, 64, C.byref(cu), C.byref(mhz), C.byref(wf)) == abi.ERR_BAD_ARG
     # multi-device, Float32, frame left on device 0
-    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 3)
+    ctx = abi.create_context(lib, _devices(3))
     try:
         d_full = torch.zeros((3, n), dtype=torch.float32, device="cuda")
         d_hit = torch.full((n,), 255, dtype=torch.uint8, device="cuda")
@@ -274,7 +284,7 @@ def test_user_metric_on_a_multi_device_context(lib):
     _, objs, cam = rt.example2_scene()
     opt, camera = rt.solver_defaults(), rt.make_camera(**cam)
     ref = hip_trace(lib, rt.make_scene(user, objs), opt, 48, 33, cam=camera)
-    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 2)
+    ctx = abi.create_context(lib, _devices(2))
     try:
         sc = rt.make_scene(user, objs, ctx=ctx)          # loads the module into THIS context
         assert lib.rtgr_user_metric_loaded(ctx, sc.user_metric) == 1
@@ -298,7 +308,7 @@ def test_more_devices_than_rows(lib):
     sc, cam = example(2)
     opt = rt.solver_defaults()
     ref = hip_trace(lib, sc, opt, 9, 2, cam=cam)
-    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 4)
+    ctx = abi.create_context(lib, _devices(4))
     try:
         rgb = np.zeros((3, 18))
         abi.check(lib, lib.rtgr_trace_sharded_f64(ctx, C.byref(sc), C.byref(opt), C.byref(cam), 9, 2, rgb.ctypes.data, None, None))
@@ -455,7 +465,7 @@ def test_trace_rays_drop_in_entry_uses_every_device_of_the_context(lib, ndev):
     integrated something."""
     import torch
     metric, objs, cam = rt.example2_scene()
-    ctx = abi.create_context(lib, [torch.cuda.current_device()] * ndev)
+    ctx = abi.create_context(lib, _devices(ndev))
     try:
         canvas = rt.make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], 200, 200, ctx=ctx)
         single, info1 = rt.trace_rays(metric, objs, canvas, return_info=True)                 # default context: one device
@@ -500,7 +510,7 @@ def test_host_entry_with_caller_rays_and_every_output_over_all_devices(lib, ndev
     slab = np.ascontiguousarray(st[j0 * ni:j1 * ni])
     ref_s = hip_trace(lib, sc, opt, ni, nj, j0, j1, state0=slab)
     ref_c = hip_trace(lib, sc, opt, ni, nj, j0, j1, cam=cam)
-    ctx = abi.create_context(lib, [torch.cuda.current_device()] * ndev)
+    ctx = abi.create_context(lib, _devices(ndev))
     try:
         n = ni * (j1 - j0)
         for ref, s0, cm in ((ref_s, slab.ctypes.data, None), (ref_c, None, C.byref(cam))):
@@ -534,7 +544,7 @@ def test_gather_without_peer_access_and_peer_option(lib):
     ni, nj = 72, 50
     n = ni * nj
     ref = hip_trace(lib, sc, opt, ni, nj, cam=cam)
-    ctx = abi.create_context(lib, [torch.cuda.current_device()] * 3)
+    ctx = abi.create_context(lib, _devices(3))
     try:
         for peer in (0, 1, -1):
             abi.check(lib, lib.rtgr_set_option(ctx, b"peer", peer))
@@ -577,3 +587,47 @@ def test_trim_while_host_calls_are_in_flight(lib):
         stop.set()
         th.join()
     assert not errors, errors
+
+
+def test_peer_table_and_exchange_timers(lib):
+    """What makes a first multi-GPU run diagnosable (VERDICT r3 #3b): rtgr_peer_access reports, per device of the context, whether
+    its rows reach device 0 by peer copy (the same physical GPU counts as one) and why not otherwise; with timing enabled the
+    sharded call's exchange is timed per device — rows leaving a device on ITS stream, placement on device 0 — and the option
+    peer = 0 (rows through pinned host memory) is timed the same way."""
+    import torch
+    sc, cam = example(2)
+    opt = rt.solver_defaults()
+    ni, nj, nd = 128, 96, 3
+    ids = _devices(nd)
+    ctx = abi.create_context(lib, ids)
+    try:
+        why = C.create_string_buffer(256)
+        for k in range(nd):
+            ok = lib.rtgr_peer_access(ctx, k, why, 256)
+            assert ok in (0, 1)
+            assert ok == 1 or why.value, k                      # no peer access: the reason is recorded
+            if ids[k] == ids[0]:
+                assert ok == 1
+        assert lib.rtgr_peer_access(ctx, nd, why, 256) == abi.ERR_BAD_ARG
+        d0 = torch.device("cuda", ids[0])
+        d_rgb = torch.zeros((3, ni * nj), dtype=torch.float64, device=d0)
+        for peer in (-1, 0):
+            abi.check(lib, lib.rtgr_set_option(ctx, b"peer", peer))
+            for k in range(nd):
+                abi.check(lib, lib.rtgr_timing_enable(ctx, k, 1))
+            ctr = abi.rtgr_counters()
+            abi.check(lib, lib.rtgr_trace_sharded_device_f64(ctx, C.byref(sc), C.byref(opt), C.byref(cam), ni, nj, d_rgb.data_ptr(), None, C.byref(ctr)))
+            assert ctr.rays == ni * nj
+            for k in range(nd):
+                ms, ln = (C.c_double * 2)(), (C.c_uint64 * 2)()
+                abi.check(lib, lib.rtgr_timing_read_exchange(ctx, k, C.byref(ms), C.byref(ln)))
+                assert ln[0] == (1 if k > 0 else 0) and (ms[0] > 0.0) == (k > 0), (peer, k, ms[0], ln[0])
+                assert ln[1] == (nd if k == 0 else 0) and (ms[1] > 0.0) == (k == 0), (peer, k, ms[1], ln[1])
+                kms, kln = (C.c_double * 4)(), (C.c_uint64 * 4)()
+                abi.check(lib, lib.rtgr_timing_read(ctx, k, C.byref(kms), C.byref(kln)))
+                assert kln[1] >= 1 and kms[1] > 0.0             # this device's own FAR pass
+                abi.check(lib, lib.rtgr_timing_read_exchange(ctx, k, C.byref(ms), C.byref(ln)))
+                assert ln[0] == 0 and ln[1] == 0                # read = reset
+                abi.check(lib, lib.rtgr_timing_enable(ctx, k, 0))
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))

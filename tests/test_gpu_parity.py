@@ -13,7 +13,7 @@ import pytest
 
 import oracle_lib as O
 from conftest import ROOT
-from scenes import example, rt, scene_variant, wrap_aware_rgb_err
+from scenes import circular_channels, example, rt, scene_variant, wrap_aware_rgb_err
 
 pytestmark = pytest.mark.gpu
 abi = rt._abi
@@ -45,11 +45,11 @@ def hip_trace(lib, sc, opt, ni, nj, j0=0, j1=None, cam=None, state0=None, dtype=
     return arrs
 
 
-def compare(gpu, ref, nobj=3, max_class_flips=0, max_step_diff=0):
+def compare(gpu, ref, nobj=3, max_class_flips=0, max_step_diff=0, sc=None):
     flips = gpu["hit"] != ref["hit"]
     assert int(flips.sum()) <= max_class_flips, f"{int(flips.sum())} hit-class flips"
     same = ~flips
-    err = wrap_aware_rgb_err(gpu["rgb"][:, same], ref["rgb"][:, same], gpu["hit"][same], nobj)
+    err = wrap_aware_rgb_err(gpu["rgb"][:, same], ref["rgb"][:, same], gpu["hit"][same], nobj, sc=sc)
     assert err <= RGB_TOL, err
     sd = np.abs((gpu["n_accept"] + gpu["n_reject"]).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))
     assert int(sd[same].max(initial=0)) <= max_step_diff, int(sd[same].max())
@@ -282,7 +282,7 @@ def test_variant_crops_match_oracle(lib, name):
     opt = rt.solver_defaults()
     gpu = hip_trace(lib, sc, opt, 64, 64, cam=cam)
     ref = O.trace(sc, opt, 64, 64, cam=cam)
-    compare(gpu, ref, max_class_flips=4, max_step_diff=2)
+    compare(gpu, ref, max_class_flips=4, max_step_diff=2, sc=sc)
 
 
 def test_slab_and_state0_inputs_agree_with_full_frame(lib):
@@ -442,7 +442,7 @@ def test_far_near_split_is_bit_identical_to_full_scan(lib):
         flips = a["hit"] != c["hit"]
         assert int(flips.sum()) <= (40 if name == "mink" else 2)
         same = ~flips
-        assert wrap_aware_rgb_err(a["rgb"][:, same], c["rgb"][:, same], a["hit"][same]) <= RGB_TOL
+        assert wrap_aware_rgb_err(a["rgb"][:, same], c["rgb"][:, same], a["hit"][same], sc=sc) <= RGB_TOL
 
 
 def test_four_waves_per_simd_far_variant_is_bit_identical(lib):
@@ -578,7 +578,7 @@ def test_f32_crops_of_the_spinning_variants_match_f32_oracle(lib, name):
     flips = gpu["hit"] != ref["hit"]
     assert flips.mean() <= F32_FLIP_FRAC, flips.mean()
     same = ~flips
-    assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same]) < F32_RGB_TOL
+    assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same], sc=sc) < F32_RGB_TOL
     g = gpu["counters"]["accepted"] + gpu["counters"]["rejected"]
     r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
     assert F32_STEPS[0] * r <= g <= F32_STEPS[1] * r, (gpu["counters"], ref["counters"])
@@ -613,7 +613,7 @@ def test_f32_packed_two_rays_per_lane_kernel_equals_the_scalar_kernel(lib, name)
         assert flips.sum() <= max(1, n // 500), flips.sum()
         same = ~flips
         # (two Float32 solutions, each within ~1e-4 of the true geodesic — tests/test_truth.py — differ by up to twice that)
-        assert wrap_aware_rgb_err(two["rgb"][:, same].astype(float), one["rgb"][:, same].astype(float), two["hit"][same]) < 5e-4
+        assert wrap_aware_rgb_err(two["rgb"][:, same].astype(float), one["rgb"][:, same].astype(float), two["hit"][same], sc=sc) < 5e-4
         a2, a1 = (two["counters"][k] for k in ("accepted", "rejected")), (one["counters"][k] for k in ("accepted", "rejected"))
         assert abs(sum(a2) - sum(a1)) <= 0.01 * sum(one["counters"][k] for k in ("accepted", "rejected")) + 2
         ok = same & (one["hit"] != 2)      # (captured rays end with |u| ~ 1e4: relative bars only)
@@ -631,7 +631,7 @@ def test_f32_packed_two_rays_per_lane_kernel_equals_the_scalar_kernel(lib, name)
     ref = O.trace(sc, opt, 64, 64, cam=cam, dtype=np.float32)
     flips = gpu["hit"] != ref["hit"]
     assert flips.mean() <= (0.03 if name == "mink" else F32_FLIP_FRAC), flips.mean()
-    assert wrap_aware_rgb_err(gpu["rgb"][:, ~flips].astype(float), ref["rgb"][:, ~flips].astype(float), gpu["hit"][~flips]) < F32_RGB_TOL
+    assert wrap_aware_rgb_err(gpu["rgb"][:, ~flips].astype(float), ref["rgb"][:, ~flips].astype(float), gpu["hit"][~flips], sc=sc) < F32_RGB_TOL
     g = gpu["counters"]["accepted"] + gpu["counters"]["rejected"]
     r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
     assert name == "mink" or F32_STEPS[0] * r <= g <= F32_STEPS[1] * r      # (Minkowski: the step sequence is rounding noise)
@@ -940,7 +940,8 @@ def random_scene_violations(gpu, ref, sc, nobj):
     d = np.abs(gpu["rgb"][:, same] - ref["rgb"][:, same])
     per = gpu["hit"][same].astype(np.float64) / max(nobj, 1)   # sawtooth period of a coloured hit (:427, :530)
     per = np.where(per > 0, per, 1.0)[None, :]
-    e = np.minimum(d, np.abs(per - d)).max(axis=0) if same.any() else np.zeros(0)
+    # circular only on the channels that carry a sawtooth for the object hit (scenes.circular_channels)
+    e = np.where(circular_channels(gpu["hit"][same], sc), np.minimum(d, np.abs(per - d)), d).max(axis=0) if same.any() else np.zeros(0)
     bad = e > RGB_TOL
     # rays that orbit the hole many times before they hit something (>= 500 step attempts) amplify rounding differences
     # exponentially (unstable photon orbit); they are the only ones allowed over the bound, and only a few

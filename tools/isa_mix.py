@@ -67,7 +67,7 @@ def kernel_body(lines, needle):
     start = None
     for i, l in enumerate(lines):
         head = l.split(";")[0].rstrip()
-        if start is None and head.endswith(":") and needle in head and head.startswith("_Z"):
+        if start is None and head.endswith(":") and needle in head and (head.startswith("_Z") or head == needle + ":"):   # (extern "C" kernels of the user units are not mangled)
             start = i
         elif start is not None and l.startswith(".Lfunc_end"):
             return lines[start:i]
