@@ -158,6 +158,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     const float beta1 = 0.14f, beta2 = 0.08f;
     const int npts = (int)A.opt.interp_points;
     const R eps = sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7);
+    const R t1_snap = uniform_(t1 - R(16) * eps * rmaxabs<R>(t0, t1));   // below this λ the snap-to-λ1 test cannot hold
 
     int state = L_FREE;
     bool exhausted = false;
@@ -212,6 +213,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 default: __builtin_amdgcn_s_setprio(0); break;
             }
         }
+        // [budget: refill]
         // ================= refill: free lanes take ray ids from the wave's slice of the queue ====================
         const bool resume = (MODE == MODE_NEAR || A.pick_flag != 0u);
         unsigned long long m_need = __ballot(state == L_FREE);
@@ -307,6 +309,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         // (One exit and one back-edge: a `continue` here was a second latch path and cost a round trip of phi copies.)
         if (__ballot(state == L_RUN) == 0ull) break;
 
+        // [budget: stage sums]
         // ================= one Tsit5 attempt per runnable lane ====================================================
         // The seven stages run in UNIFORM control flow: a lane without a ray computes along with h = 0 on whatever
         // state it holds (a VALU instruction costs the same with 1 or 64 lanes active) and nothing it computes is
@@ -344,7 +347,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 for (int q = 0; q < 3; q++) X[q] = rfma(hc, u[1 + q], x[1 + q]);
                 if constexpr (TDEP) Xt = rfma(hc, u[0], x[0]);
             }
+            // [budget: rhs]
             accel<R, METRIC, SPIN, true>(X, U, MK, k[1], Xt);
+            // [budget: stage sums]
             KSTORE(1);
             // ---- stage 3 -------------------------------------------------------------------------------------
             {
@@ -355,7 +360,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 for (int q = 0; q < 3; q++) X[q] = rfma(h2a, k[0][1 + q], rfma(hc, u[1 + q], x[1 + q]));
                 if constexpr (TDEP) Xt = rfma(h2a, k[0][0], rfma(hc, u[0], x[0]));
             }
+            // [budget: rhs]
             accel<R, METRIC, SPIN, true>(X, U, MK, k[2], Xt);
+            // [budget: stage sums]
             KSTORE(2);
             // ---- stages 4, 5, 6 ----------------------------------------------------------------------------------
 #pragma unroll
@@ -366,7 +373,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 X[q] = rfma(h2, rfma(N::A2[3][1], KL(1, 1 + q), N::A2[3][0] * k[0][1 + q]),
                             rfma(h * N::c[3], u[1 + q], x[1 + q]));
             if constexpr (TDEP) Xt = rfma(h2, rfma(N::A2[3][1], KL(1, 0), N::A2[3][0] * k[0][0]), rfma(h * N::c[3], u[0], x[0]));
+            // [budget: rhs]
             accel<R, METRIC, SPIN, true>(X, U, MK, k[3], Xt);
+            // [budget: stage sums]
             KSTORE(3);
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -378,7 +387,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             rfma(h * N::c[4], u[1 + q], x[1 + q]));
             if constexpr (TDEP) Xt = rfma(h2, rfma(N::A2[4][2], KL(2, 0), rfma(N::A2[4][1], KL(1, 0), N::A2[4][0] * k[0][0])),
                                           rfma(h * N::c[4], u[0], x[0]));
+            // [budget: rhs]
             accel<R, METRIC, SPIN, true>(X, U, MK, k[4], Xt);
+            // [budget: stage sums]
             KSTORE(4);
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -390,7 +401,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             N::A2[5][0] * k[0][1 + q]))), rfma(h * N::c[5], u[1 + q], x[1 + q]));
             if constexpr (TDEP) Xt = rfma(h2, rfma(N::A2[5][3], KL(3, 0), rfma(N::A2[5][2], KL(2, 0), rfma(N::A2[5][1], KL(1, 0),
                                           N::A2[5][0] * k[0][0]))), rfma(h * N::c[5], u[0], x[0]));
+            // [budget: rhs]
             accel<R, METRIC, SPIN, true>(X, U, MK, k[5], Xt);
+            // [budget: stage sums]
             KSTORE(5);
             // ---- stage 7 = the step result (FSAL) ----------------------------------------------------------------
 #pragma unroll
@@ -400,6 +413,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 xn[q] = rfma(h2, rfma(N::A2[6][4], KL(4, q), rfma(N::A2[6][3], KL(3, q), rfma(N::A2[6][2], KL(2, q),
                              rfma(N::A2[6][1], KL(1, q), N::A2[6][0] * k[0][q])))), rfma(h * N::c[6], u[q], x[q]));
             }
+            // [budget: rhs]
             accel<R, METRIC, SPIN, true>(xn + 1, un, MK, k[6], xn[0]);
 
             // The error estimate, the controller, the reach bound and (NEAR) the sample-point scan ALSO run in uniform control
@@ -411,6 +425,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
             // hold and h = 0; every side effect below is gated by `run`, and their decisions are wiped at the end of the block.
             // (-DRTGR_GHOST_LANES=0: the block under the running lanes' EXEC mask, for A/B.)
             if (RTGR_GHOST_LANES ? true : run) {
+        // [budget: error norm]
                 // ---- embedded error, residual norm in f32 ----------------------------------------
                 // ũ_q = h e_q with e = (Σ b̃_l k_l, h Σ BT2_l k_l + Σb̃ u): the common factor h is applied ONCE, to the f32 sum
                 // of squares (eight f64 products less per step), and the (u, x) pair of a component goes through the
@@ -439,6 +454,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #else
                 const float EEst2 = ((acc2.x + acc2.y) * hf32) * (0.125f * hf32);
 #endif
+        // [budget: controller]
                 uint32_t done = 0xffu;  // 0xff = still running, else rtgr_ray_status
                 bool is_event = false, is_interior = false, handed = false, hand_back = false;
                 R top = R(0);
@@ -448,9 +464,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 } else {
                     // ---- PI controller in log2 space: q = EEst^β1 / qold^β2 / γ ----------------------
                     const float le = 0.5f * flog2(fmax1(EEst2, 1e-37f));  // log2 of the error estimate itself (floor 3e-19)
-                    const float q11 = fexp2(beta1 * le);
                     float qf = fexp2(__builtin_fmaf(beta1, le, -beta2 * lq)) * igamma;
                     qf = (EEst2 == 0.0f) ? qmax_inv : fclamp1(qf, qmax_inv, qmin_inv);
+        // [budget: reach bound]
                     bool hand_over = false;
                     bool need_scan = true;  // NEAR: false when no lane of the wave can see a sign change in this step
                     if constexpr (MODE == MODE_FAR || MODE == MODE_NEAR) {
@@ -498,6 +514,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         // whenever NO active lane needs it — a wave-uniform decision, same results by the same bound.
                         if constexpr (MODE == MODE_NEAR) need_scan = __ballot(run && (EEst2 <= 1.0f) && need_scan) != 0ull;
                     }
+        // [budget: hand over]
                     if (hand_over) {
                         // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
                         R* hd = A.hand + idx * (uint64_t)A.recw;
@@ -513,12 +530,18 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         // start with them, packed together (collected per wave in LDS, see the end of the loop body).
                         if (early_ray) list_it = true;
                         handed = true;
+        // [budget: controller]
                     } else if (EEst2 <= 1.0f) {
                         nacc++;
                         lq = fmax1(le, lq_init);  // log2(max(EEst, qoldinit))
                         const R dtnew = dt * (R)__builtin_amdgcn_rcpf(qf);
                         R tnew = t + dt;
-                        if (rabs(tnew - t1) < R(10) * eps * rmaxabs<R>(tnew, t1)) tnew = t1;
+                        // snap to λ1 within 10 ulp (OrdinaryDiffEq's fixed-tstop rule) — tested only where it can hold: λ ∈ [λ0, λ1], so
+                        // |tnew − λ1| < 10 eps max(|tnew|, |λ1|) needs tnew > t1_snap (a wave-uniform constant): one compare per step
+                        if (tnew > t1_snap) {
+                            if (rabs(tnew - t1) < R(10) * eps * rmaxabs<R>(tnew, t1)) tnew = t1;
+                        }
+        // [budget: scan]
                         // ---- ContinuousCallback ----------------------------------------------------
                         // x(θ) = x + θ c1 + θ² c2 + θ³ c3 + θ⁴ c4 ;  c1 = h u,  c_m = h² Σ_l R2[l][m] k_l
                         // (FAR pass: proven above that no object's distance changes sign in this step — nothing to scan)
@@ -600,6 +623,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         }
                         if (!is_event) ps = rsign(nextc);
                         }  // scan
+        // [budget: controller]
                         if (!is_event) {
                             commit = true;
                             t = tnew;
@@ -611,11 +635,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         }
                     } else {
                         nrej++;
-                        dt = dt * (R)__builtin_amdgcn_rcpf(fmin1(qmin_inv, q11 * igamma));
+                        // (EEst^β1, the rejected step's factor, is formed HERE: Float64 rays reject about one step in 10⁴, and an
+                        //  exp2 + a product in every step's uniform flow were two issue slots — 3.6 with the transcendental's cost — for them)
+                        dt = dt * (R)__builtin_amdgcn_rcpf(fmin1(qmin_inv, fexp2(beta1 * le) * igamma));
                         if (nacc + nrej >= A.opt.max_steps) done = RTGR_RAY_MAXSTEPS;
                         else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
                     }
                 }
+        // [budget: records and bookkeeping]
                 if (!run) {  // a ghost lane decides nothing
                     done = 0xffu; is_event = false; is_interior = false; handed = false; hand_back = false; commit = false;
                     list_it = false;
@@ -704,6 +731,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 }
             }
         }
+        // [budget: commit]
         // ---- commit the accepted step: the only place (besides the refill) where the ray state is assigned ------------
         // (the compiler emits this as 12 v_mov_b64 under the lanes' EXEC mask — not as 24 v_cndmask_b32 selects; checked
         //  in the ISA, tools/isa_mix.py --list mov)
@@ -711,6 +739,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #pragma unroll
             for (int q = 0; q < 4; q++) { x[q] = xn[q]; u[q] = un[q]; k0[q] = k[6][q]; }
         }
+        // [budget: early list]
         // ---- FAR: early-list entries are collected in LDS and appended to the global list RTGR_EARLY_BUF/2 at a time:
         // an append with its own device atomic stalls the wave for the atomic's round trip every time ANY lane has one
         // (measured: +13 % on the whole pass when a sixth of the rays qualified)
@@ -722,6 +751,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 if (e_cnt > RTGR_EARLY_BUF / 2) { flush_early(A, early_buf, e_cnt, lane); e_cnt = 0; }
             }
         }
+        // [budget: end]
     }
     if constexpr (MODE == MODE_FAR) {
         if (e_cnt != 0u) flush_early(A, early_buf, e_cnt, lane);

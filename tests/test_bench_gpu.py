@@ -44,6 +44,10 @@ def test_bench_line_schema_and_one_rank_exchange_path():
     assert ex["exchange"] == "overlapped with the next pass" and ex["frames_in_flight"] == 2
     assert ex["gathered_status_not_event"] == 0 and ex["step_attempts_per_pass"] == base["step_attempts_per_pass"]
     assert ex["cpu_baseline"] is None                                  # the CPU leg is N = 1 only
+    # what makes a multi-GPU line diagnosable: every rank's kernel times, rays, attempts and its exchange time
+    assert len(ex["per_rank"]) == 1 and ex["per_rank"][0]["far_ms"] > 0 and ex["per_rank"][0]["exchange_ms"] > 0
+    assert ex["per_rank"][0]["rays"] == 512 * 512 and ex["per_rank"][0]["step_attempts"] == base["step_attempts_per_pass"]
+    assert ex["rank_imbalance"]["integrate_ms_max"] >= ex["rank_imbalance"]["integrate_ms_min"] > 0
     serial = _bench("--size", "512", "--steps", "2", "--warmup", "1", "--exchange-at-n1", "--no-overlap")
     assert serial["frame_checksum"] == base["frame_checksum"] and serial["exchange"] == "in turn"
 
@@ -72,5 +76,32 @@ def test_bench_single_process_multi_device_entries():
             n = int(args[-1])
             assert d["ctx_devices"] == [0] * n and "rehearsal" in d["ctx_note"]
             assert len(d["per_device_kernel_ms"]) == n and all(v["far"] > 0 for v in d["per_device_kernel_ms"])
+            assert d["roofline"]["achieved"] is None and "approximate" in d["roofline"]   # logical devices time-share one GPU: no roofline
+        if args[1] == "sharded":   # peer-access table + the library's exchange timers, per device of the context
+            assert [p["peer_access_with_device_0"] for p in d["peer_access"]] == [1, 1, 1]
+            ex = d["exchange_per_device"]
+            assert ex[0]["rows_out_ms"] == 0 and ex[0]["place_rows_ms"] > 0 and all(e["rows_out_ms"] > 0 and e["copies"] == 1 for e in ex[1:])
     for k in ("contract_8d_frac", "contract_8d_note"):
         assert k in base["roofline"]
+
+
+def test_bench_two_rank_rehearsal_line_is_diagnosable():
+    """The driver's N > 1 launch form with two gloo ranks sharing this one GPU (RCCL does not allow that; gloo stages the gather
+    through the host): the line carries every rank's kernel times, rays, step attempts and exchange time, the imbalance summary,
+    and the frame equals the N = 1 frame bit for bit.  A rehearsal of the code path — not a scaling figure."""
+    base = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "256",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_checked"] == 2 and d["frame_checksum"] == base["frame_checksum"]
+    assert d["step_attempts_per_pass"] == base["step_attempts_per_pass"] and d["gathered_status_not_event"] == 0
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and sum(p["rays"] for p in pr) == 256 * 256
+    assert sum(p["step_attempts"] for p in pr) == base["step_attempts_per_pass"]
+    assert all(p["far_ms"] > 0 and p["near_ms"] > 0 and p["exchange_ms"] > 0 and p["wall_ms"] > 0 for p in pr)
+    assert 1.0 <= d["rank_imbalance"]["max_over_mean"] < 2.0

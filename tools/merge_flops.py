@@ -35,6 +35,10 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
         key += "/scalar_kernel"
     e["config_dir"] = f"profiles/{rnd}/{cfg}"
     out["entries"][key] = e
+    # the N = 1 device-entry frame of this configuration from THESE kernel sources: bench.py asserts that every other way of
+    # delivering the frame (N ranks, the sharded / host / pixels entries) yields the same order-independent bit-level checksum
+    if line.get("frame_checksum") is not None and line["n_gpus"] == 1 and line["config"].get("entry") == "device" and not cfg.endswith("_scalar"):
+        out.setdefault("frame_checksums", {})[f'{key}/{line["config"]["size"]}'] = line["frame_checksum"]
     dst = os.path.join(ROOT, "profiles", rnd, cfg)
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(d, "summary.txt"), dst)
