@@ -195,8 +195,9 @@ int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len
 /* Launch-policy options (experiments and schedule-invariance tests).  Names: "waves_per_cu", "waves_per_cu_near", "chunk",
  * "split", "order", "fair", "near_early", "far4", "rounds", "qchunk", "qchunk_near", "host_chunk", "peer" (multi-device gather:
  * 0 = through the host, 1 = peer copies or fail) — these decide WHEN and WHERE a ray is integrated and never change a result
- * bit —, and two that select another FORMULATION of the same algorithm, with results equal up to rounding: "tile" (1: the
- * simple tile-per-wave kernel) and "pack" (Float32: 0 = one ray per lane, 1 = two rays per lane in packed arithmetic).
+ * bit —, and three that select another FORMULATION of the same algorithm, with results equal up to rounding: "tile" (1: the
+ * simple tile-per-wave kernel), "pack" (Float32: 0 = one ray per lane, 1 = two rays per lane in packed arithmetic) and "packfar"
+ * (Float32 experiment, default 0: 1 = the packed kernel without its scan as a FAR pass + the scalar NEAR pass; measured slower).
  * value -1 = automatic.  Initial values come from the environment variables RTGR_<NAME> read ONCE when the context is created. */
 int rtgr_set_option(rtgr_context* ctx, const char* name, long value);
 int rtgr_get_option(rtgr_context* ctx, const char* name, long* value);

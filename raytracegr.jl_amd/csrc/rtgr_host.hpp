@@ -64,6 +64,7 @@ struct Knobs {
     long dbg_pass_far = 0;        // debug builds: which pass reports its wave timeline
     long pack = -1;               // Float32 closed-form FULL pass: 0 = scalar kernel (one ray per lane), 1 = packed two-rays-per-lane
                                   // kernel, -1 = packed where it pays (a != 0)
+    long packfar = 0;             // Float32 experiment: 1 = packed scan-free FAR pass at three waves per SIMD + the scalar NEAR pass
     long peer = -1;               // multi-device gather (rtgr_trace_sharded_device_*): 0 = always stage the rows through pinned
                                   // host memory (the no-peer-access fallback, forced), 1 = peer copies or fail, -1 = peer copies
                                   // where rtgr_create could enable peer access, the fallback elsewhere

@@ -83,7 +83,12 @@ RTGR_DEV void fold_distances2(const DevObject<float>& o, const V2 (&pos)[P][4], 
 // ---------------------------------------------------------------------------------------------------------------------
 // the FULL pass, two rays per lane.  Structure and comments follow integrate_body (rtgr_persistent.hpp), MODE_FULL, NPTS10.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int METRIC, bool SPIN>
+// FARP = true (round 4, experiment behind option `packfar`): the scan-free FAR instantiation.  The nine sample positions and
+// distances of both rays and the position polynomial are what push this kernel from 159 to 205 registers (two waves per SIMD,
+// where a wave issues at most 83 % of the slots); without them it fits three.  The scan is replaced, as in the Float64 FAR pass,
+// by the rigorous reach bound; a half whose accepted step is not provably clear of every object is handed — in its pre-step
+// state — to the scalar NEAR pass (integrate_kernel<float, …, MODE_NEAR>), which redoes that step with the full scan.
+template <int METRIC, bool SPIN, bool FARP = false>
 RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
     using N = Tsit5N<float>;
     const uint32_t lane = threadIdx.x & 63;
@@ -240,7 +245,43 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
         float top[2] = {0.0f, 0.0f};
         const bool want_state = (A.recw == REC_W_STATE);
         const bool any_accept = __ballot((run[0] && EE2.x <= 1.0f) || (run[1] && EE2.y <= 1.0f)) != 0ull;
-        if (any_accept) {
+        bool safe[2] = {true, true};         // FARP: no object's distance can change sign anywhere in this step
+        if constexpr (FARP) {
+            // |x_q(θ) − x_q| <= δ_q for all θ in [0,1] (integrate_body, "reach bound"), both rays packed
+            V2 dl[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                V2 a2 = N::beta[0] * rabs<V2>(k[0][q]);
+#pragma unroll
+                for (int l = 1; l < 6; l++) a2 = rfma<V2>(V2(N::beta[l]), rabs<V2>(k[l][q]), a2);
+                dl[q] = h * rfma<V2>(h, a2, rabs<V2>(u[q]));
+            }
+            const float guard = 1.0f + 1e-6f;
+            for (uint32_t o = 0; o < A.sc.nobj; o++) {
+                const DevObject<float>& ob = A.sc.obj[o];
+                V2 lhs, rhs;
+                if (ob.kind == RTGR_PLANE) {
+                    lhs = rabs<V2>(x[0] - V2(ob.p[0]));
+                    rhs = rfma<V2>(V2(guard), dl[0], V2(256.0f * eps) * (rabs<V2>(x[0]) + V2(__builtin_fabsf(ob.p[0]))));
+                } else if (ob.kind == RTGR_SPHERE) {
+                    const V2 X0 = x[1] - V2(ob.p[1]), X1 = x[2] - V2(ob.p[2]), X2 = x[3] - V2(ob.p[3]);
+                    const float Rr = ob.p[8];
+                    const V2 D0 = rfma<V2>(X0, X0, rfma<V2>(X1, X1, rfma<V2>(X2, X2, V2(-Rr * Rr))));
+                    const V2 B = rfma<V2>(dl[1], rfma<V2>(V2(2.0f), rabs<V2>(X0), dl[1]),
+                                          rfma<V2>(dl[2], rfma<V2>(V2(2.0f), rabs<V2>(X1), dl[2]), dl[3] * rfma<V2>(V2(2.0f), rabs<V2>(X2), dl[3])));
+                    lhs = rabs<V2>(D0);
+                    rhs = rfma<V2>(V2(guard), B, V2(256.0f * eps) * (lhs + V2(2.0f * Rr * Rr)));
+                } else {
+                    V2 px = x[1], py = x[2];
+                    asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's root inside this branch
+                    lhs = rabs<V2>(V2{disk_distance_fast<float>(ob, px.x, py.x, x[3].x), disk_distance_fast<float>(ob, px.y, py.y, x[3].y)});
+                    rhs = V2(guard) * rmax<V2>(dl[3], dl[1] + dl[2]);
+                }
+                safe[0] = safe[0] && (lhs.x > rhs.x);
+                safe[1] = safe[1] && (lhs.y > rhs.y);
+            }
+        }
+        if (!FARP && any_accept) {
             if (want_state) {
                 // the caller wants end states: the velocity polynomial u(θ) = u + h Σ_j b_j(θ) k_j of THIS step goes into the
                 // slot's record now, whether or not the step turns out to end the ray (a later step overwrites it; the
@@ -317,15 +358,24 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 const float q11 = fexp2(beta1 * le);
                 float qf = fexp2(__builtin_fmaf(beta1, le, -beta2 * lq[hh])) * igamma;
                 qf = (EEst2 == 0.0f) ? qmax_inv : fclamp1(qf, qmax_inv, qmin_inv);
-                if (EEst2 <= 1.0f) {
+                if (FARP && EEst2 <= 1.0f && (!safe[hh] || pss == 0.0f)) {
+                    // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
+                    float* hd = A.hand + idx[hh] * (uint64_t)A.recw;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { hd[q] = x[q][hh]; hd[4 + q] = u[q][hh]; hd[8 + q] = k[0][q][hh]; }
+                    hd[12] = ts; hd[13] = dt[hh]; hd[14] = pss; hd[15] = lq[hh];
+                    A.meta[idx[hh] * 3] = nacc[hh]; A.meta[idx[hh] * 3 + 1] = nrej[hh];
+                    A.meta[idx[hh] * 3 + 2] = META_HANDED;
+                    state[hh] = L_FREE;
+                } else if (EEst2 <= 1.0f) {
                     nacc[hh]++;
                     lq[hh] = fmax1(le, lq_init);
                     const float dtnew = dt[hh] * __builtin_amdgcn_rcpf(qf);
                     float tnew = ts + dt[hh];
                     if (rabs(tnew - t1) < 10.0f * eps * rmaxabs<float>(tnew, t1)) tnew = t1;
                     const float nc = nextc[hh];
-                    const bool endpoint = (pss != 0.0f) && (pss * nc <= 0.0f);
-                    const bool interior = found[hh] && (pss != 0.0f) && !endpoint;
+                    const bool endpoint = !FARP && (pss != 0.0f) && (pss * nc <= 0.0f);
+                    const bool interior = !FARP && found[hh] && (pss != 0.0f) && !endpoint;
                     if (endpoint || interior) {
                         top[hh] = endpoint ? 1.0f : top[hh];
                         is_event = true;
@@ -333,7 +383,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                         done = RTGR_RAY_EVENT;
                     }
                     if (!is_event) {
-                        ps[hh] = rsign(nc);
+                        if constexpr (!FARP) ps[hh] = rsign(nc);   // (FAR: proven above that no distance changes sign in this step)
                         commit[hh] = true;
                         t[hh] = tnew;
                         dt[hh] = fmin1(dtmax, dtnew);
@@ -413,6 +463,13 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
 template <int METRIC, bool SPIN>
 __global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD_PACKED) void integrate2_kernel(const IntegrateArgs<float> A) {
     integrate2_body<METRIC, SPIN>(A);
+}
+#ifndef RTGR_WAVES_PER_SIMD_PACKED_FAR
+#define RTGR_WAVES_PER_SIMD_PACKED_FAR 3   // the scan-free instantiation: 159-168 registers
+#endif
+template <int METRIC, bool SPIN>
+__global__ __launch_bounds__(64, RTGR_WAVES_PER_SIMD_PACKED_FAR) void integrate2_far_kernel(const IntegrateArgs<float> A) {
+    integrate2_body<METRIC, SPIN, true>(A);
 }
 
 }  // namespace rtgr

@@ -473,7 +473,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         if (EEst2 <= 1.0f) {
                             // ---- can ANY object's distance change sign anywhere in this step?  |x_q(θ) − x_q| <= δ_q for all
                             // θ in [0,1] (Nyström form of the dense output, beta[l] = max|B2_l(θ)|); a plane's distance then
-                            // moves by <= δ_t, a sphere's by <= Σ_q δ_q (2|X_q| + δ_q), a disk's by <= δ_x + δ_y + δ_z.
+                            // moves by <= δ_t, a sphere's by <= Σ_q δ_q (2|X_q| + δ_q), a disk's by <= max(δ_z, δ_x + δ_y).
                             R dl[4];
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
@@ -500,7 +500,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 } else {
                                     R px = x[1], py = x[2];
                                     asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's root inside this branch
-                                    safe = safe && (rabs(disk_distance_fast<R>(ob, px, py, x[3])) > guard * (dl[1] + dl[2] + dl[3]));
+                                    // (a maximum of three terms moves by at most the LARGEST of their moves: |z| by δ_z, the two radial
+                                    //  terms by δ_ϱ <= δ_x + δ_y — not by their sum, which round 3 charged)
+                                    safe = safe && (rabs(disk_distance_fast<R>(ob, px, py, x[3])) > guard * rmax(dl[3], dl[1] + dl[2]));
                                 }
                             }
                             if constexpr (MODE == MODE_FAR) hand_over = run && (!safe || (ps == R(0)));

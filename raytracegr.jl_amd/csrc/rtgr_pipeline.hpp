@@ -14,6 +14,7 @@
 //   waves_per_cu_near  resident waves per CU of the NEAR pass (auto 4 below 2.4 M rays — 6.3 M with spin —, else all)
 //   far4 = 0/1         force the 3- / 4-waves-per-SIMD instantiation of the a = 0 FAR pass (auto: by launch size)
 //   pack = 0           Float32: the scalar one-ray-per-lane kernel instead of the packed two-rays-per-lane one
+//   packfar = 1        Float32 experiment: packed scan-free FAR pass (3 waves/SIMD) + scalar NEAR pass instead of the one FULL pass
 #pragma once
 #include "rtgr_host.hpp"
 #include "rtgr_persistent.hpp"
@@ -162,7 +163,7 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
 #ifdef RTGR_ROOT_STATS
         P.dbg = D.dbg;   // debug builds: the FULL pass reports its wave timeline too
 #endif
-        KernelTimer tm(D, st, 1);
+        std::unique_ptr<KernelTimer> tm(new KernelTimer(D, st, 1));
         int full_waves = waves_per_simd_of<R, METRIC>(MODE_FULL);
         if constexpr (USER) {   // the occupancy the unit's FULL passes were built for (rtgr_user_near_waves / _f32_waves)
             const unsigned uw = sizeof(R) == 8 ? E.user->near_waves : E.user->f32_waves;
@@ -176,6 +177,24 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
         // of which packs, is 40 % of the step), -5 % at a = 0 (a 50-flop RHS).  Hence automatic for a != 0 only; option pack = 0 / 1
         // forces the scalar / the packed kernel (A/B, tests).
         if constexpr (sizeof(R) == 4 && METRIC < RTGR_GENERIC_BASE) {
+            if (npts10 && K.packfar > 0) {
+                // EXPERIMENT (option packfar = 1; DESIGN §4.2a has the measurement): packed scan-free FAR pass at three waves per
+                // SIMD, then the scalar NEAR pass over what it hands over
+                const uint64_t waves2 = (IA.n + 127) / 128;
+                const uint64_t per_cu = K.waves_per_cu > 0 ? (uint64_t)K.waves_per_cu : (uint64_t)(4 * RTGR_WAVES_PER_SIMD_PACKED_FAR);
+                const uint64_t resident = (uint64_t)D.num_cu * per_cu;
+                P.early = nullptr;          // (no early list: Float32 rays stay ~2 steps in the NEAR pass)
+                P.pick_flag = 0;
+                hipLaunchKernelGGL((integrate2_far_kernel<METRIC, SPIN>), dim3((unsigned)(waves2 < resident ? waves2 : resident)), dim3(64), 0, st, P);
+                tm.reset();                                  // the FAR pass's time ends here …
+                tm.reset(new KernelTimer(D, st, 3));         // … and the NEAR pass is timed as such
+                P.pick_flag = META_HANDED;
+                P.allow_handback = 0;
+                const uint64_t share = P.n / ((uint64_t)g.x * 8 + 1);
+                P.queue_chunk = (uint32_t)(K.qchunk_near > 0 ? K.qchunk_near : (long)(share < 64 ? 64 : (share > RTGR_QUEUE_CHUNK ? RTGR_QUEUE_CHUNK : share)));
+                hipLaunchKernelGGL((integrate_kernel<R, METRIC, SPIN, true, MODE_NEAR>), g, dim3(64), 0, st, P);
+                return RTGR_OK;
+            }
             if (npts10 && (K.pack >= 0 ? K.pack != 0 : SPIN)) {
                 const uint64_t waves2 = (IA.n + 127) / 128;
                 const uint64_t per_cu = K.waves_per_cu > 0 ? (uint64_t)K.waves_per_cu : (uint64_t)(4 * RTGR_WAVES_PER_SIMD_PACKED);

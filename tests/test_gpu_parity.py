@@ -637,6 +637,30 @@ def test_f32_packed_two_rays_per_lane_kernel_equals_the_scalar_kernel(lib, name)
     assert name == "mink" or F32_STEPS[0] * r <= g <= F32_STEPS[1] * r      # (Minkowski: the step sequence is rounding noise)
 
 
+@pytest.mark.parametrize("name", ["ks_ref0", "ks_true08", "ks_true0998_disk"])
+def test_f32_packed_far_pass_experiment_traces_the_same_frame(lib, name):
+    """Option packfar = 1 (round 4's Float32 experiment, measured slower and left off: profiles/r04/f32_packfar_experiment.log): the
+    packed kernel without the scan as a FAR pass at three waves per SIMD + the scalar NEAR pass.  Same algorithm by the same
+    argument as the Float64 FAR / NEAR split — the scan is skipped only where the bound proves it finds nothing, a handed ray
+    redoes its step —, two kernels of different arithmetic shape: statuses equal, every ray accounted for, hit maps and RGB equal
+    up to the packed-vs-scalar last-bit differences (the bars of the packed-vs-scalar test)."""
+    sc, cam = scene_variant(name)
+    opt = rt.solver_defaults(np.float32)
+    for ni, nj in ((96, 64), (33, 7)):
+        with abi.options(lib, pack=1, packfar=0):
+            one = hip_trace(lib, sc, opt, ni, nj, cam=cam, dtype=np.float32)
+        with abi.options(lib, pack=1, packfar=1):
+            two = hip_trace(lib, sc, opt, ni, nj, cam=cam, dtype=np.float32)
+        n = ni * nj
+        assert two["counters"]["rays"] == n and two["counters"]["events"] + two["counters"]["not_finished"] <= n
+        assert (two["status"] != one["status"]).sum() <= max(1, n // 500)
+        flips = two["hit"] != one["hit"]
+        assert flips.sum() <= max(1, n // 500), flips.sum()
+        assert wrap_aware_rgb_err(two["rgb"][:, ~flips].astype(float), one["rgb"][:, ~flips].astype(float), two["hit"][~flips], sc=sc) < 5e-4
+        a2, a1 = sum(two["counters"][k] for k in ("accepted", "rejected")), sum(one["counters"][k] for k in ("accepted", "rejected"))
+        assert abs(a2 - a1) <= 0.01 * a1 + 2
+
+
 @pytest.mark.parametrize("name", ["ks_ref0", "ks_true08"])
 def test_f32_generic_path_bounds_the_step_count_gap(lib, name):
     """The Float32 closed contraction takes 15-20 % fewer steps than the Float32 oracle (above).  Explanation under
