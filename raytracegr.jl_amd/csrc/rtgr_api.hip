@@ -71,7 +71,7 @@ template size_t workspace_bytes<double>(uint64_t, bool);
 template size_t workspace_bytes<float>(uint64_t, bool);
 
 // Rays per pipeline chunk.  Every chunk pays the tails of its passes once, so bigger is better (8192² in one chunk instead
-// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (14.3 GB of workspace at 213 B/ray; 25.0 GB at the 373 B/ray of a call that asks for end states), halved
+// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (18.6 GB of workspace at 277 B/ray; 27.2 GB at the 405 B/ray of a call that asks for end states), halved
 // until the workspace fits into a quarter of the memory that is free when it has to be (re)allocated.
 template <class R>
 uint64_t pick_chunk(const DeviceCtx& d, const StreamState& ss, uint64_t n, bool with_state) {

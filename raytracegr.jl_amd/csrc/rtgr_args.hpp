@@ -46,8 +46,11 @@ constexpr int REC_T = 22;     // λ at the step start
 constexpr int REC_H = 23;     // step size
 constexpr int REC_U = 24;     // u[4] and cu[m][q] (only when the caller wants state_end)
 constexpr int REC_CU = 28;
-constexpr int REC_W = 24;
-constexpr int REC_W_STATE = 44;
+// slot widths: the record proper is 24 scalars (44 with the velocity polynomial); the SLOT is padded to a multiple of 16 scalars
+// (128 B in Float64) so that the 128-byte hand-over record at its head never straddles a cache line — at a stride of 24 scalars
+// every other record did, and the pipeline's measured HBM traffic rose from 991 to 1124 B per ray (profiles/r04, first collection)
+constexpr int REC_W = 32;
+constexpr int REC_W_STATE = 48;
 
 template <class R>
 struct TraceArgs {

@@ -118,6 +118,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
     const unsigned long long qchunk = A.queue_chunk;
     const unsigned long long first_span = 128ull * gridDim.x;   // a wave starts 128 rays: positions [128 b, 128 b + 128) go to workgroup b
     for (;;) {
+        // [budget: refill]
         // ================= refill: free slots (half 0, then half 1) take ray ids from the wave's slice of the queue ========
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
@@ -161,6 +162,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
         // The refill loops only give up when the queue is exhausted, so a wave without a running slot is done.
         if (__ballot(state[0] == L_RUN || state[1] == L_RUN) == 0ull) break;
 
+        // [budget: stage sums]
         // ================= one Tsit5 attempt per runnable slot, both halves in packed arithmetic =============================
         const bool run[2] = {state[0] == L_RUN, state[1] == L_RUN};
         V2 xn[4], un[4], k[7][4];
@@ -178,7 +180,9 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma<V2>(hc, u[1 + q], x[1 + q]);
             }
+            // [budget: rhs]
             accel<V2, METRIC, SPIN, true>(X, U, MK, k[1]);
+            // [budget: stage sums]
             {   // ---- stage 3
                 const V2 w1 = h * N::a[2][1], w0 = h * N::a[2][0], hc = h * N::c[2], h2a = h2 * N::A2[2][0];
 #pragma unroll
@@ -186,7 +190,9 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
 #pragma unroll
                 for (int q = 0; q < 3; q++) X[q] = rfma<V2>(h2a, k[0][1 + q], rfma<V2>(hc, u[1 + q], x[1 + q]));
             }
+            // [budget: rhs]
             accel<V2, METRIC, SPIN, true>(X, U, MK, k[2]);
+            // [budget: stage sums]
             // ---- stages 4, 5, 6
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -195,7 +201,9 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma<V2>(h2, rfma<V2>(V2(N::A2[3][1]), k[1][1 + q], N::A2[3][0] * k[0][1 + q]),
                                 rfma<V2>(h * N::c[3], u[1 + q], x[1 + q]));
+            // [budget: rhs]
             accel<V2, METRIC, SPIN, true>(X, U, MK, k[3]);
+            // [budget: stage sums]
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 U[q] = rfma<V2>(h, rfma<V2>(V2(N::a[4][3]), k[3][q], rfma<V2>(V2(N::a[4][2]), k[2][q], rfma<V2>(V2(N::a[4][1]), k[1][q],
@@ -204,7 +212,9 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma<V2>(h2, rfma<V2>(V2(N::A2[4][2]), k[2][1 + q], rfma<V2>(V2(N::A2[4][1]), k[1][1 + q], N::A2[4][0] * k[0][1 + q])),
                                 rfma<V2>(h * N::c[4], u[1 + q], x[1 + q]));
+            // [budget: rhs]
             accel<V2, METRIC, SPIN, true>(X, U, MK, k[4]);
+            // [budget: stage sums]
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 U[q] = rfma<V2>(h, rfma<V2>(V2(N::a[5][4]), k[4][q], rfma<V2>(V2(N::a[5][3]), k[3][q], rfma<V2>(V2(N::a[5][2]), k[2][q],
@@ -213,7 +223,9 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
             for (int q = 0; q < 3; q++)
                 X[q] = rfma<V2>(h2, rfma<V2>(V2(N::A2[5][3]), k[3][1 + q], rfma<V2>(V2(N::A2[5][2]), k[2][1 + q], rfma<V2>(V2(N::A2[5][1]), k[1][1 + q],
                                 N::A2[5][0] * k[0][1 + q]))), rfma<V2>(h * N::c[5], u[1 + q], x[1 + q]));
+            // [budget: rhs]
             accel<V2, METRIC, SPIN, true>(X, U, MK, k[5]);
+            // [budget: stage sums]
             // ---- stage 7 = the step result (FSAL)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -222,8 +234,10 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 xn[q] = rfma<V2>(h2, rfma<V2>(V2(N::A2[6][4]), k[4][q], rfma<V2>(V2(N::A2[6][3]), k[3][q], rfma<V2>(V2(N::A2[6][2]), k[2][q],
                                  rfma<V2>(V2(N::A2[6][1]), k[1][q], N::A2[6][0] * k[0][q])))), rfma<V2>(h * N::c[6], u[q], x[q]));
             }
+            // [budget: rhs]
             accel<V2, METRIC, SPIN, true>(xn + 1, un, MK, k[6]);
         }
+        // [budget: error norm]
         // ---- embedded error: both rays' sums packed, the two reciprocal seeds per component per half ----
         V2 acc2 = V2(0.0f);
 #pragma unroll
@@ -237,6 +251,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
             acc2 = rfma<V2>(ru, ru, rfma<V2>(rx, rx, acc2));
         }
         const V2 EE2 = (acc2 * h) * (V2(0.125f) * h);   // (h twice, not h²: see integrate_body)
+        // [budget: scan]
         // ---- ContinuousCallback scan, packed for both rays; used by the halves that accept their step ----
         // x(θ) = x + θ c1 + θ² c2 + θ³ c3 + θ⁴ c4 ;  c1 = h u,  c_m = h² Σ_l R2[l][m] k_l
         V2 cc[4][4];
@@ -341,6 +356,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 }
             }
         }
+        // [budget: controller and records per half]
         // ================= per half: decisions and side effects (what has no packed form) ====================================
         bool commit[2] = {false, false};
 #pragma unroll
@@ -433,6 +449,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 state[hh] = L_FREE;
             }
         }
+        // [budget: commit]
         // ---- commit the accepted steps: per half (the only place besides the refill where the ray states are assigned) -------
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
@@ -441,6 +458,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 for (int q = 0; q < 4; q++) { x[q][hh] = xn[q][hh]; u[q][hh] = un[q][hh]; k0[q][hh] = k[6][q][hh]; }
             }
         }
+        // [budget: end]
     }
     if (A.counters) {
         const unsigned long long s0 = wave_sum(c_rays), s1 = wave_sum(c_acc), s2 = wave_sum(c_rej),

@@ -2,7 +2,7 @@
 # The round's profile set: rocprofv3 kernel-trace stats + PMC passes (each --pmc set in a run of its own, tools/prof.sh) for
 # every BASELINE configuration that has a kernel of its own; then, locally, tools/merge_flops.py <round> writes
 # profiles/<round>/flops.json (keyed by the kernel-source hash).      usage (on the GPU box): tools/collect_profiles.sh r03
-R=${1:-r03}
+R=${1:-r04}
 tools/prof.sh ${R}_ks_ref0 --steps 3 --warmup 1 > /dev/null 2>&1; echo done ks_ref0
 tools/prof.sh ${R}_ks_true08 --steps 3 --warmup 1 --variant ks_true08 > /dev/null 2>&1; echo done ks_true08
 tools/prof.sh ${R}_f32 --steps 5 --warmup 1 --variant ks_true08 --size 2048 --dtype f32 > /dev/null 2>&1; echo done f32 "(packed two-rays-per-lane kernel)"

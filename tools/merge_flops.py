@@ -13,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))
 b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
