@@ -203,7 +203,7 @@ int rtgr_set_option(rtgr_context* ctx, const char* name, long value);
 int rtgr_get_option(rtgr_context* ctx, const char* name, long* value);
 
 /* The device entry points never allocate once the stream's workspace (start / hand-over / event records, per-ray meta,
- * queue order: 277 B per ray, 405 B when end states are asked for; bounded by a pipeline chunk of 2^26 rays — fewer when that would not fit a quarter of
+ * queue order: 213 B per ray, 373 B when end states are asked for; bounded by a pipeline chunk of 2^26 rays — fewer when that would not fit a quarter of
  * the free device memory) is large enough.  Call this once up front (e.g. before hipGraph capture) to size the workspace
  * of `stream` on the device that owns `d_any` (any device pointer of the later call; NULL: device 0 of the context). */
 int rtgr_reserve_workspace(rtgr_context* ctx, const void* d_any, void* stream, uint64_t n_rays, int with_state_end, int is_f32);

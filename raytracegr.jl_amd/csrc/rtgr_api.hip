@@ -62,16 +62,16 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 template <class R>
 size_t workspace_bytes(uint64_t rays, bool with_state) {
-    const int recw = with_state ? REC_W_STATE : REC_W;
-    static_assert(HAND_W <= REC_W, "the hand-over record shares the ray's record slot");
-    return align256(rays * recw * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
+    const int recw = with_state ? REC_TAIL_STATE : REC_TAIL;   // the event records' tails; their heads overlay the hand-over records
+    static_assert(HAND_W <= REC_W, "an event record's head overlays the ray's hand-over record");
+    return align256(rays * recw * sizeof(R)) + align256(rays * HAND_W * sizeof(R)) + align256(rays * 3 * sizeof(uint32_t)) +
            2 * align256(rays * sizeof(uint32_t)) + align256(rays) + 4096;
 }
 template size_t workspace_bytes<double>(uint64_t, bool);
 template size_t workspace_bytes<float>(uint64_t, bool);
 
 // Rays per pipeline chunk.  Every chunk pays the tails of its passes once, so bigger is better (8192² in one chunk instead
-// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (18.6 GB of workspace at 277 B/ray; 27.2 GB at the 405 B/ray of a call that asks for end states), halved
+// of four: 581 -> 565 ms) and 288 GB of HBM can afford it: up to 2^26 rays (14.3 GB of workspace at 213 B/ray; 25.0 GB at the 373 B/ray of a call that asks for end states), halved
 // until the workspace fits into a quarter of the memory that is free when it has to be (re)allocated.
 template <class R>
 uint64_t pick_chunk(const DeviceCtx& d, const StreamState& ss, uint64_t n, bool with_state) {

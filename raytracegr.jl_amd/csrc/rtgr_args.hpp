@@ -46,11 +46,9 @@ constexpr int REC_T = 22;     // λ at the step start
 constexpr int REC_H = 23;     // step size
 constexpr int REC_U = 24;     // u[4] and cu[m][q] (only when the caller wants state_end)
 constexpr int REC_CU = 28;
-// slot widths: the record proper is 24 scalars (44 with the velocity polynomial); the SLOT is padded to a multiple of 16 scalars
-// (128 B in Float64) so that the 128-byte hand-over record at its head never straddles a cache line — at a stride of 24 scalars
-// every other record did, and the pipeline's measured HBM traffic rose from 991 to 1124 B per ray (profiles/r04, first collection)
-constexpr int REC_W = 32;
-constexpr int REC_W_STATE = 48;
+// widths of the record proper: 24 scalars, 44 with the velocity polynomial (how they are stored: RecRef below)
+constexpr int REC_W = 24;
+constexpr int REC_W_STATE = 44;
 
 template <class R>
 struct TraceArgs {
@@ -82,10 +80,10 @@ struct IntegrateArgs {
     const R* state0;        // n x 8
     const uint32_t* order;  // queue position -> ray index (longest-expected-first), or null = natural order
     uint64_t n;             // rays in this chunk
-    R* rec;                 // n x recw
+    R* rec;                 // n x recw: the event records' TAILS (RecRef)
     uint32_t* meta;         // n x 3: accepted, rejected, status | interior << 8
-    int recw;               // REC_W or REC_W_STATE
-    R* hand;                // the rays' start / hand-over records: HAND_W scalars at the head of each ray's record slot (== rec, stride recw)
+    int recw;               // REC_TAIL or REC_TAIL_STATE
+    R* hand;                // n x HAND_W: start / hand-over records; an ending ray's event record overlays its own (RecRef)
     unsigned long long* ctrl;  // [0] ray queue head of the FULL / FAR pass, [1] queue head of the NEAR pass (per round)
     uint32_t pick_flag;     // passes that resume rays (NEAR, FAR of round >= 1): meta flag of the rays to pick up; 0 = camera rays
     uint32_t allow_handback;  // NEAR: hand a ray back to the next round's FAR pass once it has left every object's reach
@@ -116,9 +114,20 @@ struct IntegrateArgs {
 // where it provably finds nothing); rays spend >90 % of their steps in the FAR pass, which is ~30 % cheaper per step.
 enum IntegrateMode : int { MODE_FULL = 0, MODE_FAR = 1, MODE_NEAR = 2 };
 // A ray's start / hand-over record and its event record are never alive at the same time (prepare -> FAR -> [hand-over ->] NEAR
-// -> event record -> resolve: each writer holds the ray in registers when it writes), so they share ONE slot of recw scalars
-// per ray: the hand-over record is its first HAND_W scalars.  (Round 3 kept them apart: 128 B per ray more.)
+// -> event record -> resolve: each writer holds the ray in registers when it writes), so the event record's first HAND_W scalars
+// OVERLAY the hand-over record (array `hand`: one 128-byte line per ray in Float64, always aligned) and only its tail — 8 scalars,
+// 28 with the velocity polynomial — has storage of its own (array `rec`, stride recw = REC_TAIL / REC_TAIL_STATE).  Round 3 kept
+// the two records apart (128 B per ray more).  Two layouts tried and measured on the way (profiles/r04/README.md): one slot of 24
+// scalars per ray made every other hand-over record straddle a line (HBM traffic 991 -> 1124 B per ray), one slot padded to 32 made
+// resolve fetch two full lines per ray (1089).
 constexpr int HAND_W = 16;  // x[4] u[4] k0[4] t dt ps lq
+constexpr int REC_TAIL = REC_W - HAND_W;              // 8
+constexpr int REC_TAIL_STATE = REC_W_STATE - HAND_W;  // 28
+template <class P>
+struct RecRef {   // rec[i] of the event record of one ray: i < HAND_W lives in the ray's hand-over line, the rest in its tail
+    P* head; P* tail;
+    __host__ __device__ P& operator[](int i) const { return i < HAND_W ? head[i] : tail[i - HAND_W]; }
+};
 constexpr uint32_t META_HANDED = 0xffff0000u;    // meta[3*idx+2] of a ray waiting for a NEAR pass
 constexpr uint32_t META_HANDBACK = 0xffff0001u;  // … of a ray a NEAR pass handed back to the next round's FAR pass
 constexpr uint32_t META_HANDED_EARLY = 0xffff0002u;  // … of a ray waiting for the NEAR pass ON ITS EARLY LIST
@@ -130,7 +139,8 @@ template <class R>
 struct ResolveArgs {
     DevScene<R> sc;
     DevSolver<R> opt;
-    const R* rec;
+    const R* rec;      // event-record tails (stride recw) …
+    const R* hand;     // … and heads (the rays' hand-over lines, stride HAND_W)
     const uint32_t* meta;
     int recw;
     uint64_t n;        // rays in this chunk

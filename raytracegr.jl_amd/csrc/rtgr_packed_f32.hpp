@@ -151,7 +151,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 m_need = __ballot(state[hh] == L_FREE);
             }
             if (state[hh] == L_TAKEN) {
-                const float* hd = A.hand + idx[hh] * (uint64_t)A.recw;
+                const float* hd = A.hand + idx[hh] * HAND_W;
 #pragma unroll
                 for (int q = 0; q < 4; q++) { x[q][hh] = hd[q]; u[q][hh] = hd[4 + q]; k0[q][hh] = hd[8 + q]; }
                 t[hh] = hd[12]; dt[hh] = hd[13]; ps[hh] = hd[14]; lq[hh] = hd[15];
@@ -258,7 +258,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
         V2 nextc = V2(0.0f);                 // min_distance at the end point
         bool found[2] = {false, false};      // first interior sample with the opposite sign, per half
         float top[2] = {0.0f, 0.0f};
-        const bool want_state = (A.recw == REC_W_STATE);
+        const bool want_state = (A.recw == REC_TAIL_STATE);
         const bool any_accept = __ballot((run[0] && EE2.x <= 1.0f) || (run[1] && EE2.y <= 1.0f)) != 0ull;
         bool safe[2] = {true, true};         // FARP: no object's distance can change sign anywhere in this step
         if constexpr (FARP) {
@@ -304,7 +304,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
                     if (run[hh]) {
-                        float* rec = A.rec + idx[hh] * (uint64_t)A.recw;
+                        const RecRef<float> rec{A.hand + idx[hh] * HAND_W, A.rec + idx[hh] * (uint64_t)A.recw};
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             rec[REC_U + q] = u[q][hh];
@@ -376,7 +376,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 qf = (EEst2 == 0.0f) ? qmax_inv : fclamp1(qf, qmax_inv, qmin_inv);
                 if (FARP && EEst2 <= 1.0f && (!safe[hh] || pss == 0.0f)) {
                     // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
-                    float* hd = A.hand + idx[hh] * (uint64_t)A.recw;
+                    float* hd = A.hand + idx[hh] * HAND_W;
 #pragma unroll
                     for (int q = 0; q < 4; q++) { hd[q] = x[q][hh]; hd[4 + q] = u[q][hh]; hd[8 + q] = k[0][q][hh]; }
                     hd[12] = ts; hd[13] = dt[hh]; hd[14] = pss; hd[15] = lq[hh];
@@ -415,7 +415,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 }
             }
             if (done != 0xffu) {
-                float* rec = A.rec + idx[hh] * (uint64_t)A.recw;
+                const RecRef<float> rec{A.hand + idx[hh] * HAND_W, A.rec + idx[hh] * (uint64_t)A.recw};
                 if (is_event) {   // the step's position polynomial, from the step-START state
 #pragma unroll
                     for (int q = 0; q < 4; q++) rec[REC_X + q] = x[q][hh];

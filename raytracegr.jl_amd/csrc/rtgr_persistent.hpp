@@ -294,7 +294,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         dbg_rays += __builtin_popcountll(__ballot(state == L_TAKEN));
 #endif
         if (state == L_TAKEN) {
-            const R* hd = A.hand + idx * (uint64_t)A.recw;
+            const R* hd = A.hand + idx * HAND_W;
 #pragma unroll
             for (int q = 0; q < 4; q++) { x[q] = hd[q]; u[q] = hd[4 + q]; k0[q] = hd[8 + q]; }
             t = hd[12]; dt = hd[13]; ps = hd[14]; lq = (float)hd[15];
@@ -519,7 +519,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         // [budget: hand over]
                     if (hand_over) {
                         // hand the ray, in its PRE-step state, to the NEAR pass (which redoes this step with the full scan)
-                        R* hd = A.hand + idx * (uint64_t)A.recw;
+                        R* hd = A.hand + idx * HAND_W;
 #pragma unroll
                         for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k[0][q]; }
                         hd[12] = t; hd[13] = dt; hd[14] = ps; hd[15] = (R)lq;
@@ -651,9 +651,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 }
                 // ---- an event: hand the step's position polynomial to the resolve kernel (built from the step-START state,
                 // so it has to happen before the commit below) -----------------------------------------------------------------
-                const bool want_state = (A.recw == REC_W_STATE);
+                const bool want_state = (A.recw == REC_TAIL_STATE);
                 if (is_event) {
-                    R* rec = A.rec + idx * (uint64_t)A.recw;
+                    const RecRef<R> rec{A.hand + idx * HAND_W, A.rec + idx * (uint64_t)A.recw};
 #pragma unroll
                     for (int q = 0; q < 4; q++) rec[REC_X + q] = x[q];
 #pragma unroll
@@ -681,7 +681,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 if (hand_back) {
                     // NEAR -> next round's FAR pass: the ray has been out of every object's reach for two steps; its
                     // committed state goes back into the hand-over record and the cheaper pass carries it on
-                    R* hd = A.hand + idx * (uint64_t)A.recw;
+                    R* hd = A.hand + idx * HAND_W;
 #pragma unroll
                     for (int q = 0; q < 4; q++) { hd[q] = xn[q]; hd[4 + q] = un[q]; hd[8 + q] = k[6][q]; }
                     hd[12] = t; hd[13] = dt; hd[14] = ps; hd[15] = (R)lq;
@@ -692,7 +692,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                 if (done != 0xffu) {
                     if (!is_event) {
                         // ended without an event (λ1, step cap, dt underflow, NaN): the state as it stands, θ = 0
-                        R* rec = A.rec + idx * (uint64_t)A.recw;
+                        const RecRef<R> rec{A.hand + idx * HAND_W, A.rec + idx * (uint64_t)A.recw};
 #pragma unroll
                         for (int q = 0; q < 4; q++) rec[REC_X + q] = commit ? xn[q] : x[q];
                         rec[REC_PS] = R(0);
@@ -875,7 +875,7 @@ RTGR_DEV void prepare_body(const IntegrateArgs<R>& A) {
     // dt1 = 10^(-(2 + log10 md)/5) = 2^(-(2 log2 10 + log2 md)/5)
     const float dt1f = (md <= 1e-15f) ? fmaxf(1e-6f, (float)dt0 * 1e-3f) : fexp2(-0.2f * (6.643856189774724f + flog2(md)));
     const R dt_init = rmin(rmin(R(100) * dt0, (R)dt1f), dtmax);
-    R* hd = A.hand + w * (uint64_t)A.recw;
+    R* hd = A.hand + w * HAND_W;
 #pragma unroll
     for (int q = 0; q < 4; q++) { hd[q] = x[q]; hd[4 + q] = u[q]; hd[8 + q] = k1[q]; }
     hd[12] = A.opt.lambda0;
@@ -1076,7 +1076,7 @@ template <class R>
 __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= A.n) return;
-    const R* rec = A.rec + w * (uint64_t)A.recw;
+    const RecRef<const R> rec{A.hand + w * HAND_W, A.rec + w * (uint64_t)A.recw};
     R x0[4], xe[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) xe[q] = x0[q] = rec[REC_X + q];
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
             se[q] = xe[q];
             R ue = rec[REC_U + q];
             if (ps != R(0)) {
-                const R* cu = rec + REC_CU;
+                const R* cu = rec.tail + (REC_CU - HAND_W);
                 ue = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, cu[12 + q], cu[8 + q]), cu[4 + q]), cu[q]), ue);
             }
             se[4 + q] = ue;

@@ -231,13 +231,14 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     const uint64_t chunk = pick_chunk<R>(D, E.ss, n, with_state);
     int rc = ensure_workspace(D, E.ss, workspace_bytes<R>(chunk, with_state), st);
     if (rc) return rc;
-    const int recw = with_state ? REC_W_STATE : REC_W;
+    const int recw = with_state ? REC_TAIL_STATE : REC_TAIL;   // (the event records' first HAND_W scalars overlay the hand-over records)
     char* base = (char*)E.ss.ws;
     R* rec = (R*)base;
     char* cur = base + align256(chunk * recw * sizeof(R));
+    R* hand = (R*)cur;
+    cur += align256(chunk * HAND_W * sizeof(R));
     uint32_t* meta = (uint32_t*)cur;
     cur += align256(chunk * 3 * sizeof(uint32_t));
-    R* hand = rec;  // start / hand-over records live at the head of the rays' record slots (rtgr_args.hpp: HAND_W)
     uint32_t* order = (uint32_t*)cur;
     cur += align256(chunk * sizeof(uint32_t));
     uint32_t* early = (uint32_t*)cur;
@@ -301,7 +302,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
         rc = launch_integrate<R, METRIC, SPIN>(E, IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
         if (rc) return rc;
         ResolveArgs<R> RA;
-        RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = A.out_offset + off;
+        RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.hand = hand; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = A.out_offset + off;
         RA.n_slab = A.plane_stride ? A.plane_stride : n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
         RA.status = A.status; RA.hit = A.hit; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
         {

@@ -745,7 +745,7 @@ def test_c4_float32_frame_against_the_float64_frame(lib):
 
 
 def test_8192_disk_frame_properties(lib):
-    """BASELINE config 5 (Kerr a = 0.998 + thin disk, 8192²: one 2^26-ray pipeline chunk, 18.6 GB of workspace):
+    """BASELINE config 5 (Kerr a = 0.998 + thin disk, 8192²: one 2^26-ray pipeline chunk, 14.3 GB of workspace):
     every ray accounted for, hit-class fractions and step attempts per ray equal a 512² frame of the same camera within
     0.5 % / 1 %, and a 64-row strided share is bit-equal to the same rows of the full frame."""
     import torch
