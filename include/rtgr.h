@@ -372,6 +372,16 @@ int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint6
  * directory next to librtgr_hip.so (or $RTGR_CSRC).  On a compile error the compiler's log is the rtgr_last_error(). */
 int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out);
 int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
+/* Both entry points AUDIT the code object before it is loaded: ROCm 7.2's compiler can place a register copy or spill at the top of
+ * the FLOW block of a divergent if / else, ahead of the instruction that switches EXEC to the `else` lanes, and code of that shape
+ * computes wrong values in some lanes (the Float64 FULL pass of a heavy metric was wrong from it in round 4).  An
+ * image that carries the shape is refused with RTGR_ERR_BAD_ARG and the offending instructions in rtgr_last_error();
+ * rtgr_user_metric_compile then tries its other occupancy levels (other code), and raytracegr.jl_amd/user_metric.py — the hipcc
+ * route — repairs the listing before it assembles it.  rtgr_code_object_audit is that check on its own (no GPU, no context needed):
+ * *found = number of such blocks, their description in `report` (may be NULL).  The file is a gfx950 code object, or a host library
+ * that embeds code objects — librtgr_hip.so itself: the build checks audit the kernels the library ships.  RTGR_ERR_BAD_ARG when it
+ * is neither, or the disassembler (libamd_comgr, resolved with dlopen) is not on the box. */
+int rtgr_code_object_audit(const char* code_object_path, int* found, char* report, uint64_t report_len);
 /* 1 if module `id` is resident (id 0: any module), else 0 */
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id);
 

@@ -67,7 +67,7 @@ EXPORTS = [
     "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64", "rtgr_make_canvas_device_f32", "rtgr_make_canvas_f32",
     "rtgr_eval_metric_f64", "rtgr_eval_metric_f32", "rtgr_eval_geodesic_f64", "rtgr_eval_geodesic_f32",
     "rtgr_eval_fastmath_f64", "rtgr_quantize_device_f64",
-    "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded",
+    "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded", "rtgr_code_object_audit",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -133,6 +133,7 @@ def _declare(lib):
     lib.rtgr_user_metric_compile.argtypes = [ctx, C.c_char_p, i32, P(u64)]
     lib.rtgr_user_metric_unload.argtypes = [ctx, u64]
     lib.rtgr_user_metric_loaded.argtypes = [ctx, u64]
+    lib.rtgr_code_object_audit.argtypes = [C.c_char_p, P(i32), C.c_char_p, u64]
     for name in EXPORTS:
         if name != "rtgr_last_error":
             getattr(lib, name).restype = i32

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include "rtgr_host.hpp"
+#include "rtgr_isa_audit.hpp"
 
 namespace rtgr {
 
@@ -1599,8 +1600,17 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 // load a gfx950 code object image into every device of the context; its id is a hash of the image
 constexpr int RTGR_USER_MAX_SCRATCH = 64;   // bytes per lane above which rtgr_user_metric_compile rebuilds a unit at a lower occupancy
 static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out,
-                             int max_scratch = 1 << 30, int* scratch_out = nullptr) {
+                             int max_scratch = 1 << 30, int* scratch_out = nullptr, int* audit_out = nullptr) {
     const uint64_t id = fnv1a(image);
+    {   // refuse code that carries the EXEC-flip fault of this LLVM (rtgr_isa_audit.hpp): a unit traced wrong from it in round 4.
+        // (An image that cannot be audited — no libamd_comgr on the box — is loaded as it is.)
+        std::string report;
+        const int bad = isa_audit::audit(image.data(), image.size(), &report);
+        if (audit_out) *audit_out = bad;
+        if (bad > 0)
+            return fail(RTGR_ERR_BAD_ARG, what + ": " + std::to_string(bad) + " FLOW block(s) with vector instructions ahead of the EXEC flip "
+                        "(a code-generation fault of the compiler, DESIGN.md §4.6; raytracegr.jl_amd/user_metric.py builds repaired units):\n" + report);
+    }
     std::lock_guard<std::mutex> load_lock(c->modules_mu);   // one load / unload at a time per context
     for (auto& d : c->devs) {
         DeviceGuard guard(d->dev);
@@ -1750,6 +1760,22 @@ int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint6
     return load_module_image(c, image, code_object_path, id_out);
 }
 
+int rtgr_code_object_audit(const char* code_object_path, int* found, char* report, uint64_t report_len) {
+    if (!code_object_path || !*code_object_path || !found) return fail(RTGR_ERR_BAD_ARG, "code object path or found is NULL");
+    std::vector<char> image;
+    if (int rc = read_file(code_object_path, image)) return rc;
+    std::string text;
+    const int n = isa_audit::audit_any(image.data(), image.size(), &text);
+    if (n < 0) return fail(RTGR_ERR_BAD_ARG, std::string(code_object_path) + ": cannot be audited: " + text);
+    *found = n;
+    if (report && report_len) {
+        const size_t k = std::min<size_t>(text.size(), (size_t)report_len - 1);
+        std::memcpy(report, text.data(), k);
+        report[k] = 0;
+    }
+    return RTGR_OK;
+}
+
 int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
@@ -1777,11 +1803,19 @@ int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationa
     static const char* const hdr_name[] = {"hip/hip_runtime.h", "stdint.h"};
     const std::string inc = "-I" + dir;
     // occupancy levels (waves per SIMD of the Float64 / Float32 generic-RHS kernels): the defaults first; a unit whose integrate
-    // kernels spill there is rebuilt with more registers per lane (the last level is taken as it comes)
-    static const char* const LEVELS[][2] = {{nullptr, nullptr},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2"},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1"}};
-    for (int level = 0; level < 3; level++) {
+    // kernels spill there is rebuilt with more registers per lane (the last level is taken as it comes).  Levels 3-5 are the same
+    // three with the step's control block under the running lanes' EXEC mask: other code, for the metric whose every level above
+    // comes out of the compiler with the EXEC-flip fault (load_module_image audits; nothing can be repaired in-process).
+    static const char* const LEVELS[][3] = {{nullptr, nullptr, nullptr},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2", nullptr},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1", nullptr},
+                                            {"-DRTGR_GHOST_LANES=0", nullptr, nullptr},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2", "-DRTGR_GHOST_LANES=0"},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1", "-DRTGR_GHOST_LANES=0"}};
+    bool any_faulty = false;
+    std::vector<char> sound_but_spilling;
+    for (int level = 0; level < 6; level++) {
+        if (level == 3 && !any_faulty) break;   // the masked-control variants are only for a metric the audit refused
         void* prog = nullptr;
         if (R.create(&prog, unit.c_str(), "rtgr_user_unit.hip", 2, hdr_src, hdr_name) != 0) return fail(RTGR_ERR_HIP, "hiprtcCreateProgram failed");
         std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
@@ -1804,10 +1838,19 @@ int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationa
         const int gr = R.code(prog, image.data());
         (void)R.destroy(&prog);
         if (gr != 0) return fail(RTGR_ERR_HIP, "hiprtcGetCode failed");
-        int spilled = 0;
-        rc = load_module_image(c, image, "compiled user metric", id_out, level < 2 ? RTGR_USER_MAX_SCRATCH : 1 << 30, &spilled);
-        if (rc == RTGR_OK || spilled <= RTGR_USER_MAX_SCRATCH) return rc;   // loaded; or failed for another reason than spilling
+        int spilled = 0, faulty = 0;
+        rc = load_module_image(c, image, "compiled user metric", id_out, level % 3 < 2 ? RTGR_USER_MAX_SCRATCH : 1 << 30, &spilled, &faulty);
+        if (rc == RTGR_OK) return rc;
+        if (faulty > 0) { any_faulty = true; continue; }   // this level's code carries the EXEC-flip fault: the next level is other code
+        if (spilled <= RTGR_USER_MAX_SCRATCH) return rc;    // failed for another reason than spilling
+        if (sound_but_spilling.empty()) sound_but_spilling.swap(image);
     }
+    // hiprtc hands back the code object only, so a faulty listing cannot be repaired here the way user_metric.compile_user_metric
+    // does: sound code that spills is taken before none at all
+    if (!sound_but_spilling.empty()) return load_module_image(c, sound_but_spilling, "compiled user metric", id_out);
+    if (any_faulty)
+        return fail(RTGR_ERR_BAD_ARG, std::string(rtgr_last_error()) + "\n(no occupancy level of this metric compiles to sound code in-process: build "
+                    "the unit with `python -m raytracegr.jl_amd.user_metric source.hip`, which repairs the listing, and load it with rtgr_user_metric_load)");
     return rc;
 }
 

@@ -21,6 +21,7 @@ import subprocess
 
 from . import _abi
 from . import build as _build
+from . import isa_exec as _isa
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -28,7 +29,8 @@ TEMPLATE = os.path.join(CSRC, "rtgr_user_unit.hip.in")
 _HEADERS = [os.path.join(CSRC, f) for f in ("rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp",
                                             "rtgr_persistent.hpp", "rtgr_tsit5_tables.hpp")] + \
            [os.path.join(HERE, "..", "include", "rtgr.h")]
-FLAGS = ["--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--cuda-device-only", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function"]
+LLVM_BIN = os.path.join(os.path.dirname(os.path.realpath(_build.HIPCC)), "..", "lib", "llvm", "bin")
 _ids = {}  # (context handle value or None, code object path) -> module id returned by rtgr_user_metric_load
 
 
@@ -42,7 +44,7 @@ def _digest(source, extra_flags=()):
     h = hashlib.sha256()
     h.update(source.encode())
     h.update(" ".join(extra_flags).encode())
-    for f in [TEMPLATE] + _HEADERS:
+    for f in [TEMPLATE, _isa.__file__] + _HEADERS:   # (the listing check / repair is part of how a unit is built)
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
@@ -80,26 +82,65 @@ def compile_user_metric(source, verbose=False, stationary=False):
         fh.write(unit)
     os.replace(tmp_src, src)
     tmp = out + f".tmp{os.getpid()}"
+    # Two steps, hipcc -S then assemble + link (the same code object as `hipcc --genco`, instruction for instruction: checked
+    # in tests/test_user_metric.py), because the LISTING is looked at in between: isa_exec finds — and rewrites — register
+    # copies / spills that this LLVM places ahead of a FLOW block's EXEC flip, which is what the Float64 FULL
+    # pass of the heavy example metric was wrong from in round 4.
     # Occupancy levels: the unit's generic-RHS kernels are built for 2 (Float64) / 3 (Float32) waves per SIMD; a metric whose
     # integrate kernels SPILL there (more than MAX_SCRATCH bytes per lane) is rebuilt with more registers per lane — 1 / 2, then
     # 1 / 1 (512 registers), the last level taken as it comes: the heavy example metrics spill 200-400 registers per step at two
     # waves per SIMD, which costs more than the second wave returns.  rtgr_user_metric_compile does the same in-process.
-    worst = {}
+    usable, problems = [], []          # [(listing path, scratch bytes per lane)] of the levels whose code is sound
     for n_level, level in enumerate(LEVELS):
-        cmd = [_build.HIPCC] + FLAGS + extra + level + ["-Rpass-analysis=kernel-resource-usage", "-I", CSRC, "-o", tmp, src]
+        asm = f"{src[:-4]}.L{n_level}.tmp{os.getpid()}.s"
+        cmd = [_build.HIPCC] + FLAGS + extra + level + ["-S", "-Rpass-analysis=kernel-resource-usage", "-I", CSRC, "-o", asm, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            if os.path.exists(tmp):
-                os.unlink(tmp)
             raise RuntimeError(f"hipcc failed on the user metric ({src}):\n{r.stderr[-4000:]}")
-        worst = integrate_kernel_scratch(r.stderr)
+        worst = max(integrate_kernel_scratch(r.stderr).values(), default=0)
+        with open(asm) as fh:
+            lines = fh.read().split("\n")
+        try:
+            lines, repaired = _isa.repair(lines)
+        except _isa.RepairError as e:      # this level's code carries the fault in a form the rewrite is not proven for
+            problems.append(f"level {n_level}: {e}")
+            os.unlink(asm)
+            continue
         if verbose:
-            print("   scratch bytes per lane:", worst, flush=True)
-        if max(worst.values(), default=0) <= MAX_SCRATCH or n_level == len(LEVELS) - 1:
-            os.replace(tmp, out)  # atomic: concurrent ranks may compile the same metric
-            return out
+            print(f"   level {n_level}: scratch {worst} B per lane, {repaired} FLOW block(s) rewritten", flush=True)
+        if repaired:
+            with open(asm, "w") as fh:
+                fh.write("\n".join(lines))
+        usable.append((asm, worst))
+        if worst <= MAX_SCRATCH:
+            break
+    if not usable:
+        raise RuntimeError(f"user metric {tag}: every occupancy level compiles to code with vector instructions ahead of an EXEC "
+                           f"flip that cannot be repaired (raytracegr.jl_amd/isa_exec.py):\n" + "\n".join(problems))
+    best = usable[-1]                  # the level without spills if there is one (the loop stops there), else the last sound one
+    for asm, _ in usable[:-1]:
+        os.unlink(asm)
+    _assemble(best[0], tmp)
+    os.unlink(best[0])
+    os.replace(tmp, out)  # atomic: concurrent ranks may compile the same metric
+    return out
+
+
+def _assemble(asm, out):
+    """gfx950 listing -> code object: what `hipcc --genco` runs after code generation (clang as the assembler, lld -shared)"""
+    obj = out + ".o"
+    try:
+        subprocess.run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", obj],
+                       check=True, capture_output=True, text=True)
+        subprocess.run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", out, obj],
+                       check=True, capture_output=True, text=True)
+    except subprocess.CalledProcessError as e:
+        raise RuntimeError(f"assembling {asm} failed:\n{e.stderr[-3000:]}")
+    finally:
+        if os.path.exists(obj):
+            os.unlink(obj)
 
 
 MAX_SCRATCH = 64   # bytes per lane; == RTGR_USER_MAX_SCRATCH of rtgr_api.hip
@@ -189,3 +230,29 @@ class UserMetric:
 
     def __repr__(self):
         return f"UserMetric({self.name}, M={self.M}, a={self.a}, {'hiprtc' if self.jit else os.path.basename(self.code_object)})"
+
+
+def audit(path):
+    """(number of FLOW blocks with vector instructions ahead of their EXEC flip, report) of a code object — or of a library that
+    embeds code objects — through rtgr_code_object_audit (include/rtgr.h; no GPU needed)"""
+    import ctypes as C
+    lib = _abi.load()
+    n, buf = C.c_int32(0), C.create_string_buffer(8192)
+    _abi.check(lib, lib.rtgr_code_object_audit(path.encode(), C.byref(n), buf, len(buf)))
+    return n.value, buf.value.decode()
+
+
+if __name__ == "__main__":
+    # python -m raytracegr.jl_amd.user_metric metric.hip [--stationary] [-o unit.hsaco]: build a unit for rtgr_user_metric_load —
+    # the route for C / Julia callers whose metric rtgr_user_metric_compile cannot build soundly in-process (include/rtgr.h)
+    import shutil
+    import sys
+    args = sys.argv[1:]
+    if not args or args[0].startswith("-"):
+        raise SystemExit("usage: python -m raytracegr.jl_amd.user_metric metric.hip [--stationary] [-o unit.hsaco]")
+    with open(args[0]) as fh:
+        built = compile_user_metric(fh.read(), verbose=True, stationary="--stationary" in args)
+    if "-o" in args:
+        shutil.copyfile(built, args[args.index("-o") + 1])
+        built = args[args.index("-o") + 1]
+    print(built)

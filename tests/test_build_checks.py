@@ -60,3 +60,97 @@ def test_plain_build_relinks_after_an_experiment_build(tmp_path):
     assert links() == 2 and m.linked_tag(out) not in (None, "std")
     m.build(out=out, obj_dir=obj, verbose=False)          # objects of the plain build are fresh and OLDER than the library
     assert links() == 3 and m.linked_tag(out) == "std"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The EXEC-flip fault of ROCm 7.2's LLVM (raytracegr.jl_amd/isa_exec.py, csrc/rtgr_isa_audit.hpp)
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+FAULTY_LISTING = """\
+	.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+	.text
+	.globl	probe
+	.p2align	8
+	.type	probe,@function
+probe:
+	v_cmp_gt_u32_e32 vcc, 7, v0
+	s_and_saveexec_b64 s[6:7], vcc
+	s_xor_b64 s[2:3], exec, s[6:7]
+	s_cbranch_execz .LBB0_2
+; %bb.1:
+	v_mov_b32_e32 v1, 1
+.LBB0_2:                                ; the FLOW block: what the allocator put ahead of the flip runs for the `then` lanes only
+	v_accvgpr_write_b32 a0, v2
+	s_mov_b32 s8, 0x54442d18
+	scratch_store_dwordx2 off, v[4:5], off offset:16
+	s_andn2_saveexec_b64 s[2:3], s[2:3]
+	s_cbranch_execz .LBB0_4
+; %bb.3:
+	v_mov_b32_e32 v1, 2
+.LBB0_4:
+	s_or_b64 exec, exec, s[2:3]
+	v_accvgpr_read_b32 v3, a0
+	s_endpgm
+.Lfunc_end0:
+	.size	probe, .Lfunc_end0-probe
+"""
+
+
+def _isa_exec():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rtgr_isa_exec_t", os.path.join(ROOT, "raytracegr.jl_amd", "isa_exec.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _assemble(listing, out):
+    asm = out + ".s"
+    with open(asm, "w") as fh:
+        fh.write(listing)
+    subprocess.check_call([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", out + ".o"])
+    subprocess.check_call([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "-shared", "-o", out, out + ".o"])
+    return out
+
+
+def test_exec_flip_fault_is_found_and_repaired_in_a_listing_and_in_a_code_object(tmp_path):
+    """The shape in a hand-written listing: isa_exec.find reports it, isa_exec.repair rewrites the flip into s_or_saveexec … s_xor
+    around the misplaced instructions (and refuses a block it is not proven for); the library's load-time audit
+    (rtgr_code_object_audit: the same rule on the DISASSEMBLY) sees it in the assembled code object and not in the repaired one."""
+    ie = _isa_exec()
+    lines = FAULTY_LISTING.split("\n")
+    hits = ie.find(lines)
+    assert len(hits) == 1 and hits[0].label == ".LBB0_2" and [s.split()[0] for _, s in hits[0].early] == ["v_accvgpr_write_b32", "scratch_store_dwordx2"]
+    fixed, n = ie.repair(lines)
+    assert n == 1 and ie.find(fixed) == []
+    body = [l.split(";")[0].strip() for l in fixed]
+    at = body.index(".LBB0_2:")
+    assert body[at + 1] == "s_or_saveexec_b64 s[2:3], s[2:3]" and body[at + 5] == "s_xor_b64 exec, exec, s[2:3]"
+    assert "s_andn2_saveexec_b64 s[2:3], s[2:3]" not in body
+    # a clean listing is returned as it is; a block with anything but copies / spills / constants ahead of the flip is refused
+    assert ie.repair(fixed) == (fixed, 0)
+    odd = FAULTY_LISTING.replace("v_accvgpr_write_b32 a0, v2", "v_add_f32_e32 v2, v2, v2")
+    with pytest.raises(ie.RepairError):
+        ie.repair(odd.split("\n"))
+    masks = FAULTY_LISTING.replace("s_mov_b32 s8, 0x54442d18", "s_mov_b32 s2, 0x54442d18")
+    with pytest.raises(ie.RepairError):
+        ie.repair(masks.split("\n"))
+    # the `then` side's own instructions ahead of a flip in a block nothing branches to are NOT the shape
+    merged = FAULTY_LISTING.replace("\ts_cbranch_execz .LBB0_2\n", "")
+    assert ie.find(merged.split("\n")) == []
+    from scenes import rt
+    um = sys.modules[rt.__name__ + ".user_metric"]
+    bad = _assemble(FAULTY_LISTING, str(tmp_path / "faulty.hsaco"))
+    good = _assemble("\n".join(fixed), str(tmp_path / "fixed.hsaco"))
+    n_bad, report = um.audit(bad)
+    assert n_bad == 1 and "v_accvgpr_write_b32 a0, v2" in report and "scratch_store_dwordx2" in report and "s_andn2_saveexec_b64" in report
+    assert um.audit(good) == (0, "")
+    with pytest.raises(RuntimeError, match="cannot be audited"):
+        um.audit(os.path.join(ROOT, "include", "rtgr.h"))
+
+
+def test_the_kernels_the_library_ships_are_free_of_the_exec_flip_fault():
+    """Every gfx950 code object embedded in librtgr_hip.so (one offload bundle per translation unit), audited by the library itself."""
+    from scenes import rt
+    um = sys.modules[rt.__name__ + ".user_metric"]
+    n, report = um.audit(rt._abi.LIB_PATH)
+    assert n == 0, report

@@ -62,6 +62,25 @@ def test_heavy_user_metric_is_built_without_spills():
         vg = [int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", note)]
         ag = [int(v) for v in re.findall(r"\.agpr_count:\s+(\d+)", note)]
         assert (max(a + v for a, v in zip(ag, vg)) > 256) == heavy, (vg, ag)
+        assert um.audit(path) == (0, ""), src[:60]      # … and without the EXEC-flip fault (repaired in the listing where it arose)
+
+
+def test_listing_route_builds_the_same_code_object_as_genco(tmp_path):
+    """compile_user_metric goes hipcc -S -> (check / repair of the listing) -> assembler -> lld instead of `hipcc --genco`: for a
+    unit that needs no repair the two routes give the same instructions, kernel descriptors and metadata."""
+    path = um.compile_user_metric(user_metrics.SCHWARZSCHILD_ISOTROPIC, stationary=True)
+    direct = str(tmp_path / "direct.hsaco")
+    src = path[:-len(".hsaco")] + ".hip"
+    subprocess.check_call([um._build.HIPCC, "--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-DRTGR_USER_NE=3", "-I", um.CSRC, "-o", direct, src], stderr=subprocess.DEVNULL)
+    tool = lambda *a: subprocess.run([os.path.join(um.LLVM_BIN, a[0]), *a[1:]], capture_output=True, text=True, check=True).stdout
+
+    def text(p):      # instruction text without the per-line address / file-name decoration
+        return [l.split("//")[0].rstrip() for l in tool("llvm-objdump", "-d", "--no-show-raw-insn", p).splitlines() if "file format" not in l]
+    assert text(path) == text(direct)
+    assert tool("llvm-readelf", "--notes", path) == tool("llvm-readelf", "--notes", direct)
+    rodata = lambda p: tool("llvm-objdump", "-s", "-j", ".rodata", p).split("Contents of section")[1]
+    assert rodata(path) == rodata(direct)
 
 
 @pytest.fixture(scope="module")
@@ -180,23 +199,14 @@ def test_user_helper_functions_match_oracle_twins(lib):
     opt = rt.solver_defaults()
     ref = O.trace(sco, opt, 32, 32, cam=camera)
     compare(hip_trace(lib, scn, opt, 32, 32, cam=camera), ref, max_class_flips=2, max_step_diff=2)
-    # … and through the single FULL pass (option split = 0), then on a bigger screen three times over.  This is the pass in
-    # which this metric's unit traced wrong AND irreproducible frames up to round 3 (381 of these 1024 rays flew through the sky
-    # sphere; at 96 x 80, 700-6800 rays differed from run to run): rtgr_user_unit.hip.in has what was established and what the
-    # units do about it.  What is asserted of the FULL pass: every ray ends on the oracle's object with the oracle's step count
-    # +-1, reproducibly, within 1e-3 of the oracle's end point — NOT the 1e-6 bar the default FAR + NEAR passes meet just above:
-    # the FULL instantiation of this one heavy unit still drifts in the TIME coordinate (|Δt| ~ 1e-2 at the end of a ray,
-    # |Δλ_end| <= 6e-5, RGB <= 2e-4; lighter units — Kerr–Schild, isotropic Schwarzschild — give the SAME BITS in both pass
-    # structures, gpurun_out/r04/diag_zoo9.log).  Known issue, stated in DESIGN.md §4.6; the FULL pass of a Float64 unit only
-    # runs under the experiment option split = 0 or with interp_points != 10.
+    # … and through the single FULL pass (option split = 0), to the same bar, then on a bigger screen three times over.  This is
+    # the pass in which this metric's unit traced wrong AND irreproducible frames up to round 3 (381 of these 1024 rays flew through
+    # the sky sphere; at 96 x 80, 700-6800 rays differed from run to run), and x^t shifted by 1e-2 in round 4: a register copy that
+    # ROCm 7.2's LLVM places ahead of a FLOW block's EXEC flip (rtgr_user_unit.hip.in).  compile_user_metric now
+    # rewrites that block in the listing, and both pass structures meet the oracle at the default bars.
     with abi.options(lib, split=0):
         full = hip_trace(lib, scn, opt, 32, 32, cam=camera)
-    flips = full["hit"] != ref["hit"]
-    steps = np.abs((full["n_accept"] + full["n_reject"]).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))
-    assert (full["status"] == ref["status"]).all() and flips.sum() <= 2 and steps.max() <= 2, (int(flips.sum()), int(steps.max()))
-    assert np.abs(full["lambda_end"] - ref["lambda_end"])[~flips].max() <= 1e-3
-    assert np.abs(full["state_end"][:, 1:4] - ref["state_end"][:, 1:4])[~flips].max() <= 1e-3
-    assert np.abs(full["rgb"] - ref["rgb"]).max(axis=0)[~flips].max() <= 2e-3
+    compare(full, ref, max_class_flips=2, max_step_diff=2)
     dflt = hip_trace(lib, scn, opt, 96, 80, cam=camera)
     first = None
     for _ in range(3):
@@ -209,8 +219,8 @@ def test_user_helper_functions_match_oracle_twins(lib):
     flips = first["hit"] != dflt["hit"]
     steps = np.abs((first["n_accept"] + first["n_reject"]).astype(np.int64) - (dflt["n_accept"] + dflt["n_reject"]).astype(np.int64))
     drgb = np.abs(first["rgb"] - dflt["rgb"]).max(axis=0)
-    assert flips.sum() <= 6 and (steps > 2).mean() <= 0.005 and drgb[~flips].max() <= 2e-3, \
-        (int(flips.sum()), float((steps > 2).mean()), float(drgb[~flips].max()))
+    assert flips.sum() <= 2 and steps.max() <= 2 and drgb[~flips].max() <= 1e-6, (int(flips.sum()), int(steps.max()), float(drgb[~flips].max()))
+    assert np.abs(first["state_end"] - dflt["state_end"])[~flips].max() <= 1e-6      # every component, the time coordinate too
     again = hip_trace(lib, scn, opt, 96, 80, cam=camera)
     for k in ("rgb", "hit", "n_accept"):
         assert np.array_equal(again[k], dflt[k], equal_nan=True), k
@@ -332,6 +342,49 @@ def test_metric_from_source_text_in_one_call(lib):
     rc = lib.rtgr_user_metric_compile(None, b"template <class S> __device__ void rtgr_user_metric(const S x[4], double M, double a, S g[4][4]) { g[0][0] = undefined_symbol; }", 0, C.byref(out))
     assert rc == abi.ERR_BAD_ARG and b"undefined_symbol" in lib.rtgr_last_error()
     assert lib.rtgr_user_metric_compile(None, b"int x;", 0, C.byref(out)) == abi.ERR_BAD_ARG
+
+
+@pytest.mark.gpu
+def test_code_objects_with_the_exec_flip_fault_are_refused_at_load_and_in_process(lib, tmp_path):
+    """rtgr_user_metric_load audits what it is handed: the heavy example metric built the plain way (`hipcc --genco`, no look at the
+    listing) carries the EXEC-flip fault of ROCm 7.2's LLVM in its FULL kernels and is refused with the offending instructions in
+    the message — if this compiler still produces it; a hand-assembled image with the shape always is.  rtgr_user_metric_compile
+    (hiprtc: no listing to repair) goes through its occupancy levels, then the masked-control variants, until the audit passes —
+    or reports that none does and which route repairs."""
+    from test_build_checks import FAULTY_LISTING, _assemble
+    from test_gpu_parity import compare, hip_trace
+    out = C.c_uint64(0)
+    bad = _assemble(FAULTY_LISTING, str(tmp_path / "faulty.hsaco"))
+    assert lib.rtgr_user_metric_load(None, bad.encode(), C.byref(out)) == abi.ERR_BAD_ARG
+    msg = lib.rtgr_last_error().decode()
+    assert "ahead of the EXEC flip" in msg and "v_accvgpr_write_b32 a0, v2" in msg
+    aot = um.compile_user_metric(user_metrics.HELPER_ZOO, stationary=True)
+    plain = str(tmp_path / "plain.hsaco")
+    subprocess.check_call([um._build.HIPCC, "--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DRTGR_USER_NE=3",
+                           "-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2", "-I", um.CSRC, "-o", plain,
+                           aot[:-len(".hsaco")] + ".hip"], stderr=subprocess.DEVNULL)
+    n_plain, _ = um.audit(plain)
+    rc = lib.rtgr_user_metric_load(None, plain.encode(), C.byref(out))
+    assert (rc == abi.ERR_BAD_ARG) == (n_plain > 0), (rc, n_plain)
+    if rc == 0:
+        abi.check(lib, lib.rtgr_user_metric_unload(None, out.value))
+    # in-process: every variant hiprtc builds of THIS metric carries the fault with this compiler (six of six) — the call must say
+    # so and name the route that repairs; should a later compiler build it soundly, the frame must be the oracle's
+    jit = rt.UserMetric(user_metrics.HELPER_ZOO, M=1.3, stationary=True, jit=True)
+    _, objs, cam = rt.example2_scene()
+    camera, opt = rt.make_camera(**cam), rt.solver_defaults()
+    try:
+        scn = rt.make_scene(jit, objs)
+    except abi.RtgrError as e:
+        assert e.code == abi.ERR_BAD_ARG and "ahead of the EXEC flip" in str(e) and "python -m raytracegr.jl_amd.user_metric" in str(e)
+        assert lib.rtgr_user_metric_loaded(None, 0) in (0, 1)      # nothing half-loaded is left behind that a later call trips over
+        return
+    sco = rt.make_scene(jit, objs)
+    sco.user_metric = 0x200
+    ref = O.trace(sco, opt, 32, 32, cam=camera)
+    compare(hip_trace(lib, scn, opt, 32, 32, cam=camera), ref, max_class_flips=2, max_step_diff=2)
+    with abi.options(lib, split=0):
+        compare(hip_trace(lib, scn, opt, 32, 32, cam=camera), ref, max_class_flips=2, max_step_diff=2)
 
 
 @pytest.mark.gpu
