@@ -365,23 +365,33 @@ int rtgr_eval_fastmath_f64(rtgr_context* ctx, const double* x, uint64_t n, doubl
  * (f, k_x, k_y, k_z) and use the closed contraction of the built-in metrics — no 4x4 solve.
  * rtgr_eval_geodesic_f64(path = 2) on a user scene evaluates exactly that loop RHS. */
 int rtgr_user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out);
-/* The same in ONE call from source text: `source` (the definition of rtgr_user_metric<S>, as above) is pasted into the
- * unit template, compiled IN-PROCESS with hiprtc (libhiprtc is resolved with dlopen at first use; ~3 s; no hipcc needed on
- * the box) and loaded.  stationary != 0 declares that the metric does not depend on t (-DRTGR_USER_NE=3: the integrate
- * kernels carry the three spatial partials only).  The unit template and device headers are read from the `csrc`
+/* The same in ONE call from source text: `source` (the definition of rtgr_user_metric<S>, as above) is pasted into the unit
+ * template, compiled IN-PROCESS and loaded — no hipcc on the box, no child process, ~10 s for a light metric.  The build goes
+ * hiprtc (source -> optimised bitcode) -> libamd_comgr (bitcode -> assembly listing -> code object), both resolved with dlopen at
+ * first use, with a look at the LISTING in between: the check and repair described below.  stationary != 0 declares that the metric
+ * does not depend on t (-DRTGR_USER_NE=3: the integrate kernels carry the three spatial partials only).  A unit whose integrate
+ * kernels would spill is rebuilt with more registers per lane.  The unit template and device headers are read from the `csrc`
  * directory next to librtgr_hip.so (or $RTGR_CSRC).  On a compile error the compiler's log is the rtgr_last_error(). */
 int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out);
+/* The build step of rtgr_user_metric_compile on its own: source text -> code object FILE for rtgr_user_metric_load (build once,
+ * keep the file, load it in every later process).  Needs no GPU and no context. */
+int rtgr_user_metric_build(const char* source, int stationary, const char* code_object_path);
 int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
-/* Both entry points AUDIT the code object before it is loaded: ROCm 7.2's compiler can place a register copy or spill at the top of
- * the FLOW block of a divergent if / else, ahead of the instruction that switches EXEC to the `else` lanes, and code of that shape
- * computes wrong values in some lanes (the Float64 FULL pass of a heavy metric was wrong from it in round 4).  An
- * image that carries the shape is refused with RTGR_ERR_BAD_ARG and the offending instructions in rtgr_last_error();
- * rtgr_user_metric_compile then tries its other occupancy levels (other code), and raytracegr.jl_amd/user_metric.py — the hipcc
- * route — repairs the listing before it assembles it.  rtgr_code_object_audit is that check on its own (no GPU, no context needed):
- * *found = number of such blocks, their description in `report` (may be NULL).  The file is a gfx950 code object, or a host library
- * that embeds code objects — librtgr_hip.so itself: the build checks audit the kernels the library ships.  RTGR_ERR_BAD_ARG when it
- * is neither, or the disassembler (libamd_comgr, resolved with dlopen) is not on the box. */
+/* The EXEC-flip check.  ROCm 7.2's compiler can place a register copy or spill at the top of the FLOW block of a divergent if / else,
+ * AHEAD of the instruction that switches EXEC to the `else` lanes; code of that shape computes wrong values in some lanes (DESIGN.md
+ * §4.6: the Float64 FULL pass of a heavy metric was wrong from it in round 4).  rtgr_user_metric_compile / _build look for the shape
+ * in the listing and rewrite it there (as raytracegr.jl_amd/user_metric.py does on the hipcc route); rtgr_user_metric_load AUDITS
+ * every code object it is handed — whatever built it — and refuses one that carries the shape with RTGR_ERR_BAD_ARG and the offending
+ * instructions in rtgr_last_error().  rtgr_code_object_audit is that audit on its own (no GPU, no context needed): *found = number
+ * of such blocks, their description in `report` (may be NULL).  The file is a gfx950 code object, or a host library that embeds
+ * code objects — librtgr_hip.so itself: the build checks audit the kernels the library ships.  RTGR_ERR_BAD_ARG when it is neither,
+ * or the disassembler (libamd_comgr) is not on the box. */
 int rtgr_code_object_audit(const char* code_object_path, int* found, char* report, uint64_t report_len);
+/* … and the check / repair of a gfx950 assembly LISTING (`hipcc -S`), the step rtgr_user_metric_build runs between code generation and
+ * the assembler: repaired_path == NULL: *blocks = FLOW blocks that carry the shape; otherwise the listing is rewritten into
+ * repaired_path and *blocks = blocks rewritten (RTGR_ERR_BAD_ARG, nothing written, when a block is not of the form the rewrite is
+ * proven for).  The same rule as raytracegr.jl_amd/isa_exec.py; the tests hold the two to the same answers. */
+int rtgr_listing_repair(const char* listing_path, const char* repaired_path, int* blocks);
 /* 1 if module `id` is resident (id 0: any module), else 0 */
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id);
 

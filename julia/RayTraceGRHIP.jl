@@ -213,13 +213,13 @@ ndevices(ctx) = Int(check(ccall((:rtgr_context_devices, librtgr), Cint, (Ctx,), 
     DeviceMetric(code_object; M = 1.0, a = 0.0)
 
 A metric function of the user's own — the native stand-in for passing a new Julia function as `metric` (:302-309) —
-given as C++ source text (`DeviceMetric(source = "...")`: compiled in-process with hiprtc by `rtgr_user_metric_compile`) or
+given as C++ source text (`DeviceMetric(source = "...")`: built in-process by `rtgr_user_metric_compile`, no hipcc needed) or
 as a gfx950 code object built from `rtgr_user_unit.hip.in` (INTEGRATION.md "A new metric").
 Several may be resident at once; a scene names its own by id.
 """
 struct DeviceMetric
-    code_object::String     # path of a code object built with hipcc --genco, or "" when `source` is given
-    source::String          # C++ source of rtgr_user_metric<S>: compiled in-process by the library (hiprtc), one ccall
+    code_object::String     # path of a code object (rtgr_user_metric_build, or `python -m raytracegr.jl_amd.user_metric`), or "" when `source` is given
+    source::String          # C++ source of rtgr_user_metric<S>: built in-process by the library, one ccall
     stationary::Bool
     M::Float64
     a::Float64

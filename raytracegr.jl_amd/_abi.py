@@ -67,7 +67,7 @@ EXPORTS = [
     "rtgr_make_canvas_device_f64", "rtgr_make_canvas_f64", "rtgr_make_canvas_device_f32", "rtgr_make_canvas_f32",
     "rtgr_eval_metric_f64", "rtgr_eval_metric_f32", "rtgr_eval_geodesic_f64", "rtgr_eval_geodesic_f32",
     "rtgr_eval_fastmath_f64", "rtgr_quantize_device_f64",
-    "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded", "rtgr_code_object_audit",
+    "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded", "rtgr_code_object_audit", "rtgr_user_metric_build", "rtgr_listing_repair",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -134,6 +134,8 @@ def _declare(lib):
     lib.rtgr_user_metric_unload.argtypes = [ctx, u64]
     lib.rtgr_user_metric_loaded.argtypes = [ctx, u64]
     lib.rtgr_code_object_audit.argtypes = [C.c_char_p, P(i32), C.c_char_p, u64]
+    lib.rtgr_user_metric_build.argtypes = [C.c_char_p, i32, C.c_char_p]
+    lib.rtgr_listing_repair.argtypes = [C.c_char_p, C.c_char_p, P(i32)]
     for name in EXPORTS:
         if name != "rtgr_last_error":
             getattr(lib, name).restype = i32

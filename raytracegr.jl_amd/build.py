@@ -19,7 +19,7 @@ UNITS = ["tu_f64_ksref.hip", "tu_f64_kstrue.hip", "tu_f64_generic.hip", "tu_f64_
 # the device-side headers: what the KERNELS are made of (bench.py keys its roofline profile on their hash)
 KERNEL_HEADERS = ["rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_packed_f32.hpp",
                   "rtgr_tsit5_tables.hpp"]
-HEADERS = KERNEL_HEADERS + ["rtgr_host.hpp", "rtgr_pipeline.hpp", "rtgr_isa_audit.hpp"]
+HEADERS = KERNEL_HEADERS + ["rtgr_host.hpp", "rtgr_pipeline.hpp", "rtgr_isa_audit.hpp", "rtgr_isa_repair.hpp", "rtgr_unit_build.hpp"]
 DEPS = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(HERE, "..", "include", "rtgr.h")]
 OUT = os.path.join(HERE, "librtgr_hip.so")
 OBJ = os.path.join(HERE, "build", "obj")

@@ -4,6 +4,7 @@
 // conversion, dispatch to the translation unit that owns the metric variant's kernels (tu_*.hip), the host-pointer
 // entry points (pinned staging + a three-stream H2D / compute / D2H pipeline), the single-process multi-device path
 // (cyclic rows, peer copies to device 0) and run-time loaded metric modules.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -13,9 +14,11 @@
 #include <thread>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include "rtgr_host.hpp"
 #include "rtgr_isa_audit.hpp"
+#include "rtgr_unit_build.hpp"
 
 namespace rtgr {
 
@@ -1598,15 +1601,12 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 }  // extern "C"
 
 // load a gfx950 code object image into every device of the context; its id is a hash of the image
-constexpr int RTGR_USER_MAX_SCRATCH = 64;   // bytes per lane above which rtgr_user_metric_compile rebuilds a unit at a lower occupancy
-static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out,
-                             int max_scratch = 1 << 30, int* scratch_out = nullptr, int* audit_out = nullptr) {
+static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out) {
     const uint64_t id = fnv1a(image);
     {   // refuse code that carries the EXEC-flip fault of this LLVM (rtgr_isa_audit.hpp): a unit traced wrong from it in round 4.
         // (An image that cannot be audited — no libamd_comgr on the box — is loaded as it is.)
         std::string report;
         const int bad = isa_audit::audit(image.data(), image.size(), &report);
-        if (audit_out) *audit_out = bad;
         if (bad > 0)
             return fail(RTGR_ERR_BAD_ARG, what + ": " + std::to_string(bad) + " FLOW block(s) with vector instructions ahead of the EXEC flip "
                         "(a code-generation fault of the compiler, DESIGN.md §4.6; raytracegr.jl_amd/user_metric.py builds repaired units):\n" + report);
@@ -1667,23 +1667,6 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
                 *w.f = nullptr;
             }
         if (!u.prepare_f32 || !u.fulln_f32) u.full10_f32 = nullptr;  // all or nothing
-        // scratch bytes per lane of the unit's integrate kernels: rtgr_user_metric_compile rebuilds a unit that spills at a lower
-        // occupancy (a performance matter: the heavy example metrics spill 200-400 registers per step at two waves per SIMD)
-        {
-            hipFunction_t ik[] = {u.far, u.near, u.full10, u.fulln, u.full10_f32, u.fulln_f32};
-            int worst = 0;
-            for (hipFunction_t f : ik) {
-                int local = 0;
-                if (!f || hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) != hipSuccess) { (void)hipGetLastError(); continue; }
-                worst = local > worst ? local : worst;
-            }
-            if (scratch_out) *scratch_out = worst;
-            if (worst > max_scratch) {
-                (void)hipModuleUnload(u.module);
-                return fail(RTGR_ERR_BAD_ARG, what + ": the integrate kernels spill " + std::to_string(worst) + " B per lane to scratch (limit asked: " +
-                            std::to_string(max_scratch) + ")");
-            }
-        }
         d->modules.push_back(u);
     }
     if (id_out) *id_out = id;
@@ -1704,38 +1687,8 @@ static int read_file(const std::string& path, std::vector<char>& out) {
     return RTGR_OK;
 }
 
-// ---- in-process compilation with hiprtc (resolved lazily with dlopen: no link-time dependency) ----------------------------
+// ---- in-process compilation (rtgr_unit_build.hpp: hiprtc + libamd_comgr, resolved lazily with dlopen) ------------------------------
 namespace {
-struct Hiprtc {
-    void* h = nullptr;
-    int (*create)(void**, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
-    int (*compile)(void*, int, const char* const*) = nullptr;
-    int (*log_size)(void*, size_t*) = nullptr;
-    int (*log)(void*, char*) = nullptr;
-    int (*code_size)(void*, size_t*) = nullptr;
-    int (*code)(void*, char*) = nullptr;
-    int (*destroy)(void**) = nullptr;
-    bool ok() const { return create && compile && log_size && log && code_size && code && destroy; }
-};
-Hiprtc& hiprtc() {
-    static Hiprtc r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
-            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.h) break;
-        }
-        if (!r.h) return;
-        r.create = (decltype(r.create))dlsym(r.h, "hiprtcCreateProgram");
-        r.compile = (decltype(r.compile))dlsym(r.h, "hiprtcCompileProgram");
-        r.log_size = (decltype(r.log_size))dlsym(r.h, "hiprtcGetProgramLogSize");
-        r.log = (decltype(r.log))dlsym(r.h, "hiprtcGetProgramLog");
-        r.code_size = (decltype(r.code_size))dlsym(r.h, "hiprtcGetCodeSize");
-        r.code = (decltype(r.code))dlsym(r.h, "hiprtcGetCode");
-        r.destroy = (decltype(r.destroy))dlsym(r.h, "hiprtcDestroyProgram");
-    });
-    return r;
-}
 std::string csrc_dir() {  // the device headers ship next to the library: <dir of librtgr_hip.so>/csrc (RTGR_CSRC overrides)
     if (const char* e = std::getenv("RTGR_CSRC")) if (*e) return e;
     Dl_info info;
@@ -1776,82 +1729,75 @@ int rtgr_code_object_audit(const char* code_object_path, int* found, char* repor
     return RTGR_OK;
 }
 
-int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
-    rtgr_context* c = nullptr;
-    int rc = resolve_ctx(ctx, &c);
-    if (rc) return rc;
+// source text -> the unit's code object, in-process (no GPU needed); RTGR_OK or a negative status with the reason as last error
+static int build_unit_image(const char* source, int stationary, unit_build::Built* built) {
     const bool ks_form = source && std::strstr(source, "rtgr_user_ks") != nullptr;
     if (!source || (!ks_form && !std::strstr(source, "rtgr_user_metric")))
         return fail(RTGR_ERR_BAD_ARG, "the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
                                       "double M, double a, S g[4][4])` (or, for a metric of Kerr-Schild form, rtgr_user_ks(const S "
                                       "x[4], double M, double a, S& f, S k[3]))");
-    Hiprtc& R = hiprtc();
-    if (!R.ok()) return fail(RTGR_ERR_BAD_ARG, "libhiprtc not found: build the unit with hipcc --genco and use rtgr_user_metric_load");
     const std::string dir = csrc_dir();
     std::vector<char> tmpl;
-    if ((rc = read_file(dir + "/rtgr_user_unit.hip.in", tmpl))) return rc;
+    if (int rc = read_file(dir + "/rtgr_user_unit.hip.in", tmpl)) return rc;
     std::string unit(tmpl.begin(), tmpl.end());
     const std::string mark = "@RTGR_USER_SOURCE@";
     const size_t at = unit.find(mark);
     if (at == std::string::npos) return fail(RTGR_ERR_BAD_ARG, dir + "/rtgr_user_unit.hip.in: no " + mark);
     unit.replace(at, mark.size(), source);
-    // hiprtc pre-includes the HIP device API and has no system headers: the two the units ask for are given in memory
-    static const char* const hdr_src[] = {
-        "#pragma once\n",
-        "#pragma once\ntypedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
-        "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"};
-    static const char* const hdr_name[] = {"hip/hip_runtime.h", "stdint.h"};
-    const std::string inc = "-I" + dir;
-    // occupancy levels (waves per SIMD of the Float64 / Float32 generic-RHS kernels): the defaults first; a unit whose integrate
-    // kernels spill there is rebuilt with more registers per lane (the last level is taken as it comes).  Levels 3-5 are the same
-    // three with the step's control block under the running lanes' EXEC mask: other code, for the metric whose every level above
-    // comes out of the compiler with the EXEC-flip fault (load_module_image audits; nothing can be repaired in-process).
-    static const char* const LEVELS[][3] = {{nullptr, nullptr, nullptr},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2", nullptr},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1", nullptr},
-                                            {"-DRTGR_GHOST_LANES=0", nullptr, nullptr},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2", "-DRTGR_GHOST_LANES=0"},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1", "-DRTGR_GHOST_LANES=0"}};
-    bool any_faulty = false;
-    std::vector<char> sound_but_spilling;
-    for (int level = 0; level < 6; level++) {
-        if (level == 3 && !any_faulty) break;   // the masked-control variants are only for a metric the audit refused
-        void* prog = nullptr;
-        if (R.create(&prog, unit.c_str(), "rtgr_user_unit.hip", 2, hdr_src, hdr_name) != 0) return fail(RTGR_ERR_HIP, "hiprtcCreateProgram failed");
-        std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
-        if (stationary || ks_form) opts.push_back("-DRTGR_USER_NE=3");   // (Kerr–Schild form: stationary by contract)
-        if (ks_form) opts.push_back("-DRTGR_USER_KS=1");
-        for (const char* o : LEVELS[level]) if (o) opts.push_back(o);
-        const int cr = R.compile(prog, (int)opts.size(), opts.data());
-        if (cr != 0) {
-            size_t ls = 0;
-            std::string log;
-            if (R.log_size(prog, &ls) == 0 && ls > 1) { log.resize(ls); (void)R.log(prog, &log[0]); }
-            (void)R.destroy(&prog);
-            if (log.size() > 6000) log.resize(6000);
-            return fail(RTGR_ERR_BAD_ARG, "hiprtc failed on the user metric:\n" + log);
-        }
-        size_t cs = 0;
-        std::vector<char> image;
-        if (R.code_size(prog, &cs) != 0 || cs == 0) { (void)R.destroy(&prog); return fail(RTGR_ERR_HIP, "hiprtcGetCodeSize failed"); }
-        image.resize(cs);
-        const int gr = R.code(prog, image.data());
-        (void)R.destroy(&prog);
-        if (gr != 0) return fail(RTGR_ERR_HIP, "hiprtcGetCode failed");
-        int spilled = 0, faulty = 0;
-        rc = load_module_image(c, image, "compiled user metric", id_out, level % 3 < 2 ? RTGR_USER_MAX_SCRATCH : 1 << 30, &spilled, &faulty);
-        if (rc == RTGR_OK) return rc;
-        if (faulty > 0) { any_faulty = true; continue; }   // this level's code carries the EXEC-flip fault: the next level is other code
-        if (spilled <= RTGR_USER_MAX_SCRATCH) return rc;    // failed for another reason than spilling
-        if (sound_but_spilling.empty()) sound_but_spilling.swap(image);
+    std::string why;
+    const int r = unit_build::build(unit, dir, stationary != 0, ks_form, built, &why);
+    if (r == 1) return fail(RTGR_ERR_BAD_ARG, why);          // the user's source does not compile: the compiler's log
+    if (r != 0) return fail(RTGR_ERR_HIP, why);
+    return RTGR_OK;
+}
+
+int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    unit_build::Built built;
+    if ((rc = build_unit_image(source, stationary, &built))) return rc;
+    const std::vector<char> image(built.image.begin(), built.image.end());
+    return load_module_image(c, image, "compiled user metric", id_out);   // (audited there like any other image)
+}
+
+int rtgr_user_metric_build(const char* source, int stationary, const char* code_object_path) {
+    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
+    unit_build::Built built;
+    if (int rc = build_unit_image(source, stationary, &built)) return rc;
+    const std::string tmp = std::string(code_object_path) + ".tmp" + std::to_string((long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(RTGR_ERR_BAD_ARG, "cannot write " + tmp);
+    const size_t put = std::fwrite(built.image.data(), 1, built.image.size(), f);
+    if (std::fclose(f) != 0 || put != built.image.size()) { std::remove(tmp.c_str()); return fail(RTGR_ERR_BAD_ARG, "short write on " + tmp); }
+    if (std::rename(tmp.c_str(), code_object_path) != 0) { std::remove(tmp.c_str()); return fail(RTGR_ERR_BAD_ARG, std::string("cannot rename to ") + code_object_path); }
+    return RTGR_OK;
+}
+
+int rtgr_listing_repair(const char* listing_path, const char* repaired_path, int* blocks) {
+    if (!listing_path || !*listing_path || !blocks) return fail(RTGR_ERR_BAD_ARG, "listing path or blocks is NULL");
+    std::vector<char> text;
+    if (int rc = read_file(listing_path, text)) return rc;
+    std::vector<std::string> lines;
+    for (size_t p = 0; p <= text.size();) {
+        const auto e = std::find(text.begin() + (long)p, text.end(), '\n');
+        lines.emplace_back(text.begin() + (long)p, e);
+        if (e == text.end()) break;
+        p = (size_t)(e - text.begin()) + 1;
     }
-    // hiprtc hands back the code object only, so a faulty listing cannot be repaired here the way user_metric.compile_user_metric
-    // does: sound code that spills is taken before none at all
-    if (!sound_but_spilling.empty()) return load_module_image(c, sound_but_spilling, "compiled user metric", id_out);
-    if (any_faulty)
-        return fail(RTGR_ERR_BAD_ARG, std::string(rtgr_last_error()) + "\n(no occupancy level of this metric compiles to sound code in-process: build "
-                    "the unit with `python -m raytracegr.jl_amd.user_metric source.hip`, which repairs the listing, and load it with rtgr_user_metric_load)");
-    return rc;
+    if (!repaired_path) { *blocks = (int)isa_repair::find(lines).size(); return RTGR_OK; }
+    std::string why;
+    const int n = isa_repair::repair(lines, &why);
+    if (n < 0) return fail(RTGR_ERR_BAD_ARG, std::string(listing_path) + ": " + why);
+    FILE* f = std::fopen(repaired_path, "wb");
+    if (!f) return fail(RTGR_ERR_BAD_ARG, std::string("cannot write ") + repaired_path);
+    for (size_t k = 0; k < lines.size(); k++) {
+        std::fwrite(lines[k].data(), 1, lines[k].size(), f);
+        if (k + 1 < lines.size()) std::fputc('\n', f);
+    }
+    if (std::fclose(f) != 0) return fail(RTGR_ERR_BAD_ARG, std::string("short write on ") + repaired_path);
+    *blocks = n;
+    return RTGR_OK;
 }
 
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id) {

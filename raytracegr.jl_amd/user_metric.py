@@ -202,8 +202,8 @@ class UserMetric:
     def __init__(self, source, M=1.0, a=0.0, name="user_metric", verbose=False, stationary=False, jit=False):
         """jit=False: the unit is built with `hipcc --genco` here and now (needs hipcc, not a GPU; cached on disk by content
         hash) and loaded with rtgr_user_metric_load on first use.  jit=True: the SOURCE is handed to the library, which
-        compiles it in-process with hiprtc when the metric is first used in a context (rtgr_user_metric_compile: one call,
-        no hipcc on the box, ~3 s, not cached across processes)."""
+        builds it in-process (hiprtc + libamd_comgr) when the metric is first used in a context (rtgr_user_metric_compile: one call,
+        no hipcc on the box, ~5 s, not cached across processes)."""
         self.source, self.M, self.a, self.name = source, float(M), float(a), name
         self.stationary, self.jit = bool(stationary), bool(jit)
         self.code_object = None if jit else compile_user_metric(source, verbose=verbose, stationary=stationary)
@@ -240,6 +240,14 @@ def audit(path):
     n, buf = C.c_int32(0), C.create_string_buffer(8192)
     _abi.check(lib, lib.rtgr_code_object_audit(path.encode(), C.byref(n), buf, len(buf)))
     return n.value, buf.value.decode()
+
+
+def build_in_process(source, path, stationary=False):
+    """rtgr_user_metric_build: the unit built by the LIBRARY (hiprtc + libamd_comgr, listing checked and repaired in between) into
+    `path` — what a C or Julia caller gets without hipcc; no GPU needed"""
+    lib = _abi.load()
+    _abi.check(lib, lib.rtgr_user_metric_build(source.encode(), 1 if stationary else 0, path.encode()))
+    return path
 
 
 if __name__ == "__main__":

@@ -47,6 +47,28 @@ def test_bad_user_source_is_reported_not_swallowed():
         um.compile_user_metric(bad)
 
 
+def test_in_process_build_needs_no_gpu_and_gives_a_sound_unit(tmp_path):
+    """rtgr_user_metric_build — the build step of rtgr_user_metric_compile (hiprtc -> bitcode -> libamd_comgr listing -> check / repair
+    -> assembler -> linker, all inside librtgr_hip.so) — for a light metric, the heavy one (every plain-hiprtc variant of which this
+    compiler gets wrong) and a broken source: every kernel the loader asks for, no spills, audit clean, and the
+    compiler's log for the broken one."""
+    for name, src in (("light", user_metrics.SCHWARZSCHILD_ISOTROPIC), ("heavy", user_metrics.HELPER_ZOO)):
+        path = um.build_in_process(src, str(tmp_path / f"{name}.hsaco"), stationary=True)
+        syms = subprocess.run([os.path.join(um.LLVM_BIN, "llvm-readelf"), "--dyn-syms", "-W", path], capture_output=True, text=True, check=True).stdout
+        names = {line.split()[-1] for line in syms.splitlines() if line.strip()}
+        for k in KERNELS + ["rtgr_user_abi_version", "rtgr_user_far_waves", "rtgr_user_near_waves", "rtgr_user_f32_waves"]:
+            assert k in names, (name, k)
+        scratch = um.code_object_scratch(path)
+        assert len(scratch) == 6 and max(scratch.values()) <= um.MAX_SCRATCH, (name, scratch)
+        assert um.audit(path) == (0, ""), name
+    lib = abi.load()
+    bad = user_metrics.SCHWARZSCHILD_ISOTROPIC.replace("msqrt", "no_such_function")
+    out = str(tmp_path / "bad.hsaco")
+    assert lib.rtgr_user_metric_build(bad.encode(), 1, out.encode()) == abi.ERR_BAD_ARG
+    assert b"no_such_function" in lib.rtgr_last_error() and not os.path.exists(out)
+    assert lib.rtgr_user_metric_build(b"int nothing_here;", 0, out.encode()) == abi.ERR_BAD_ARG
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_heavy_user_metric_is_built_without_spills():
     """A metric that needs more registers than two waves per SIMD leave (HELPER_ZOO: 376-544 B of scratch per lane there; Kerr in
@@ -349,8 +371,7 @@ def test_code_objects_with_the_exec_flip_fault_are_refused_at_load_and_in_proces
     """rtgr_user_metric_load audits what it is handed: the heavy example metric built the plain way (`hipcc --genco`, no look at the
     listing) carries the EXEC-flip fault of ROCm 7.2's LLVM in its FULL kernels and is refused with the offending instructions in
     the message — if this compiler still produces it; a hand-assembled image with the shape always is.  rtgr_user_metric_compile
-    (hiprtc: no listing to repair) goes through its occupancy levels, then the masked-control variants, until the audit passes —
-    or reports that none does and which route repairs."""
+    builds through the listing like the hipcc route, and its unit of the heavy metric traces the oracle's frame."""
     from test_build_checks import FAULTY_LISTING, _assemble
     from test_gpu_parity import compare, hip_trace
     out = C.c_uint64(0)
@@ -368,18 +389,12 @@ def test_code_objects_with_the_exec_flip_fault_are_refused_at_load_and_in_proces
     assert (rc == abi.ERR_BAD_ARG) == (n_plain > 0), (rc, n_plain)
     if rc == 0:
         abi.check(lib, lib.rtgr_user_metric_unload(None, out.value))
-    # in-process: every variant hiprtc builds of THIS metric carries the fault with this compiler (six of six) — the call must say
-    # so and name the route that repairs; should a later compiler build it soundly, the frame must be the oracle's
+    # in-process (rtgr_user_metric_compile): the library builds through the LISTING too (rtgr_unit_build.hpp), so the same metric
+    # from source text in one call traces the oracle's frame in both pass structures
     jit = rt.UserMetric(user_metrics.HELPER_ZOO, M=1.3, stationary=True, jit=True)
     _, objs, cam = rt.example2_scene()
     camera, opt = rt.make_camera(**cam), rt.solver_defaults()
-    try:
-        scn = rt.make_scene(jit, objs)
-    except abi.RtgrError as e:
-        assert e.code == abi.ERR_BAD_ARG and "ahead of the EXEC flip" in str(e) and "python -m raytracegr.jl_amd.user_metric" in str(e)
-        assert lib.rtgr_user_metric_loaded(None, 0) in (0, 1)      # nothing half-loaded is left behind that a later call trips over
-        return
-    sco = rt.make_scene(jit, objs)
+    scn, sco = rt.make_scene(jit, objs), rt.make_scene(jit, objs)
     sco.user_metric = 0x200
     ref = O.trace(sco, opt, 32, 32, cam=camera)
     compare(hip_trace(lib, scn, opt, 32, 32, cam=camera), ref, max_class_flips=2, max_step_diff=2)
