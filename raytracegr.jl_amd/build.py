@@ -1,13 +1,21 @@
 """hipcc driver: builds raytracegr.jl_amd/librtgr_hip.so for gfx950 IN-TREE (the .so travels with gpurun snapshots).
 
-    python raytracegr.jl_amd/build.py [--force] [--resource-usage] [--save-temps] [-DNAME[=V] ...]
+    python raytracegr.jl_amd/build.py [--force] [--resource-usage] [--save-temps] [--via-listing] [-DNAME[=V] ...]
 
 The library is several translation units (csrc/tu_*.hip hold the kernels of one metric-variant group each,
 csrc/rtgr_misc.hip the small kernels, csrc/rtgr_api.hip the C ABI and no kernel at all); they are compiled in parallel
 into raytracegr.jl_amd/build/obj/ and linked with `hipcc -shared`.
+
+After linking, the library AUDITS the kernels embedded in it for the EXEC-flip fault of ROCm 7.2's compiler (DESIGN.md §4.6;
+rtgr_code_object_audit).  Clean so far.  If an edit of the kernels ever brings the fault out, the kernel units are rebuilt through
+their assembly LISTING (--via-listing, or RTGR_BUILD_VIA_LISTING=1, forces that route): `hipcc --cuda-device-only -S`, the check /
+repair of isa_exec.py, assembler, lld, clang-offload-bundler, then the host half with `-fcuda-include-gpubinary` — the steps hipcc
+runs itself, with a look at the listing in between; for a unit that needs no repair the device code is the same, instruction for
+instruction (tests/test_build_checks.py).
 """
 import concurrent.futures
 import hashlib
+import importlib.util
 import os
 import subprocess
 import sys
@@ -24,6 +32,8 @@ DEPS = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(HERE, "..", "inc
 OUT = os.path.join(HERE, "librtgr_hip.so")
 OBJ = os.path.join(HERE, "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+LLVM_BIN = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin")
+HOST_ONLY_UNITS = ("rtgr_api.hip",)   # no kernel in it: never needs the listing route
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -41,7 +51,66 @@ def _stale(target, deps):
     return (not os.path.exists(target)) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
 
 
-def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ):
+def _isa_exec():
+    spec = importlib.util.spec_from_file_location("rtgr_isa_exec_b", os.path.join(HERE, "isa_exec.py"))
+    m = importlib.util.module_from_spec(spec)   # (by path: importing the package would load the library being built)
+    spec.loader.exec_module(m)
+    return m
+
+
+def compile_via_listing(src, obj, extra=(), verbose=True, cwd=None):
+    """One translation unit through its device LISTING: what `hipcc -c` does in one go, in five steps with the check / repair of
+    isa_exec.py after the first.  Returns the number of FLOW blocks rewritten."""
+    base = obj[:-2] if obj.endswith(".o") else obj
+    asm, dev_o, hsaco, fatbin = base + ".dev.s", base + ".dev.o", base + ".hsaco", base + ".hipfb"
+    cuid = "-cuid=" + hashlib.sha256(os.path.basename(src).encode()).hexdigest()[:16]   # the two halves must agree on it
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{cmd[0]} failed on {src}:\n{r.stderr[-6000:]}")
+        return r
+
+    run([HIPCC] + FLAGS + list(extra) + [cuid, "--cuda-device-only", "-S", "-o", asm, src])
+    with open(asm) as fh:
+        lines = fh.read().split("\n")
+    lines, repaired = _isa_exec().repair(lines)      # RepairError: a block the rewrite is not proven for — the build stops there
+    if repaired:
+        with open(asm, "w") as fh:
+            fh.write("\n".join(lines))
+        if verbose:
+            print(f"   {os.path.basename(src)}: {repaired} FLOW block(s) rewritten in the listing", flush=True)
+    run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", dev_o])
+    run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", hsaco, dev_o])
+    run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={hsaco}", f"-output={fatbin}"])
+    run([HIPCC] + FLAGS + list(extra) + [cuid, "--cuda-host-only", "-Wno-unused-command-line-argument", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin,
+                                         "-c", "-o", obj, src])
+    for f in (dev_o, hsaco, fatbin):
+        os.unlink(f)
+    return repaired
+
+
+def audit(lib):
+    """(FLOW blocks with the EXEC-flip fault in the kernels embedded in `lib`, report) — by the library itself, in a child process
+    (this process may go on to import torch, whose libamdhip64 must be the first one loaded: _abi.load)"""
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); n = ctypes.c_int32(-1); buf = ctypes.create_string_buffer(8192);"
+            "rc = lib.rtgr_code_object_audit(sys.argv[1].encode(), ctypes.byref(n), buf, 8192);"
+            "print(rc, n.value); print(buf.value.decode())")
+    r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True)
+    head = r.stdout.split("\n", 1)
+    try:
+        rc, n = (int(v) for v in head[0].split())
+    except ValueError:
+        return None, r.stderr[-2000:]          # could not be run (no libamdhip64 / libamd_comgr here): the tests audit again
+    return (n if rc == 0 else None), (head[1] if len(head) > 1 else "")
+
+
+def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ, via_listing=None):
+    if via_listing is None:
+        via_listing = os.environ.get("RTGR_BUILD_VIA_LISTING") == "1"
     os.makedirs(obj_dir, exist_ok=True)
     tag = hashlib.sha256(" ".join(extra).encode()).hexdigest()[:8] if extra else "std"
     jobs = []
@@ -54,6 +123,12 @@ def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ):
 
     def compile_one(job):
         src, obj = job
+        if via_listing and os.path.basename(src) not in HOST_ONLY_UNITS:
+            try:
+                compile_via_listing(src, obj, extra, verbose, cwd=obj_dir)
+                return job, subprocess.CompletedProcess([], 0, "", "")
+            except RuntimeError as e:
+                return job, subprocess.CompletedProcess([], 1, "", str(e))
         cmd = [HIPCC] + FLAGS + list(extra) + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -81,6 +156,14 @@ def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ):
         subprocess.check_call(cmd, cwd=HERE)
         with open(tag_file, "w") as fh:
             fh.write(tag + "\n")
+        # the kernels just linked in must be free of the compiler's EXEC-flip fault; if they are not, once more through the listings
+        found, report = audit(out)
+        if found:
+            if via_listing:
+                raise RuntimeError(f"{out}: {found} FLOW block(s) with vector instructions ahead of the EXEC flip survive the listing route:\n{report}")
+            print(f"{out}: {found} FLOW block(s) with vector instructions ahead of the EXEC flip (DESIGN.md §4.6): rebuilding the kernel units "
+                  f"through their listings\n{report}", flush=True)
+            return build(force=True, extra=extra, verbose=verbose, out=out, obj_dir=obj_dir, via_listing=True)
     return out
 
 
@@ -99,4 +182,5 @@ if __name__ == "__main__":
     if "--save-temps" in sys.argv:
         extra += ["-save-temps=obj"]
     # (--resource-usage / --save-temps only print or write something when the units are actually compiled)
-    build(force=("--force" in sys.argv or "--resource-usage" in sys.argv or "--save-temps" in sys.argv), extra=extra)
+    build(force=("--force" in sys.argv or "--resource-usage" in sys.argv or "--save-temps" in sys.argv or "--via-listing" in sys.argv), extra=extra,
+          via_listing=True if "--via-listing" in sys.argv else None)

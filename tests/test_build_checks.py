@@ -201,3 +201,79 @@ def test_the_kernels_the_library_ships_are_free_of_the_exec_flip_fault():
     um = sys.modules[rt.__name__ + ".user_metric"]
     n, report = um.audit(rt._abi.LIB_PATH)
     assert n == 0, report
+
+
+def _build_module(name="rtgr_build_t2"):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _embedded_code(path):
+    """disassembly (instruction text only) of the gfx950 code objects bundled into an object file / library"""
+    import re
+    import struct
+    blob, out = open(path, "rb").read(), []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob):
+        o = m.start()
+        n = struct.unpack_from("<Q", blob, o + 24)[0]
+        p = o + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "amdgcn" in triple and size:
+                co = path + f".{len(out)}.hsaco"
+                with open(co, "wb") as fh:
+                    fh.write(blob[o + off:o + off + size])
+                dis = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+                out.append([l.split("//")[0].rstrip() for l in dis.splitlines() if "file format" not in l])
+    return out
+
+
+def test_a_library_unit_built_through_its_listing_is_the_same_code(tmp_path):
+    """build.py's fallback route for the library's own kernels (taken when the post-link audit finds the EXEC-flip fault, or with
+    --via-listing): device half to a listing, check / repair, assembler, lld, bundler, host half with the fat binary included —
+    for a unit that needs no repair the object carries the same device instructions and the same host symbols as `hipcc -c`."""
+    b = _build_module()
+    src = os.path.join(CSRC, "tu_f64_mink.hip")
+    via, std = str(tmp_path / "via.o"), str(tmp_path / "std.o")
+    assert b.compile_via_listing(src, via, verbose=False) == 0
+    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-c", "-o", std, src], stderr=subprocess.DEVNULL)
+    code_via, code_std = _embedded_code(via), _embedded_code(std)
+    assert len(code_via) == len(code_std) == 1 and code_via == code_std and len(code_via[0]) > 1000
+    syms = lambda p: sorted(l.split()[-1] for l in subprocess.run(["nm", p], capture_output=True, text=True, check=True).stdout.splitlines()
+                            if "__hip_cuid_" not in l and "__hip_gpubin_handle_" not in l)   # (named after the compilation-unit id: the listing route fixes its own)
+    assert syms(via) == syms(std)
+    assert not [f for f in os.listdir(tmp_path) if f.endswith((".hipfb", ".dev.o"))]      # intermediates are removed
+
+
+def test_build_falls_back_to_the_listing_route_when_the_audit_finds_the_fault(tmp_path):
+    """The driver logic with stand-in tools (every tool just creates its output file): a post-link audit that reports the fault makes
+    build() compile the kernel units again through compile_via_listing — not the kernel-free rtgr_api.hip — and link again; an
+    audit that still reports it after that is an error."""
+    b = _build_module("rtgr_build_t3")
+    log = tmp_path / "calls.log"
+    tool = ("#!/bin/sh\nprev=\nfor a in \"$@\"; do [ \"$prev\" = -o ] && out=\"$a\"; case \"$a\" in -output=*) out=\"${a#-output=}\";; esac; prev=\"$a\"; done\n"
+            f"echo \"$(basename $0) $@\" >> {log}\n: > \"$out\"\n")
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    for name in ("hipcc", "clang", "lld", "clang-offload-bundler"):
+        (bindir / name).write_text(tool)
+        (bindir / name).chmod(0o755)
+    b.HIPCC, b.LLVM_BIN = str(bindir / "hipcc"), str(bindir)
+    answers = [(2, "  .text+0x10: `v_accvgpr_write_b32 a0, v2` stands BEFORE the EXEC flip"), (0, "")]
+    b.audit = lambda lib: answers.pop(0)
+    out, obj = str(tmp_path / "lib.so"), str(tmp_path / "obj")
+    b.build(out=out, obj_dir=obj, verbose=False)
+    calls = open(log).read().splitlines()
+    links = [c for c in calls if " -shared " in c and c.startswith("hipcc")]
+    device_listings = [c for c in calls if "--cuda-device-only" in c]
+    assert len(links) == 2 and len(device_listings) == len(b.UNITS) - len(b.HOST_ONLY_UNITS)
+    assert not any("rtgr_api.hip" in c for c in device_listings) and answers == []
+    assert sum(1 for c in calls if c.startswith("clang-offload-bundler")) == len(device_listings)
+    answers.extend([(1, "x"), (1, "x")])
+    with pytest.raises(RuntimeError, match="survive the listing route"):
+        b.build(out=out, obj_dir=obj, verbose=False, force=True)
