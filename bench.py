@@ -12,12 +12,16 @@ coloured, rows — RGB and status bytes — gathered on rank 0).  `value` = Tsit
 device (make_canvas fused into the set-up kernel), so nothing crosses PCIe inside the timed region (`--entry device`).
 
 `roofline` (dominant kernels: the integrate kernel's FAR + NEAR passes) is an EXECUTED-flop figure:
-    achieved = executed f64 flop per step attempt (hardware-counted: 64 x (2 FMA + MUL + ADD) wave-instructions, from the
-               rocprofv3 --pmc pass recorded in profiles/rNN/flops.json) x the step attempts THIS run counted
-               / the integrate kernels' time THIS run measured with HIP events on the launch stream
+    achieved = executed f64 flop per step attempt (hardware-counted: 64 x (2 FMA + MUL + ADD) wave-instructions)
+               x the step attempts THIS run counted / the integrate kernels' time THIS run measured with HIP events on the launch stream
     frac     = achieved / 78.6 TF/s  (fp64 vector peak)  — always <= 1
-and it is emitted only when flops.json was collected from the SAME kernel sources (sha256 of the device headers + flags,
-raytracegr.jl_amd/build.py:kernel_source_hash); otherwise achieved / frac / traffic are null and `stale_profile` says why.
+    traffic  = HBM bytes per pass of the whole pipeline (2 x FETCH_SIZE + WRITE_SIZE)
+The counters are read BY THIS RUN on this box (`roofline.counters: "live"`; default run at N = 1): after the timed region one frame of
+the same workload is run three times under `rocprofv3 --pmc` in child processes — arithmetic counters, FETCH_SIZE, WRITE_SIZE, each
+set in a run of its own, never with a trace (live_counters()).  The committed profile of the same kernel sources
+(profiles/rNN/flops.json, keyed by the sha256 of the device headers + flags, raytracegr.jl_amd/build.py:kernel_source_hash) is
+then the cross-check (`live_over_profile`), and the source when the live passes are off (--extras 0 / --live-counters 0, N > 1)
+or fail; with neither, achieved / frac / traffic are null and `stale_profile` / `live_counters_skipped` say why.
 The reference-formulation figure of SURVEY §8d (5404 flop per attempt, what Julia's dual-number chain would execute for
 the same steps) is reported separately as `reference_equivalent_tflops` and may exceed the hardware peak: the closed
 Kerr–Schild contraction does not execute that work.
@@ -77,6 +81,12 @@ def parse():
     ap.add_argument("--extras", type=int, default=1,
                     help="1: after the timed region (rank 0, N = 1, default workload) also time the host and pixels entry "
                          "points and the Kerr a = 0.8 variant, reported in entry_points / variants; 0: skip")
+    ap.add_argument("--live-counters", type=int, default=-1,
+                    help="-1 (default): as --extras.  1: after the timed region (rank 0, N = 1, device entry) run ONE pass of the same workload three times under "
+                         "`rocprofv3 --pmc` in child processes (f64 / f32 FMA-MUL-ADD counters; FETCH_SIZE; WRITE_SIZE — each set in a "
+                         "run of its own) and compute the roofline's executed flops and HBM traffic from THIS box's counters; the "
+                         "hash-keyed profile of profiles/rNN/flops.json is then the cross-check, and the fallback when a pass fails "
+                         "or rocprofv3 is not there.  0: the profile only")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one stream, trace and gather strictly in turn (no frames in flight)")
@@ -88,7 +98,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real thing) or gloo (CPU-staged; lets "
                          "the multi-rank logic be rehearsed with several ranks sharing one GPU)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.live_counters < 0:
+        a.live_counters = 1 if a.extras else 0
+    return a
 
 
 def build_scene(rt, variant, generic=False):
@@ -191,6 +204,78 @@ def load_profile(a):
             e["kernel_source_hash"] = cur
             return e, None
     return None, f"no profiles/r*/flops.json entry {key!r} collected from kernel sources {cur} (found: {seen})"
+
+
+def live_counters(a, log=None):
+    """Executed flops and HBM bytes of ONE pass of this workload, hardware-counted here and now: bench.py re-run (one pass, no
+    extras, no CPU leg) under `rocprofv3 --pmc` in child processes — the arithmetic counters, FETCH_SIZE and WRITE_SIZE each in a
+    run of its own, never combined with a trace (MI355X_MICROARCH.md's recipe).  Returns (dict, None) or (None, why).  Children
+    are started only from a process that is not itself profiled, and start nothing themselves (RTGR_NO_COMPILE=1, --live-counters 0)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler itself"
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None, "rocprofv3 not found"
+    if a.size * a.size > (1 << 26):
+        return None, "more than one pipeline chunk per pass"
+    sfx = "F64" if a.dtype == "f64" else "F32"
+    sets = {"flop": [f"SQ_INSTS_VALU_FMA_{sfx}", f"SQ_INSTS_VALU_MUL_{sfx}", f"SQ_INSTS_VALU_ADD_{sfx}", "SQ_INSTS_VALU"],
+            "fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"]}
+    work = tempfile.mkdtemp(prefix="rtgr_pmc_", dir="/tmp")
+    tot, attempts, rays = {}, None, None
+    t0 = time.time()
+    try:
+        for name, counters in sets.items():
+            out = os.path.join(work, name)
+            cmd = [tool, "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "1", "--warmup", "0",
+                   "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
+            env = dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            child = json.loads(lines[-1])
+            attempts, rays = child["step_attempts_per_pass"], child["rays"]
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 wrote no counter_collection.csv for {counters}"
+            part, passes = {}, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    kernel = row["Kernel_Name"]
+                    # arithmetic: the integrate kernels (FAR + NEAR / FULL, built-in or of a run-time unit); bytes: every kernel of
+                    # the library's pipeline (torch's own kernels of the bench harness are not the path's)
+                    mine = "integrate" in kernel if name == "flop" else ("rtgr" in kernel)
+                    if mine:
+                        part[row["Counter_Name"]] = part.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    if "prepare" in kernel and row["Counter_Name"] == counters[0]:
+                        passes += 1      # the set-up kernel runs once per pass (one pipeline chunk: checked below)
+            if passes < 1:
+                return None, f"no set-up kernel among the dispatches rocprofv3 recorded for {counters}"
+            for k, v in part.items():     # (the child runs its one timed pass plus the warm-up the bench always does)
+                tot[k] = v / passes
+    except subprocess.TimeoutExpired:
+        return None, "a rocprofv3 --pmc pass did not finish in 240 s"
+    except Exception as e:  # noqa: BLE001  (a measurement aid must never cost the headline line)
+        return None, repr(e)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    fma, mul, add = (tot.get(f"SQ_INSTS_VALU_{k}_{sfx}", 0.0) for k in ("FMA", "MUL", "ADD"))
+    if fma <= 0 or not attempts:
+        return None, f"counters came back empty: {tot}"
+    return {"flop_per_step_attempt": 64.0 * (2 * fma + mul + add) / attempts,
+            "valu_per_wave_step": tot.get("SQ_INSTS_VALU", 0.0) / (attempts / 64.0),
+            "fma_mul_add_per_wave_step": [fma / (attempts / 64.0), mul / (attempts / 64.0), add / (attempts / 64.0)],
+            # FETCH_SIZE / WRITE_SIZE count KB; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes on gfx950
+            "hbm_bytes_per_ray": (2 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / rays,
+            "hbm_note": "2 x FETCH_SIZE + WRITE_SIZE over the library's pipeline kernels (KB x 1024), per pass, per ray",
+            "step_attempts_counted": attempts, "seconds": round(time.time() - t0, 1),
+            "how": "rocprofv3 --pmc in child processes of this run: arithmetic counters, FETCH_SIZE, WRITE_SIZE each in a run of its own"}, None
 
 
 def expected_checksum(a):
@@ -454,6 +539,12 @@ def main():
         approx_roofline = bool(ctx) and len(ctx_ids) > 1
         k_s = (float(kms[1]) + float(kms[3])) * 1e-3   # seconds in the integrate kernels, all launches of this rank
         prof, why = load_profile(a)
+        # … and the same two figures counted HERE, on this box, by this run (N = 1, device entry): the profile is then the cross-check
+        live, why_not_live = (None, "off")
+        if a.live_counters and not multi and a.entry == "device" and not ctx and not (a.dtype == "f32" and os.environ.get("RTGR_PACK", "1") != "0"):
+            live, why_not_live = live_counters(a)
+        elif a.live_counters:
+            why_not_live = "N = 1, device entry, scalar kernels only (the packed Float32 kernel's flops need the v_pk counters' reading of the profile)"
         peak = FP64_VALU_PEAK_TFLOPS if a.dtype == "f64" else F32_SCALAR_VALU_PEAK_TFLOPS
         roof = {"bound": "valu_f64" if a.dtype == "f64" else "valu_f32_scalar", "achieved": None, "peak": peak,
                 "unit": "TFLOP/s", "frac": None, "traffic": None,
@@ -478,20 +569,30 @@ def main():
             roof["approximate"] = ("multi-device context: counters are summed over the devices (an even share is assumed) and the "
                                    "kernel time is the busiest device's" + ("; the logical devices share one GPU, so achieved / frac "
                                    "are omitted" if n_physical < len(ctx_ids) else ""))
-        if prof is not None and not (approx_roofline and n_physical < len(ctx_ids)):
-            flop = prof["flop_per_step_attempt"] * my_attempts
+        src = live if live is not None else prof
+        roof["counters"] = "live" if live is not None else ("profile" if prof is not None else None)
+        if live is None and a.live_counters:
+            roof["live_counters_skipped"] = why_not_live
+        if src is not None and not (approx_roofline and n_physical < len(ctx_ids)):
+            flop = src["flop_per_step_attempt"] * my_attempts
             roof["achieved"] = flop / k_s / 1e12
             roof["frac"] = roof["achieved"] / peak
-            roof["executed_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
-            roof["traffic"] = prof["hbm_bytes_per_ray"] * my_rays / a.steps if prof.get("hbm_bytes_per_ray") else None
-            if prof.get("hbm_bytes_per_ray"):   # what the pipeline's hand-over records cost over the algorithm's own bytes
-                roof["traffic_over_algorithmic"] = prof["hbm_bytes_per_ray"] / ALGORITHMIC_BYTES_PER_RAY
+            roof["executed_flop_per_step_attempt"] = src["flop_per_step_attempt"]
+            roof["traffic"] = src["hbm_bytes_per_ray"] * my_rays / a.steps if src.get("hbm_bytes_per_ray") else None
+            if src.get("hbm_bytes_per_ray"):   # what the pipeline's hand-over records cost over the algorithm's own bytes
+                roof["traffic_over_algorithmic"] = src["hbm_bytes_per_ray"] / ALGORITHMIC_BYTES_PER_RAY
+            if live is not None:
+                roof["live"] = live
+                if prof is not None:   # the builder-collected profile of the same kernel sources, as the cross-check
+                    roof["profile_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
+                    roof["live_over_profile"] = live["flop_per_step_attempt"] / prof["flop_per_step_attempt"]
+        if prof is not None and not (approx_roofline and n_physical < len(ctx_ids)):
             roof["profile"] = prof
             ic = prof.get("issue_ceiling")
             if ic and ic.get("frac_of_peak_this_mix_can_issue"):   # what the machine can issue for THIS kernel's instruction mix with no operand ever waited for (measured)
                 roof["issue_ceiling_frac"] = ic["frac_of_peak_this_mix_can_issue"]
                 roof["frac_of_issue_ceiling"] = roof["frac"] / ic["frac_of_peak_this_mix_can_issue"]
-        elif prof is None:
+        if prof is None:
             roof["stale_profile"] = why
         name = C_name(lib)
         extras = {}
@@ -587,10 +688,11 @@ def main():
         dist.destroy_process_group()
 
 
-def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1):
+def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, live_on=False):
     """One BASELINE configuration outside the headline's timed region: `reps` device-resident frames (camera on the device,
     nothing over PCIe), wall time + the library's HIP-event kernel times, and the same executed-flop roofline as the headline's,
-    from THIS configuration's profile entry (profiles/rNN/flops.json, used only when its kernel-source hash is the current one)."""
+    from counters read by this run (live_counters(); Float64 configurations) or THIS configuration's profile entry
+    (profiles/rNN/flops.json, used only when its kernel-source hash is the current one)."""
     import ctypes
     import torch
     from raytracegr_jl_amd import sharded
@@ -622,8 +724,9 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1):
     k_s = (float(kms[1]) + float(kms[3])) * 1e-3 / reps
     class _A:  # noqa: E701
         pass
-    _A.variant, _A.dtype, _A.rhs = variant, dtype, rhs
+    _A.variant, _A.dtype, _A.rhs, _A.size = variant, dtype, rhs, size
     prof, why = load_profile(_A)
+    live, why_not_live = live_counters(_A) if (live_on and dtype == "f64") else (None, "off (Float32: the packed kernel is priced from its profile)")
     # Float32: the packed two-rays-per-lane kernel is priced against the fp32 VECTOR peak (v_pk_fma_f32), as asked
     peak = FP64_VALU_PEAK_TFLOPS if dtype == "f64" else F32_PACKED_VALU_PEAK_TFLOPS
     r = {"bound": "valu_f64" if dtype == "f64" else "valu_f32_packed", "peak": peak, "unit": "TFLOP/s", "kernel_ms_per_pass": k_s * 1e3,
@@ -633,15 +736,22 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1):
          "achieved": None, "frac": None,
          # SURVEY 8(d)'s own formula: a UTILISATION only where the kernel executes the reference formulation (rhs generic)
          "contract_8d_frac": (att * F_STEP + 2 * rays * F_RHS) / k_s / 1e12 / FP64_VALU_PEAK_TFLOPS if dtype == "f64" else None}
-    if prof is not None:
-        r["achieved"] = prof["flop_per_step_attempt"] * att / k_s / 1e12
+    src = live if live is not None else prof
+    r["counters"] = "live" if live is not None else ("profile" if prof is not None else None)
+    if live is None and live_on and dtype == "f64":
+        r["live_counters_skipped"] = why_not_live
+    if src is not None:
+        r["achieved"] = src["flop_per_step_attempt"] * att / k_s / 1e12
         r["frac"] = r["achieved"] / peak
         if dtype == "f32":
             r["frac_of_scalar_issue_peak"] = r["achieved"] / F32_SCALAR_VALU_PEAK_TFLOPS
-        r["executed_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
-        r["valu_per_wave_step"] = prof.get("per_wave_step", {}).get("valu")
+        r["executed_flop_per_step_attempt"] = src["flop_per_step_attempt"]
+        r["valu_per_wave_step"] = live["valu_per_wave_step"] if live is not None else prof.get("per_wave_step", {}).get("valu")
+        r["traffic"] = src["hbm_bytes_per_ray"] * rays if src.get("hbm_bytes_per_ray") else None
+        if live is not None and prof is not None:
+            r["live_over_profile"] = live["flop_per_step_attempt"] / prof["flop_per_step_attempt"]
+    if prof is not None:
         r["valu_busy"] = prof.get("valu_busy")
-        r["traffic"] = prof["hbm_bytes_per_ray"] * rays if prof.get("hbm_bytes_per_ray") else None
         r["source"] = prof.get("source")
         ic = prof.get("issue_ceiling")
         if ic and ic.get("frac_of_peak_this_mix_can_issue"):
@@ -684,7 +794,7 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
     ex["variants"] = {}
     for key, variant, size, dtype, rhs, reps, warm in plan:
         try:
-            ex["variants"][key] = time_variant(rt, variant, size, dtype, rhs, reps, warm)
+            ex["variants"][key] = time_variant(rt, variant, size, dtype, rhs, reps, warm, live_on=bool(a.live_counters))
         except Exception as e:  # noqa: BLE001   (one configuration must not cost the others their place on the line)
             ex["variants"][key] = {"error": repr(e)}
         rt._abi.check(lib, lib.rtgr_trim(None))   # (the 14 GB workspace of C5 is not kept for the next configuration)

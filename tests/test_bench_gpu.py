@@ -52,6 +52,23 @@ def test_bench_line_schema_and_one_rank_exchange_path():
     assert serial["frame_checksum"] == base["frame_checksum"] and serial["exchange"] == "in turn"
 
 
+def test_bench_counts_its_own_flops_and_bytes():
+    """--live-counters 1: the roofline's executed flops per step attempt and the HBM bytes per ray are hardware-counted by the run
+    itself (rocprofv3 --pmc passes of one frame in child processes) and agree with the committed profile of the same kernel
+    sources — which is then the cross-check, not the source."""
+    d = _bench("--size", "1024", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--extras", "0", "--live-counters", "1")
+    roof = d["roofline"]
+    assert roof["counters"] == "live", roof.get("live_counters_skipped")
+    live = roof["live"]
+    assert live["step_attempts_counted"] == d["step_attempts_per_pass"] and 600 < live["valu_per_wave_step"] < 1200
+    assert 0.3 < roof["frac"] <= 1.0 and abs(roof["executed_flop_per_step_attempt"] - live["flop_per_step_attempt"]) < 1e-9
+    assert 500 < live["hbm_bytes_per_ray"] < 1500 and roof["traffic"] > 0
+    if "profile_flop_per_step_attempt" in roof:      # same sources profiled at 4096²: small launches idle a few more lanes
+        assert 0.9 < roof["live_over_profile"] < 1.15
+    off = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0")
+    assert off["roofline"]["counters"] in ("profile", None) and "live" not in off["roofline"]
+
+
 def test_bench_host_entry_points():
     """--entry host / pixels: the timed passes go through rtgr_trace_f64 / rtgr_trace_pixels_f64 (PCIe-inclusive)."""
     base = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0")
