@@ -184,6 +184,8 @@ struct Built {
 
 // 0 = ok; 1 = the user's source does not compile (log in *why); 2 = anything else (*why)
 inline int build(const std::string& unit, const std::string& include_dir, bool stationary, bool ks_form, Built* out, std::string* why) {
+    static std::mutex one_build_at_a_time;   // (the compiler libraries keep process-wide state; builds are seconds long and rare)
+    std::lock_guard<std::mutex> lock(one_build_at_a_time);
     Hiprtc& R = hiprtc();
     if (!R.ok()) { *why = "libhiprtc not found: build the unit with `python -m raytracegr.jl_amd.user_metric` and use rtgr_user_metric_load"; return 2; }
     if (!comgr().ok()) { *why = "libamd_comgr not found: build the unit with `python -m raytracegr.jl_amd.user_metric` and use rtgr_user_metric_load"; return 2; }
