@@ -226,6 +226,17 @@ struct DeviceMetric
 end
 DeviceMetric(path::AbstractString; M = 1.0, a = 0.0) = DeviceMetric(path, "", false, M, a)
 DeviceMetric(; source::AbstractString, stationary = false, M = 1.0, a = 0.0) = DeviceMetric("", source, stationary, M, a)
+"""
+    build_metric(source, path; stationary = false) -> DeviceMetric(path)
+
+The build step of `DeviceMetric(source = ...)` on its own (`rtgr_user_metric_build`): source text -> code object file, built by the
+library in-process — no GPU, no hipcc needed —, to be kept and loaded in later sessions with `DeviceMetric(path)`.
+"""
+function build_metric(source::AbstractString, path::AbstractString; stationary = false, M = 1.0, a = 0.0)
+    check(ccall((:rtgr_user_metric_build, librtgr), Cint, (Cstring, Cint, Cstring), source, stationary, path))
+    DeviceMetric(path, "", stationary, M, a)
+end
+
 function module_id(m::DeviceMetric, ctx)
     id = Ref{UInt64}(0)
     if isempty(m.source)
