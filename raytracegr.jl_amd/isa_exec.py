@@ -108,6 +108,25 @@ def find(lines):
     return hits
 
 
+def suspicious(lines):
+    """[(line index, instruction, flip)] — a WIDER, heuristic net for listings one can look at by hand (build checks of the library's
+    own kernels): an allocator-kind instruction (AGPR copy, scratch spill / reload) DIRECTLY ahead of a flip or of a join's
+    `s_or_b64 exec`, with nothing but `s_mov` constants in between, whether or not a label precedes it.  Where the compiler has dropped
+    the `s_cbranch_execz` that skips the `then` side, find() cannot tell a misplaced copy from the `then` side's own last
+    instruction; neither can this — it only says where to look.  Never repaired automatically."""
+    code = [_code(l) for l in lines]
+    out = []
+    for i, c in enumerate(code):
+        if not (FLIP.match(c) or END_CF.match(c)):
+            continue
+        j = i - 1
+        while j > 0 and (not code[j] or PLAIN_SALU.match(code[j]) or (code[j].startswith(".") and not code[j].endswith(":"))):
+            j -= 1
+        if ALLOCATOR_VECTOR.match(code[j]) and not code[j].startswith("v_mov"):
+            out.append((j, code[j], c))
+    return out
+
+
 def _sgprs(operand_text):
     """the set of SGPR numbers an instruction's text mentions (s5, s[2:3]; vcc / exec are reported as -1 / -2)"""
     out = set()

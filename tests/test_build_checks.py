@@ -30,6 +30,11 @@ def test_no_trans_use_hazard_next_to_inline_asm(unit, tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), asm, k, "--hazards"],
                            capture_output=True, text=True)
         assert r.returncode == 0, (k, r.stdout[-2000:])
+    # the same listing through the EXEC-flip check: the strict rule, and the wider heuristic net that would point
+    # at a misplaced allocator copy even where the compiler has dropped the skip branch
+    ie = _isa_exec()
+    lines = open(asm).read().split("\n")
+    assert ie.find(lines) == [] and ie.suspicious(lines) == [], (ie.find(lines), ie.suspicious(lines))
 
 
 def test_plain_build_relinks_after_an_experiment_build(tmp_path):
@@ -120,8 +125,9 @@ def test_exec_flip_fault_is_found_and_repaired_in_a_listing_and_in_a_code_object
     lines = FAULTY_LISTING.split("\n")
     hits = ie.find(lines)
     assert len(hits) == 1 and hits[0].label == ".LBB0_2" and [s.split()[0] for _, s in hits[0].early] == ["v_accvgpr_write_b32", "scratch_store_dwordx2"]
+    assert [c.split()[0] for _, c, _ in ie.suspicious(lines)] == ["scratch_store_dwordx2"]     # (the wider net sees the last one)
     fixed, n = ie.repair(lines)
-    assert n == 1 and ie.find(fixed) == []
+    assert n == 1 and ie.find(fixed) == [] and ie.suspicious(fixed) == []
     body = [l.split(";")[0].strip() for l in fixed]
     at = body.index(".LBB0_2:")
     assert body[at + 1] == "s_or_saveexec_b64 s[2:3], s[2:3]" and body[at + 5] == "s_xor_b64 exec, exec, s[2:3]"
