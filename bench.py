@@ -768,7 +768,7 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
     never `value`); (2) EVERY BASELINE.json configuration on this GPU — C2 (1024², as written and Kerr a = 0.8), C3 as
     BASELINE words it (a = 0.8, 4096²), C4 (2048² Float32), C5 (8192², a = 0.998 + disk) — and the reference FORMULATION of the
     RHS (generic dual-number path) at 4096², the one kernel for which SURVEY 8(d)'s contract fraction is a utilisation.  Each with
-    its own hash-keyed executed-flop roofline.  About 12 s of GPU time (VERDICT r3 #2: the driver's line carries them)."""
+    its own executed-flop roofline (live counters for the Float64 ones).  About 12 s of GPU time + the counter passes (VERDICT r3 #2: the driver's line carries them)."""
     ex = {}
     ep = {"device_ms": device_s * 1e3}
     for name, fn in (("host", host_pass), ("pixels", pixels_pass)):
