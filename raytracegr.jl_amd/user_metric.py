@@ -74,6 +74,13 @@ def compile_user_metric(source, verbose=False, stationary=False):
         raise RuntimeError(f"user metric {tag} is not in the cache ({d}) and RTGR_NO_COMPILE=1: build it first in a single "
                            f"plain process (__graft_entry__.build() precompiles the example metrics; "
                            f"user_metric.compile_user_metric(source) any other)")
+    if not os.path.exists(_build.HIPCC):
+        # no hipcc on this box (a runtime-only ROCm): the library builds the same unit in-process (hiprtc + libamd_comgr, listing
+        # checked and repaired the same way) — cached here under the same content hash
+        tmp = out + f".tmp{os.getpid()}"
+        build_in_process(source, tmp, stationary=bool(stationary or ks_form))
+        os.replace(tmp, out)
+        return out
     with open(TEMPLATE) as fh:
         unit = fh.read().replace("@RTGR_USER_SOURCE@", source)
     src = os.path.join(d, f"metric_{tag}.hip")
@@ -151,7 +158,7 @@ LEVELS = [[], ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC
 def code_object_scratch(path):
     """{kernel: private_segment_fixed_size} of a code object's integrate kernels, from its metadata notes (llvm-readelf; tests, tools)"""
     import re
-    txt = subprocess.run([os.path.join(os.path.dirname(_build.HIPCC), "..", "lib", "llvm", "bin", "llvm-readelf"), "--notes", path],
+    txt = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", path],
                          capture_output=True, text=True, check=True).stdout
     out, cur = {}, None
     for line in txt.splitlines():

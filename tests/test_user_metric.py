@@ -69,6 +69,15 @@ def test_in_process_build_needs_no_gpu_and_gives_a_sound_unit(tmp_path):
     assert lib.rtgr_user_metric_build(b"int nothing_here;", 0, out.encode()) == abi.ERR_BAD_ARG
 
 
+def test_units_are_built_in_process_where_hipcc_is_absent(tmp_path, monkeypatch):
+    """compile_user_metric on a box without hipcc (a runtime-only ROCm): the library's in-process build fills the same cache."""
+    monkeypatch.setattr(um._build, "HIPCC", str(tmp_path / "no_hipcc_here"))
+    monkeypatch.setenv("RTGR_USER_CACHE", str(tmp_path / "cache"))
+    path = um.compile_user_metric(user_metrics.KERR_SCHILD_KS)
+    assert path.startswith(str(tmp_path / "cache")) and um.audit(path) == (0, "") and len(um.code_object_scratch(path)) == 6
+    assert um.compile_user_metric(user_metrics.KERR_SCHILD_KS) == path
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_heavy_user_metric_is_built_without_spills():
     """A metric that needs more registers than two waves per SIMD leave (HELPER_ZOO: 376-544 B of scratch per lane there; Kerr in
