@@ -110,7 +110,7 @@ inline int audit(const char* image, size_t bytes, std::string* report) {
         eh->e_shstrndx >= eh->e_shnum) { note("no section table"); return -1; }
     const Elf64_Shdr* sh = (const Elf64_Shdr*)(image + eh->e_shoff);
     const Elf64_Shdr& names = sh[eh->e_shstrndx];
-    if (names.sh_offset + names.sh_size > bytes) { note("bad section names"); return -1; }
+    if (names.sh_size == 0 || names.sh_offset + names.sh_size > bytes || image[names.sh_offset + names.sh_size - 1] != 0) { note("bad section names"); return -1; }
     Reader r{image, 0, 0, 0, {}};
     for (int i = 0; i < eh->e_shnum; i++) {
         if (sh[i].sh_name >= names.sh_size) continue;
