@@ -4,6 +4,8 @@ FLOW block's EXEC flip in a gfx950 assembly listing — a code-generation fault 
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-gpu-rdc -S --cuda-device-only -o unit.s csrc/tu_f64_ksref.hip
     python tools/isa_exec_check.py unit.s [--repair fixed.s]          exit code 1 when the shape is found (and not repaired)
+    python tools/isa_exec_check.py --object unit.hsaco | librtgr_hip.so   the library's audit of a code object's disassembly
+                                                                          (rtgr_code_object_audit; loads librtgr_hip.so, no GPU needed)
 """
 import importlib.util
 import os
@@ -16,6 +18,14 @@ spec.loader.exec_module(isa_exec)
 
 
 def main():
+    if sys.argv[1] == "--object":
+        sys.path.insert(0, ROOT)
+        from __graft_entry__ import load_package
+        rt = load_package()
+        found, report = sys.modules[rt.__name__ + ".user_metric"].audit(os.path.abspath(sys.argv[2]))
+        print(report, end="")
+        print(f"== FLOW blocks with vector instructions ahead of the EXEC flip: {found}")
+        return 1 if found else 0
     path = sys.argv[1]
     lines = open(path).read().split("\n")
     hits = isa_exec.find(lines)
