@@ -113,7 +113,10 @@ def suspicious(lines):
     own kernels): an allocator-kind instruction (AGPR copy, scratch spill / reload) DIRECTLY ahead of a flip or of a join's
     `s_or_b64 exec`, with nothing but `s_mov` constants in between, whether or not a label precedes it.  Where the compiler has dropped
     the `s_cbranch_execz` that skips the `then` side, find() cannot tell a misplaced copy from the `then` side's own last
-    instruction; neither can this — it only says where to look.  Never repaired automatically."""
+    instruction; neither can this — it only says where to look.  Never repaired automatically, and NOT a criterion for run-time
+    units: tried as one in round 4, it rejected every occupancy level of the Boyer–Lindquist example metric (35-53 places: the
+    `then` sides of the short branches inside acos / atan2 legitimately END in the AGPR copy that defines the joined value), a unit
+    that traces true geodesics to 5e-12.  It reports nothing in the library's own listings, which is what the build checks use it for."""
     code = [_code(l) for l in lines]
     out = []
     for i, c in enumerate(code):
