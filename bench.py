@@ -268,6 +268,7 @@ def live_counters(a, log=None):
     fma, mul, add = (tot.get(f"SQ_INSTS_VALU_{k}_{sfx}", 0.0) for k in ("FMA", "MUL", "ADD"))
     if fma <= 0 or not attempts:
         return None, f"counters came back empty: {tot}"
+    trace = kernel_trace_pass(a, tool)     # (best effort: the kernels' average durations as rocprofv3 itself reports them)
     return {"flop_per_step_attempt": 64.0 * (2 * fma + mul + add) / attempts,
             "valu_per_wave_step": tot.get("SQ_INSTS_VALU", 0.0) / (attempts / 64.0),
             "fma_mul_add_per_wave_step": [fma / (attempts / 64.0), mul / (attempts / 64.0), add / (attempts / 64.0)],
@@ -275,7 +276,36 @@ def live_counters(a, log=None):
             "hbm_bytes_per_ray": (2 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / rays,
             "hbm_note": "2 x FETCH_SIZE + WRITE_SIZE over the library's pipeline kernels (KB x 1024), per pass, per ray",
             "step_attempts_counted": attempts, "seconds": round(time.time() - t0, 1),
-            "how": "rocprofv3 --pmc in child processes of this run: arithmetic counters, FETCH_SIZE, WRITE_SIZE each in a run of its own"}, None
+            "rocprof_kernel_trace": trace,
+            "how": "rocprofv3 --pmc in child processes of this run: arithmetic counters, FETCH_SIZE, WRITE_SIZE each in a run of its own; "
+                   "rocprofv3 --kernel-trace --stats in one more (never combined with --pmc)"}, None
+
+
+def kernel_trace_pass(a, tool):
+    """{kernel: {calls, avg_ms}} of the integrate kernels from `rocprofv3 --kernel-trace --stats` over three frames of this workload
+    in a child process — the durations the profiler reports, to set beside the HIP-event times of the timed region — or None."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    work = tempfile.mkdtemp(prefix="rtgr_trace_", dir="/tmp")
+    try:
+        cmd = [tool, "--kernel-trace", "--stats", "--output-format", "csv", "-d", work, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "3", "--warmup", "1",
+               "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            return None
+        out = {}
+        for f in glob.glob(os.path.join(work, "**", "*kernel_stats.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "integrate" in row["Name"]:
+                    out[row["Name"].split("(")[0][-60:]] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6}
+        return out or None
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def expected_checksum(a):
@@ -583,6 +613,11 @@ def main():
                 roof["traffic_over_algorithmic"] = src["hbm_bytes_per_ray"] / ALGORITHMIC_BYTES_PER_RAY
             if live is not None:
                 roof["live"] = live
+                tr = live.get("rocprof_kernel_trace")
+                if tr:   # the profiler's own average durations of the two passes beside this run's HIP-event times (must agree)
+                    prof_ms = sum(v["avg_ms"] for v in tr.values())
+                    roof["rocprof_integrate_ms_per_pass"] = prof_ms
+                    roof["event_over_rocprof"] = (k_s * 1e3 / a.steps) / prof_ms if prof_ms > 0 else None
                 if prof is not None:   # the builder-collected profile of the same kernel sources, as the cross-check
                     roof["profile_flop_per_step_attempt"] = prof["flop_per_step_attempt"]
                     roof["live_over_profile"] = live["flop_per_step_attempt"] / prof["flop_per_step_attempt"]

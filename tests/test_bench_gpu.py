@@ -66,6 +66,9 @@ def test_bench_counts_its_own_flops_and_bytes():
     assert live["step_attempts_counted"] == d["step_attempts_per_pass"] and 600 < live["valu_per_wave_step"] < 1200
     assert 0.3 < roof["frac"] <= 1.0 and abs(roof["executed_flop_per_step_attempt"] - live["flop_per_step_attempt"]) < 1e-9
     assert 500 < live["hbm_bytes_per_ray"] < 1500 and roof["traffic"] > 0
+    # … and the profiler's own average kernel durations (one more child run, --kernel-trace --stats) agree with the HIP-event times
+    assert len(live["rocprof_kernel_trace"]) == 2 and all(v["calls"] == 4 for v in live["rocprof_kernel_trace"].values())
+    assert 0.9 < roof["event_over_rocprof"] < 1.1
     if "profile_flop_per_step_attempt" in roof:      # same sources profiled at 4096²: small launches idle a few more lanes
         assert 0.9 < roof["live_over_profile"] < 1.15
     off = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0")
