@@ -206,6 +206,10 @@ def load_profile(a):
     return None, f"no profiles/r*/flops.json entry {key!r} collected from kernel sources {cur} (found: {seen})"
 
 
+_LIVE_BROKEN = None
+_TRACE_BROKEN = False
+
+
 def live_counters(a, log=None):
     """Executed flops and HBM bytes of ONE pass of this workload, hardware-counted here and now: bench.py re-run (one pass, no
     extras, no CPU leg) under `rocprofv3 --pmc` in child processes — the arithmetic counters, FETCH_SIZE and WRITE_SIZE each in a
@@ -215,6 +219,9 @@ def live_counters(a, log=None):
     import shutil
     import subprocess
     import tempfile
+    global _LIVE_BROKEN
+    if _LIVE_BROKEN:      # one failed or hung pass ends the live counting of this run: the other configurations use their profiles
+        return None, "skipped after: " + _LIVE_BROKEN
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process runs under a profiler itself"
     tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -235,10 +242,11 @@ def live_counters(a, log=None):
                    "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "1", "--warmup", "0",
                    "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
             env = dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
-                return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-300:]}"
+                _LIVE_BROKEN = f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-300:]}"
+                return None, _LIVE_BROKEN
             child = json.loads(lines[-1])
             attempts, rays = child["step_attempts_per_pass"], child["rays"]
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -260,9 +268,11 @@ def live_counters(a, log=None):
             for k, v in part.items():     # (the child runs its one timed pass plus the warm-up the bench always does)
                 tot[k] = v / passes
     except subprocess.TimeoutExpired:
-        return None, "a rocprofv3 --pmc pass did not finish in 240 s"
+        _LIVE_BROKEN = "a rocprofv3 --pmc pass did not finish in 150 s"
+        return None, _LIVE_BROKEN
     except Exception as e:  # noqa: BLE001  (a measurement aid must never cost the headline line)
-        return None, repr(e)
+        _LIVE_BROKEN = repr(e)
+        return None, _LIVE_BROKEN
     finally:
         shutil.rmtree(work, ignore_errors=True)
     fma, mul, add = (tot.get(f"SQ_INSTS_VALU_{k}_{sfx}", 0.0) for k in ("FMA", "MUL", "ADD"))
@@ -288,12 +298,15 @@ def kernel_trace_pass(a, tool):
     import shutil
     import subprocess
     import tempfile
+    global _TRACE_BROKEN
+    if _TRACE_BROKEN:
+        return None
     work = tempfile.mkdtemp(prefix="rtgr_trace_", dir="/tmp")
     try:
         cmd = [tool, "--kernel-trace", "--stats", "--output-format", "csv", "-d", work, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "3", "--warmup", "1",
                "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
-        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
         if r.returncode != 0:
             return None
         out = {}
@@ -302,7 +315,8 @@ def kernel_trace_pass(a, tool):
                 if "integrate" in row["Name"]:
                     out[row["Name"].split("(")[0][-60:]] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6}
         return out or None
-    except Exception:  # noqa: BLE001
+    except Exception:  # noqa: BLE001   (a hung or failed trace pass is not tried again in this run)
+        _TRACE_BROKEN = True
         return None
     finally:
         shutil.rmtree(work, ignore_errors=True)
