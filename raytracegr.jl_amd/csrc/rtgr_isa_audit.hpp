@@ -179,6 +179,7 @@ inline int audit_any(const char* image, size_t bytes, std::string* report) {
         if (!hit) break;
         const size_t b = (size_t)((const char*)hit - image);
         o = b + ml;
+        if (b + ml + 8 > bytes) break;   // (a truncated header at the very end of the file)
         uint64_t n = 0;
         std::memcpy(&n, image + b + ml, 8);
         size_t p = b + ml + 8;
