@@ -50,7 +50,11 @@
 extern "C" {
 #endif
 
-#define RTGR_ABI_VERSION 2
+/* 3 (round 5): run-time units may carry OBJECTS (RTGR_USER_OBJECT) and a resolve kernel; rtgr_object.reserved became .type;
+ * the device-side record layout changed in round 4 (event-record tails, RecRef) without a bump — a unit built against the
+ * older headers would have loaded and overrun the workspace.  Units also carry a hash of the device headers they were built
+ * from (rtgr_user_header_hash), checked at load. */
+#define RTGR_ABI_VERSION 3
 #define RTGR_MAX_OBJECTS 16
 #define RTGR_MAX_DEVICES 16
 
@@ -88,13 +92,17 @@ enum rtgr_object_kind {
     RTGR_SPHERE = 2, /* Sphere{T}(pos, vel, radius)  p[0..3]=pos  p[4..7]=vel  p[8]=radius   (:409-413)
                         vel is dead data in the reference (:411, "TODO: Use metric?" :416); here it is the emitter's
                         coordinate 4-velocity for the optional redshift output (rtgr_ray_outputs.redshift)       */
-    RTGR_DISK = 3    /* thin disk (no reference counterpart): p[0]=half thickness h, p[1]=r_in, p[2]=r_out;
+    RTGR_DISK = 3,   /* thin disk (no reference counterpart): p[0]=half thickness h, p[1]=r_in, p[2]=r_out;
                         distance = max(|z|-h, r_in-rho_cyl, rho_cyl-r_out) obeying the contract at :377-383    */
+    RTGR_USER_OBJECT = 4 /* a NEW subtype of the reference's open `abstract type Object{T}` (:374-389): its two methods,
+                        `distance(obj, pos)::T` and `objcolor(obj, pos)::SVector{3,T}`, are given as device source and
+                        compiled at run time into the scene's unit (rtgr_user_unit_compile, below); `type` tells the
+                        caller's own object types apart inside that source, p[0..8] are the object's fields           */
 };
 
 typedef struct rtgr_object {
     uint32_t kind; /* rtgr_object_kind */
-    uint32_t reserved;
+    uint32_t type; /* RTGR_USER_OBJECT: the tag handed to rtgr_user_distance / rtgr_user_objcolor; 0 otherwise */
     double p[9];
 } rtgr_object;
 
@@ -103,8 +111,10 @@ typedef struct rtgr_scene {
     uint32_t nobj;   /* 0..RTGR_MAX_OBJECTS */
     double M;        /* mass  (reference: 1, :275) */
     double a;        /* spin  (reference: 0, :276) */
-    uint64_t user_metric; /* RTGR_USER: id of the loaded metric module this scene is written for (rtgr_user_metric_load);
-                             a scene can never run with another module's kernels.  0 otherwise. */
+    uint64_t user_metric; /* id of the run-time compiled UNIT this scene is written for — the module that carries the kernels
+                             of a user metric (RTGR_USER), of user objects (RTGR_USER_OBJECT), or of both
+                             (rtgr_user_metric_load / _compile, rtgr_user_unit_compile); a scene can never run with another
+                             unit's kernels.  0: built-in metric and built-in objects only. */
     rtgr_object obj[RTGR_MAX_OBJECTS];
 } rtgr_scene;
 
@@ -377,6 +387,48 @@ int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationa
  * keep the file, load it in every later process).  Needs no GPU and no context. */
 int rtgr_user_metric_build(const char* source, int stationary, const char* code_object_path);
 int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
+
+/* ---- user objects: `Object{T}` is an OPEN abstract type (src/RayTraceGR.jl:374-389) ------------------------------------------
+ * The reference's second extension point: any `struct MyThing{T} <: Object{T}` with the two methods
+ *     distance(obj, pos::SVector{D,T})::T                "zero on the surface, positive outside, negative inside"   (:377-386)
+ *     objcolor(obj, pos::SVector{D,T})::SVector{3,T}                                                                 (:387-389)
+ * is traced — the ContinuousCallback condition min_distance dispatches on it (:433-441) and so does the colour rule (:518-530).
+ * The native counterpart mirrors user metrics: the two methods are written once as device function templates over the scalar
+ *     template <class S> __device__ S    rtgr_user_distance(unsigned type, const S x[4], const S p[9]);
+ *     template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]);
+ * (S = double or float; `type` and `p` are the rtgr_object's: one source may define several object types and switch on `type`;
+ * the m* helpers of user metrics — msqrt mabs macos matan2 ... — are available), and compiled at run time into the scene's UNIT,
+ * the code object that carries every kernel that calls them: ray set-up (the condition's initial sign), the FAR / NEAR / FULL
+ * integrate passes (the sample-point scan) and the resolve kernel (event root-find, colour rule).  Objects are independent of
+ * the metric in the reference; in compiled code the integrate kernels contain both, so a unit is built for ONE metric variant:
+ * its own (the same source also defines rtgr_user_metric / rtgr_user_ks), or a built-in one, named by `built_for` — the scene
+ * the unit is meant for: its metric enum, RTGR_METRIC_GENERIC flag and whether a != 0 select the kernels' instantiation; its
+ * objects and the values of M and a do not matter — exactly what Julia specialises `solve` on.  A scene whose metric variant
+ * differs from the unit's is refused (RTGR_ERR_BAD_ARG), never traced with the wrong kernels.
+ *   Optional third function: the FAR pass skips the scan of a step when no object's distance can change sign within the
+ * step's reach; for a user object it needs a bound from the source,
+ *     template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]);
+ * = an upper bound of |distance(x') - distance(x)| over all x' with |x'_q - x_q| <= dl[q].  Without it ("rtgr_user_reach" does
+ * not occur in the source) a user object is never provably out of reach and scenes of the unit run the single FULL pass
+ * (every accepted step scanned, as the reference does): same results, the FAR pass's saving is lost.
+ *   Scenes: obj[k].kind = RTGR_USER_OBJECT, .type, .p as the source expects; scene.user_metric = the unit's id.  Built-in
+ * objects may stand beside user objects in any order (:518-530's order rule applies to all).  Limits: the tile kernel
+ * (option tile = 1) and the packed Float32 kernel know no user objects — scenes of a unit take the pipeline's scalar kernels;
+ * the redshift output treats a user object's emitter as the static observer (as for planes and disks).
+ * rtgr_user_metric_compile(ctx, source, stationary, id) == rtgr_user_unit_compile(ctx, source, stationary, NULL, id). */
+int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary, const rtgr_scene* built_for, uint64_t* id_out);
+/* ... the build step on its own (no GPU, no context): source -> code object file for rtgr_user_metric_load */
+int rtgr_user_unit_build(const char* source, int stationary, const rtgr_scene* built_for, const char* code_object_path);
+/* What a resident unit was built for. */
+typedef struct rtgr_unit_info {
+    uint32_t metric;       /* rtgr_metric (| RTGR_METRIC_GENERIC) its kernels are instantiated for; RTGR_USER: its own */
+    uint32_t spin;         /* built-in closed-form kernels: 1 = the a != 0 instantiation                               */
+    uint32_t has_objects;  /* the source defined rtgr_user_distance / rtgr_user_objcolor                               */
+    uint32_t has_reach;    /* ... and rtgr_user_reach: scenes with its objects run FAR + NEAR                          */
+    uint32_t far_waves, near_waves, f32_waves; /* waves per SIMD its integrate passes were built for                  */
+    uint32_t probe_ok;     /* 1: the load-time probe ran (FULL == FAR + NEAR, twice each); 0: skipped (RTGR_UNIT_PROBE=0) */
+} rtgr_unit_info;
+int rtgr_user_unit_info(rtgr_context* ctx, uint64_t id, rtgr_unit_info* info);
 /* The EXEC-flip check.  ROCm 7.2's compiler can place a register copy or spill at the top of the FLOW block of a divergent if / else,
  * AHEAD of the instruction that switches EXEC to the `else` lanes; code of that shape computes wrong values in some lanes (DESIGN.md
  * §4.6: the Float64 FULL pass of a heavy metric was wrong from it in round 4).  rtgr_user_metric_compile / _build look for the shape

@@ -1,5 +1,5 @@
 # RayTraceGRHIP.jl — the reference-side binding a RayTraceGR.jl maintainer would add to route the hot path
-# (`trace_rays`, src/RayTraceGR.jl:482-536) through librtgr_hip.so (include/rtgr.h, ABI version 2).
+# (`trace_rays`, src/RayTraceGR.jl:482-536) through librtgr_hip.so (include/rtgr.h, ABI version 3).
 #
 # NOT EXECUTED IN THIS REPOSITORY: the build image has no Julia.  What stands in for running it:
 #   * tests/c/abi_layout.c — a compiled C caller that passes the same bytes this file would (structs by pointer, an
@@ -17,7 +17,7 @@
 # fieldoffset table (bytes; Julia lays isbits structs out by the C rules, so `fieldoffset(T, i)` must print exactly this —
 # a maintainer can check with `[(fieldname(T,i), fieldoffset(T,i)) for i in 1:fieldcount(T)]`; runtests_hip.jl does):
 #
-#   RtgrObject       80   kind 0, reserved 4, p 8
+#   RtgrObject       80   kind 0, type 4, p 8
 #   RtgrScene      1312   metric 0, nobj 4, M 8, a 16, user_metric 24, obj 32
 #   RtgrSolver       72   reltol 0, abstol 8, lambda0 16, lambda1 24, hit_threshold 32, miss_rgb 40, max_steps 64, interp_points 68
 #   RtgrCamera      128   pos 0, widthx 32, widthy 64, normal 96
@@ -48,7 +48,7 @@ const D = RayTraceGR.D          # 4 (src/RayTraceGR.jl:253-254)
 # ---- PODs of include/rtgr.h ------------------------------------------------------------------------------------------
 struct RtgrObject
     kind::UInt32
-    reserved::UInt32
+    type::UInt32                # RTGR_USER_OBJECT: the tag handed to the unit's rtgr_user_distance / rtgr_user_objcolor
     p::NTuple{9,Float64}
 end
 struct RtgrScene
@@ -98,6 +98,7 @@ const RTGR_METRIC_GENERIC = UInt32(0x100)
 const RTGR_PLANE = UInt32(1)
 const RTGR_SPHERE = UInt32(2)
 const RTGR_DISK = UInt32(3)
+const RTGR_USER_OBJECT = UInt32(4)
 const RTGR_RAY_EVENT = UInt8(0)
 const RTGR_RAY_LAMBDA1 = UInt8(1)
 const RTGR_RAY_MAXSTEPS = UInt8(2)
@@ -176,7 +177,40 @@ end
 pack(pl::RayTraceGR.Plane) = RtgrObject(RTGR_PLANE, 0, (Float64(pl.time), 0, 0, 0, 0, 0, 0, 0, 0))
 pack(s::RayTraceGR.Sphere) = RtgrObject(RTGR_SPHERE, 0, (Float64.(s.pos)..., Float64.(s.vel)..., Float64(s.radius)))
 pack(d::Disk) = RtgrObject(RTGR_DISK, 0, (Float64(d.half_thickness), Float64(d.r_in), Float64(d.r_out), 0, 0, 0, 0, 0, 0))
-pack(o::RayTraceGR.Object) = nothing            # an object type this library does not know: the CPU path handles it
+"""
+    DeviceObjects(source)                       a family of NEW Object subtypes, given as device source
+    DeviceObject{T}(family, type, fields...)    one object of it: `<: RayTraceGR.Object{T}`, goes into `objs` like a Sphere
+
+The reference's `Object{T}` is an open abstract type (src/RayTraceGR.jl:374-389): a new subtype brings `distance(obj, pos)` and
+`objcolor(obj, pos)`.  A Julia method cannot cross the C ABI; the native counterpart is the same two methods as C++ source,
+
+    template <class S> __device__ S    rtgr_user_distance(unsigned type, const S x[4], const S p[9]);
+    template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]);
+
+(optionally `rtgr_user_reach`: include/rtgr.h "user objects"), compiled at run time — together with the metric the objects are
+traced with — into the scene's unit (`rtgr_user_unit_compile`: one ccall, built in-process, no hipcc).  `type` tells the family's
+object types apart inside the source, `fields` (up to 9 numbers) are the object's parameters `p`.  All DeviceObjects of one `objs`
+vector share one family.  An object type WITHOUT device source still takes the reference's CPU path, as before.
+"""
+struct DeviceObjects
+    source::String
+end
+struct DeviceObject{T} <: RayTraceGR.Object{T}
+    family::DeviceObjects
+    type::UInt32
+    p::NTuple{9,Float64}
+end
+function DeviceObject{T}(family::DeviceObjects, type::Integer, fields::Real...) where {T}
+    length(fields) <= 9 || error("an object has at most 9 scalar fields (rtgr_object.p)")
+    DeviceObject{T}(family, UInt32(type), ntuple(i -> i <= length(fields) ? Float64(fields[i]) : 0.0, 9))
+end
+# (the two methods exist on the device only: the reference's CPU trace_rays cannot evaluate them — say so instead of a MethodError)
+RayTraceGR.distance(o::DeviceObject{T}, pos::SVector{4,T}) where {T} =
+    error("a DeviceObject carries device source only; give the type Julia methods `distance` / `objcolor` to trace it on the CPU")
+RayTraceGR.objcolor(o::DeviceObject{T}, pos::SVector{4,T}) where {T} =
+    error("a DeviceObject carries device source only; give the type Julia methods `distance` / `objcolor` to trace it on the CPU")
+pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECT, o.type, o.p)
+pack(o::RayTraceGR.Object) = nothing            # an object type without device source: the CPU path handles it
 const NOOBJ = RtgrObject(0, 0, ntuple(_ -> 0.0, 9))
 
 """
@@ -256,13 +290,35 @@ metric_desc(m, ctx) = m === RayTraceGR.minkowski ? (RTGR_MINKOWSKI, 1.0, 0.0, UI
                       m === RayTraceGR.kerr_schild ? (RTGR_KS_REF, 1.0, 0.0, UInt64(0)) :   # as written: M = 1, a = 0 (:275-276)
                       nothing
 
+# id of the unit that carries the kernels of `family`'s objects for the metric variant of `scene` (rtgr_user_unit_compile reads the
+# metric enum, the RTGR_METRIC_GENERIC flag and whether a != 0 off the scene; a DeviceMetric given as source is compiled into the
+# same unit) — built once per (context, source, metric variant)
+const UNIT_IDS = Dict{Tuple{Ctx,UInt64,UInt32,Bool},UInt64}()
+function unit_id(family::DeviceObjects, metric, scene::Ref{RtgrScene}, ctx)
+    own = metric isa DeviceMetric
+    own && isempty(metric.source) && error("DeviceObjects with a DeviceMetric: give the metric as source text too (the two share one unit)")
+    source = own ? metric.source * "\n" * family.source : family.source
+    key = (handle(ctx), hash(source), scene[].metric, scene[].a != 0)
+    get!(UNIT_IDS, key) do
+        id = Ref{UInt64}(0)
+        check(ccall((:rtgr_user_unit_compile, librtgr), Cint, (Ctx, Cstring, Cint, Ptr{RtgrScene}, Ptr{UInt64}),
+                    handle(ctx), source, own && metric.stationary, own ? C_NULL : scene, id))
+        id[]
+    end
+end
+
 function scene_of(metric, objs, ctx)
-    d = metric_desc(metric, ctx)
+    fams = unique(o.family for o in objs if o isa DeviceObject)
+    length(fams) > 1 && error("the DeviceObjects of one scene must come from one DeviceObjects source")
+    # (a DeviceMetric beside DeviceObjects lives in the objects' unit: its own module is not loaded)
+    d = (!isempty(fams) && metric isa DeviceMetric) ? (RTGR_USER, metric.M, metric.a, UInt64(0)) : metric_desc(metric, ctx)
     (d === nothing || length(objs) > RTGR_MAX_OBJECTS) && return nothing
     po = map(pack, objs)
     any(isnothing, po) && return nothing
     packed = ntuple(i -> i <= length(po) ? po[i] : NOOBJ, RTGR_MAX_OBJECTS)
-    Ref(RtgrScene(d[1], length(objs), d[2], d[3], d[4], packed))
+    scene = Ref(RtgrScene(d[1], length(objs), d[2], d[3], d[4], packed))
+    isempty(fams) && return scene
+    Ref(RtgrScene(d[1], length(objs), d[2], d[3], unit_id(fams[1], metric, scene, ctx), packed))
 end
 solver_of(::Type{T}) where {T} = begin
     opt = Ref{RtgrSolver}()
@@ -313,7 +369,7 @@ Drop-in for `RayTraceGR.trace_rays` (src/RayTraceGR.jl:483-484).  Passes `pointe
 filled (:532).  The tolerance is `eps(T)^(3/4)` as in the reference (:485).  `ctx = Context(0:7)`: all eight GPUs of a
 node work on the canvas (rows dealt cyclically); the result does not depend on the number of devices, bit for bit.
 `metric`: `minkowski`, `kerr_schild`, `KerrSchild(M, a)`, a `DeviceMetric`; anything else runs the reference's CPU path.
-`objs`: `Plane`, `Sphere`, `Disk`.
+`objs`: `Plane`, `Sphere`, `Disk`, `DeviceObject`s; any other `Object` subtype runs the reference's CPU path.
 """
 function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Canvas{T}; ctx = nothing) where {T<:Union{Float64,Float32}}
     scene = scene_of(metric, objs, ctx)

@@ -397,6 +397,19 @@ inline T distance(const rtgr_object& o, const T pos[D]) {
             d = std::fmax(d, rc - rout);
             return d;
         }
+        case RTGR_USER_OBJECT:   // new subtypes of the reference's open `abstract type Object{T}` (:374-389): the oracle's twins of
+            switch (o.type) {    // examples/user_objects.py SHAPES — same formulas, written against the contract of :377-383
+                case 0: {        // torus around the z axis: centre p[0..2], major radius p[3], minor radius p[4]
+                    T X = pos[1] - T(o.p[0]), Y = pos[2] - T(o.p[1]), Z = pos[3] - T(o.p[2]);
+                    T w = std::sqrt(X * X + Y * Y) - T(o.p[3]);
+                    return w * w + Z * Z - T(o.p[4]) * T(o.p[4]);
+                }
+                case 1: {        // ellipsoid: centre p[0..2], semi-axes p[3..5]
+                    T X = (pos[1] - T(o.p[0])) / T(o.p[3]), Y = (pos[2] - T(o.p[1])) / T(o.p[4]), Z = (pos[3] - T(o.p[2])) / T(o.p[5]);
+                    return X * X + Y * Y + Z * Z - T(1);
+                }
+            }
+            break;
     }
     return std::numeric_limits<T>::infinity();
 }
@@ -433,6 +446,26 @@ inline void objcolor(const rtgr_object& o, const T pos[D], T col[3]) {
             col[2] = julia_mod1(T(12) * ph / pi);
             return;
         }
+        case RTGR_USER_OBJECT:
+            switch (o.type) {
+                case 0: {   // torus: toroidal and poloidal angle
+                    T X = pos[1] - T(o.p[0]), Y = pos[2] - T(o.p[1]), Z = pos[3] - T(o.p[2]);
+                    T w = std::sqrt(X * X + Y * Y) - T(o.p[3]);
+                    col[0] = julia_mod1(T(6) * std::atan2(Y, X) / pi);
+                    col[1] = julia_mod1(T(6) * std::atan2(Z, w) / pi);
+                    col[2] = T(1) / T(2);
+                    return;
+                }
+                case 1: {   // ellipsoid: the sphere's rule (:420-428) in the scaled coordinates
+                    T X = (pos[1] - T(o.p[0])) / T(o.p[3]), Y = (pos[2] - T(o.p[1])) / T(o.p[4]), Z = (pos[3] - T(o.p[2])) / T(o.p[5]);
+                    T r = std::sqrt(X * X + Y * Y + Z * Z);
+                    col[0] = julia_mod1(T(12) * std::acos(Z / r) / pi);
+                    col[1] = T(1) / T(2);
+                    col[2] = julia_mod1(T(12) * std::atan2(Y, X) / pi);
+                    return;
+                }
+            }
+            break;
     }
     col[0] = col[1] = col[2] = T(0);
 }

@@ -8,14 +8,14 @@ import ctypes as C
 import os
 
 RTGR_MAX_OBJECTS = 16
-RTGR_ABI_VERSION = 2
+RTGR_ABI_VERSION = 3
 RTGR_MAX_DEVICES = 16
 
 # enum rtgr_metric
 MINKOWSKI, KS_REF, KS_TRUE, USER = 0, 1, 2, 3
 METRIC_GENERIC = 0x100  # RTGR_METRIC_GENERIC flag
 # enum rtgr_object_kind
-PLANE, SPHERE, DISK = 1, 2, 3
+PLANE, SPHERE, DISK, USER_OBJECT = 1, 2, 3, 4
 # enum rtgr_ray_status
 RAY_EVENT, RAY_LAMBDA1, RAY_MAXSTEPS, RAY_DTMIN, RAY_NAN = 0, 1, 2, 3, 4
 # enum rtgr_status
@@ -23,7 +23,7 @@ OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NAN_INPUT, ERR_NOT_INIT = 0, -1, -2
 
 
 class rtgr_object(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("reserved", C.c_uint32), ("p", C.c_double * 9)]
+    _fields_ = [("kind", C.c_uint32), ("type", C.c_uint32), ("p", C.c_double * 9)]
 
 
 class rtgr_scene(C.Structure):
@@ -51,6 +51,14 @@ class rtgr_counters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
 
 
+class rtgr_unit_info(C.Structure):
+    _fields_ = [("metric", C.c_uint32), ("spin", C.c_uint32), ("has_objects", C.c_uint32), ("has_reach", C.c_uint32),
+                ("far_waves", C.c_uint32), ("near_waves", C.c_uint32), ("f32_waves", C.c_uint32), ("probe_ok", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 class rtgr_ray_outputs(C.Structure):
     _fields_ = [("state_end", C.c_void_p), ("lambda_end", C.c_void_p), ("status", C.c_void_p),
                 ("hit", C.c_void_p), ("n_accept", C.c_void_p), ("n_reject", C.c_void_p), ("redshift", C.c_void_p)]
@@ -68,6 +76,7 @@ EXPORTS = [
     "rtgr_eval_metric_f64", "rtgr_eval_metric_f32", "rtgr_eval_geodesic_f64", "rtgr_eval_geodesic_f32",
     "rtgr_eval_fastmath_f64", "rtgr_quantize_device_f64",
     "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded", "rtgr_code_object_audit", "rtgr_user_metric_build", "rtgr_listing_repair",
+    "rtgr_user_unit_compile", "rtgr_user_unit_build", "rtgr_user_unit_info",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -136,6 +145,9 @@ def _declare(lib):
     lib.rtgr_code_object_audit.argtypes = [C.c_char_p, P(i32), C.c_char_p, u64]
     lib.rtgr_user_metric_build.argtypes = [C.c_char_p, i32, C.c_char_p]
     lib.rtgr_listing_repair.argtypes = [C.c_char_p, C.c_char_p, P(i32)]
+    lib.rtgr_user_unit_compile.argtypes = [ctx, C.c_char_p, i32, P(rtgr_scene), P(u64)]
+    lib.rtgr_user_unit_build.argtypes = [C.c_char_p, i32, P(rtgr_scene), C.c_char_p]
+    lib.rtgr_user_unit_info.argtypes = [ctx, u64, P(rtgr_unit_info)]
     for name in EXPORTS:
         if name != "rtgr_last_error":
             getattr(lib, name).restype = i32

@@ -8,7 +8,7 @@ behaviour as the reference's exported API, so tests read like the reference's ow
     ------------------------------------------------   --------------------------------------------------
     minkowski, kerr_schild            :258-294          minkowski, kerr_schild  (+ KerrSchild(M, a, textbook))
     dmetric, christoffel, geodesic    :298-370          dmetric, christoffel, geodesic   (evaluated on the GPU)
-    Object / Plane / Sphere           :374-428          Plane, Sphere (+ Disk)
+    Object / Plane / Sphere           :374-428          Plane, Sphere (+ Disk); new subtypes: UserObjects(source)(type, fields)
     Pixel / Canvas / make_canvas      :445-478          Pixel (numpy record), Canvas, make_canvas
     trace_rays(metric, objs, canvas)  :482-536          trace_rays(metric, objs, canvas) -> Canvas
     trace_ray(metric, objs, cb, p)    test/runtests.jl:76   trace_ray(metric, objs, cb, p) -> Pixel
@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _abi
 from ._abi import rtgr_camera, rtgr_counters, rtgr_ray_outputs, rtgr_scene, rtgr_solver
-from .user_metric import UserMetric
+from .user_metric import UserMetric, UserObject, UserObjects
 
 D = 4  # src/RayTraceGR.jl:253-254
 
@@ -100,26 +100,38 @@ class Disk(Object):
         return [self.h, self.r_in, self.r_out] + [0.0] * 6
 
 
-def make_scene(metric, objs, ctx=None):
+def make_scene(metric, objs, ctx=None, units=True):
     """(metric, objs::Vector{Object}) -> rtgr_scene (order of objs preserved: it matters, :518-530).  A scene of a
-    UserMetric carries the id of that metric's module in `ctx` (loaded on first use), so it can only ever run with its
-    own kernels — whichever other metrics are resident."""
-    user_id = 0
-    if isinstance(metric, UserMetric):
-        user_id = metric.module_id(ctx)
-    elif not isinstance(metric, Metric):
+    UserMetric and / or of UserObjects carries the id of its run-time unit in `ctx` (built and loaded on first use), so it
+    can only ever run with its own kernels — whichever other units are resident.  units=False leaves the id 0 and touches
+    neither compiler nor GPU (a scene description for something else than this library: the tests' CPU oracle)."""
+    if not isinstance(metric, (Metric, UserMetric)):
         raise TypeError(
             "a metric is one of the built-ins (minkowski, kerr_schild, KerrSchild(M,a)) or a UserMetric(source) "
             "compiled for the device; a Python callable cannot cross the C ABI (SURVEY §8b)")
     objs = list(objs)
     if len(objs) > _abi.RTGR_MAX_OBJECTS:
         raise ValueError(f"at most {_abi.RTGR_MAX_OBJECTS} objects")
+    # New Object subtypes (src/RayTraceGR.jl:374-389) come as a UserObjects family: its distance / objcolor methods are compiled
+    # into ONE unit together with the metric they are traced with (compiled code holds both in the same kernels), so all user
+    # objects of a scene belong to one family
+    families = {id(o.family): o.family for o in objs if isinstance(o, UserObject)}
+    if len(families) > 1:
+        raise ValueError("the user objects of one scene must come from one UserObjects source (a source may define several types)")
+    user_id = 0
+    if not units:
+        pass
+    elif families:
+        user_id = next(iter(families.values())).unit_id(metric, ctx)
+    elif isinstance(metric, UserMetric):
+        user_id = metric.module_id(ctx)
     sc = rtgr_scene()
     sc.metric = metric.kind | (_abi.METRIC_GENERIC if metric.generic else 0)
     sc.nobj, sc.M, sc.a = len(objs), metric.M, metric.a
     sc.user_metric = user_id
     for o, obj in enumerate(objs):
         sc.obj[o].kind = obj.kind
+        sc.obj[o].type = getattr(obj, "type", 0)
         p = obj._pack()
         for q in range(9):
             sc.obj[o].p[q] = p[q]
@@ -344,7 +356,7 @@ def example2(ni=200, nj=200, save=True, ctx=None):
     return _run_example(example2_scene(), ni, nj, "sphere2.png", save, ctx)
 
 
-__all__ = ["D", "Metric", "UserMetric", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
+__all__ = ["D", "Metric", "UserMetric", "UserObjects", "UserObject", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
            "make_scene", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
            "trace_rays", "trace_ray", "dmetric", "christoffel", "geodesic", "example1", "example2",
            "example1_scene", "example2_scene"]

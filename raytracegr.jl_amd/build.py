@@ -7,7 +7,8 @@ csrc/rtgr_misc.hip the small kernels, csrc/rtgr_api.hip the C ABI and no kernel 
 into raytracegr.jl_amd/build/obj/ and linked with `hipcc -shared`.
 
 After linking, the library AUDITS the kernels embedded in it for the EXEC-flip fault of ROCm 7.2's compiler (DESIGN.md §4.6;
-rtgr_code_object_audit).  Clean so far.  If an edit of the kernels ever brings the fault out, the kernel units are rebuilt through
+rtgr_code_object_audit).  Clean so far — by a rule that sees the fault only where the compiler kept the `s_cbranch_execz` that skips the
+`then` side (isa_exec.py): "clean" means "none of THAT shape".  If an edit of the kernels ever brings the fault out, the kernel units are rebuilt through
 their assembly LISTING (--via-listing, or RTGR_BUILD_VIA_LISTING=1, forces that route): `hipcc --cuda-device-only -S`, the check /
 repair of isa_exec.py, assembler, lld, clang-offload-bundler, then the host half with `-fcuda-include-gpubinary` — the steps hipcc
 runs itself, with a look at the listing in between; for a unit that needs no repair the device code is the same, instruction for
@@ -37,14 +38,36 @@ HOST_ONLY_UNITS = ("rtgr_api.hip",)   # no kernel in it: never needs the listing
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
-def kernel_source_hash():
-    """sha256 over the device headers + compile flags: identifies the kernels' source (profiles/*/flops.json records it)."""
+def kernel_source_hash(out=None):
+    """sha256 over the device headers + compile flags (+ the listing check / repair and whether the linked library went through it:
+    a repaired build is other device code than an unrepaired one from the same sources — ADVICE r4): identifies the kernels
+    (profiles/*/flops.json records it)."""
     h = hashlib.sha256()
     for f in KERNEL_HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    with open(os.path.join(HERE, "isa_exec.py"), "rb") as fh:
+        h.update(fh.read())
+    if (linked_tag(out or OUT) or "").endswith("+listing"):
+        h.update(b"via-listing")
     return h.hexdigest()[:16]
+
+
+# the headers a run-time unit is compiled against (user_metric._HEADERS, rtgr_api.hip header_hash_of: same files, same order)
+UNIT_HEADERS = ["rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_tsit5_tables.hpp",
+                os.path.join("..", "..", "include", "rtgr.h")]
+
+
+def header_hash():
+    """FNV-1a (64 bit) over the device headers of run-time units: compiled into the library (-DRTGR_HEADER_HASH, rtgr_api.hip) and
+    into every unit (rtgr_user_header_hash); a unit built from other headers than the library's kernels is refused at load."""
+    h = 1469598103934665603
+    for f in UNIT_HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            for b in fh.read():
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h or 1
 
 
 def _stale(target, deps):
@@ -130,6 +153,8 @@ def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ, via_listing
             except RuntimeError as e:
                 return job, subprocess.CompletedProcess([], 1, "", str(e))
         cmd = [HIPCC] + FLAGS + list(extra) + ["-c", "-o", obj, src]
+        if os.path.basename(src) == "rtgr_api.hip":   # (depends on every header: rebuilt whenever the hash moves)
+            cmd.insert(-4, f"-DRTGR_HEADER_HASH={header_hash():#x}ull")
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, cwd=obj_dir, capture_output=True, text=True)
@@ -148,16 +173,24 @@ def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ, via_listing
     # (`build.py -DRTGR_ROOT_STATS`, --save-temps, …) a plain build finds its own objects fresh and OLDER than the library,
     # and must still relink — or tests and bench would silently run the experiment binary.
     tag_file = out + ".tag"
-    linked_tag = open(tag_file).read().strip() if os.path.exists(tag_file) else None
-    if jobs or force or _stale(out, objs) or linked_tag != tag:
+    linked = open(tag_file).read().strip() if os.path.exists(tag_file) else None
+    full_tag = tag + ("+listing" if via_listing else "")
+    if jobs or force or _stale(out, objs) or linked != full_tag:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs + ["-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=HERE)
         with open(tag_file, "w") as fh:
-            fh.write(tag + "\n")
+            fh.write(full_tag + "\n")
         # the kernels just linked in must be free of the compiler's EXEC-flip fault; if they are not, once more through the listings
         found, report = audit(out)
+        if found is None:
+            # the audit could not RUN (no libamdhip64 / libamd_comgr for the child, a crash): say so — an unaudited library must not
+            # look like a clean one.  __graft_entry__.build() and tests/test_build_checks.py assert a real result.
+            msg = f"WARNING: {out}: the post-link EXEC-flip audit could not be run ({report.strip()[-300:] or 'no output'}): kernels NOT audited"
+            if os.environ.get("RTGR_REQUIRE_AUDIT") == "1":
+                raise RuntimeError(msg)
+            print(msg, file=sys.stderr, flush=True)
         if found:
             if via_listing:
                 raise RuntimeError(f"{out}: {found} FLOW block(s) with vector instructions ahead of the EXEC flip survive the listing route:\n{report}")
@@ -168,7 +201,8 @@ def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ, via_listing
 
 
 def linked_tag(out=OUT):
-    """'std' for the production flag set, a hash for an experiment build, None when unknown."""
+    """'std' for the production flag set, a hash for an experiment build ('+listing' appended when the kernel units were built
+    through their listings), None when unknown."""
     try:
         return open(out + ".tag").read().strip()
     except OSError:

@@ -36,12 +36,13 @@ int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------------------
 static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
                                          "far4", "rounds", "qchunk", "qchunk_near", "tile", "host_chunk",
-                                         "dbg_pass_far", "peer", "pack", "packfar", nullptr};
+                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", nullptr};
 const char* const* knob_names() { return KNOB_NAMES; }
 long* knob_slot(Knobs& k, const char* name) {
     if (!name) return nullptr;
     long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
-                     &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far, &k.peer, &k.pack, &k.packfar};
+                     &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far, &k.peer, &k.pack, &k.packfar,
+                     &k.unit_probe, &k.unit_audit};
     for (int i = 0; KNOB_NAMES[i]; i++)
         if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
     return nullptr;
@@ -343,30 +344,58 @@ void disk_sqrt_band(R r, R& lo, R& hi) {
     hi = c;
 }
 
+// The (metric enum | generic flag, spin) a scene selects among the kernels' instantiations — what dispatch() below switches on, and
+// what a run-time unit without a metric of its own is built for (rtgr_user_unit_desc, rtgr_user_unit.hip.in).
+static void scene_variant(const rtgr_scene* s, uint32_t* metric, bool* spin) {
+    const uint32_t kind = s->metric & ~RTGR_METRIC_GENERIC;
+    const bool generic = (s->metric & RTGR_METRIC_GENERIC) != 0 && kind != RTGR_MINKOWSKI;
+    *metric = kind | (generic ? RTGR_METRIC_GENERIC : 0u);
+    *spin = kind == RTGR_MINKOWSKI ? false : (generic ? true : s->a != 0.0);
+}
+
 template <class R>
 int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserModule** user) {
     if (!s) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
     if ((s->metric & ~RTGR_METRIC_GENERIC) > RTGR_USER) return fail(RTGR_ERR_BAD_ARG, "unknown metric enum");
     *user = nullptr;
-    if ((s->metric & ~RTGR_METRIC_GENERIC) == RTGR_USER) {
-        if (D.modules.empty()) return fail(RTGR_ERR_BAD_ARG, "RTGR_USER: no user metric loaded (rtgr_user_metric_load)");
+    if (s->nobj > RTGR_MAX_OBJECTS) return fail(RTGR_ERR_BAD_ARG, "too many objects");
+    const bool user_metric = (s->metric & ~RTGR_METRIC_GENERIC) == RTGR_USER;
+    bool user_objects = false;
+    for (uint32_t o = 0; o < s->nobj; o++) user_objects = user_objects || s->obj[o].kind == RTGR_USER_OBJECT;
+    if (user_metric || user_objects) {
+        const char* what = user_metric ? "RTGR_USER" : "RTGR_USER_OBJECT";
+        if (D.modules.empty())
+            return fail(RTGR_ERR_BAD_ARG, std::string(what) + ": no run-time unit loaded (rtgr_user_metric_load / rtgr_user_unit_compile)");
         *user = D.find_module(s->user_metric);
         if (!*user)
-            return fail(RTGR_ERR_BAD_ARG, "RTGR_USER: rtgr_scene.user_metric names a module that is not loaded in this "
-                                          "context (a scene only ever runs with the kernels of its own metric)");
-        if (sizeof(R) != 8 && !(*user)->full10_f32)
-            return fail(RTGR_ERR_BAD_ARG, "this user-metric code object carries no Float32 kernels");
+            return fail(RTGR_ERR_BAD_ARG, std::string(what) + ": rtgr_scene.user_metric names a unit that is not loaded in this "
+                                          "context (a scene only ever runs with the kernels of its own unit)");
+        const UserModule& U = **user;
+        if (user_metric && !U.has_metric)
+            return fail(RTGR_ERR_BAD_ARG, "RTGR_USER: this unit defines no metric (it was built for a built-in one: rtgr_user_unit_info)");
+        if (user_objects && !U.has_objects)
+            return fail(RTGR_ERR_BAD_ARG, "RTGR_USER_OBJECT: this unit's source defines no rtgr_user_distance / rtgr_user_objcolor");
+        if (!user_metric) {   // the unit's kernels are ONE built-in metric variant's: the scene's must be that one
+            uint32_t mv; bool sp;
+            scene_variant(s, &mv, &sp);
+            if (U.has_metric || U.metric != mv || U.spin != sp)
+                return fail(RTGR_ERR_BAD_ARG, "RTGR_USER_OBJECT: this unit's kernels were built for another metric variant (metric enum / "
+                                              "RTGR_METRIC_GENERIC / a != 0 differ from the scene's): build one for THIS scene — "
+                                              "rtgr_user_unit_compile(ctx, source, stationary, &scene, &id)");
+        }
+        if (sizeof(R) != 8 && !U.full10_f32)
+            return fail(RTGR_ERR_BAD_ARG, "this unit carries no Float32 kernels");
     }
-    if (s->nobj > RTGR_MAX_OBJECTS) return fail(RTGR_ERR_BAD_ARG, "too many objects");
     std::memset(&d, 0, sizeof d);
     d.metric = s->metric & ~RTGR_METRIC_GENERIC;
     d.nobj = s->nobj;
     d.M = (R)s->M;
     d.a = (R)s->a;
     for (uint32_t o = 0; o < s->nobj; o++) {
-        if (s->obj[o].kind < RTGR_PLANE || s->obj[o].kind > RTGR_DISK)
+        if (s->obj[o].kind < RTGR_PLANE || s->obj[o].kind > RTGR_USER_OBJECT)
             return fail(RTGR_ERR_BAD_ARG, "unknown object kind (abstract Object has no distance)");
         d.obj[o].kind = s->obj[o].kind;
+        d.obj[o].type = s->obj[o].kind == RTGR_USER_OBJECT ? s->obj[o].type : 0u;
         for (int q = 0; q < 9; q++) d.obj[o].p[q] = (R)s->obj[o].p[q];
         if (s->obj[o].kind == RTGR_DISK) {   // p[3..6]: the scan's sign thresholds on x² + y² (device-side only; the ABI's disk is p[0..2])
             disk_sqrt_band<R>(d.obj[o].p[1], d.obj[o].p[3], d.obj[o].p[4]);
@@ -402,7 +431,7 @@ void convert_camera(const rtgr_camera* c, DevCamera<R>& d) {
 }
 
 int dispatch(LaunchEnv& E, const TraceArgs<double>& A, bool generic, bool spin, hipStream_t st) {
-    if (generic) return launch_f64_generic(E, A, st);
+    if (generic || E.user) return launch_f64_generic(E, A, st);   // (a scene with a run-time unit launches the unit's kernels from there)
     switch (A.sc.metric) {
         case RTGR_MINKOWSKI: return launch_f64_mink(E, A, st);
         case RTGR_KS_REF: return launch_f64_ksref(E, A, spin, st);
@@ -410,7 +439,7 @@ int dispatch(LaunchEnv& E, const TraceArgs<double>& A, bool generic, bool spin, 
     }
 }
 int dispatch(LaunchEnv& E, const TraceArgs<float>& A, bool generic, bool spin, hipStream_t st) {
-    if (generic) return launch_f32_generic(E, A, st);
+    if (generic || E.user) return launch_f32_generic(E, A, st);
     return launch_f32_closed(E, A, spin, st);
 }
 
@@ -468,7 +497,7 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
     const bool spin = scene->a != 0.0;
     const bool generic = ((scene->metric & RTGR_METRIC_GENERIC) != 0 && A.sc.metric != RTGR_MINKOWSKI) || A.sc.metric == RTGR_USER;
     if (D.knobs.tile) {
-        if (generic) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC needs the persistent pipeline (option tile = 0)");
+        if (generic || user) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC and run-time units need the persistent pipeline (option tile = 0)");
         if (win && (win->plane_stride || win->out_offset)) return fail(RTGR_ERR_BAD_ARG, "the tile kernel writes whole slabs only");
     }
     StreamState* ss = nullptr;
@@ -1575,12 +1604,10 @@ int rtgr_eval_fastmath_f64(rtgr_context* ctx, const double* x, uint64_t n, doubl
     return RTGR_OK;
 }
 
-// ---- run-time loaded metrics -------------------------------------------------------------------------------------------
-int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
-    rtgr_context* c = nullptr;
-    int rc = resolve_ctx(ctx, &c);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> load_lock(c->modules_mu);
+// ---- run-time loaded units (metrics, objects) ------------------------------------------------------------------------------
+}  // extern "C"
+// drop unit `id` (0: all) from every device; the caller holds c->modules_mu
+static int unload_locked(rtgr_context* c, uint64_t id) {
     for (auto& d : c->devs) {
         DeviceGuard guard(d->dev);
         std::lock_guard<std::mutex> lk(d->mu);
@@ -1597,21 +1624,143 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
     }
     return RTGR_OK;
 }
+extern "C" {
+int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> load_lock(c->modules_mu);
+    return unload_locked(c, id);
+}
 
 }  // extern "C"
+
+// ---- load-time probe of a unit ---------------------------------------------------------------------------------------------
+// Round 4's compiler fault was a SILENT wrong answer that survived a round of green tests; its symptoms were
+// frames that differ from run to run and a single FULL pass that disagrees with the FAR + NEAR pair.  The textual audit knows one
+// shape of it.  This is the check that does not depend on the shape: a fresh unit traces a fixed 32 x 32 frame of example2's
+// camera and objects (src/RayTraceGR.jl:581-593) through both pass structures, twice each (and its Float32 FULL pass twice), and is
+// refused when (a) two runs of the same structure differ in ANY bit — every wave is independent of every other, so they must not —
+// or (b) the two structures disagree beyond what different inlining of the user's own arithmetic explains (the built-in kernels are
+// bit-identical between them; a user metric's products may contract differently in the FAR and the FULL kernel): more than 2 % of
+// the rays with another hit / status / step count (±2), or an end state off by more than 1e-5 (relative) on a ray they agree on.
+// A ~10 ms look at the fault's own symptom; a probe, not a proof (a unit wrong the same way in every pass goes through).
+template <class R> struct ProbeFrame { std::vector<R> rgb, se, lam; std::vector<uint8_t> status, hit; std::vector<uint32_t> na, nr; };
+template <class R>
+static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFrame<R>& f) {
+    constexpr uint64_t NI = 32, N = NI * NI;
+    rtgr_solver opt;
+    rtgr_solver_defaults(&opt, sizeof(R) == 4);
+    opt.max_steps = 4000;   // (bounds the probe on a metric this camera makes no sense for; such rays end with a status, identically)
+    rtgr_camera cam;
+    std::memset(&cam, 0, sizeof cam);
+    cam.pos[1] = 4; cam.pos[2] = -2; cam.widthx[1] = 1; cam.widthy[3] = 1; cam.normal[2] = 1;
+    DevBuf b;
+    const size_t off_se = 3 * N * sizeof(R), off_lam = off_se + 8 * N * sizeof(R), off_na = off_lam + N * sizeof(R),
+                 off_nr = off_na + N * 4, off_st = off_nr + N * 4, off_hit = off_st + N, total = off_hit + N;
+    int rc;
+    if ((rc = b.alloc(total))) return rc;
+    char* base = (char*)b.p;
+    HIP_TRY(hipMemset(base, 0, total));
+    rtgr_ray_outputs out;
+    std::memset(&out, 0, sizeof out);
+    out.state_end = base + off_se; out.lambda_end = base + off_lam; out.n_accept = (uint32_t*)(base + off_na);
+    out.n_reject = (uint32_t*)(base + off_nr); out.status = (uint8_t*)(base + off_st); out.hit = (uint8_t*)(base + off_hit);
+    long saved;
+    { std::lock_guard<std::mutex> lk(D.mu); saved = D.knobs.split; D.knobs.split = split; }
+    rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NI, 0, NI, (R*)base, &out, nullptr, nullptr);
+    { std::lock_guard<std::mutex> lk(D.mu); D.knobs.split = saved; }
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    f.rgb.resize(3 * N); f.se.resize(8 * N); f.lam.resize(N); f.na.resize(N); f.nr.resize(N); f.status.resize(N); f.hit.resize(N);
+    HIP_TRY(hipMemcpy(f.rgb.data(), base, off_se, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.se.data(), base + off_se, 8 * N * sizeof(R), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.lam.data(), base + off_lam, N * sizeof(R), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.na.data(), base + off_na, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.nr.data(), base + off_nr, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.status.data(), base + off_st, N, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.hit.data(), base + off_hit, N, hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+template <class R>
+static bool probe_same_bits(const ProbeFrame<R>& a, const ProbeFrame<R>& b) {
+    auto eq = [](const auto& x, const auto& y) { return x.size() == y.size() && std::memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0; };
+    return eq(a.rgb, b.rgb) && eq(a.se, b.se) && eq(a.lam, b.lam) && eq(a.na, b.na) && eq(a.nr, b.nr) && eq(a.status, b.status) && eq(a.hit, b.hit);
+}
+static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
+    rtgr_scene sc;
+    std::memset(&sc, 0, sizeof sc);
+    sc.metric = U.has_metric ? (uint32_t)RTGR_USER : U.metric;
+    sc.M = 1.0;
+    sc.a = (!U.has_metric && U.spin && (U.metric & RTGR_METRIC_GENERIC) == 0) ? 0.5 : 0.0;
+    sc.user_metric = U.id;
+    sc.nobj = 3;                                                         // example2's objects, src/RayTraceGR.jl:582-586
+    sc.obj[0].kind = RTGR_SPHERE; sc.obj[0].p[4] = 1; sc.obj[0].p[8] = -10;
+    sc.obj[1].kind = RTGR_PLANE;  sc.obj[1].p[0] = -20;
+    sc.obj[2].kind = RTGR_SPHERE; sc.obj[2].p[1] = 4; sc.obj[2].p[4] = 1; sc.obj[2].p[8] = 0.5;
+    int rc;
+    ProbeFrame<double> full[2], pair[2];
+    for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 0, full[k]))) return rc;
+    if (!probe_same_bits(full[0], full[1])) { *why = "two runs of its Float64 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
+    const bool has_pair = !(U.has_objects && !U.has_reach);
+    if (has_pair) {
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 1, pair[k]))) return rc;
+        if (!probe_same_bits(pair[0], pair[1])) { *why = "two runs of its Float64 FAR + NEAR passes over the same 32 x 32 probe frame differ"; return 1; }
+        const size_t n = full[0].hit.size();
+        size_t other = 0;
+        double worst = 0;
+        for (size_t i = 0; i < n; i++) {
+            const long sa = (long)full[0].na[i] + full[0].nr[i], sb = (long)pair[0].na[i] + pair[0].nr[i];
+            if (full[0].hit[i] != pair[0].hit[i] || full[0].status[i] != pair[0].status[i] || std::labs(sa - sb) > 2) { other++; continue; }
+            for (int q = 0; q < 8; q++) {
+                const double x = full[0].se[8 * i + q], y = pair[0].se[8 * i + q];
+                if (x != x && y != y) continue;
+                const double e = std::fabs(x - y) / (1.0 + std::fabs(x));
+                if (!(e <= worst)) worst = e;   // (NaN on one side only: counted)
+            }
+        }
+        char buf[256];
+        if (other > std::max<size_t>(2, n / 50)) {
+            std::snprintf(buf, sizeof buf, "its FULL pass and its FAR + NEAR passes disagree on %zu of %zu probe rays (hit / status / step count)", other, n);
+            *why = buf; return 1;
+        }
+        if (!(worst <= 1e-5)) {
+            std::snprintf(buf, sizeof buf, "its FULL pass and its FAR + NEAR passes end rays they agree on %.3g apart (relative; 1e-5 allowed)", worst);
+            *why = buf; return 1;
+        }
+    }
+    if (U.full10_f32) {
+        ProbeFrame<float> f32[2];
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<float>(D, sc, -1, f32[k]))) return rc;
+        if (!probe_same_bits(f32[0], f32[1])) { *why = "two runs of its Float32 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
+    }
+    return RTGR_OK;
+}
+
+#ifndef RTGR_HEADER_HASH
+#define RTGR_HEADER_HASH 0ull   // (build.py passes the FNV-1a of the device headers the library's kernels were built from)
+#endif
 
 // load a gfx950 code object image into every device of the context; its id is a hash of the image
 static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out) {
     const uint64_t id = fnv1a(image);
-    {   // refuse code that carries the EXEC-flip fault of this LLVM (rtgr_isa_audit.hpp): a unit traced wrong from it in round 4.
-        // (An image that cannot be audited — no libamd_comgr on the box — is loaded as it is.)
+    const Knobs policy = [&] { std::lock_guard<std::mutex> lk(c->devs[0]->mu); return c->devs[0]->knobs; }();
+    if (policy.unit_audit != 0) {
+        // refuse code that carries the EXEC-flip fault of this LLVM (rtgr_isa_audit.hpp): a unit traced wrong from it in round 4.
+        // audit_any also unwraps the offload bundle a plain `hipcc --genco` writes (those were loaded unaudited).  A box
+        // without libamd_comgr cannot audit anything and loads the image as it is — the probe below still runs; a file the audit does
+        // not understand (a compressed bundle, say) that the runtime might load all the same is REFUSED, not waved through.
         std::string report;
-        const int bad = isa_audit::audit(image.data(), image.size(), &report);
+        const int bad = isa_audit::audit_any(image.data(), image.size(), &report);
         if (bad > 0)
             return fail(RTGR_ERR_BAD_ARG, what + ": " + std::to_string(bad) + " FLOW block(s) with vector instructions ahead of the EXEC flip "
                         "(a code-generation fault of the compiler, DESIGN.md §4.6; raytracegr.jl_amd/user_metric.py builds repaired units):\n" + report);
+        if (bad == isa_audit::NOT_UNDERSTOOD)
+            return fail(RTGR_ERR_BAD_ARG, what + ": cannot be audited (" + report + "): hand over a plain gfx950 code object "
+                        "(hipcc --genco --no-gpu-bundle-output) or an uncompressed offload bundle");
     }
     std::lock_guard<std::mutex> load_lock(c->modules_mu);   // one load / unload at a time per context
+    bool fresh = false;                                       // loaded by this call on at least one device (else: already resident)
     for (auto& d : c->devs) {
         DeviceGuard guard(d->dev);
         bool same_phys = false;  // a logical duplicate of a device shares the module of its twin
@@ -1638,9 +1787,17 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
             size_t bytes = 0;
             unsigned ver = 0;
             if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_abi_version") != hipSuccess || bytes != sizeof ver)
-                return bail("not a user-metric code object (no rtgr_user_abi_version)");
+                return bail("not a run-time unit of this library (no rtgr_user_abi_version)");
             if (hipMemcpyDtoH(&ver, dptr, sizeof ver) != hipSuccess) return bail("cannot read rtgr_user_abi_version");
-            if (ver != RTGR_ABI_VERSION) return bail("built against another ABI version");
+            if (ver != RTGR_ABI_VERSION)
+                return bail("built against ABI version " + std::to_string(ver) + ", this library is version " + std::to_string(RTGR_ABI_VERSION) + ": rebuild the unit");
+            // … the very headers: the record layouts and argument blocks the unit's kernels share with the library's are not part of
+            // the C ABI and change without its version moving (round 4's record overlay would have loaded an older unit and
+            // overrun the workspace).  0 on either side = not recorded (a unit built by hand, a library built without build.py).
+            unsigned long long hh = 0;
+            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_header_hash") == hipSuccess && bytes == sizeof hh &&
+                hipMemcpyDtoH(&hh, dptr, sizeof hh) == hipSuccess && hh != 0ull && RTGR_HEADER_HASH != 0ull && hh != RTGR_HEADER_HASH)
+                return bail("built from other device headers than this library's kernels (header hash differs): rebuild the unit");
             // optional: the occupancies the unit's FAR / NEAR+FULL / Float32 passes were built for
             struct { const char* name; unsigned* dst; } occ[] = {{"rtgr_user_far_waves", &u.far_waves}, {"rtgr_user_near_waves", &u.near_waves},
                                                                 {"rtgr_user_f32_waves", &u.f32_waves}};
@@ -1649,15 +1806,27 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
                 if (hipModuleGetGlobal(&dptr, &bytes, u.module, o.name) == hipSuccess && bytes == sizeof fw &&
                     hipMemcpyDtoH(&fw, dptr, sizeof fw) == hipSuccess && fw >= 1 && fw <= 8) *o.dst = fw;
             }
+            // what it was built for: {metric enum | generic flag, spin, metric of its own, objects, reach bound}
+            unsigned desc[8] = {0};
+            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_unit_desc") != hipSuccess || bytes != sizeof desc ||
+                hipMemcpyDtoH(desc, dptr, sizeof desc) != hipSuccess)
+                return bail("no rtgr_user_unit_desc (a unit of an older template): rebuild the unit");
+            u.metric = desc[0]; u.spin = desc[1] != 0; u.has_metric = desc[2] != 0; u.has_objects = desc[3] != 0; u.has_reach = desc[4] != 0;
+            if ((u.metric & ~RTGR_METRIC_GENERIC) > RTGR_USER || (u.has_metric != ((u.metric & ~RTGR_METRIC_GENERIC) == RTGR_USER)))
+                return bail("inconsistent rtgr_user_unit_desc");
+            if (!u.has_metric && !u.has_objects) return bail("the unit defines neither a metric nor objects");
             (void)hipGetLastError();
         }
+        const bool M = u.has_metric, O = u.has_objects;   // which kernels the unit must carry
         struct { hipFunction_t* f; const char* name; bool required; } want[] = {
             {&u.far, "rtgr_user_integrate_far", true},       {&u.near, "rtgr_user_integrate_near", true},
             {&u.full10, "rtgr_user_integrate_full10", true}, {&u.fulln, "rtgr_user_integrate_fulln", true},
-            {&u.canvas, "rtgr_user_canvas", true},           {&u.eval_metric, "rtgr_user_eval_metric", true},
-            {&u.eval_geodesic, "rtgr_user_eval_geodesic", true}, {&u.prepare, "rtgr_user_prepare", true},
+            {&u.prepare, "rtgr_user_prepare", true},         {&u.resolve, "rtgr_user_resolve", O},
+            {&u.canvas, "rtgr_user_canvas", M},              {&u.eval_metric, "rtgr_user_eval_metric", M},
+            {&u.eval_geodesic, "rtgr_user_eval_geodesic", M},
             {&u.full10_f32, "rtgr_user_integrate_full10_f32", false}, {&u.fulln_f32, "rtgr_user_integrate_fulln_f32", false},
             {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false},
+            {&u.resolve_f32, "rtgr_user_resolve_f32", false},
             {&u.eval_accel, "rtgr_user_eval_accel", false}, {&u.redshift, "rtgr_user_redshift", false},
             {&u.redshift_f32, "rtgr_user_redshift_f32", false}};
         for (auto& w : want)
@@ -1666,8 +1835,34 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
                 if (w.required) return bail(std::string("missing kernel ") + w.name);
                 *w.f = nullptr;
             }
-        if (!u.prepare_f32 || !u.fulln_f32) u.full10_f32 = nullptr;  // all or nothing
+        if (!u.prepare_f32 || !u.fulln_f32 || (O && !u.resolve_f32)) u.full10_f32 = nullptr;  // all or nothing
         d->modules.push_back(u);
+        fresh = true;
+    }
+    if (fresh && policy.unit_probe != 0) {
+        // one probe per physical device that now owns a copy of the module
+        std::vector<int> seen;
+        for (auto& d : c->devs) {
+            if (std::find(seen.begin(), seen.end(), d->dev) != seen.end()) continue;
+            seen.push_back(d->dev);
+            UserModule u;
+            { std::lock_guard<std::mutex> lk(d->mu); const UserModule* m = d->find_module(id); if (!m) continue; u = *m; }
+            if (u.probe_ok) continue;
+            std::string why;
+            DeviceGuard guard(d->dev);
+            const int pr = probe_unit(*d, u, &why);
+            if (pr != RTGR_OK) {
+                const std::string msg = pr > 0 ? what + ": refused by the load-time probe — " + why +
+                                                 " (the symptom of a mis-compiled unit, DESIGN.md §4.6; option unit_probe = 0 skips the probe)"
+                                               : what + ": the load-time probe could not run: " + rtgr_last_error();
+                (void)unload_locked(c, id);
+                return fail(pr > 0 ? RTGR_ERR_BAD_ARG : pr, msg);
+            }
+        }
+        for (auto& d : c->devs) {
+            std::lock_guard<std::mutex> lk(d->mu);
+            for (auto& m : d->modules) if (m.id == id) m.probe_ok = true;
+        }
     }
     if (id_out) *id_out = id;
     return RTGR_OK;
@@ -1729,13 +1924,61 @@ int rtgr_code_object_audit(const char* code_object_path, int* found, char* repor
     return RTGR_OK;
 }
 
-// source text -> the unit's code object, in-process (no GPU needed); RTGR_OK or a negative status with the reason as last error
-static int build_unit_image(const char* source, int stationary, unit_build::Built* built) {
-    const bool ks_form = source && std::strstr(source, "rtgr_user_ks") != nullptr;
-    if (!source || (!ks_form && !std::strstr(source, "rtgr_user_metric")))
+}  // extern "C"
+// What a unit is made of, read off its source text and the scene it is meant for (the same rules as user_metric.py: unit_defines)
+struct UnitPlan { bool metric = false, ks_form = false, objects = false, reach = false; std::vector<std::string> defines; };
+static int plan_unit(const char* source, int stationary, const rtgr_scene* built_for, UnitPlan* P) {
+    if (!source) return fail(RTGR_ERR_BAD_ARG, "source is NULL");
+    P->ks_form = std::strstr(source, "rtgr_user_ks") != nullptr;
+    P->metric = P->ks_form || std::strstr(source, "rtgr_user_metric") != nullptr;
+    const bool dist = std::strstr(source, "rtgr_user_distance") != nullptr, colr = std::strstr(source, "rtgr_user_objcolor") != nullptr;
+    if (dist != colr)
+        return fail(RTGR_ERR_BAD_ARG, "objects need both methods of the reference's Object (src/RayTraceGR.jl:377-389): rtgr_user_distance AND rtgr_user_objcolor");
+    P->objects = dist;
+    P->reach = std::strstr(source, "rtgr_user_reach") != nullptr;
+    if (P->reach && !P->objects) return fail(RTGR_ERR_BAD_ARG, "rtgr_user_reach without rtgr_user_distance / rtgr_user_objcolor");
+    if (!P->metric && !P->objects)
         return fail(RTGR_ERR_BAD_ARG, "the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
                                       "double M, double a, S g[4][4])` (or, for a metric of Kerr-Schild form, rtgr_user_ks(const S "
-                                      "x[4], double M, double a, S& f, S k[3]))");
+                                      "x[4], double M, double a, S& f, S k[3])) and / or the object methods rtgr_user_distance / rtgr_user_objcolor");
+    if (P->metric) {
+        if (built_for && (built_for->metric & ~RTGR_METRIC_GENERIC) != RTGR_USER)
+            return fail(RTGR_ERR_BAD_ARG, "the source defines a metric of its own, but built_for names a built-in one: pass NULL (or a RTGR_USER scene)");
+        if (stationary || P->ks_form) P->defines.push_back("-DRTGR_USER_NE=3");   // (Kerr–Schild form: stationary by contract)
+        if (P->ks_form) P->defines.push_back("-DRTGR_USER_KS=1");
+    } else {
+        if (!built_for || (built_for->metric & ~RTGR_METRIC_GENERIC) >= RTGR_USER)
+            return fail(RTGR_ERR_BAD_ARG, "a unit of objects alone is built for ONE built-in metric variant: pass the scene it is meant for as built_for "
+                                          "(its metric enum, RTGR_METRIC_GENERIC flag and whether a != 0 are read)");
+        uint32_t mv; bool sp;
+        scene_variant(built_for, &mv, &sp);
+        const bool generic = (mv & RTGR_METRIC_GENERIC) != 0;
+        P->defines.push_back("-DRTGR_UNIT_BUILTIN_METRIC=" + std::to_string(mv & ~RTGR_METRIC_GENERIC));
+        P->defines.push_back(std::string("-DRTGR_UNIT_GENERIC=") + (generic ? "1" : "0"));
+        P->defines.push_back(std::string("-DRTGR_UNIT_SPIN=") + ((sp && !generic) ? "1" : "0"));
+    }
+    if (P->objects) P->defines.push_back("-DRTGR_USER_OBJECTS=1");
+    if (P->reach) P->defines.push_back("-DRTGR_USER_REACH=1");
+    return RTGR_OK;
+}
+
+// FNV-1a over the device headers a unit is compiled against, in the order user_metric.py hashes them (header_hash): what a unit
+// records as rtgr_user_header_hash and load_module_image compares with the hash the library's own kernels were built from
+static int header_hash_of(const std::string& dir, unsigned long long* out) {
+    uint64_t h = 1469598103934665603ull;
+    for (const char* f : {"rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_tsit5_tables.hpp", "../../include/rtgr.h"}) {
+        std::vector<char> b;
+        if (int rc = read_file(dir + "/" + f, b)) return rc;
+        for (char ch : b) { h ^= (unsigned char)ch; h *= 1099511628211ull; }
+    }
+    *out = h ? h : 1;
+    return RTGR_OK;
+}
+
+// source text -> the unit's code object, in-process (no GPU needed); RTGR_OK or a negative status with the reason as last error
+static int build_unit_image(const char* source, int stationary, const rtgr_scene* built_for, unit_build::Built* built) {
+    UnitPlan P;
+    if (int rc = plan_unit(source, stationary, built_for, &P)) return rc;
     const std::string dir = csrc_dir();
     std::vector<char> tmpl;
     if (int rc = read_file(dir + "/rtgr_user_unit.hip.in", tmpl)) return rc;
@@ -1744,33 +1987,63 @@ static int build_unit_image(const char* source, int stationary, unit_build::Buil
     const size_t at = unit.find(mark);
     if (at == std::string::npos) return fail(RTGR_ERR_BAD_ARG, dir + "/rtgr_user_unit.hip.in: no " + mark);
     unit.replace(at, mark.size(), source);
+    unsigned long long hh = 0;
+    if (int rc = header_hash_of(dir, &hh)) return rc;
+    char hbuf[64];
+    std::snprintf(hbuf, sizeof hbuf, "-DRTGR_HEADER_HASH=0x%llxull", hh);
+    P.defines.push_back(hbuf);
     std::string why;
-    const int r = unit_build::build(unit, dir, stationary != 0, ks_form, built, &why);
+    const int r = unit_build::build(unit, dir, P.defines, built, &why);
     if (r == 1) return fail(RTGR_ERR_BAD_ARG, why);          // the user's source does not compile: the compiler's log
     if (r != 0) return fail(RTGR_ERR_HIP, why);
     return RTGR_OK;
 }
-
-int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
-    rtgr_context* c = nullptr;
-    int rc = resolve_ctx(ctx, &c);
-    if (rc) return rc;
-    unit_build::Built built;
-    if ((rc = build_unit_image(source, stationary, &built))) return rc;
-    const std::vector<char> image(built.image.begin(), built.image.end());
-    return load_module_image(c, image, "compiled user metric", id_out);   // (audited there like any other image)
-}
-
-int rtgr_user_metric_build(const char* source, int stationary, const char* code_object_path) {
-    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
-    unit_build::Built built;
-    if (int rc = build_unit_image(source, stationary, &built)) return rc;
+static int write_image(const unit_build::Built& built, const char* code_object_path) {
     const std::string tmp = std::string(code_object_path) + ".tmp" + std::to_string((long)getpid());
     FILE* f = std::fopen(tmp.c_str(), "wb");
     if (!f) return fail(RTGR_ERR_BAD_ARG, "cannot write " + tmp);
     const size_t put = std::fwrite(built.image.data(), 1, built.image.size(), f);
     if (std::fclose(f) != 0 || put != built.image.size()) { std::remove(tmp.c_str()); return fail(RTGR_ERR_BAD_ARG, "short write on " + tmp); }
     if (std::rename(tmp.c_str(), code_object_path) != 0) { std::remove(tmp.c_str()); return fail(RTGR_ERR_BAD_ARG, std::string("cannot rename to ") + code_object_path); }
+    return RTGR_OK;
+}
+extern "C" {
+
+int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary, const rtgr_scene* built_for, uint64_t* id_out) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    unit_build::Built built;
+    if ((rc = build_unit_image(source, stationary, built_for, &built))) return rc;
+    const std::vector<char> image(built.image.begin(), built.image.end());
+    return load_module_image(c, image, "compiled unit", id_out);   // (audited and probed there like any other image)
+}
+int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
+    return rtgr_user_unit_compile(ctx, source, stationary, nullptr, id_out);
+}
+
+int rtgr_user_unit_build(const char* source, int stationary, const rtgr_scene* built_for, const char* code_object_path) {
+    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
+    unit_build::Built built;
+    if (int rc = build_unit_image(source, stationary, built_for, &built)) return rc;
+    return write_image(built, code_object_path);
+}
+int rtgr_user_metric_build(const char* source, int stationary, const char* code_object_path) {
+    return rtgr_user_unit_build(source, stationary, nullptr, code_object_path);
+}
+
+int rtgr_user_unit_info(rtgr_context* ctx, uint64_t id, rtgr_unit_info* info) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!info) return fail(RTGR_ERR_BAD_ARG, "info is NULL");
+    DeviceCtx& d = *c->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    const UserModule* m = d.find_module(id);
+    if (!m) return fail(RTGR_ERR_BAD_ARG, "no such unit in this context");
+    std::memset(info, 0, sizeof *info);
+    info->metric = m->metric; info->spin = m->spin; info->has_objects = m->has_objects; info->has_reach = m->has_reach;
+    info->far_waves = m->far_waves; info->near_waves = m->near_waves; info->f32_waves = m->f32_waves; info->probe_ok = m->probe_ok;
     return RTGR_OK;
 }
 

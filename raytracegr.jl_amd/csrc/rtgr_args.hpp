@@ -11,7 +11,7 @@ namespace rtgr {
 template <class R>
 struct DevObject {
     uint32_t kind;
-    uint32_t pad;
+    uint32_t type;   // RTGR_USER_OBJECT: the caller's tag for rtgr_user_distance / rtgr_user_objcolor (rtgr_object.type)
     R p[9];
 };
 

@@ -12,7 +12,8 @@
 //                           hand-over / event records, per-ray meta, queue order, work-queue heads).  Launches on ONE
 //                           stream are ordered by the stream and share a workspace; launches on DIFFERENT streams get
 //                           different workspaces, so they never race (round 1 had one process-global workspace)
-//       user modules        run-time compiled metrics, keyed by the 64-bit id a scene carries (rtgr_scene.user_metric)
+//       user modules        run-time compiled units (a metric, Object subtypes, or both), keyed by the 64-bit id a scene carries
+//                           (rtgr_scene.user_metric)
 //       staging             pinned host buffers + device buffers + 3 streams of the host-pointer entry points
 //
 // A workspace only grows; the superseded allocation is RETIRED, not freed (a hipGraph captured earlier may still
@@ -68,11 +69,15 @@ struct Knobs {
     long peer = -1;               // multi-device gather (rtgr_trace_sharded_device_*): 0 = always stage the rows through pinned
                                   // host memory (the no-peer-access fallback, forced), 1 = peer copies or fail, -1 = peer copies
                                   // where rtgr_create could enable peer access, the fallback elsewhere
+    long unit_probe = 1;          // run-time units: trace a small probe frame through both pass structures at load and refuse a unit
+                                  // whose frames are irreproducible or disagree (rtgr_api.hip: probe_unit); 0 = skip
+    long unit_audit = 1;          // … and audit the code object for the compiler's EXEC-flip fault before loading it; 0 = skip
+                                  // (a test hook: the probe must catch a faulty unit on its own)
 };
 const char* const* knob_names();  // NULL-terminated
 long* knob_slot(Knobs& k, const char* name);
 
-// ---- run-time loaded metric: the metric-dependent kernels of the pipeline from a code object ------------------------------
+// ---- run-time loaded unit: the kernels of the pipeline that depend on the caller's metric / objects, from a code object ------
 struct UserModule {
     uint64_t id = 0;
     hipModule_t module = nullptr;
@@ -84,6 +89,12 @@ struct UserModule {
     // Float32 twins (absent in units built without them)
     hipFunction_t full10_f32 = nullptr, fulln_f32 = nullptr, prepare_f32 = nullptr, canvas_f32 = nullptr;
     hipFunction_t redshift = nullptr, redshift_f32 = nullptr;   // optional (units built before round 3 have none)
+    hipFunction_t resolve = nullptr, resolve_f32 = nullptr;     // the resolve kernel with the unit's objects (used when has_objects)
+    // what the unit was built for (rtgr_user_unit_desc): a scene runs with it only if its own variant is this one
+    uint32_t metric = RTGR_USER;   // rtgr_metric (| RTGR_METRIC_GENERIC) of its kernels; RTGR_USER: a metric of its own
+    bool spin = true;              // closed-form built-in kernels: the a != 0 instantiation
+    bool has_metric = true, has_objects = false, has_reach = false;
+    bool probe_ok = false;         // the load-time probe ran and passed (rtgr_api.hip: probe_unit)
 };
 
 struct TimedLaunch { hipEvent_t a, b; int which; };
@@ -150,7 +161,7 @@ struct KernelTimer {  // RAII: records start now, stop at scope exit
 struct LaunchEnv {
     DeviceCtx& d;
     StreamState& ss;
-    const UserModule* user;  // resolved from the scene's user_metric id (RTGR_USER) or null
+    const UserModule* user;  // the scene's unit (rtgr_scene.user_metric: RTGR_USER metric and / or RTGR_USER_OBJECT objects) or null
     hipEvent_t after_setup = nullptr;  // optional: recorded on the launch stream behind the ray set-up / queue-order kernels
 };
 

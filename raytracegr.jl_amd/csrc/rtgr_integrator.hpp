@@ -302,6 +302,10 @@ RTGR_DEV uint8_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, co
         col[0] = mod1<R>(R(12) * th / pi);
         col[1] = mod1<R>(R(12) * ph / pi);
         col[2] = R(1);
+#ifdef RTGR_USER_OBJECTS
+    } else if (ob.kind == RTGR_USER_OBJECT) {                                         // objcolor(obj::MyThing, pos)  :387-389
+        rtgr_user_objcolor<R>(ob.type, x, ob.p, col);
+#endif
     } else {  // RTGR_DISK — no reference counterpart
         const R rc = rsqrt_(x[1] * x[1] + x[2] * x[2]);
         const R ph = ratan2<R>(x[2], x[1]);

@@ -100,30 +100,37 @@ inline bool writes_exec(const std::string& s) {
     return op != std::string::npos && s.compare(op, 4, "exec") == 0;
 }
 
+// [off, off + size) lies inside a file of `bytes` bytes — written in subtraction form: the operands come from an untrusted file, and
+// `off + size > bytes` wraps for offsets near 2^64
+inline bool in_file(uint64_t off, uint64_t size, uint64_t bytes) { return off <= bytes && size <= bytes - off; }
+
 // number of FLOW blocks of `image` with vector instructions ahead of their EXEC flip (their description appended to *report);
-// -1 when the image cannot be audited (no libamd_comgr, not an ELF64 code object with a .text section), the reason in *report
+// NOT_UNDERSTOOD (-1) when the image is not an ELF64 code object with a .text section this code can walk, NO_DISASSEMBLER (-2) when
+// libamd_comgr is not on the box — the reason in *report.  The two are different findings: a box without the disassembler cannot
+// audit anything, a file that is not understood may be a container the runtime WOULD load (rtgr_api.hip: load_module_image).
+constexpr int NOT_UNDERSTOOD = -1, NO_DISASSEMBLER = -2;
 inline int audit(const char* image, size_t bytes, std::string* report) {
     auto note = [&](const std::string& s) { if (report) *report += s; };
-    if (bytes < sizeof(Elf64_Ehdr) || std::memcmp(image, ELFMAG, SELFMAG) != 0 || image[EI_CLASS] != ELFCLASS64) { note("not an ELF64 image"); return -1; }
+    if (bytes < sizeof(Elf64_Ehdr) || std::memcmp(image, ELFMAG, SELFMAG) != 0 || image[EI_CLASS] != ELFCLASS64) { note("not an ELF64 image"); return NOT_UNDERSTOOD; }
     const Elf64_Ehdr* eh = (const Elf64_Ehdr*)image;
-    if (eh->e_shoff == 0 || eh->e_shentsize != sizeof(Elf64_Shdr) || eh->e_shoff + (uint64_t)eh->e_shnum * sizeof(Elf64_Shdr) > bytes ||
-        eh->e_shstrndx >= eh->e_shnum) { note("no section table"); return -1; }
+    if (eh->e_shoff == 0 || eh->e_shentsize != sizeof(Elf64_Shdr) || !in_file(eh->e_shoff, (uint64_t)eh->e_shnum * sizeof(Elf64_Shdr), bytes) ||
+        eh->e_shstrndx >= eh->e_shnum) { note("no section table"); return NOT_UNDERSTOOD; }
     const Elf64_Shdr* sh = (const Elf64_Shdr*)(image + eh->e_shoff);
     const Elf64_Shdr& names = sh[eh->e_shstrndx];
-    if (names.sh_size == 0 || names.sh_offset + names.sh_size > bytes || image[names.sh_offset + names.sh_size - 1] != 0) { note("bad section names"); return -1; }
+    if (names.sh_size == 0 || !in_file(names.sh_offset, names.sh_size, bytes) || image[names.sh_offset + names.sh_size - 1] != 0) { note("bad section names"); return NOT_UNDERSTOOD; }
     Reader r{image, 0, 0, 0, {}};
     for (int i = 0; i < eh->e_shnum; i++) {
         if (sh[i].sh_name >= names.sh_size) continue;
         if (std::strcmp(image + names.sh_offset + sh[i].sh_name, ".text") == 0 && sh[i].sh_type == SHT_PROGBITS) {
-            if (sh[i].sh_offset + sh[i].sh_size > bytes) { note("bad .text section"); return -1; }
+            if (!in_file(sh[i].sh_offset, sh[i].sh_size, bytes)) { note("bad .text section"); return NOT_UNDERSTOOD; }
             r.addr = sh[i].sh_addr; r.off = sh[i].sh_offset; r.size = sh[i].sh_size;
         }
     }
-    if (r.size == 0) { note("no .text section"); return -1; }
+    if (r.size == 0 || r.addr > UINT64_MAX - r.size) { note("no .text section"); return NOT_UNDERSTOOD; }
     Comgr& C = comgr();
-    if (!C.ok()) { note("libamd_comgr not found"); return -1; }
+    if (!C.ok()) { note("libamd_comgr not found"); return NO_DISASSEMBLER; }
     Comgr::info_t info{0};
-    if (C.create("amdgcn-amd-amdhsa--gfx950", read_cb, inst_cb, addr_cb, &info) != 0) { note("amd_comgr_create_disassembly_info failed"); return -1; }
+    if (C.create("amdgcn-amd-amdhsa--gfx950", read_cb, inst_cb, addr_cb, &info) != 0) { note("amd_comgr_create_disassembly_info failed"); return NO_DISASSEMBLER; }
     std::vector<Inst> insts;
     insts.reserve(r.size / 6);
     for (uint64_t a = r.addr; a < r.addr + r.size;) {
@@ -187,18 +194,18 @@ inline int audit_any(const char* image, size_t bytes, std::string* report) {
             uint64_t off, size, tl;
             std::memcpy(&off, image + p, 8); std::memcpy(&size, image + p + 8, 8); std::memcpy(&tl, image + p + 16, 8);
             p += 24;
-            if (tl > 256 || p + tl > bytes) break;
+            if (tl > 256 || tl > bytes - p) break;
             const std::string triple(image + p, (size_t)tl);
             p += tl;
-            if (triple.find("amdgcn") == std::string::npos || size == 0 || b + off + size > bytes) continue;
+            if (triple.find("amdgcn") == std::string::npos || size == 0 || off > bytes - b || size > bytes - b - off) continue;
             std::string sub;
             const int f = audit(image + b + off, (size_t)size, &sub);
-            if (f < 0) { if (report) *report += triple + ": " + sub + "\n"; return -1; }
+            if (f < 0) { if (report) *report += triple + ": " + sub + "\n"; return f; }
             if (f > 0 && report) *report += triple + " (bundle at 0x" + std::to_string(b) + "):\n" + sub;
             total = (total < 0 ? 0 : total) + f;
         }
     }
-    if (total < 0 && report) *report += "neither a gfx950 code object nor a file with embedded offload bundles";
+    if (total < 0 && report) *report += "neither a gfx950 code object nor a file with embedded (uncompressed) offload bundles";
     return total;
 }
 

@@ -106,6 +106,11 @@ RTGR_DEV void fold_distances(const DevObject<R>& o, const R (&pos)[P][4], R (&dm
                 dmin[p] = rmin(dmin[p], rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, nR2))));
             }
         }
+#ifdef RTGR_USER_OBJECTS
+    } else if (o.kind == RTGR_USER_OBJECT) {                                           // the unit's own distance method (:377-386)
+#pragma unroll
+        for (int p = 0; p < P; p++) dmin[p] = rmin(dmin[p], rtgr_user_distance<R>(o.type, pos[p], o.p));
+#endif
     } else {
         // RTGR_DISK: the scan needs the distance's SIGN only — disk_sign_distance reads it off x² + y² without a square
         // root, exactly (rtgr_physics.hpp).  The asm barrier pins the operands inside this branch: without it LLVM hoists
@@ -497,6 +502,20 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                                      rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
                                     const R mag = rabs(D0) + R(2) * Rr * Rr;  // >= |X|² + R²: the operands' magnitude, for the floor
                                     safe = safe && (rabs(D0) > rfma(guard, B, R(256) * eps * mag));
+#ifdef RTGR_USER_OBJECTS
+                                } else if (ob.kind == RTGR_USER_OBJECT) {
+#ifdef RTGR_USER_REACH
+                                    // the source's own bound of how far its distance can move inside the box |x'_q − x_q| <= δ_q
+                                    // (+ a floor of a few hundred ulp of the distance's natural scale, 1 + |d|: a distance that is
+                                    //  itself rounding noise goes through the real scan, as for the built-ins)
+                                    const R gd[4] = {guard * dl[0], guard * dl[1], guard * dl[2], guard * dl[3]};
+                                    const R du = rtgr_user_distance<R>(ob.type, x, ob.p);
+                                    const R bu = rtgr_user_reach<R>(ob.type, x, ob.p, gd);
+                                    safe = safe && (rabs(du) > bu + R(256) * eps * (R(1) + rabs(du)));
+#else
+                                    safe = false;   // no bound given: never provably out of reach (such units run the FULL pass)
+#endif
+#endif
                                 } else {
                                     R px = x[1], py = x[2];
                                     asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's root inside this branch
@@ -1072,8 +1091,10 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
 #define RTGR_ROOT_STATS_ARG
 #endif
 
+// (a body function: a unit with user objects wraps it in a resolve kernel of its own — the root-find evaluates the objects'
+//  distances and the colour rule their objcolor)
 template <class R>
-__global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
+RTGR_DEV void resolve_body(const ResolveArgs<R>& A) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= A.n) return;
     const RecRef<const R> rec{A.hand + w * HAND_W, A.rec + w * (uint64_t)A.recw};
@@ -1124,6 +1145,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
     if (A.hit) A.hit[idx] = hit;
     if (A.n_accept) A.n_accept[idx] = mt[0];
     if (A.n_reject) A.n_reject[idx] = mt[1];
+}
+template <class R>
+__global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {
+    resolve_body<R>(A);
 }
 
 }  // namespace rtgr

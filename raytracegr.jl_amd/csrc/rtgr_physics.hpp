@@ -823,6 +823,23 @@ RTGR_DEV void christoffel_dev(const R g[4][4], const R dg[4][4][4], R Gam[4][4][
 }
 
 // ---- objects (src/RayTraceGR.jl:374-441) -------------------------------------------------------------------------------
+// `Object{T}` is an open abstract type with two methods, distance and objcolor (:374-389).  A run-time unit whose source
+// defines them (rtgr_user_unit.hip.in sets RTGR_USER_OBJECTS) supplies
+//     template <class S> __device__ S    rtgr_user_distance(unsigned type, const S x[4], const S p[9]);
+//     template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]);
+// and, optionally (RTGR_USER_REACH), the bound the FAR pass needs to skip a step's scan:
+//     template <class S> __device__ S    rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]);
+//     >= |distance(x') − distance(x)| for every x' with |x'_q − x_q| <= dl[q]
+// (include/rtgr.h "user objects").  The library's own kernels are compiled without them: a scene with an RTGR_USER_OBJECT
+// only ever runs with the kernels of its unit (convert_scene, rtgr_api.hip).
+#ifdef RTGR_USER_OBJECTS
+template <class S> __device__ S rtgr_user_distance(unsigned type, const S x[4], const S p[9]);
+template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]);
+#ifdef RTGR_USER_REACH
+template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]);
+#endif
+#endif
+
 template <class R>
 RTGR_DEV R obj_distance(const DevObject<R>& o, const R pos[4]) {
     if (o.kind == RTGR_PLANE) return pos[0] - o.p[0];                                    // :399-401
@@ -832,6 +849,9 @@ RTGR_DEV R obj_distance(const DevObject<R>& o, const R pos[4]) {
         const R d = rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, -Rr * Rr)));
         return Rr < R(0) ? -d : d;  // sign(R)*( … ); R = 0 never used
     }
+#ifdef RTGR_USER_OBJECTS
+    if (o.kind == RTGR_USER_OBJECT) return rtgr_user_distance<R>(o.type, pos, o.p);     // distance(obj::MyThing, pos)  :377-386
+#endif
     // RTGR_DISK: max(|z|−h, r_in−ϱ, ϱ−r_out)
     const R rc = rsqrt_(rfma(pos[1], pos[1], pos[2] * pos[2]));
     R d = rabs(pos[3]) - o.p[0];

@@ -151,7 +151,9 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
               int near_waves = waves_per_simd_of<R, METRIC>(MODE_NEAR);
               if constexpr (USER) if (E.user->near_waves) near_waves = (int)E.user->near_waves;
               dim3 gn = grid(near_waves);
-              const uint64_t one_wave_below = (uint64_t)D.num_cu * 12 * 64 * (SPIN ? 32 : 12);
+              bool spin_rt = SPIN;
+              if constexpr (USER) spin_rt = E.user->spin;   // (a unit's kernels may be a built-in metric's a = 0 instantiation)
+              const uint64_t one_wave_below = (uint64_t)D.num_cu * 12 * 64 * (spin_rt ? 32 : 12);
               const long wn = K.waves_per_cu_near >= 0 ? K.waves_per_cu_near : (P.n < one_wave_below ? 4 : 0);
               if (wn > 0 && (uint64_t)D.num_cu * (uint64_t)wn < gn.x) gn.x = (unsigned)((uint64_t)D.num_cu * (uint64_t)wn);
               if constexpr (USER) HIP_TRY(launch_module(E.user->near, gn.x, 64, st, P));
@@ -249,7 +251,10 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     cur += 4096;
     // Float32 rays last ~20 steps: one FULL pass wins (measured 5-6 %)
     // (a user unit carries Float32 twins of the FULL pass only)
-    const bool split = (K.split >= 0 ? K.split != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
+    // (… and a unit whose objects come without a reach bound has nothing to decide a hand-over by: every accepted step is
+    //  scanned, as the reference does — the single FULL pass; include/rtgr.h "user objects")
+    bool split = (K.split >= 0 ? K.split != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
+    if constexpr (USER) if (E.user->has_objects && !E.user->has_reach) split = false;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;
         const R* s0 = A.state0 ? A.state0 + off * 8 : nullptr;  // null: prepare_kernel generates the camera rays
@@ -257,7 +262,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
         // last ~20 steps, so above 2 M rays the order's own kernels and the scattered record traffic cost more than the
         // shorter tail returns (measured: 2048² a = 0.8 3.21 -> 2.98 ms, 4096² 12.4 -> 10.8 ms; 1024² a = 0 0.98 <- 1.56)
         const bool order_auto = sizeof(R) == 8 || m <= (1ull << 21);
-        const bool use_order = METRIC != RTGR_MINKOWSKI && m >= 4096 && (K.order >= 0 ? K.order != 0 : order_auto);
+        const bool use_order = METRIC != RTGR_MINKOWSKI && A.sc.metric != RTGR_MINKOWSKI && m >= 4096 && (K.order >= 0 ? K.order != 0 : order_auto);
         unsigned long long* q = E.ss.queue;  // one slot per stream: the stream orders this chunk behind the previous one
         hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, st, q, use_order ? hist : (uint32_t*)nullptr);
         IntegrateArgs<R> IA;
@@ -307,7 +312,12 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
         RA.status = A.status; RA.hit = A.hit; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
         {
             KernelTimer tm(D, st, 2);
-            hipLaunchKernelGGL(resolve_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, RA);
+            bool done = false;
+            if constexpr (USER) if (E.user->has_objects) {   // the unit's resolve kernel: its objects' distance / objcolor
+                HIP_TRY(launch_module(sizeof(R) == 8 ? E.user->resolve : E.user->resolve_f32, (unsigned)((m + 255) / 256), 256, st, RA));
+                done = true;
+            }
+            if (!done) hipLaunchKernelGGL(resolve_kernel<R>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, RA);
         }
     }
     return RTGR_OK;

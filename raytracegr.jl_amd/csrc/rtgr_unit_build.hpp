@@ -183,7 +183,9 @@ struct Built {
 };
 
 // 0 = ok; 1 = the user's source does not compile (log in *why); 2 = anything else (*why)
-inline int build(const std::string& unit, const std::string& include_dir, bool stationary, bool ks_form, Built* out, std::string* why) {
+// `defines`: what the unit is made of (-DRTGR_USER_NE=3, -DRTGR_USER_KS=1, -DRTGR_USER_OBJECTS=1, -DRTGR_UNIT_BUILTIN_METRIC=…,
+// -DRTGR_HEADER_HASH=…: rtgr_api.hip plan_unit, the same rules as user_metric.py unit_defines)
+inline int build(const std::string& unit, const std::string& include_dir, const std::vector<std::string>& defines, Built* out, std::string* why) {
     static std::mutex one_build_at_a_time;   // (the compiler libraries keep process-wide state; builds are seconds long and rare)
     std::lock_guard<std::mutex> lock(one_build_at_a_time);
     Hiprtc& R = hiprtc();
@@ -195,9 +197,12 @@ inline int build(const std::string& unit, const std::string& include_dir, bool s
         "#pragma once\ntypedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
         "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"};
     static const char* const hdr_name[] = {"hip/hip_runtime.h", "stdint.h"};
-    static const char* const LEVELS[][2] = {{nullptr, nullptr},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2"},
-                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1"}};
+    // occupancy levels (generic-RHS kernels | closed-form kernels of a built-in metric: whichever the unit instantiates reads its own)
+    static const char* const LEVELS[][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2",
+                                             "-DRTGR_WAVES_PER_SIMD_FAR=2", "-DRTGR_WAVES_PER_SIMD=1", "-DRTGR_WAVES_PER_SIMD_F32=2"},
+                                            {"-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1",
+                                             "-DRTGR_WAVES_PER_SIMD_FAR=1", "-DRTGR_WAVES_PER_SIMD=1", "-DRTGR_WAVES_PER_SIMD_F32=1"}};
     const std::string inc = "-I" + include_dir;
     std::string problems;
     Built best;
@@ -206,8 +211,7 @@ inline int build(const std::string& unit, const std::string& include_dir, bool s
         if (R.create(&prog, unit.c_str(), "rtgr_user_unit.hip", 2, hdr_src, hdr_name) != 0) { *why = "hiprtcCreateProgram failed"; return 2; }
         // -fgpu-rdc: hiprtc then keeps the optimised bitcode (hiprtcGetBitcode) instead of going on to a code object
         std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fgpu-rdc", inc.c_str()};
-        if (stationary || ks_form) opts.push_back("-DRTGR_USER_NE=3");   // (Kerr–Schild form: stationary by contract)
-        if (ks_form) opts.push_back("-DRTGR_USER_KS=1");
+        for (const std::string& d : defines) opts.push_back(d.c_str());
         for (const char* o : LEVELS[level]) if (o) opts.push_back(o);
         const int cr = R.compile(prog, (int)opts.size(), opts.data());
         if (cr != 0) {
@@ -216,7 +220,7 @@ inline int build(const std::string& unit, const std::string& include_dir, bool s
             if (R.log_size(prog, &ls) == 0 && ls > 1) { log.resize(ls); (void)R.log(prog, &log[0]); }
             (void)R.destroy(&prog);
             if (log.size() > 6000) log.resize(6000);
-            *why = "hiprtc failed on the user metric:\n" + log;
+            *why = "hiprtc failed on the unit's source:\n" + log;
             return 1;
         }
         size_t bs = 0;

@@ -51,20 +51,53 @@ def _digest(source, extra_flags=()):
     return h.hexdigest()[:20]
 
 
-def compile_user_metric(source, verbose=False, stationary=False):
-    """Build (or fetch from the cache) the code object of a user metric; returns its path.  Needs hipcc, no GPU.
-    stationary=True declares that the metric does not depend on t: the integrate kernels then carry the three spatial
-    partials only (-DRTGR_USER_NE=3), a quarter less dual arithmetic."""
+def unit_defines(source, stationary=False, built_for=None):
+    """What a unit is made of, read off its source text and the metric variant it is meant for — the same rules as rtgr_api.hip:
+    plan_unit.  built_for = (metric kind, generic, spin) of a built-in metric for a source that defines OBJECTS only."""
     ks_form = "rtgr_user_ks" in source    # the metric given in Kerr–Schild form: f and k instead of the 16 entries
-    if "rtgr_user_metric" not in source and not ks_form:
+    metric = ks_form or "rtgr_user_metric" in source
+    dist, colr = "rtgr_user_distance" in source, "rtgr_user_objcolor" in source
+    if dist != colr:
+        raise ValueError("objects need both methods of the reference's Object (src/RayTraceGR.jl:377-389): rtgr_user_distance AND rtgr_user_objcolor")
+    if not metric and not dist:
         raise ValueError("the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
                          "double M, double a, S g[4][4])` (or rtgr_user_ks(const S x[4], double M, double a, S& f, S k[3]) "
-                         "for a metric of Kerr-Schild form)")
+                         "for a metric of Kerr-Schild form) and / or the object methods rtgr_user_distance / rtgr_user_objcolor")
+    extra = []
+    if metric:
+        if built_for is not None:
+            raise ValueError("the source defines a metric of its own: built_for must be None")
+        if stationary or ks_form:
+            extra.append("-DRTGR_USER_NE=3")
+        if ks_form:
+            extra.append("-DRTGR_USER_KS=1")
+    else:
+        if built_for is None:
+            raise ValueError("a unit of objects alone is built for ONE built-in metric variant: built_for = (kind, generic, spin)")
+        kind, generic, spin = int(built_for[0]), bool(built_for[1]), bool(built_for[2])
+        if kind == _abi.MINKOWSKI:
+            generic = spin = False
+        if not 0 <= kind < _abi.USER:
+            raise ValueError("built_for names no built-in metric")
+        extra += [f"-DRTGR_UNIT_BUILTIN_METRIC={kind}", f"-DRTGR_UNIT_GENERIC={int(generic)}", f"-DRTGR_UNIT_SPIN={int(spin and not generic)}"]
+    if dist:
+        extra.append("-DRTGR_USER_OBJECTS=1")
+        if "rtgr_user_reach" in source:
+            extra.append("-DRTGR_USER_REACH=1")
+    elif "rtgr_user_reach" in source:
+        raise ValueError("rtgr_user_reach without rtgr_user_distance / rtgr_user_objcolor")
+    return extra, (stationary or ks_form) if metric else False
+
+
+def compile_user_metric(source, verbose=False, stationary=False, built_for=None):
+    """Build (or fetch from the cache) the code object of a run-time unit — a user metric, user objects, or both; returns its
+    path.  Needs hipcc, no GPU.
+    stationary=True declares that the metric does not depend on t: the integrate kernels then carry the three spatial
+    partials only (-DRTGR_USER_NE=3), a quarter less dual arithmetic.  built_for: see unit_defines."""
+    extra, stat = unit_defines(source, stationary, built_for)
     d = cache_dir()
-    extra = ["-DRTGR_USER_NE=3"] if (stationary or ks_form) else []
-    if ks_form:
-        extra.append("-DRTGR_USER_KS=1")
     tag = _digest(source, extra + [f"max_scratch={MAX_SCRATCH}"])
+    extra = extra + [f"-DRTGR_HEADER_HASH={_build.header_hash():#x}ull"]   # (the headers are part of the digest already)
     out = os.path.join(d, f"metric_{tag}.hsaco")
     if os.path.exists(out):
         return out
@@ -78,7 +111,7 @@ def compile_user_metric(source, verbose=False, stationary=False):
         # no hipcc on this box (a runtime-only ROCm): the library builds the same unit in-process (hiprtc + libamd_comgr, listing
         # checked and repaired the same way) — cached here under the same content hash
         tmp = out + f".tmp{os.getpid()}"
-        build_in_process(source, tmp, stationary=bool(stationary or ks_form))
+        build_in_process(source, tmp, stationary=bool(stat), built_for=built_for)
         os.replace(tmp, out)
         return out
     with open(TEMPLATE) as fh:
@@ -105,7 +138,7 @@ def compile_user_metric(source, verbose=False, stationary=False):
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed on the user metric ({src}):\n{r.stderr[-4000:]}")
+            raise RuntimeError(f"hipcc failed on the unit's source ({src}):\n{r.stderr[-4000:]}")
         worst = max(integrate_kernel_scratch(r.stderr).values(), default=0)
         with open(asm) as fh:
             lines = fh.read().split("\n")
@@ -151,8 +184,11 @@ def _assemble(asm, out):
 
 
 MAX_SCRATCH = 64   # bytes per lane; == RTGR_USER_MAX_SCRATCH of rtgr_api.hip
-LEVELS = [[], ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2"],
-          ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1"]]
+# (generic-RHS kernels | closed-form kernels of a built-in metric in a unit of objects: whichever the unit instantiates reads its own)
+LEVELS = [[], ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2",
+               "-DRTGR_WAVES_PER_SIMD_FAR=2", "-DRTGR_WAVES_PER_SIMD=1", "-DRTGR_WAVES_PER_SIMD_F32=2"],
+          ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=1",
+           "-DRTGR_WAVES_PER_SIMD_FAR=1", "-DRTGR_WAVES_PER_SIMD=1", "-DRTGR_WAVES_PER_SIMD_F32=1"]]
 
 
 def code_object_scratch(path):
@@ -239,6 +275,88 @@ class UserMetric:
         return f"UserMetric({self.name}, M={self.M}, a={self.a}, {'hiprtc' if self.jit else os.path.basename(self.code_object)})"
 
 
+class UserObjects:
+    """A family of NEW `Object{T}` subtypes (src/RayTraceGR.jl:374-389) given as device source: the reference's two methods
+
+        template <class S> __device__ S    rtgr_user_distance(unsigned type, const S x[4], const S p[9]);
+        template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]);
+
+    (+ optionally rtgr_user_reach, include/rtgr.h "user objects").  Calling the family makes an object:
+
+        shapes = UserObjects(SOURCE)
+        torus = shapes(0, [R, r])            # type 0 of the source, fields p[0..8]
+        trace_rays(kerr_schild, [sky, torus, plane], canvas)
+
+    The unit that carries the objects' kernels is built for the metric it is traced with (make_scene: one unit per (metric
+    variant, source), cached on disk by content hash like user metrics)."""
+
+    def __init__(self, source, name="user_objects", jit=False):
+        if "rtgr_user_distance" not in source or "rtgr_user_objcolor" not in source:
+            raise ValueError("the source must define rtgr_user_distance and rtgr_user_objcolor (the two methods of the reference's Object)")
+        if "rtgr_user_metric" in source or "rtgr_user_ks" in source:
+            raise ValueError("a UserObjects source defines objects only; give the metric as a UserMetric (make_scene joins the two sources)")
+        self.source, self.name, self.jit = source, name, bool(jit)
+        self._jit_ids = {}
+
+    def __call__(self, type, params=()):
+        return UserObject(self, type, params)
+
+    def unit_id(self, metric, ctx=None):
+        """id (in ctx) of the unit carrying this family's kernels for `metric` — a built-in Metric or a UserMetric, whose source
+        is then compiled into the same unit.  Builds (hipcc, cached; or in-process when jit) and loads on first use."""
+        import ctypes as C
+        if isinstance(metric, UserMetric):
+            source, stationary, built_for = metric.source + "\n" + self.source, metric.stationary, None
+            jit = self.jit or metric.jit
+        else:
+            kind = int(metric.kind)
+            generic = bool(metric.generic) and kind != _abi.MINKOWSKI
+            source, stationary = self.source, False
+            built_for = (kind, generic, kind != _abi.MINKOWSKI and (generic or metric.a != 0.0))
+            jit = self.jit
+        if not jit:
+            return load(compile_user_metric(source, stationary=stationary, built_for=built_for), ctx)
+        lib = _abi.load()
+        key = (getattr(ctx, "value", ctx), source, built_for)
+        mid = self._jit_ids.get(key)
+        if mid is not None and lib.rtgr_user_metric_loaded(ctx, mid) == 1:
+            return mid
+        out = C.c_uint64(0)
+        sc = _built_for_scene(built_for)
+        _abi.check(lib, lib.rtgr_user_unit_compile(ctx, source.encode(), 1 if stationary else 0, C.byref(sc) if sc is not None else None, C.byref(out)))
+        self._jit_ids[key] = out.value
+        return out.value
+
+    def __repr__(self):
+        return f"UserObjects({self.name})"
+
+
+class UserObject:
+    """One object of a UserObjects family: (type tag, up to 9 fields) — what rtgr_object carries for RTGR_USER_OBJECT."""
+    kind = _abi.USER_OBJECT
+
+    def __init__(self, family, type, params=()):
+        self.family, self.type = family, int(type)
+        self.params = [float(v) for v in params]
+        if len(self.params) > 9:
+            raise ValueError("an object has at most 9 scalar fields (rtgr_object.p)")
+
+    def _pack(self):
+        return self.params + [0.0] * (9 - len(self.params))
+
+    def __repr__(self):
+        return f"UserObject({self.family.name}, type={self.type}, p={self.params})"
+
+
+def unit_info(mid, ctx=None):
+    """rtgr_user_unit_info as a dict: what a resident unit was built for"""
+    import ctypes as C
+    lib = _abi.load()
+    info = _abi.rtgr_unit_info()
+    _abi.check(lib, lib.rtgr_user_unit_info(ctx, mid, C.byref(info)))
+    return info.as_dict()
+
+
 def audit(path):
     """(number of FLOW blocks with vector instructions ahead of their EXEC flip, report) of a code object — or of a library that
     embeds code objects — through rtgr_code_object_audit (include/rtgr.h; no GPU needed)"""
@@ -249,11 +367,23 @@ def audit(path):
     return n.value, buf.value.decode()
 
 
-def build_in_process(source, path, stationary=False):
-    """rtgr_user_metric_build: the unit built by the LIBRARY (hiprtc + libamd_comgr, listing checked and repaired in between) into
+def _built_for_scene(built_for):
+    """(kind, generic, spin) -> the rtgr_scene rtgr_user_unit_compile / _build read the metric variant from (or None)"""
+    if built_for is None:
+        return None
+    sc = _abi.rtgr_scene()
+    sc.metric = int(built_for[0]) | (_abi.METRIC_GENERIC if built_for[1] else 0)
+    sc.M, sc.a = 1.0, (0.5 if built_for[2] else 0.0)
+    return sc
+
+
+def build_in_process(source, path, stationary=False, built_for=None):
+    """rtgr_user_unit_build: the unit built by the LIBRARY (hiprtc + libamd_comgr, listing checked and repaired in between) into
     `path` — what a C or Julia caller gets without hipcc; no GPU needed"""
+    import ctypes as C
     lib = _abi.load()
-    _abi.check(lib, lib.rtgr_user_metric_build(source.encode(), 1 if stationary else 0, path.encode()))
+    sc = _built_for_scene(built_for)
+    _abi.check(lib, lib.rtgr_user_unit_build(source.encode(), 1 if stationary else 0, C.byref(sc) if sc is not None else None, path.encode()))
     return path
 
 

@@ -32,7 +32,7 @@
 
 /* ---- the table (bytes) -------------------------------------------------------------------------------------------- */
 _Static_assert(sizeof(rtgr_object) == 80, "rtgr_object");
-_Static_assert(offsetof(rtgr_object, kind) == 0 && offsetof(rtgr_object, reserved) == 4 && offsetof(rtgr_object, p) == 8, "rtgr_object fields");
+_Static_assert(offsetof(rtgr_object, kind) == 0 && offsetof(rtgr_object, type) == 4 && offsetof(rtgr_object, p) == 8, "rtgr_object fields");
 _Static_assert(sizeof(rtgr_scene) == 1312, "rtgr_scene");
 _Static_assert(offsetof(rtgr_scene, metric) == 0 && offsetof(rtgr_scene, nobj) == 4 && offsetof(rtgr_scene, M) == 8 &&
                offsetof(rtgr_scene, a) == 16 && offsetof(rtgr_scene, user_metric) == 24 && offsetof(rtgr_scene, obj) == 32, "rtgr_scene fields");

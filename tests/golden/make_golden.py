@@ -18,11 +18,12 @@ import oracle_lib as O  # noqa: E402
 from scenes import scene_variant, rt  # noqa: E402
 
 VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk"]
+SHAPES = ["ks_ref0_shapes", "ks_true08_shapes", "mink_shapes"]   # user-defined Object subtypes (examples/user_objects.py; oracle twins)
 N = 32
 
 if __name__ == "__main__":
-    for name in VARIANTS:
-        sc, cam = scene_variant(name)
+    for name in (sys.argv[1:] or VARIANTS + SHAPES):
+        sc, cam = scene_variant(name, units=False)
         r = O.trace(sc, rt.solver_defaults(), N, N, cam=cam)
         out = os.path.join(HERE, f"oracle_{name}_{N}.npz")
         np.savez_compressed(out, rgb=r["rgb"], state_end=r["state_end"], lambda_end=r["lambda_end"],

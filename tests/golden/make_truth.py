@@ -19,7 +19,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk", "schw_iso", "kerr_bl"]
+VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk", "schw_iso", "kerr_bl",
+            "ks_ref0_shapes", "ks_true08_shapes"]   # *_shapes: user-defined Object subtypes (examples/user_objects.py)
 N, GRID = 200, 8
 
 
@@ -35,7 +36,7 @@ def truth_scene(name):
     (the user-metric example; only kind / M enter here, no module is compiled or loaded)."""
     from scenes import scene_variant, rt
     if name not in ("schw_iso", "kerr_bl"):
-        return scene_variant(name)
+        return scene_variant(name, units=False)
     sc, cam = scene_variant("ks_true0" if name == "schw_iso" else "ks_true08")
     sc.metric = rt._abi.USER
     if name == "kerr_bl":          # Kerr a = 0.8 in Boyer–Lindquist coordinates (examples/user_metrics.py)

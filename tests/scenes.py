@@ -11,9 +11,39 @@ def example(n):
     return rt.make_scene(metric, objs), rt.make_camera(**cam)
 
 
-def scene_variant(name):
+def user_shapes(reach=True, jit=False):
+    """The two Object subtypes of examples/user_objects.py as a UserObjects family (one instance per (reach, jit): make_scene wants
+    the user objects of a scene to share their family), and the two objects the *_shapes scenes put where example2 has its
+    small sphere: a torus seen edge-on, an ellipsoid partly behind it and a second, smaller torus."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import user_objects as uo
+    key = (bool(reach), bool(jit))
+    if key not in _FAMILIES:
+        _FAMILIES[key] = rt.UserObjects(uo.SHAPES_WITH_REACH if reach else uo.SHAPES, name="shapes" + ("+reach" if reach else ""), jit=jit)
+    fam = _FAMILIES[key]
+    # (the screen's rays fan out to x in [2.5, 5.5], z in [-1.5, 1.5] at y = 0: the three objects cover about a third of the frame)
+    return fam, [fam(uo.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]), fam(uo.ELLIPSOID, [3.3, 1.0, -0.8, 0.7, 0.5, 0.5]),
+                 fam(uo.TORUS, [4.7, 0.6, 0.95, 0.45, 0.2])]
+
+
+_FAMILIES = {}
+
+
+def scene_variant(name, units=True, reach=True, jit=False):
     """BASELINE.json configs: 'ks_ref0' (example2 as written), 'ks_ref08', 'ks_true0', 'ks_true08', 'ks_true0998',
-    'ks_true0998_disk' (config 5), 'mink' (example1)."""
+    'ks_true0998_disk' (config 5), 'mink' (example1).  '<variant>_shapes': the same with example2's small sphere replaced by two
+    user-defined objects (user_shapes; units=False: a scene for the oracle — nothing is compiled or loaded)."""
+    if name.endswith("_shapes"):
+        base = name[:-len("_shapes")]
+        metric, objs, cam = rt.example1_scene() if base == "mink" else rt.example2_scene()
+        if base != "mink":
+            metric = {"ks_ref0": rt.kerr_schild, "ks_ref08": rt.KerrSchild(1, 0.8, textbook=False), "ks_true0": rt.KerrSchild(1, 0.0),
+                      "ks_true08": rt.KerrSchild(1, 0.8), "ks_ref0_generic": rt.KerrSchild(1, 0.0, textbook=False, generic=True)}[base]
+        else:
+            cam = rt.example2_scene()[2]   # (example2's camera: the shapes sit around (4, 0, 0))
+        return rt.make_scene(metric, objs[:2] + user_shapes(reach, jit)[1], units=units), rt.make_camera(**cam)
     _, objs, cam = rt.example2_scene()
     m = {"ks_ref0": rt.kerr_schild, "ks_ref08": rt.KerrSchild(1, 0.8, textbook=False),
          "ks_true0": rt.KerrSchild(1, 0.0), "ks_true08": rt.KerrSchild(1, 0.8),
@@ -41,6 +71,12 @@ def circular_channels(hit, sc=None):
     circ[0] = sph
     circ[1] = sph | dsk
     circ[2] = dsk
+    if sc is not None:   # the user objects of examples/user_objects.py: torus (type 0) R and G, ellipsoid (type 1) R and B
+        types = np.array([0] + [sc.obj[o].type for o in range(sc.nobj)])[np.minimum(hit, sc.nobj)]
+        usr = (kinds == rt._abi.USER_OBJECT) & (hit > 0)
+        circ[0] |= usr
+        circ[1] |= usr & (types == 0)
+        circ[2] |= usr & (types == 1)
     return circ
 
 

@@ -23,6 +23,7 @@ from conftest import ROOT
 from scenes import rt, scene_variant
 
 VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk"]
+SHAPES = ["ks_ref0_shapes", "ks_true08_shapes"]   # example2 with user-defined Object subtypes in the small sphere's place (scenes.user_shapes)
 USER = "schw_iso"   # example2's scene around an isotropic-coordinates Schwarzschild hole: the run-time compiled metric example
 TOL_SPHERE = 1e-9
 TOL_CAPTURED_LAMBDA, TOL_CAPTURED_STATE = 1e-8, 1e-5
@@ -33,16 +34,16 @@ def _truth(name):
     return np.load(os.path.join(ROOT, "tests", "golden", f"truth_{name}.npz"))
 
 
-def _scene(name):
+def _scene(name, **kw):
     if name != USER:
-        return scene_variant(name)
+        return scene_variant(name, **kw)
     sc, cam = scene_variant("ks_true0")       # same objects, camera, M; only the metric kind differs
     sc.metric = rt._abi.USER                  # (the oracle evaluates kind USER as the isotropic Schwarzschild example)
     return sc, cam
 
 
 def _check_against_truth(name, got, f, tol_sphere=TOL_SPHERE, tol_cap_lambda=TOL_CAPTURED_LAMBDA,
-                         tol_cap_state=TOL_CAPTURED_STATE, extra_flips=0, tol_cap_rgb=0.0, min_sphere_rays=30):
+                         tol_cap_state=TOL_CAPTURED_STATE, extra_flips=0, tol_cap_rgb=0.0, min_sphere_rays=30, nobj=3):
     """got: dict(hit, state_end, lambda_end, rgb[3, n]) of a full 200² frame."""
     n = int(f["n"])
     p = f["ij"][:, 0] + n * f["ij"][:, 1]
@@ -59,7 +60,7 @@ def _check_against_truth(name, got, f, tol_sphere=TOL_SPHERE, tol_cap_lambda=TOL
     ds = np.abs(got["state_end"][p] - f["state_end"]).max(axis=1)
     dl = np.abs(got["lambda_end"][p] - f["lambda_end"])
     drgb = np.abs(got["rgb"][:, p].T - f["rgb"])
-    per = (th / 3.0)[:, None]                                   # period of the sawtooth channels of a coloured hit
+    per = (th / float(nobj))[:, None]                           # period of the sawtooth channels of a coloured hit
     drgb = np.minimum(drgb, np.abs(per - drgb)).max(axis=1)
     sph = same & (th != PLANE)
     cap = same & (th == PLANE)
@@ -122,17 +123,36 @@ def test_truth_rhs_agrees_with_the_as_written_chain():
         assert (np.abs(got - ref) / scale).max() < 1e-12
 
 
-@pytest.mark.parametrize("name", VARIANTS + [USER])
+@pytest.mark.parametrize("name", VARIANTS + [USER] + SHAPES)
 def test_oracle_global_error_against_true_geodesics(name):
     import oracle_lib as O
     f = _truth(name)
-    sc, cam = _scene(name)
+    sc, cam = _scene(name, units=False) if name in SHAPES else _scene(name)
     n = int(f["n"])
     st0 = O.make_canvas(sc, cam, n, n)
     p = f["ij"][:, 0] + n * f["ij"][:, 1]
     assert np.abs(st0[p] - f["state0"]).max() < 1e-15           # make_canvas, restated twice
     r = O.trace(sc, rt.solver_defaults(), n, n, cam=cam)
-    _check_against_truth(name, r, f, min_sphere_rays=25)
+    _check_against_truth(name, r, f, min_sphere_rays=25, nobj=sc.nobj)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SHAPES)
+@pytest.mark.parametrize("jit", [False, True])
+def test_hip_user_objects_global_error_against_true_geodesics(name, jit):
+    """New Object subtypes compiled at run time (rtgr_user_unit_compile; src/RayTraceGR.jl:374-389): the torus and the ellipsoid of
+    examples/user_objects.py in example2's scene, against geodesics and object formulas that share nothing with the unit or the
+    oracle — built with hipcc ahead of time and in-process from source text."""
+    from test_gpu_parity import hip_trace
+    abi = rt._abi
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(-1))
+    f = _truth(name)
+    sc, cam = scene_variant(name, jit=jit)
+    assert set(f["hit"]) >= {3, 4, 5}            # the fixture's pixels see all three user objects
+    n = int(f["n"])
+    r = hip_trace(lib, sc, rt.solver_defaults(), n, n, cam=cam)
+    _check_against_truth(name, r, f, nobj=sc.nobj)
 
 
 @pytest.mark.gpu

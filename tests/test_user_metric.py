@@ -103,7 +103,8 @@ def test_listing_route_builds_the_same_code_object_as_genco(tmp_path):
     direct = str(tmp_path / "direct.hsaco")
     src = path[:-len(".hsaco")] + ".hip"
     subprocess.check_call([um._build.HIPCC, "--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17",
-                           "-DRTGR_USER_NE=3", "-I", um.CSRC, "-o", direct, src], stderr=subprocess.DEVNULL)
+                           "-DRTGR_USER_NE=3", f"-DRTGR_HEADER_HASH={um._build.header_hash():#x}ull", "-I", um.CSRC, "-o", direct, src],
+                          stderr=subprocess.DEVNULL)
     tool = lambda *a: subprocess.run([os.path.join(um.LLVM_BIN, a[0]), *a[1:]], capture_output=True, text=True, check=True).stdout
 
     def text(p):      # instruction text without the per-line address / file-name decoration

@@ -1,0 +1,316 @@
+"""User-defined objects on the device (RTGR_USER_OBJECT; rtgr_user_unit_compile / api.UserObjects).
+
+The reference's `Object{T}` is an OPEN abstract type: any subtype with `distance(obj, pos)` and `objcolor(obj, pos)` is traced —
+the ContinuousCallback condition dispatches on it (src/RayTraceGR.jl:433-441) and so does the colour rule (:518-530); `Plane` and
+`Sphere` are merely the two the file ships (:374-428).  The product compiles new subtypes, given as device source, into the scene's
+run-time unit together with the metric they are traced with.
+
+CPU part: the build rules, the units' symbols on both build routes, the oracle's twins against their committed fixtures.
+GPU part: scenes with the torus / ellipsoid of examples/user_objects.py beside built-in objects against the oracle (and, in
+tests/test_truth.py, against independent true geodesics), Float64 and Float32, hipcc-built and in-process, FAR + NEAR bit-identical
+to FULL, a unit that carries no reach bound, a unit that carries a metric too, every entry point, and the refusals."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT
+from scenes import rt, scene_variant, user_shapes, wrap_aware_rgb_err
+
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+import user_metrics  # noqa: E402
+import user_objects  # noqa: E402
+
+abi = rt._abi
+um = sys.modules[rt.__name__ + ".user_metric"]
+UNIT_KERNELS = ["rtgr_user_integrate_far", "rtgr_user_integrate_near", "rtgr_user_integrate_full10", "rtgr_user_integrate_fulln",
+                "rtgr_user_prepare", "rtgr_user_resolve", "rtgr_user_integrate_full10_f32", "rtgr_user_integrate_fulln_f32",
+                "rtgr_user_prepare_f32", "rtgr_user_resolve_f32"]
+UNIT_GLOBALS = ["rtgr_user_abi_version", "rtgr_user_header_hash", "rtgr_user_unit_desc", "rtgr_user_far_waves", "rtgr_user_near_waves",
+                "rtgr_user_f32_waves"]
+METRIC_ONLY = ["rtgr_user_canvas", "rtgr_user_eval_metric", "rtgr_user_eval_geodesic", "rtgr_user_eval_accel"]
+
+
+def _symbols(path):
+    syms = subprocess.run([os.path.join(um.LLVM_BIN, "llvm-readelf"), "--dyn-syms", "-W", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in syms.splitlines() if line.strip()}
+
+
+# ---- CPU -----------------------------------------------------------------------------------------------------------------
+def test_what_a_unit_is_made_of_is_read_off_its_source():
+    d, st = um.unit_defines(user_objects.SHAPES_WITH_REACH, built_for=(abi.KS_REF, False, False))
+    assert d == ["-DRTGR_UNIT_BUILTIN_METRIC=1", "-DRTGR_UNIT_GENERIC=0", "-DRTGR_UNIT_SPIN=0", "-DRTGR_USER_OBJECTS=1", "-DRTGR_USER_REACH=1"] and not st
+    d, _ = um.unit_defines(user_objects.SHAPES, built_for=(abi.KS_TRUE, True, True))
+    assert d == ["-DRTGR_UNIT_BUILTIN_METRIC=2", "-DRTGR_UNIT_GENERIC=1", "-DRTGR_UNIT_SPIN=0", "-DRTGR_USER_OBJECTS=1"]   # generic: one variant
+    d, _ = um.unit_defines(user_objects.SHAPES, built_for=(abi.MINKOWSKI, True, True))
+    assert d[:3] == ["-DRTGR_UNIT_BUILTIN_METRIC=0", "-DRTGR_UNIT_GENERIC=0", "-DRTGR_UNIT_SPIN=0"]                       # Minkowski: one variant
+    d, st = um.unit_defines(user_metrics.KERR_SCHILD_KS + user_objects.SHAPES_WITH_REACH)
+    assert d == ["-DRTGR_USER_NE=3", "-DRTGR_USER_KS=1", "-DRTGR_USER_OBJECTS=1", "-DRTGR_USER_REACH=1"] and st
+    assert um.unit_defines(user_metrics.SCHWARZSCHILD_ISOTROPIC) == ([], False)                                           # a metric alone: as before
+    with pytest.raises(ValueError, match="built for ONE built-in metric"):
+        um.unit_defines(user_objects.SHAPES)
+    with pytest.raises(ValueError, match="both methods"):
+        um.unit_defines(user_objects.SHAPES.replace("rtgr_user_objcolor", "rtgr_user_paint"), built_for=(1, False, False))
+    with pytest.raises(ValueError, match="built_for must be None"):
+        um.unit_defines(user_metrics.KERR_SCHILD_KS + user_objects.SHAPES, built_for=(1, False, False))
+    with pytest.raises(ValueError, match="rtgr_user_reach without"):
+        um.unit_defines(user_metrics.KERR_SCHILD_KS + user_objects.REACH)
+    with pytest.raises(ValueError):
+        rt.UserObjects(user_metrics.KERR_SCHILD_KS + user_objects.SHAPES)
+    with pytest.raises(ValueError):
+        rt.UserObjects("int nothing_here;")
+
+
+@pytest.mark.parametrize("route", ["hipcc", "in-process"])
+def test_object_units_build_on_cpu_with_every_kernel(route, tmp_path):
+    """A unit of objects for a built-in metric variant carries the integrate / set-up / RESOLVE kernels (Float64 and Float32) and none
+    of the kernels only a metric of its own needs; a unit with both carries all of them.  No spills, audit clean."""
+    for name, src, st, bf, with_metric in (("ksref0", user_objects.SHAPES_WITH_REACH, False, (abi.KS_REF, False, False), False),
+                                           ("kstrue spin, no reach", user_objects.SHAPES, False, (abi.KS_TRUE, False, True), False),
+                                           ("own metric + objects", user_metrics.KERR_SCHILD_KS + user_objects.SHAPES_WITH_REACH, True, None, True)):
+        path = (um.compile_user_metric(src, stationary=st, built_for=bf) if route == "hipcc"
+                else um.build_in_process(src, str(tmp_path / (name.replace(" ", "_").replace(",", "") + ".hsaco")), stationary=st, built_for=bf))
+        names = _symbols(path)
+        for k in UNIT_KERNELS + UNIT_GLOBALS:
+            assert k in names, (name, k)
+        for k in METRIC_ONLY:
+            assert (k in names) == with_metric, (name, k)
+        scratch = um.code_object_scratch(path)
+        assert len(scratch) == 6 and max(scratch.values()) <= um.MAX_SCRATCH, (name, scratch)
+        assert um.audit(path) == (0, ""), name
+    lib = abi.load()
+    out = str(tmp_path / "bad.hsaco")
+    assert lib.rtgr_user_unit_build(user_objects.SHAPES.encode(), 0, None, out.encode()) == abi.ERR_BAD_ARG     # objects alone need built_for
+    assert b"built_for" in lib.rtgr_last_error() and not os.path.exists(out)
+    sc = abi.rtgr_scene()
+    sc.metric = abi.USER
+    assert lib.rtgr_user_unit_build(user_objects.SHAPES.encode(), 0, C.byref(sc), out.encode()) == abi.ERR_BAD_ARG
+    sc.metric = abi.KS_REF
+    assert lib.rtgr_user_unit_build(user_metrics.KERR_SCHILD_KS.encode(), 1, C.byref(sc), out.encode()) == abi.ERR_BAD_ARG   # own metric + built-in built_for
+    bad = user_objects.SHAPES.replace("msqrt", "no_such_function")
+    assert lib.rtgr_user_unit_build(bad.encode(), 0, C.byref(sc), out.encode()) == abi.ERR_BAD_ARG
+    assert b"no_such_function" in lib.rtgr_last_error() and not os.path.exists(out)
+
+
+def test_scene_description_without_units_needs_neither_compiler_nor_gpu():
+    sc, _ = scene_variant("ks_true08_shapes", units=False)
+    assert sc.nobj == 5 and sc.user_metric == 0 and [sc.obj[k].kind for k in range(5)] == [abi.SPHERE, abi.PLANE] + [abi.USER_OBJECT] * 3
+    assert [sc.obj[k].type for k in range(5)] == [0, 0, user_objects.TORUS, user_objects.ELLIPSOID, user_objects.TORUS]
+    assert list(sc.obj[3].p)[:6] == [3.3, 1.0, -0.8, 0.7, 0.5, 0.5]
+    fam_a, fam_b = rt.UserObjects(user_objects.SHAPES), rt.UserObjects(user_objects.SHAPES)
+    with pytest.raises(ValueError, match="one UserObjects source"):
+        rt.make_scene(rt.kerr_schild, [fam_a(0, [1, 2, 3, 1, 0.1]), fam_b(1, [0] * 6)], units=False)
+
+
+def test_oracle_twins_obey_the_distance_contract():
+    """`zero on the surface, positive outside, negative inside` (src/RayTraceGR.jl:377-383), through the oracle's trace of flat-space
+    rays that start inside and outside each shape: both end with an event ON the surface (the condition's initial sign is negative
+    for the one and positive for the other)."""
+    _, (torus, egg, _) = user_shapes()
+    opt = rt.solver_defaults()
+    d_torus = lambda x: (np.hypot(x[0] - 4.0, x[1]) - 0.9) ** 2 + x[2] ** 2 - 0.3 ** 2
+    d_egg = lambda x: ((x[0] - 3.3) / 0.7) ** 2 + ((x[1] - 1.0) / 0.5) ** 2 + ((x[2] + 0.8) / 0.5) ** 2 - 1.0
+    cases = ((torus, d_torus, (4.9, 0.0, 0.0), (0.0, 0.0, 1.0)),      # from the tube's centre line upwards: leaves the tube at z = 0.3
+             (torus, d_torus, (4.0, 0.0, 0.0), (1.0, 0.0, 0.0)),      # from the hole's centre outwards: meets the tube at x = 4.6
+             (egg, d_egg, (3.3, 1.0, -0.8), (0.0, 0.0, -1.0)),        # from the centre downwards
+             (egg, d_egg, (3.3, 1.0, 0.2), (0.0, 0.0, -1.0)))         # from above: meets the top at z = -0.3
+    for obj, dist, start, direction in cases:
+        sc = rt.make_scene(rt.minkowski, [obj], units=False)
+        s0 = np.array([[0.0, *start, -1.0, *direction]])
+        r = O.trace(sc, opt, 1, 1, state0=s0)
+        assert r["hit"][0] == 1 and r["status"][0] == abi.RAY_EVENT, (start, r["hit"], r["status"])
+        assert abs(dist(r["state_end"][0, 1:4])) < 1e-12 and np.sign(dist(np.array(start))) in (-1.0, 1.0)
+    assert d_torus(np.array((4.9, 0.0, 0.0))) < 0 < d_torus(np.array((4.0, 0.0, 0.0))) and d_egg(np.array((3.3, 1.0, -0.8))) < 0 < d_egg(np.array((3.3, 1.0, 0.2)))
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def lib():
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(-1))
+    return lib
+
+
+def _info(sc):
+    return um.unit_info(sc.user_metric)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ks_ref0_shapes", "ks_true08_shapes", "mink_shapes", "ks_ref08_shapes", "ks_ref0_generic_shapes"])
+def test_scenes_with_user_objects_match_the_oracle(lib, name):
+    """The north_star bar for the last argument of trace_rays(metric, objs, canvas): hit map equal to the oracle's, RGB within 1e-6
+    (wrap-aware on the channels the shapes put a sawtooth on), statuses equal, step counts within ±1 — and the FAR + NEAR passes (the
+    source gives a reach bound) bit-identical to the single FULL pass, as for the built-in objects."""
+    from test_gpu_parity import compare, hip_trace
+    sc, cam = scene_variant(name)
+    info = _info(sc)
+    assert info["has_objects"] == 1 and info["has_reach"] == 1 and info["probe_ok"] == 1
+    assert info["metric"] == (sc.metric if (sc.metric & ~abi.METRIC_GENERIC) != abi.MINKOWSKI else abi.MINKOWSKI)
+    assert info["spin"] == int(name in ("ks_true08_shapes", "ks_ref08_shapes", "ks_ref0_generic_shapes"))
+    opt = rt.solver_defaults()
+    ref = O.trace(sc, opt, 64, 64, cam=cam)
+    assert set(np.unique(ref["hit"])) >= {1, 3, 4, 5}                       # sky, torus, ellipsoid, second torus all on screen
+    got = hip_trace(lib, sc, opt, 64, 64, cam=cam)
+    compare(got, ref, max_class_flips=(40 if name == "mink_shapes" else 0), max_step_diff=1, sc=sc)
+    with abi.options(lib, split=0):
+        full = hip_trace(lib, sc, opt, 64, 64, cam=cam)
+    for k in ("rgb", "hit", "status", "n_accept", "n_reject", "state_end", "lambda_end"):
+        assert np.array_equal(got[k], full[k], equal_nan=got[k].dtype.kind == "f"), (name, k)
+    assert got["counters"] == full["counters"]
+    again = hip_trace(lib, sc, opt, 64, 64, cam=cam)
+    assert np.array_equal(again["rgb"], got["rgb"]) and np.array_equal(again["n_accept"], got["n_accept"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ks_ref0_shapes", "ks_true08_shapes"])
+def test_user_objects_in_float32_match_the_float32_oracle(lib, name):
+    """T = Float32 (`Object{T}` is generic in T, src/RayTraceGR.jl:375): the unit's Float32 kernels against the Float32 oracle at the
+    Float32 bars of tests/test_gpu_parity.py."""
+    from test_gpu_parity import F32_FLIP_FRAC, F32_RGB_TOL, F32_STEPS, hip_trace
+    sc, cam = scene_variant(name)
+    opt = rt.solver_defaults(np.float32)
+    gpu = hip_trace(lib, sc, opt, 64, 64, cam=cam, dtype=np.float32)
+    ref = O.trace(sc, opt, 64, 64, cam=cam, dtype=np.float32)
+    flips = gpu["hit"] != ref["hit"]
+    assert flips.mean() <= F32_FLIP_FRAC, flips.mean()
+    same = ~flips
+    assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same], sc=sc) < F32_RGB_TOL
+    g = gpu["counters"]["accepted"] + gpu["counters"]["rejected"]
+    r = ref["counters"]["accepted"] + ref["counters"]["rejected"]
+    assert F32_STEPS[0] * r <= g <= F32_STEPS[1] * r, (gpu["counters"], ref["counters"])
+    assert gpu["counters"]["rays"] == 64 * 64
+
+
+@pytest.mark.gpu
+def test_a_unit_without_a_reach_bound_runs_the_full_pass_and_traces_the_same_frame(lib):
+    """rtgr_user_reach is optional: without it no user object is ever provably out of reach, the unit's scenes run the single FULL
+    pass (every accepted step scanned, as the reference does) and the frame is the one the FAR + NEAR passes of the unit WITH the
+    bound deliver — the bound decides when a step is scanned, never what the scan finds."""
+    from test_gpu_parity import compare, hip_trace
+    sc_r, cam = scene_variant("ks_ref0_shapes")
+    sc_n, _ = scene_variant("ks_ref0_shapes", reach=False)
+    assert sc_r.user_metric != sc_n.user_metric and _info(sc_n)["has_reach"] == 0 and _info(sc_n)["probe_ok"] == 1
+    opt = rt.solver_defaults()
+    a, b = hip_trace(lib, sc_r, opt, 48, 40, cam=cam), hip_trace(lib, sc_n, opt, 48, 40, cam=cam)
+    compare(b, O.trace(sc_n, opt, 48, 40, cam=cam), max_step_diff=1, sc=sc_n)
+    for k in ("hit", "status", "n_accept", "n_reject"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.abs(a["rgb"] - b["rgb"]).max() <= 1e-12 and np.abs(a["state_end"] - b["state_end"]).max() <= 1e-12
+    lib.rtgr_timing_enable(None, 0, 1)
+    hip_trace(lib, sc_n, opt, 48, 40, cam=cam)
+    ms, n = (C.c_double * 4)(), (C.c_uint64 * 4)()
+    abi.check(lib, lib.rtgr_timing_read(None, 0, C.byref(ms), C.byref(n)))
+    lib.rtgr_timing_enable(None, 0, 0)
+    assert n[1] >= 1 and n[3] == 0                                            # one main (FULL) pass, no NEAR pass
+
+
+@pytest.mark.gpu
+def test_units_built_in_process_trace_the_same_frames(lib):
+    """rtgr_user_unit_compile — one call from source text plus the scene the unit is meant for, for C and Julia callers without hipcc —
+    against the oracle, and against the hipcc-built unit of the same source."""
+    from test_gpu_parity import compare, hip_trace
+    opt = rt.solver_defaults()
+    for name in ("ks_ref0_shapes", "ks_true08_shapes"):
+        sc_j, cam = scene_variant(name, jit=True)
+        sc_h, _ = scene_variant(name)
+        assert _info(sc_j) == {**_info(sc_h)}                                  # same variant, occupancies, probe
+        got = hip_trace(lib, sc_j, opt, 48, 48, cam=cam)
+        compare(got, O.trace(sc_j, opt, 48, 48, cam=cam), max_step_diff=1, sc=sc_j)
+        ref = hip_trace(lib, sc_h, opt, 48, 48, cam=cam)
+        assert np.array_equal(got["hit"], ref["hit"]) and np.abs(got["rgb"] - ref["rgb"]).max() <= 1e-9
+    # the raw C entry: a scene, its source, one call
+    sc, cam = scene_variant("ks_true0_shapes", units=False)
+    mid = C.c_uint64(0)
+    abi.check(lib, lib.rtgr_user_unit_compile(None, user_objects.SHAPES_WITH_REACH.encode(), 0, C.byref(sc), C.byref(mid)))
+    sc.user_metric = mid.value
+    compare(hip_trace(lib, sc, opt, 32, 32, cam=cam), O.trace(sc, opt, 32, 32, cam=cam), max_step_diff=1, sc=sc)
+
+
+@pytest.mark.gpu
+def test_a_unit_may_carry_a_metric_and_objects(lib):
+    """Both extension points of trace_rays(metric, objs, canvas) at once: textbook Kerr–Schild typed as user source (Kerr–Schild form)
+    and the shapes, compiled into one unit — against the oracle's built-in metric with its shape twins, at the user-metric bars."""
+    from test_gpu_parity import compare, hip_trace
+    user = rt.UserMetric(user_metrics.KERR_SCHILD_KS, M=1.0, a=0.8, name="ks as source")
+    _, objs, cam = rt.example2_scene()
+    fam, shapes = user_shapes()
+    sc = rt.make_scene(user, objs[:2] + shapes)
+    info = _info(sc)
+    assert info["metric"] == abi.USER and info["has_objects"] == 1 and info["has_reach"] == 1 and info["probe_ok"] == 1
+    sco, camera = scene_variant("ks_true08_shapes", units=False)
+    opt = rt.solver_defaults()
+    ref = O.trace(sco, opt, 48, 48, cam=camera)
+    compare(hip_trace(lib, sc, opt, 48, 48, cam=camera), ref, max_class_flips=2, max_step_diff=2, sc=sc)
+    with abi.options(lib, split=0):
+        compare(hip_trace(lib, sc, opt, 48, 48, cam=camera), ref, max_class_flips=2, max_step_diff=2, sc=sc)
+    # the unit's own canvas / hooks serve the metric as for a metric-only unit
+    x = np.array([[0.0, 3.0, 1.0, 0.5]])
+    g = rt.dmetric(user, x)[0]
+    assert np.abs(g - rt.dmetric(rt.KerrSchild(1.0, 0.8), x)[0]).max() < 1e-14
+
+
+@pytest.mark.gpu
+def test_user_objects_through_every_entry_point(lib):
+    """The reference's own call — trace_rays(metric, objs, canvas) with an Array{Pixel} — the single-ray shape, a strided share of
+    the rows, and a context that lists the GPU twice: the same pixels as the device-resident frame."""
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_ref0_shapes")
+    metric, objs, camd = rt.example2_scene()
+    objs = objs[:2] + user_shapes()[1]
+    opt = rt.solver_defaults()
+    ni = nj = 40
+    frame = hip_trace(lib, sc, opt, ni, nj, cam=cam)
+    canvas = rt.make_canvas(metric, camd["pos"], camd["widthx"], camd["widthy"], camd["normal"], ni, nj)
+    out = rt.trace_rays(metric, objs, canvas)
+    rgb = np.stack([p.reshape(-1, order="F") for p in out.rgb_planes()])
+    assert np.array_equal(rgb, frame["rgb"])
+    px = canvas.pixels[17, 22]
+    one = rt.trace_ray(metric, objs, None, px)
+    assert np.array_equal(one["rgb"], frame["rgb"][:, 17 + 22 * ni])
+    ctx = abi.create_context(lib, [0, 0])
+    try:
+        out2 = rt.trace_rays(metric, objs, canvas, ctx=ctx)
+        assert np.array_equal(np.stack([p.reshape(-1, order="F") for p in out2.rgb_planes()]), frame["rgb"])
+    finally:
+        lib.rtgr_destroy(ctx)
+
+
+@pytest.mark.gpu
+def test_scenes_never_run_with_the_wrong_unit(lib):
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_ref0_shapes")
+    opt = rt.solver_defaults()
+    wrong = abi.rtgr_scene.from_buffer_copy(sc)
+    wrong.a = 0.8                                            # the a != 0 instantiation is another kernel
+    with pytest.raises(abi.RtgrError, match="another metric variant"):
+        hip_trace(lib, wrong, opt, 8, 8, cam=cam)
+    wrong = abi.rtgr_scene.from_buffer_copy(sc)
+    wrong.metric = abi.KS_TRUE
+    with pytest.raises(abi.RtgrError, match="another metric variant"):
+        hip_trace(lib, wrong, opt, 8, 8, cam=cam)
+    wrong = abi.rtgr_scene.from_buffer_copy(sc)
+    wrong.user_metric = 0x1234
+    with pytest.raises(abi.RtgrError, match="not loaded"):
+        hip_trace(lib, wrong, opt, 8, 8, cam=cam)
+    metric_only = rt.UserMetric(user_metrics.SCHWARZSCHILD_ISOTROPIC, stationary=True)
+    wrong = abi.rtgr_scene.from_buffer_copy(sc)
+    wrong.user_metric = metric_only.module_id()
+    with pytest.raises(abi.RtgrError, match="defines no rtgr_user_distance"):
+        hip_trace(lib, wrong, opt, 8, 8, cam=cam)
+    wrong = abi.rtgr_scene.from_buffer_copy(sc)
+    wrong.metric = abi.USER                                  # … and a unit of objects alone has no metric of its own
+    with pytest.raises(abi.RtgrError, match="defines no metric"):
+        hip_trace(lib, wrong, opt, 8, 8, cam=cam)
+    with abi.options(lib, tile=1):
+        with pytest.raises(abi.RtgrError, match="persistent pipeline"):
+            hip_trace(lib, sc, opt, 8, 8, cam=cam)
+    # a built-in scene is untouched by resident units, and an unknown kind is still refused
+    plain, _ = scene_variant("ks_ref0")
+    assert hip_trace(lib, plain, opt, 8, 8, cam=cam)["counters"]["rays"] == 64
+    plain.obj[2].kind = 5
+    with pytest.raises(abi.RtgrError, match="unknown object kind"):
+        hip_trace(lib, plain, opt, 8, 8, cam=cam)

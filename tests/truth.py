@@ -108,6 +108,11 @@ def object_distance(o, pos):
     if o.kind == abi.SPHERE:
         d2 = sum((pos[i] - p[i]) ** 2 for i in (1, 2, 3))
         return np.sign(p[8]) * (d2 - p[8] ** 2)
+    if o.kind == abi.USER_OBJECT:      # the two Object subtypes of examples/user_objects.py, restated from their DEFINITION
+        c = np.array([pos[1] - p[0], pos[2] - p[1], pos[3] - p[2]])
+        if o.type == 0:                # torus around z: squared distance from the circle of radius p[3], minus the tube radius squared
+            return (np.hypot(c[0], c[1]) - p[3]) ** 2 + c[2] ** 2 - p[4] ** 2
+        return float(np.sum((c / np.array([p[3], p[4], p[5]])) ** 2) - 1.0)
     rc = np.hypot(pos[1], pos[2])
     return max(abs(pos[3]) - p[0], p[1] - rc, rc - p[2])
 
@@ -122,6 +127,14 @@ def object_colour(o, pos):
         th = np.arccos(d[2] / np.linalg.norm(d))
         ph = np.arctan2(d[1], d[0])
         return np.array([np.mod(12 * th / np.pi, 1.0), np.mod(12 * ph / np.pi, 1.0), 1.0])
+    if o.kind == abi.USER_OBJECT:
+        p = o.p
+        c = np.array([pos[1] - p[0], pos[2] - p[1], pos[3] - p[2]])
+        if o.type == 0:
+            w = np.hypot(c[0], c[1]) - p[3]
+            return np.array([np.mod(6 * np.arctan2(c[1], c[0]) / np.pi, 1.0), np.mod(6 * np.arctan2(c[2], w) / np.pi, 1.0), 0.5])
+        q = c / np.array([p[3], p[4], p[5]])
+        return np.array([np.mod(12 * np.arccos(q[2] / np.linalg.norm(q)) / np.pi, 1.0), 0.5, np.mod(12 * np.arctan2(q[1], q[0]) / np.pi, 1.0)])
     rc = np.hypot(pos[1], pos[2])
     return np.array([1.0, np.mod(rc, 1.0), np.mod(12 * np.arctan2(pos[2], pos[1]) / np.pi, 1.0)])
 
