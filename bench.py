@@ -30,6 +30,7 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -87,6 +88,12 @@ def parse():
                          "run of its own) and compute the roofline's executed flops and HBM traffic from THIS box's counters; the "
                          "hash-keyed profile of profiles/rNN/flops.json is then the cross-check, and the fallback when a pass fails "
                          "or rocprofv3 is not there.  0: the profile only")
+    ap.add_argument("--emit-row-checksums", action="store_true",
+                    help="put the per-image-row checksums of the delivered frame on the line (nj integers): what tools/merge_flops.py "
+                         "records as the N = 1 reference a mismatch at N > 1 is attributed to rows — and ranks — with")
+    ap.add_argument("--checksum-reference", default="",
+                    help="a file holding the JSON line of an N = 1 run with --emit-row-checksums of the SAME configuration: the reference the "
+                         "delivered frame is checked against instead of the one recorded under profiles/ (rehearsals at sizes that have none)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one stream, trace and gather strictly in turn (no frames in flight)")
@@ -104,7 +111,13 @@ def parse():
     return a
 
 
-def build_scene(rt, variant, generic=False):
+_USER_SPHERE = {}
+
+
+def build_scene(rt, variant, generic=False, user_sphere=False):
+    """user_sphere: example2's small sphere typed as a USER object (examples/user_objects.py SPHERE_AS_USER_OBJECT: the same
+    distance, colour rule and reach bound through the run-time unit's generic dispatch) — the frame is the same, the difference in
+    time is what a user-defined Object costs against a built-in one."""
     _, objs, cam = rt.example2_scene()
     if variant == "mink":
         metric, objs, cam = rt.example1_scene()
@@ -121,6 +134,14 @@ def build_scene(rt, variant, generic=False):
         src = user_metrics.KERR_SCHILD if generic == "user" else user_metrics.KERR_SCHILD_KS
         metric = rt.UserMetric(src, M=metric.M, a=metric.a, stationary=True)
         generic = False
+    if user_sphere:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import user_objects
+        fam = _USER_SPHERE.setdefault("fam", rt.UserObjects(user_objects.SPHERE_AS_USER_OBJECT, name="sphere as a user object"))
+        objs = objs[:2] + [fam(0, objs[2]._pack())]
+        if generic is True and variant != "mink":     # (the unit is built for the scene's metric variant)
+            metric = rt.Metric(metric.kind, metric.M, metric.a, name=metric.__name__, generic=True)
+            generic = False
     sc = rt.make_scene(metric, objs)
     if generic and variant != "mink":
         sc.metric |= rt._abi.METRIC_GENERIC
@@ -208,6 +229,27 @@ def load_profile(a):
 
 _LIVE_BROKEN = None
 _TRACE_BROKEN = False
+_KILLED_PASSES = []   # profiler passes of this run that had to be killed (on the line: roofline.profiler_passes_killed)
+
+
+def run_group(cmd, env, timeout, what):
+    """subprocess.run for a profiler pass, in a process GROUP of its own: `rocprofv3 -- python bench.py` is three processes deep, and
+    killing only rocprofv3 at the timeout left the profiled python running on the GPU beside the configurations timed next, with no
+    note anywhere.  On timeout the whole group is killed and waited for, and the pass is recorded."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.communicate()
+        _KILLED_PASSES.append(what)
+        raise
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 
 def live_counters(a, log=None):
@@ -242,7 +284,7 @@ def live_counters(a, log=None):
                    "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "1", "--warmup", "0",
                    "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
             env = dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+            r = run_group(cmd, env, 150, f"--pmc {' '.join(counters)} ({a.variant} {a.size} {a.dtype} {a.rhs})")
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
                 _LIVE_BROKEN = f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-300:]}"
@@ -306,7 +348,7 @@ def kernel_trace_pass(a, tool):
         cmd = [tool, "--kernel-trace", "--stats", "--output-format", "csv", "-d", work, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "3", "--warmup", "1",
                "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
-        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
+        r = run_group(cmd, dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp"), 150, f"--kernel-trace ({a.variant} {a.size} {a.dtype} {a.rhs})")
         if r.returncode != 0:
             return None
         out = {}
@@ -323,17 +365,31 @@ def kernel_trace_pass(a, tool):
 
 
 def expected_checksum(a):
-    """(checksum, where from) of the N = 1 frame of this configuration recorded from the CURRENT kernel sources, or (None, why)"""
+    """(checksum, per-row checksums or None, where from) of the N = 1 frame of this configuration recorded from the CURRENT kernel
+    sources, or (None, None, why).  The per-row vector (profiles/rNN/row_checksums.json) is what lets a mismatch name the ROWS — and
+    through the row deal the rank or context device — that delivered other bits than the N = 1 frame."""
     cur = kernel_source_hash()
     key = f"{a.variant}/{a.dtype}/{a.rhs}/{a.size}"
+    if a.checksum_reference:
+        ref = next(json.loads(l) for l in open(a.checksum_reference) if l.startswith("{"))
+        c = ref["config"]
+        assert (c["variant"], ref["dtype"], c["rhs"], c["size"]) == (a.variant, a.dtype, a.rhs, a.size), "--checksum-reference: another configuration"
+        return int(ref["frame_checksum"]), ref.get("row_checksums"), a.checksum_reference
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "flops.json")), reverse=True):
         try:
             t = json.load(open(f))
-        except Exception:
+        except (OSError, ValueError):
             continue
         if t.get("kernel_source_hash") == cur and key in t.get("frame_checksums", {}):
-            return int(t["frame_checksums"][key]), os.path.relpath(f, ROOT)
-    return None, f"no frame_checksums[{key!r}] recorded from kernel sources {cur}"
+            rows = None
+            try:
+                rj = json.load(open(os.path.join(os.path.dirname(f), "row_checksums.json")))
+                if rj.get("kernel_source_hash") == cur:
+                    rows = rj.get("rows", {}).get(key)
+            except (OSError, ValueError):
+                pass
+            return int(t["frame_checksums"][key]), rows, os.path.relpath(f, ROOT)
+    return None, None, f"no frame_checksums[{key!r}] recorded from kernel sources {cur}"
 
 
 def main():
@@ -346,6 +402,7 @@ def main():
     from raytracegr_jl_amd import sharded
     abi = rt._abi
 
+    failed, line = False, {}
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -414,6 +471,7 @@ def main():
     comm = torch.cuda.Stream(device=dev) if overlap else None
     lanes = [torch.cuda.Stream(device=dev) for _ in range(nflight)] if nflight > 1 else [None]
     npass = [0]
+    corrupt_rank = int(os.environ.get("RTGR_BENCH_CORRUPT_RANK", "-1"))
     exch_events = []   # (start, end) events around every exchange, recorded on the stream the collective is enqueued on
 
     def timed_gather(rgb_t, status_t, stream):
@@ -435,6 +493,10 @@ def main():
         with torch.cuda.stream(st):
             sharded.trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device=dev, dtype=npdt, counters=ctr,
                                      out=out, status=multi)
+            if corrupt_rank == rank and nrows > 1:
+                # TEST HOOK (RTGR_BENCH_CORRUPT_RANK, tests/test_bench_gpu.py): this rank delivers one wrong row — its local row 1 —
+                # so that the failure path of the line can be rehearsed: the line must still appear, name the row and the rank, rc 2
+                out["rgb"][1, ni:2 * ni] = 0.125
             traced[b] = torch.cuda.Event()
             traced[b].record(st)
             if multi and not a.no_gather:
@@ -601,7 +663,10 @@ def main():
                 "reference_equivalent_model": f"{F_STEP} flop/step attempt + 2x{F_RHS} per ray (SURVEY 8d: what the "
                                               f"reference's dual-number formulation would execute for the same steps; NOT "
                                               f"a utilisation — the closed Kerr-Schild contraction executes fewer)",
-                "hbm_algorithmic_GBps": (my_rays * (132 + 2 * 140 + 204 + 25)) / k_s / 1e9}
+                # <= 64 B in + 24 B out + 1 status byte per ray is what the ALGORITHM moves (round-4 review: this field
+                # priced 641 B per ray, the record layout of an earlier round); what the pipeline's kernels really move is
+                # hbm_measured_GBps below, from the FETCH_SIZE / WRITE_SIZE counters
+                "hbm_algorithmic_GBps": my_rays * 89 / max(sum(float(kms[w]) for w in range(4)) * 1e-3, 1e-12) / 1e9}
         # SURVEY §8(d)'s own fraction, for the record: the reference FORMULATION's flops for the steps taken, over the time the
         # closed contraction needed for them.  It exceeds 1 on the closed-form kernels BECAUSE they do not execute the
         # dual-number work (parity-checked pointwise instead); `frac` is the executed-flop figure and the one to read.
@@ -625,6 +690,10 @@ def main():
             roof["traffic"] = src["hbm_bytes_per_ray"] * my_rays / a.steps if src.get("hbm_bytes_per_ray") else None
             if src.get("hbm_bytes_per_ray"):   # what the pipeline's hand-over records cost over the algorithm's own bytes
                 roof["traffic_over_algorithmic"] = src["hbm_bytes_per_ray"] / ALGORITHMIC_BYTES_PER_RAY
+                # measured HBM bytes of ALL pipeline kernels (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) over the time
+                # all of them took: ~2 % of the 8 TB/s peak — the path is VALU-bound, the figure is here for completeness
+                roof["hbm_measured_GBps"] = src["hbm_bytes_per_ray"] * my_rays / max(sum(float(kms[w]) for w in range(4)) * 1e-3, 1e-12) / 1e9
+                roof["hbm_frac_of_peak"] = roof["hbm_measured_GBps"] / 8000.0
             if live is not None:
                 roof["live"] = live
                 tr = live.get("rocprof_kernel_trace")
@@ -720,24 +789,47 @@ def main():
         if frame is not None:
             bits = frame.contiguous().view(torch.int64 if a.dtype == "f64" else torch.int32).to(torch.int64)
             line["frame_checksum"] = int(bits.sum().item())
+            # one checksum per IMAGE ROW (the unit the frame is dealt by): rgb planes are [3, ni * nj] with pixel i + j * ni
+            rows = bits.view(3, nj, ni).sum(dim=(0, 2)).cpu().numpy().astype(np.int64)
+            line["row_checksums_sha256"] = hashlib.sha256(rows.tobytes()).hexdigest()[:16]
+            if a.emit_row_checksums:
+                line["row_checksums"] = [int(v) for v in rows]
             # … which must equal the N = 1 device-entry frame's of the same configuration and kernel sources, recorded with the
-            # round's profiles (profiles/rNN/flops.json "frame_checksums"): asserted at every N and through every entry point
-            want, src = expected_checksum(a)
+            # round's profiles (profiles/rNN/flops.json "frame_checksums", row_checksums.json): checked at every N and through every
+            # entry point.  A mismatch does NOT stop the line (round-4 review: an assert here killed rank 0 before it printed and left
+            # the other ranks in the closing barrier): the line says which rows differ and whose they are, then the run exits 2.
+            want, want_rows, src = expected_checksum(a)
             line["frame_checksum_expected"] = want
             line["frame_checksum_source"] = src
             if want is not None:
                 line["frame_checksum_ok"] = bool(want == line["frame_checksum"])
-                assert line["frame_checksum_ok"], (f"the delivered frame differs from the N = 1 frame of the same kernel sources: "
-                                                   f"checksum {line['frame_checksum']} != {want} ({src})")
+                if want_rows is not None and len(want_rows) == nj:
+                    bad = np.nonzero(rows != np.asarray(want_rows, dtype=np.int64))[0]
+                    line["frame_checksum_ok"] = bool(line["frame_checksum_ok"] and bad.size == 0)
+                    if bad.size:
+                        nparts = ws if a.entry == "device" else len(ctx_ids)
+                        owner = [int(r) for r in sorted({int(sharded.row_owner(nj, nparts, int(j), a.layout if a.entry == "device" else "cyclic")) for j in bad})]
+                        line["frame_checksum_bad_rows"] = {"count": int(bad.size), "first": [int(j) for j in bad[:16]],
+                                                           ("ranks" if a.entry == "device" else "context_devices"): owner,
+                                                           "note": "image rows whose bits differ from the recorded N = 1 frame, and who traced them"}
+                elif not line["frame_checksum_ok"]:
+                    line["frame_checksum_bad_rows"] = {"note": "no per-row vector recorded for this configuration: the whole-frame checksum differs"}
+                failed = not line["frame_checksum_ok"]
+        if _KILLED_PASSES:
+            roof["profiler_passes_killed"] = list(_KILLED_PASSES)   # (their whole process group was killed at the timeout: nothing left on the GPU)
         print(json.dumps(line), flush=True)
     if ctx:
         abi.check(lib, lib.rtgr_destroy(ctx))
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:   # (rank 0 only: its line has been printed and every rank has passed the closing barrier)
+        print(f"bench.py: the delivered frame differs from the N = 1 frame of the same kernel sources: {line.get('frame_checksum_bad_rows')}",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
 
 
-def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, live_on=False):
+def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, live_on=False, user_sphere=False):
     """One BASELINE configuration outside the headline's timed region: `reps` device-resident frames (camera on the device,
     nothing over PCIe), wall time + the library's HIP-event kernel times, and the same executed-flop roofline as the headline's,
     from counters read by this run (live_counters(); Float64 configurations) or THIS configuration's profile entry
@@ -746,7 +838,7 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     import torch
     from raytracegr_jl_amd import sharded
     npdt = np.float64 if dtype == "f64" else np.float32
-    sc, cam = build_scene(rt, variant, {"closed": False, "generic": True}[rhs])
+    sc, cam = build_scene(rt, variant, {"closed": False, "generic": True}[rhs], user_sphere=user_sphere)
     opt = rt.solver_defaults(npdt)
     ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
     o = {}
@@ -767,7 +859,9 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     rt._abi.check(lib, lib.rtgr_timing_enable(None, 0, 0))
     att = (int(ctr[1]) + int(ctr[2])) / reps
     rays = n * n
-    v = {"workload": f"{variant}, same camera, {n}x{n}, {dtype}, rhs {rhs}", "size": n, "dtype": dtype, "rhs": rhs,
+    bits = o["rgb"].contiguous().view(torch.int64 if dtype == "f64" else torch.int32).to(torch.int64)
+    v = {"workload": f"{variant}, same camera, {n}x{n}, {dtype}, rhs {rhs}" + (", small sphere as a USER object" if user_sphere else ""),
+         "size": n, "dtype": dtype, "rhs": rhs, "frame_checksum": int(bits.sum().item()),
          "ms_per_pass": dt * 1e3, "step_attempts_per_s": att / dt, "rays_per_s": rays / dt,
          "step_attempts_per_ray": att / rays, "rejected_per_pass": int(ctr[2]) // reps}
     k_s = (float(kms[1]) + float(kms[3])) * 1e-3 / reps
@@ -775,6 +869,8 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
         pass
     _A.variant, _A.dtype, _A.rhs, _A.size = variant, dtype, rhs, size
     prof, why = load_profile(_A)
+    if user_sphere:     # (the unit's kernels are other kernels than the profiled ones: timing only)
+        prof, why, live_on = None, "a run-time unit's kernels: no profile entry", False
     live, why_not_live = live_counters(_A) if (live_on and dtype == "f64") else (None, "off (Float32: the packed kernel is priced from its profile)")
     # Float32: the packed two-rays-per-lane kernel is priced against the fp32 VECTOR peak (v_pk_fma_f32), as asked
     peak = FP64_VALU_PEAK_TFLOPS if dtype == "f64" else F32_PACKED_VALU_PEAK_TFLOPS
@@ -847,6 +943,24 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
         except Exception as e:  # noqa: BLE001   (one configuration must not cost the others their place on the line)
             ex["variants"][key] = {"error": repr(e)}
         rt._abi.check(lib, lib.rtgr_trim(None))   # (the 14 GB workspace of C5 is not kept for the next configuration)
+    # What a USER-DEFINED Object costs against a built-in one (round-4 review item 1): example2 at 2048² with its small sphere as the
+    # built-in RTGR_SPHERE and as an RTGR_USER_OBJECT of the same geometry (the unit is built here with hipcc when it is not in the
+    # cache — never under RTGR_NO_COMPILE; a failure costs only this entry).  Same frame; the ratio is the generic dispatch.
+    try:
+        if os.environ.get("RTGR_NO_COMPILE") == "1":
+            raise RuntimeError("RTGR_NO_COMPILE=1: the unit is not built inside this run")
+        bi = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2)
+        us = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2, user_sphere=True)
+        ex["variants"]["user_sphere_ks_ref0_2048"] = {
+            "workload": us["workload"], "ms_per_pass": us["ms_per_pass"], "builtin_ms_per_pass": bi["ms_per_pass"],
+            "user_over_builtin": us["ms_per_pass"] / bi["ms_per_pass"],
+            "far_near_ms": [us["roofline"]["far_pass_ms_per_pass"], us["roofline"]["near_pass_ms_per_pass"]],
+            "builtin_far_near_ms": [bi["roofline"]["far_pass_ms_per_pass"], bi["roofline"]["near_pass_ms_per_pass"]],
+            "same_frame": bool(us["frame_checksum"] == bi["frame_checksum"]), "step_attempts_per_s": us["step_attempts_per_s"],
+            "note": "RTGR_USER_OBJECT through a run-time unit built for this scene's metric variant (rtgr_user_unit_compile): distance / objcolor / "
+                    "reach bound of the source called from the unit's own set-up, FAR, NEAR and resolve kernels"}
+    except Exception as e:  # noqa: BLE001
+        ex["variants"]["user_sphere_ks_ref0_2048"] = {"error": repr(e)}
     g = ex["variants"].get("generic_ks_ref0_4096", {}).get("roofline")
     if g:
         g["contract_8d_note"] = ("this kernel EXECUTES the reference formulation (4-wide duals through the metric, symmetric inverse, "

@@ -53,3 +53,24 @@ template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], con
 '''
 
 SHAPES_WITH_REACH = SHAPES + REACH
+
+# The reference's own Sphere (src/RayTraceGR.jl:409-428) typed as a USER object — same distance, same colour rule, and the reach
+# bound the library uses for its built-in sphere: what the generic dispatch of a user object costs against the built-in one is
+# the difference between two frames that are otherwise the same (bench.py: variants.user_sphere_*).  p = pos (4), vel (4), radius.
+SPHERE_AS_USER_OBJECT = r'''
+template <class S> __device__ S rtgr_user_distance(unsigned type, const S x[4], const S p[9]) {
+    const S dx = x[1] - p[1], dy = x[2] - p[2], dz = x[3] - p[3], d = dx * dx + dy * dy + dz * dz - p[8] * p[8];
+    return p[8] < S(0) ? -d : d;                                                  // sign(R) * (|x - c|² - R²)   :415-419
+}
+template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]) {
+    const S pi = S(3.14159265358979323846264338327950288);
+    const S dx = x[1] - p[1], dy = x[2] - p[2], dz = x[3] - p[3], r = msqrt(dx * dx + dy * dy + dz * dz);
+    rgb[0] = mod1<S>(S(12) * macos(dz / r) / pi);                                  // :420-428
+    rgb[1] = mod1<S>(S(12) * matan2(dy, dx) / pi);
+    rgb[2] = S(1);
+}
+template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]) {
+    const S dx = x[1] - p[1], dy = x[2] - p[2], dz = x[3] - p[3];
+    return dl[1] * (S(2) * mabs(dx) + dl[1]) + dl[2] * (S(2) * mabs(dy) + dl[2]) + dl[3] * (S(2) * mabs(dz) + dl[3]);
+}
+'''

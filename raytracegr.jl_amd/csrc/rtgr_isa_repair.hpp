@@ -113,7 +113,7 @@ inline bool allocator_vector(const std::string& c) {
 }
 inline bool plain_salu(const std::string& c) {
     const std::string m = mnemonic(c);
-    return m == "s_mov_b32" || m == "s_mov_b64" || m == "s_nop";
+    return m == "s_mov_b32" || m == "s_mov_b64" || m == "s_nop" || m == "s_waitcnt";   // (s_waitcnt: no register operand, indifferent to EXEC)
 }
 
 struct Hit {

@@ -77,6 +77,18 @@ def row_assignment(nj, world_size, rank, layout="cyclic"):
     return j0, 1, j1 - j0
 
 
+def row_owner(nj, world_size, j, layout="cyclic"):
+    """the rank (or context device) that traces image row j under row_assignment — what a per-row checksum mismatch is
+    attributed to (bench.py)"""
+    if layout == "cyclic":
+        return j % world_size
+    for r in range(world_size):
+        j0, j1 = slab_bounds(nj, world_size, r)
+        if j0 <= j < j1:
+            return r
+    raise ValueError(f"row {j} outside the canvas of {nj} rows")
+
+
 def trace_rows_torch(scene, opt, cam, ni, nj, j0, jstride, nrows, device="cuda", dtype=np.float64, counters=None,
                      out=None, ctx=None, status=False):
     """Trace image rows j0, j0+jstride, … (nrows of them) into a device tensor rgb[3, ni*nrows]; asynchronous."""

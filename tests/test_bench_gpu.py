@@ -128,3 +128,36 @@ def test_bench_two_rank_rehearsal_line_is_diagnosable():
     assert sum(p["step_attempts"] for p in pr) == base["step_attempts_per_pass"]
     assert all(p["far_ms"] > 0 and p["near_ms"] > 0 and p["exchange_ms"] > 0 and p["wall_ms"] > 0 for p in pr)
     assert 1.0 <= d["rank_imbalance"]["max_over_mean"] < 2.0
+    assert len(d["row_checksums_sha256"]) == 16 and "row_checksums" not in d          # the vector itself only on request
+
+
+def test_bench_line_survives_a_wrong_row_and_names_rank_and_rows(tmp_path):
+    """The failure path of the multi-GPU line (round-4 review: an assert BEFORE the print killed rank 0 without a line and left the other
+    ranks in the closing barrier).  Rank 1 of a two-rank gloo rehearsal is made to deliver one wrong row (RTGR_BENCH_CORRUPT_RANK):
+    the line must still appear — per_rank, exchange times and all —, say frame_checksum_ok false, name image row 3 (rank 1's local row 1
+    of a cyclic deal) and rank 1, every rank must leave the barrier, and the run must fail with exit code 2 — no hang."""
+    ref = tmp_path / "n1.json"
+    base = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0", "--emit-row-checksums")
+    assert len(base["row_checksums"]) == 256 and (sum(base["row_checksums"]) - base["frame_checksum"]) % 2 ** 64 == 0   # (int64 sums wrap)
+    ref.write_text(json.dumps(base) + "\n")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29548", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "256",
+           "--steps", "2", "--warmup", "1", "--checksum-reference", str(ref)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    good = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert good.returncode == 0, good.stderr[-3000:]
+    d = json.loads([x for x in good.stdout.splitlines() if x.startswith("{")][0])
+    assert d["frame_checksum_ok"] is True and d["frame_checksum_source"] == str(ref) and "frame_checksum_bad_rows" not in d
+    bad = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, RTGR_BENCH_CORRUPT_RANK="1"), timeout=600)
+    assert bad.returncode != 0
+    lines = [x for x in bad.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, bad.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["frame_checksum_ok"] is False and d["frame_checksum"] != base["frame_checksum"]
+    assert d["frame_checksum_bad_rows"]["count"] == 1 and d["frame_checksum_bad_rows"]["first"] == [3] and d["frame_checksum_bad_rows"]["ranks"] == [1]
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["exchange_ms"] > 0 for p in d["per_rank"])
+    assert "exitcode  : 2" in bad.stderr or "exitcode: 2" in bad.stderr or "exit code 2" in bad.stderr.lower(), bad.stderr[-1500:]
+    # the single-process forms attribute rows to CONTEXT DEVICES the same way (no corruption hook inside the library: the mapping only)
+    sh = _bench("--size", "256", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--extras", "0", "--entry", "sharded", "--ctx-devices", "2",
+                "--checksum-reference", str(ref))
+    assert sh["frame_checksum_ok"] is True and sh["row_checksums_sha256"] == base["row_checksums_sha256"]

@@ -1,0 +1,102 @@
+"""Run-time units are self-verifying at load (round-4 review item 2): the EXEC-flip fault of ROCm 7.2's compiler
+was a SILENT wrong answer.  Beside the textual audit of the code object there is a load-time PROBE that looks at the fault's own
+symptom — a 32 x 32 frame traced through the FULL pass and the FAR + NEAR passes, twice each — and needs no knowledge of the
+instruction shape.  Here: a unit that carries the fault, with the audit switched off, must be refused by the probe alone; sound
+units pass it; a unit compiled from other device headers than the library's kernels is refused before it can overrun a workspace
+(ADVICE r4); an offload bundle — what a plain `hipcc --genco` writes — is audited like a bare code object."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+from scenes import rt
+
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+import user_metrics  # noqa: E402
+
+abi = rt._abi
+um = sys.modules[rt.__name__ + ".user_metric"]
+
+
+def _raw_unit(tmp_path, source, name, extra=(), bundle=False, header_hash=None):
+    """the unit as plain `hipcc --genco` builds it: no listing check, no repair (what a C / Julia user with hipcc would hand over)"""
+    with open(um.TEMPLATE) as fh:
+        unit = fh.read().replace("@RTGR_USER_SOURCE@", source)
+    hip, out = str(tmp_path / f"{name}.hip"), str(tmp_path / f"{name}.hsaco")
+    with open(hip, "w") as fh:
+        fh.write(unit)
+    hh = um._build.header_hash() if header_hash is None else header_hash
+    cmd = [um._build.HIPCC, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-DRTGR_USER_NE=3", f"-DRTGR_HEADER_HASH={hh:#x}ull",
+           *extra, "-I", um.CSRC, "-o", out, hip]
+    if not bundle:
+        cmd.insert(2, "--no-gpu-bundle-output")
+    subprocess.check_call(cmd)
+    return out
+
+
+@pytest.fixture(scope="module")
+def zoo_raw(tmp_path_factory):
+    d = tmp_path_factory.mktemp("raw_units")
+    level1 = um.LEVELS[1]          # the occupancy compile_user_metric settles on for this metric (no scratch)
+    return _raw_unit(d, user_metrics.HELPER_ZOO, "zoo", level1), _raw_unit(d, user_metrics.HELPER_ZOO, "zoo_bundle", level1, bundle=True)
+
+
+def test_raw_heavy_unit_carries_the_fault_and_the_audit_sees_it_in_bundles_too(zoo_raw):
+    """(CPU) every occupancy level of the heavy example metric compiles, with plain hipcc, to code with the fault; the audit finds it
+    in the bare code object AND in the clang offload bundle that `hipcc --genco` writes by default (round 4 loaded those unaudited)."""
+    raw, bundle = zoo_raw
+    n, report = um.audit(raw)
+    assert n >= 1 and "stands BEFORE the EXEC flip" in report
+    nb, report_b = um.audit(bundle)
+    assert nb == n and "bundle at" in report_b
+    assert open(bundle, "rb").read(24) == b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = abi.load()
+    abi.check(lib, lib.rtgr_init(-1))
+    return lib
+
+
+@pytest.mark.gpu
+def test_probe_alone_refuses_a_unit_with_the_fault(lib, zoo_raw):
+    """The fault injected AFTER the audit (option unit_audit = 0 is the hook): the probe refuses the unit on its symptom, the unit
+    is not left resident, and with the audit on both the bare code object and the bundle are refused by the audit."""
+    raw, bundle = zoo_raw
+    for path in (raw, bundle):
+        with pytest.raises(abi.RtgrError, match="FLOW block"):
+            um.load(path)
+    with abi.options(lib, unit_audit=0):
+        with pytest.raises(abi.RtgrError, match="refused by the load-time probe") as e:
+            um.load(raw)
+    assert "differ" in str(e.value) or "disagree" in str(e.value) or "apart" in str(e.value)
+    assert lib.rtgr_user_metric_loaded(None, 0) in (0, 1)          # (other tests' units may be resident; this one must not be:)
+    with abi.options(lib, unit_audit=0, unit_probe=0):             # both checks off: it loads — that is what the options mean
+        mid = um.load(raw)
+        assert um.unit_info(mid)["probe_ok"] == 0
+        abi.check(lib, lib.rtgr_user_metric_unload(None, mid))
+        um._ids.clear()
+    assert lib.rtgr_user_metric_loaded(None, mid) == 0
+
+
+@pytest.mark.gpu
+def test_sound_units_pass_the_probe_and_say_so(lib):
+    for src, st in ((user_metrics.SCHWARZSCHILD_ISOTROPIC, True), (user_metrics.HELPER_ZOO, True), (user_metrics.EXPANDING_ISOTROPIC, False)):
+        mid = um.load(um.compile_user_metric(src, stationary=st))
+        info = um.unit_info(mid)
+        assert info["probe_ok"] == 1 and info["metric"] == abi.USER and info["has_objects"] == 0, info
+
+
+@pytest.mark.gpu
+def test_a_unit_built_from_other_headers_is_refused(lib, tmp_path):
+    """The record layouts and argument blocks a unit shares with the library are not part of the C ABI; a unit kept on disk from an
+    earlier build of the headers must not load (it would write records of another shape into the workspace)."""
+    stale = _raw_unit(tmp_path, user_metrics.SCHWARZSCHILD_ISOTROPIC, "stale", header_hash=0x1234)
+    with pytest.raises(abi.RtgrError, match="header hash differs"):
+        um.load(stale)
+    unrecorded = _raw_unit(tmp_path, user_metrics.SCHWARZSCHILD_ISOTROPIC, "by_hand", header_hash=0)   # built by hand: ABI version only
+    mid = um.load(unrecorded)
+    assert um.unit_info(mid)["probe_ok"] == 1

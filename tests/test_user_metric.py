@@ -139,7 +139,7 @@ def test_user_metric_needs_a_loaded_module(lib):
     x = np.array([[0.0, 3.0, 0.0, 0.0]])
     g = np.zeros((1, 4, 4))
     rc = lib.rtgr_eval_metric_f64(None, C.byref(sc), x.ctypes.data, 1, g.ctypes.data, None, None)
-    assert rc == abi.ERR_BAD_ARG and b"no user metric loaded" in lib.rtgr_last_error()
+    assert rc == abi.ERR_BAD_ARG and b"no run-time unit loaded" in lib.rtgr_last_error()
     assert lib.rtgr_user_metric_load(None, b"/nonexistent.hsaco", None) == abi.ERR_BAD_ARG
     assert lib.rtgr_user_metric_load(None, os.path.join(ROOT, "include", "rtgr.h").encode(), None) != 0  # not a code object
     assert lib.rtgr_user_metric_loaded(None, 0) == 0

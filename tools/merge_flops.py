@@ -19,6 +19,9 @@ b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 out = {"kernel_source_hash": b.kernel_source_hash(), "hash_of": "sha256 of csrc/{%s} + compile flags" % ", ".join(b.KERNEL_HEADERS),
        "how": "tools/collect_profiles.sh on one MI355X; rocprofv3 --pmc passes separate from the --kernel-trace pass", "entries": {}}
+rows_out = {"kernel_source_hash": out["kernel_source_hash"],
+            "what": "per-image-row checksums (sum of the RGB bit patterns of a row) of the N = 1 device-entry frames; bench.py compares the "
+                    "frame every other run delivers against them and names rows and ranks on a mismatch"}
 for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
     cfg = os.path.basename(d)[len(f"prof_{rnd}_"):]
     ej = os.path.join(d, "entry.json")
@@ -39,6 +42,8 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_*"))):
     # delivering the frame (N ranks, the sharded / host / pixels entries) yields the same order-independent bit-level checksum
     if line.get("frame_checksum") is not None and line["n_gpus"] == 1 and line["config"].get("entry") == "device" and not cfg.endswith("_scalar"):
         out.setdefault("frame_checksums", {})[f'{key}/{line["config"]["size"]}'] = line["frame_checksum"]
+        if line.get("row_checksums"):   # one checksum per image row (bench.py --emit-row-checksums): names the rows of a mismatch at N > 1
+            rows_out.setdefault("rows", {})[f'{key}/{line["config"]["size"]}'] = line.pop("row_checksums")
     dst = os.path.join(ROOT, "profiles", rnd, cfg)
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(d, "summary.txt"), dst)
@@ -75,4 +80,6 @@ if os.path.exists(replay):
                 "how": "tools/micro/mix_replay.hip: the per-wave-step instruction counts of this entry as INDEPENDENT "
                        "instructions, chip-wide, wall clock; " + os.path.relpath(replay, ROOT)}
 json.dump(out, open(os.path.join(ROOT, "profiles", rnd, "flops.json"), "w"), indent=1)
+if rows_out.get("rows"):
+    json.dump(rows_out, open(os.path.join(ROOT, "profiles", rnd, "row_checksums.json"), "w"))
 print("wrote profiles/%s/flops.json for kernel sources %s" % (rnd, out["kernel_source_hash"]))

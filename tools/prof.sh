@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-python3 $R/bench.py --cpu-sample 0 --extras 0 "$@" > $OUT/bench_plain.log 2>&1
+python3 $R/bench.py --cpu-sample 0 --extras 0 --emit-row-checksums "$@" > $OUT/bench_plain.log 2>&1
 export RTGR_NO_COMPILE=1   # (--rhs user: the plain run above has filled the cache; never start hipcc under the profiler)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --cpu-sample 0 --extras 0 "$@" > $OUT/bench_trace.log 2>&1
 i=0
