@@ -272,8 +272,13 @@ def live_counters(a, log=None):
     if a.size * a.size > (1 << 26):
         return None, "more than one pipeline chunk per pass"
     sfx = "F64" if a.dtype == "f64" else "F32"
-    sets = {"flop": [f"SQ_INSTS_VALU_FMA_{sfx}", f"SQ_INSTS_VALU_MUL_{sfx}", f"SQ_INSTS_VALU_ADD_{sfx}", "SQ_INSTS_VALU"],
-            "fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"]}
+    # Float32: the FULL pass is the packed two-rays-per-lane kernel, and the per-kind counters count a v_pk_fma_f32 ONCE — half its
+    # flops (calibrated: tools/micro/pk_counter_probe.hip, profiles/r05/pk_counter_probe.log: 4096 v_pk_fma_f32 -> FMA_F32 4096,
+    # FLOPS_FP32 16386).  SQ_INSTS_VALU_FLOPS_FP32 counts flops per lane per instruction (2 / FMA, 1 / MUL or ADD, 4 / v_pk_fma_f32,
+    # 2 / v_pk_mul or add): 64 x that is the executed flops, packed or not.
+    flop_set = ([f"SQ_INSTS_VALU_FMA_{sfx}", f"SQ_INSTS_VALU_MUL_{sfx}", f"SQ_INSTS_VALU_ADD_{sfx}", "SQ_INSTS_VALU"] if a.dtype == "f64"
+                else ["SQ_INSTS_VALU_FLOPS_FP32", "SQ_INSTS_VALU"])
+    sets = {"flop": flop_set, "fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"]}
     work = tempfile.mkdtemp(prefix="rtgr_pmc_", dir="/tmp")
     tot, attempts, rays = {}, None, None
     t0 = time.time()
@@ -318,12 +323,14 @@ def live_counters(a, log=None):
     finally:
         shutil.rmtree(work, ignore_errors=True)
     fma, mul, add = (tot.get(f"SQ_INSTS_VALU_{k}_{sfx}", 0.0) for k in ("FMA", "MUL", "ADD"))
-    if fma <= 0 or not attempts:
+    flops_lane = tot.get("SQ_INSTS_VALU_FLOPS_FP32", 0.0) if a.dtype == "f32" else (2 * fma + mul + add)
+    if flops_lane <= 0 or not attempts:
         return None, f"counters came back empty: {tot}"
     trace = kernel_trace_pass(a, tool)     # (best effort: the kernels' average durations as rocprofv3 itself reports them)
-    return {"flop_per_step_attempt": 64.0 * (2 * fma + mul + add) / attempts,
+    return {"flop_per_step_attempt": 64.0 * flops_lane / attempts,
+            "flop_counter": "64 x SQ_INSTS_VALU_FLOPS_FP32 (counts packed instructions in full)" if a.dtype == "f32" else "64 x (2 FMA + MUL + ADD) of SQ_INSTS_VALU_*_F64",
             "valu_per_wave_step": tot.get("SQ_INSTS_VALU", 0.0) / (attempts / 64.0),
-            "fma_mul_add_per_wave_step": [fma / (attempts / 64.0), mul / (attempts / 64.0), add / (attempts / 64.0)],
+            "fma_mul_add_per_wave_step": [fma / (attempts / 64.0), mul / (attempts / 64.0), add / (attempts / 64.0)] if a.dtype == "f64" else None,
             # FETCH_SIZE / WRITE_SIZE count KB; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes on gfx950
             "hbm_bytes_per_ray": (2 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / rays,
             "hbm_note": "2 x FETCH_SIZE + WRITE_SIZE over the library's pipeline kernels (KB x 1024), per pass, per ray",
@@ -647,10 +654,10 @@ def main():
         prof, why = load_profile(a)
         # … and the same two figures counted HERE, on this box, by this run (N = 1, device entry): the profile is then the cross-check
         live, why_not_live = (None, "off")
-        if a.live_counters and not multi and a.entry == "device" and not ctx and not (a.dtype == "f32" and os.environ.get("RTGR_PACK", "1") != "0"):
+        if a.live_counters and not multi and a.entry == "device" and not ctx:
             live, why_not_live = live_counters(a)
         elif a.live_counters:
-            why_not_live = "N = 1, device entry, scalar kernels only (the packed Float32 kernel's flops need the v_pk counters' reading of the profile)"
+            why_not_live = "N = 1, device entry only"
         peak = FP64_VALU_PEAK_TFLOPS if a.dtype == "f64" else F32_SCALAR_VALU_PEAK_TFLOPS
         roof = {"bound": "valu_f64" if a.dtype == "f64" else "valu_f32_scalar", "achieved": None, "peak": peak,
                 "unit": "TFLOP/s", "frac": None, "traffic": None,
@@ -871,7 +878,7 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     prof, why = load_profile(_A)
     if user_sphere:     # (the unit's kernels are other kernels than the profiled ones: timing only)
         prof, why, live_on = None, "a run-time unit's kernels: no profile entry", False
-    live, why_not_live = live_counters(_A) if (live_on and dtype == "f64") else (None, "off (Float32: the packed kernel is priced from its profile)")
+    live, why_not_live = live_counters(_A) if live_on else (None, "off")
     # Float32: the packed two-rays-per-lane kernel is priced against the fp32 VECTOR peak (v_pk_fma_f32), as asked
     peak = FP64_VALU_PEAK_TFLOPS if dtype == "f64" else F32_PACKED_VALU_PEAK_TFLOPS
     r = {"bound": "valu_f64" if dtype == "f64" else "valu_f32_packed", "peak": peak, "unit": "TFLOP/s", "kernel_ms_per_pass": k_s * 1e3,
@@ -883,7 +890,7 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
          "contract_8d_frac": (att * F_STEP + 2 * rays * F_RHS) / k_s / 1e12 / FP64_VALU_PEAK_TFLOPS if dtype == "f64" else None}
     src = live if live is not None else prof
     r["counters"] = "live" if live is not None else ("profile" if prof is not None else None)
-    if live is None and live_on and dtype == "f64":
+    if live is None and live_on:
         r["live_counters_skipped"] = why_not_live
     if src is not None:
         r["achieved"] = src["flop_per_step_attempt"] * att / k_s / 1e12

@@ -193,3 +193,54 @@ end
     @test all(two.pixels[k].rgb == hip.pixels[k].rgb for k in 1:256)
     close(ctx)
 end
+
+# ---- a NEW Object subtype: the reference's second extension point (abstract type Object{T}, src/RayTraceGR.jl:374-389) -----------
+# On the CPU a subtype brings two Julia methods; on the device the same two methods as C++ source, compiled into the scene's unit.
+struct Torus{T} <: Object{T}
+    centre::SVector{3,T}
+    R::T                                                          # major radius (axis along z)
+    r::T                                                          # minor radius
+end
+function RayTraceGR.distance(o::Torus{T}, pos::SVector{4,T})::T where {T}
+    X, Y, Z = pos[2] - o.centre[1], pos[3] - o.centre[2], pos[4] - o.centre[3]
+    (sqrt(X^2 + Y^2) - o.R)^2 + Z^2 - o.r^2                        # zero on the surface, positive outside, negative inside (:377-383)
+end
+function RayTraceGR.objcolor(o::Torus{T}, pos::SVector{4,T})::SVector{3,T} where {T}
+    X, Y, Z = pos[2] - o.centre[1], pos[3] - o.centre[2], pos[4] - o.centre[3]
+    w = sqrt(X^2 + Y^2) - o.R
+    SVector{3,T}(mod(6 * atan(Y, X) / π, 1), mod(6 * atan(Z, w) / π, 1), T(1) / 2)
+end
+const TORUS_SOURCE = """
+template <class S> __device__ S rtgr_user_distance(unsigned type, const S x[4], const S p[9]) {
+    const S X = x[1] - p[0], Y = x[2] - p[1], Z = x[3] - p[2], w = msqrt(X * X + Y * Y) - p[3];
+    return w * w + Z * Z - p[4] * p[4];
+}
+template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]) {
+    const S pi = S(3.14159265358979323846264338327950288);
+    const S X = x[1] - p[0], Y = x[2] - p[1], Z = x[3] - p[2], w = msqrt(X * X + Y * Y) - p[3];
+    rgb[0] = mod1<S>(S(6) * matan2(Y, X) / pi); rgb[1] = mod1<S>(S(6) * matan2(Z, w) / pi); rgb[2] = S(0.5);
+}
+template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]) {
+    const S X = x[1] - p[0], Y = x[2] - p[1], Z = x[3] - p[2], w = msqrt(X * X + Y * Y) - p[3], d = msqrt(dl[1] * dl[1] + dl[2] * dl[2]);
+    return d * (S(2) * mabs(w) + d) + dl[3] * (S(2) * mabs(Z) + dl[3]);
+}
+"""
+@testset "a user-defined Object subtype on the device" begin
+    objs, pos, wx, wy, nrm = RayTraceGRHIP.example_scene(Float64, 2)
+    small = RayTraceGR.make_canvas(kerr_schild, pos, wx, wy, nrm, 24, 24)
+    # the reference's CPU path with the Julia subtype …
+    cpu_objs = Object{Float64}[objs[1], objs[2], Torus{Float64}(SVector(4.0, 0.0, 0.0), 0.9, 0.3)]
+    cpu = RayTraceGR.trace_rays(kerr_schild, cpu_objs, small)
+    # … and the device path with the same object as a DeviceObject (type tag 0; fields = centre, R, r)
+    shapes = RayTraceGRHIP.DeviceObjects(TORUS_SOURCE)
+    hip_objs = Object{Float64}[objs[1], objs[2], RayTraceGRHIP.DeviceObject{Float64}(shapes, 0, 4.0, 0.0, 0.0, 0.9, 0.3)]
+    hip = RayTraceGRHIP.trace_rays(kerr_schild, hip_objs, small)
+    @test maximum(maximum(abs.(hip.pixels[k].rgb - cpu.pixels[k].rgb)) for k in 1:576) <= 1e-6
+    @test any(p.rgb[3] == 0.5 for p in hip.pixels)                # the torus is on screen (blue channel 1/2 x 3/3)
+    # with another metric the unit is another one (its kernels hold the metric too): built on first use, same call
+    kerr = RayTraceGRHIP.KerrSchild(1.0, 0.8)
+    @test maximum(maximum(abs.(RayTraceGRHIP.trace_rays(kerr, hip_objs, small).pixels[k].rgb -
+                               RayTraceGR.trace_rays(kerr, cpu_objs, small).pixels[k].rgb)) for k in 1:576) <= 1e-6
+    # an Object subtype WITHOUT device source still runs — on the reference's CPU path, as before
+    @test RayTraceGRHIP.trace_rays(kerr_schild, cpu_objs, small).pixels[1].rgb == cpu.pixels[1].rgb
+end

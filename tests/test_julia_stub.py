@@ -201,7 +201,7 @@ def test_enum_constants_equal_the_headers():
     jvals = {k: int(v, 0) for k, v in re.findall(r"const\s+(RTGR_[A-Z0-9_]+)\s*=\s*UInt(?:8|32)\((0x[0-9a-fA-F]+|\d+)\)", code)}
     jvals.update({k: int(v) for k, v in re.findall(r"const\s+(RTGR_[A-Z0-9_]+)\s*=\s*(\d+)\s*$", code, re.M)})
     want = {"RTGR_MINKOWSKI", "RTGR_KS_REF", "RTGR_KS_TRUE", "RTGR_USER", "RTGR_METRIC_GENERIC", "RTGR_PLANE", "RTGR_SPHERE",
-            "RTGR_DISK", "RTGR_RAY_EVENT", "RTGR_RAY_LAMBDA1", "RTGR_RAY_MAXSTEPS", "RTGR_RAY_DTMIN", "RTGR_RAY_NAN", "RTGR_MAX_OBJECTS"}
+            "RTGR_DISK", "RTGR_USER_OBJECT", "RTGR_RAY_EVENT", "RTGR_RAY_LAMBDA1", "RTGR_RAY_MAXSTEPS", "RTGR_RAY_DTMIN", "RTGR_RAY_NAN", "RTGR_MAX_OBJECTS"}
     assert want <= set(jvals), want - set(jvals)
     for k in want:
         assert jvals[k] == cvals[k], (k, jvals[k], cvals[k])
@@ -238,6 +238,23 @@ def test_baseline_vocabulary_is_wired_to_the_abi():
     assert re.search(r"function \(m::KerrSchild\)\(xx::SVector\{4,T\}\)", code), "KerrSchild must be callable like a reference metric"
     # the device camera and the per-ray outputs actually cross the ABI
     assert code.count("RtgrRayOutputs(pointer(det.state_end)") == 1 and ":rtgr_make_canvas_f64" in code
+
+
+def test_user_objects_are_wired_to_the_abi():
+    """`DeviceObject{T} <: RayTraceGR.Object{T}` (round 5: the last argument of trace_rays no longer falls back to the CPU for a new
+    Object subtype): packed as RTGR_USER_OBJECT with its type tag and fields; the unit is built by ONE ccall of
+    rtgr_user_unit_compile with the scene as `built_for` (or C_NULL when a DeviceMetric's source is in the same unit); the unit's id
+    lands in the scene; an object type without device source still yields `nothing` -> the reference's CPU path."""
+    names, code = stub_definitions()
+    assert {"DeviceObjects", "DeviceObject", "unit_id", "UNIT_IDS"} <= names, names
+    assert re.search(r"struct DeviceObject\{T\} <: RayTraceGR\.Object\{T\}", code)
+    assert re.search(r"pack\(o::DeviceObject\)\s*=\s*RtgrObject\(RTGR_USER_OBJECT, o\.type, o\.p\)", code)
+    assert re.search(r"pack\(o::RayTraceGR\.Object\)\s*=\s*nothing", code)
+    m = re.search(r"ccall\(\(:rtgr_user_unit_compile, librtgr\), Cint, \(Ctx, Cstring, Cint, Ptr\{RtgrScene\}, Ptr\{UInt64\}\),\s*"
+                  r"handle\(ctx\), source, own && metric\.stationary, own \? C_NULL : scene, id\)", code)
+    assert m, "unit_id must hand rtgr_user_unit_compile the scene the unit is meant for (C_NULL when the unit has a metric of its own)"
+    assert re.search(r"Ref\(RtgrScene\(d\[1\], length\(objs\), d\[2\], d\[3\], unit_id\(fams\[1\], metric, scene, ctx\), packed\)\)", code)
+    assert "RayTraceGR.distance(o::DeviceObject{T}" in code and "RayTraceGR.objcolor(o::DeviceObject{T}" in code
 
 
 def test_runtests_hip_uses_only_what_the_stub_defines():

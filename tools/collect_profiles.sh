@@ -1,13 +1,18 @@
 #!/bin/bash
 # The round's profile set: rocprofv3 kernel-trace stats + PMC passes (each --pmc set in a run of its own, tools/prof.sh) for
 # every BASELINE configuration that has a kernel of its own; then, locally, tools/merge_flops.py <round> writes
-# profiles/<round>/flops.json (keyed by the kernel-source hash).      usage (on the GPU box): tools/collect_profiles.sh r03
-R=${1:-r04}
+# profiles/<round>/flops.json (keyed by the kernel-source hash) and row_checksums.json.
+#     usage (on the GPU box): tools/collect_profiles.sh r05 [a|b]      (two halves: one gpurun call is at most 20 minutes)
+R=${1:-r05}; PART=${2:-ab}
+if [[ $PART == *a* ]]; then
 tools/prof.sh ${R}_ks_ref0 --steps 3 --warmup 1 > /dev/null 2>&1; echo done ks_ref0
 tools/prof.sh ${R}_ks_true08 --steps 3 --warmup 1 --variant ks_true08 > /dev/null 2>&1; echo done ks_true08
 tools/prof.sh ${R}_f32 --steps 5 --warmup 1 --variant ks_true08 --size 2048 --dtype f32 > /dev/null 2>&1; echo done f32 "(packed two-rays-per-lane kernel)"
 RTGR_PACK=0 tools/prof.sh ${R}_f32_scalar --steps 5 --warmup 1 --variant ks_true08 --size 2048 --dtype f32 > /dev/null 2>&1; echo done f32_scalar
+fi
+if [[ $PART == *b* ]]; then
 tools/prof.sh ${R}_c5 --steps 2 --warmup 1 --variant ks_true0998_disk --size 8192 > /dev/null 2>&1; echo done c5
 tools/prof.sh ${R}_generic --steps 3 --warmup 1 --rhs generic --size 2048 > /dev/null 2>&1; echo done generic
 tools/prof.sh ${R}_user_true08 --steps 3 --warmup 1 --rhs user --size 2048 --variant ks_true08 > /dev/null 2>&1; echo done user_true08
 tools/prof.sh ${R}_userks_true08 --steps 3 --warmup 1 --rhs user_ks --size 2048 --variant ks_true08 > /dev/null 2>&1; echo done userks_true08
+fi

@@ -67,7 +67,13 @@ wave_steps = attempts * passes / 64.0
 entry = {
     "kernels": integ, "size": line["config"]["size"], "passes_profiled": passes,
     "step_attempts_per_pass": attempts, "rays": rays,
-    "flop_per_step_attempt": 64.0 * (2 * fma + mul + add) / (attempts * passes),
+    # Float32: the packed kernel's v_pk_* instructions are counted ONCE by the per-kind counters (half their flops: calibrated with
+    # tools/micro/pk_counter_probe.hip, profiles/r05/pk_counter_probe.log); SQ_INSTS_VALU_FLOPS_FP32 counts them in full
+    "flop_per_step_attempt": (64.0 * tot["SQ_INSTS_VALU_FLOPS_FP32"] / (attempts * passes) if (f32 and tot["SQ_INSTS_VALU_FLOPS_FP32"])
+                              else 64.0 * (2 * fma + mul + add) / (attempts * passes)),
+    "flop_counter": "SQ_INSTS_VALU_FLOPS_FP32" if (f32 and tot["SQ_INSTS_VALU_FLOPS_FP32"]) else f"2 FMA + MUL + ADD of SQ_INSTS_VALU_*_{sfx}",
+    "flops_counter_check": ({"per_kind": 64.0 * (2 * fma + mul + add) / (attempts * passes),
+                             "flops_counter": 64.0 * tot[f"SQ_INSTS_VALU_FLOPS_FP{sfx[1:]}"] / (attempts * passes)} if tot[f"SQ_INSTS_VALU_FLOPS_FP{sfx[1:]}"] else None),
     "per_wave_step": {"valu": tot["SQ_INSTS_VALU"] / wave_steps, "fma": fma / wave_steps, "mul": mul / wave_steps,
                       "add": add / wave_steps, "trans_f64": tot["SQ_INSTS_VALU_TRANS_F64"] / wave_steps,
                       "trans_f32": tot["SQ_INSTS_VALU_TRANS_F32"] / wave_steps, "cvt": tot["SQ_INSTS_VALU_CVT"] / wave_steps,
