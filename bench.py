@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--checksum-reference", default="",
                     help="a file holding the JSON line of an N = 1 run with --emit-row-checksums of the SAME configuration: the reference the "
                          "delivered frame is checked against instead of the one recorded under profiles/ (rehearsals at sizes that have none)")
+    ap.add_argument("--user-sphere", action="store_true",
+                    help="example2's small sphere as a USER-DEFINED object of the same geometry (examples/user_objects.py "
+                         "SPHERE_AS_USER_OBJECT through a run-time unit): what variants.user_sphere_* times, as a workload of its own")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one stream, trace and gather strictly in turn (no frames in flight)")
@@ -211,7 +214,7 @@ def load_profile(a):
     from the newest profiles/rNN/flops.json whose recorded kernel-source hash equals the current sources' — or (None, why).
     PMC counters cannot be collected from inside the bench; a profile of other sources must not be presented as this run's."""
     cur = kernel_source_hash()
-    key = f"{a.variant}/{a.dtype}/{a.rhs}"
+    key = f"{a.variant}/{a.dtype}/{getattr(a, 'rhs_key', a.rhs)}"
     seen = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "flops.json")), reverse=True):
         try:
@@ -287,7 +290,7 @@ def live_counters(a, log=None):
             out = os.path.join(work, name)
             cmd = [tool, "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "1", "--warmup", "0",
-                   "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
+                   "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"] + (["--user-sphere"] if getattr(a, "user_sphere", False) else [])
             env = dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp")
             r = run_group(cmd, env, 150, f"--pmc {' '.join(counters)} ({a.variant} {a.size} {a.dtype} {a.rhs})")
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -354,7 +357,7 @@ def kernel_trace_pass(a, tool):
     try:
         cmd = [tool, "--kernel-trace", "--stats", "--output-format", "csv", "-d", work, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "3", "--warmup", "1",
-               "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"]
+               "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"] + (["--user-sphere"] if getattr(a, "user_sphere", False) else [])
         r = run_group(cmd, dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp"), 150, f"--kernel-trace ({a.variant} {a.size} {a.dtype} {a.rhs})")
         if r.returncode != 0:
             return None
@@ -376,11 +379,11 @@ def expected_checksum(a):
     sources, or (None, None, why).  The per-row vector (profiles/rNN/row_checksums.json) is what lets a mismatch name the ROWS — and
     through the row deal the rank or context device — that delivered other bits than the N = 1 frame."""
     cur = kernel_source_hash()
-    key = f"{a.variant}/{a.dtype}/{a.rhs}/{a.size}"
+    key = f"{a.variant}/{a.dtype}/{getattr(a, 'rhs_key', a.rhs)}/{a.size}"
     if a.checksum_reference:
         ref = next(json.loads(l) for l in open(a.checksum_reference) if l.startswith("{"))
         c = ref["config"]
-        assert (c["variant"], ref["dtype"], c["rhs"], c["size"]) == (a.variant, a.dtype, a.rhs, a.size), "--checksum-reference: another configuration"
+        assert (c["variant"], ref["dtype"], c["rhs"], c["size"]) == (a.variant, a.dtype, getattr(a, "rhs_key", a.rhs), a.size), "--checksum-reference: another configuration"
         return int(ref["frame_checksum"]), ref.get("row_checksums"), a.checksum_reference
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "flops.json")), reverse=True):
         try:
@@ -410,6 +413,7 @@ def main():
     abi = rt._abi
 
     failed, line = False, {}
+    a.rhs_key = a.rhs + ("+user_sphere" if a.user_sphere else "")   # (profile / checksum key: a unit's kernels are not the library's)
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -455,7 +459,7 @@ def main():
     if ws > 1:
         os.environ["RTGR_NO_COMPILE"] = "1"   # --rhs user on a cold cache: fail fast instead of N ranks starting hipcc
     npdt = np.float64 if a.dtype == "f64" else np.float32
-    scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user", "user_ks": "user_ks"}[a.rhs])
+    scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user", "user_ks": "user_ks"}[a.rhs], user_sphere=a.user_sphere)
     opt = rt.solver_defaults(npdt)
     ni = nj = a.size
     # rows are dealt cyclically (rank r: rows r, r+N, …): contiguous slabs of a black-hole image are unbalanced
@@ -721,7 +725,7 @@ def main():
             roof["stale_profile"] = why
         name = C_name(lib)
         extras = {}
-        if a.extras and not multi and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64":
+        if a.extras and not multi and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64" and not a.user_sphere:
             try:   # (outside the timed region; a failure here must not cost the headline line)
                 extras = run_extras(a, rt, host_pass, pixels_pass, dt / a.steps)
             except Exception as e:  # noqa: BLE001
@@ -736,7 +740,7 @@ def main():
                                    f"tol=eps^(3/4), lambda in [0,100]; rows dealt {a.layout} over "
                                    f"{ws if a.entry == 'device' else str(len(ctx_ids)) + ' context device(s) on ' + str(n_physical)} GPU(s)"
                                    f"{'' if ws == 1 or a.no_gather else ' + ' + ('RCCL' if a.backend == 'nccl' else 'gloo') + ' gather of RGB + status to rank 0'}",
-                       "size": a.size, "variant": a.variant, "rhs": a.rhs, "entry": a.entry,
+                       "size": a.size, "variant": a.variant, "rhs": a.rhs_key, "entry": a.entry,
                        "parallelism": f"rows/{ws if a.entry == 'device' else len(ctx_ids)}"},
             "rays_per_s": rays / dt, "rays": rays // a.steps, "step_attempts_per_pass": attempts // a.steps,
             "accepted": acc // a.steps, "rejected": rej // a.steps, "rhs_evals_per_pass": nrhs // a.steps,
@@ -836,7 +840,10 @@ def main():
         sys.exit(2)
 
 
-def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, live_on=False, user_sphere=False):
+_LAST_FRAME = [None]
+
+
+def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, live_on=False, user_sphere=False, keep_frame=False):
     """One BASELINE configuration outside the headline's timed region: `reps` device-resident frames (camera on the device,
     nothing over PCIe), wall time + the library's HIP-event kernel times, and the same executed-flop roofline as the headline's,
     from counters read by this run (live_counters(); Float64 configurations) or THIS configuration's profile entry
@@ -867,6 +874,7 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     att = (int(ctr[1]) + int(ctr[2])) / reps
     rays = n * n
     bits = o["rgb"].contiguous().view(torch.int64 if dtype == "f64" else torch.int32).to(torch.int64)
+    _LAST_FRAME[0] = o["rgb"].clone() if user_sphere or keep_frame else None
     v = {"workload": f"{variant}, same camera, {n}x{n}, {dtype}, rhs {rhs}" + (", small sphere as a USER object" if user_sphere else ""),
          "size": n, "dtype": dtype, "rhs": rhs, "frame_checksum": int(bits.sum().item()),
          "ms_per_pass": dt * 1e3, "step_attempts_per_s": att / dt, "rays_per_s": rays / dt,
@@ -956,14 +964,19 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
     try:
         if os.environ.get("RTGR_NO_COMPILE") == "1":
             raise RuntimeError("RTGR_NO_COMPILE=1: the unit is not built inside this run")
-        bi = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2)
+        bi = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2, keep_frame=True)
+        f_bi = _LAST_FRAME[0]
         us = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2, user_sphere=True)
+        f_us = _LAST_FRAME[0]
+        _LAST_FRAME[0] = None
         ex["variants"]["user_sphere_ks_ref0_2048"] = {
             "workload": us["workload"], "ms_per_pass": us["ms_per_pass"], "builtin_ms_per_pass": bi["ms_per_pass"],
             "user_over_builtin": us["ms_per_pass"] / bi["ms_per_pass"],
             "far_near_ms": [us["roofline"]["far_pass_ms_per_pass"], us["roofline"]["near_pass_ms_per_pass"]],
             "builtin_far_near_ms": [bi["roofline"]["far_pass_ms_per_pass"], bi["roofline"]["near_pass_ms_per_pass"]],
-            "same_frame": bool(us["frame_checksum"] == bi["frame_checksum"]), "step_attempts_per_s": us["step_attempts_per_s"],
+            "same_frame": bool(us["frame_checksum"] == bi["frame_checksum"]),
+            "pixels_that_differ": int(((f_us != f_bi).any(dim=0)).sum().item()), "max_rgb_difference": float((f_us - f_bi).abs().max().item()),
+            "step_attempts_per_s": us["step_attempts_per_s"],
             "note": "RTGR_USER_OBJECT through a run-time unit built for this scene's metric variant (rtgr_user_unit_compile): distance / objcolor / "
                     "reach bound of the source called from the unit's own set-up, FAR, NEAR and resolve kernels"}
     except Exception as e:  # noqa: BLE001

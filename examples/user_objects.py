@@ -59,7 +59,8 @@ SHAPES_WITH_REACH = SHAPES + REACH
 # the difference between two frames that are otherwise the same (bench.py: variants.user_sphere_*).  p = pos (4), vel (4), radius.
 SPHERE_AS_USER_OBJECT = r'''
 template <class S> __device__ S rtgr_user_distance(unsigned type, const S x[4], const S p[9]) {
-    const S dx = x[1] - p[1], dy = x[2] - p[2], dz = x[3] - p[3], d = dx * dx + dy * dy + dz * dz - p[8] * p[8];
+    const S dx = x[1] - p[1], dy = x[2] - p[2], dz = x[3] - p[3];
+    const S d = rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, -p[8] * p[8])));           // (the built-in's own order of fused operations)
     return p[8] < S(0) ? -d : d;                                                  // sign(R) * (|x - c|² - R²)   :415-419
 }
 template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]) {

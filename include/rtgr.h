@@ -429,6 +429,15 @@ typedef struct rtgr_unit_info {
     uint32_t probe_ok;     /* 1: the load-time probe ran (FULL == FAR + NEAR, twice each); 0: skipped (RTGR_UNIT_PROBE=0) */
 } rtgr_unit_info;
 int rtgr_user_unit_info(rtgr_context* ctx, uint64_t id, rtgr_unit_info* info);
+/* The library's central schedule-invariance property, as a check a caller can run on ITS scene: the FAR + NEAR passes skip the
+ * ContinuousCallback scan of a step only where no object's distance can change sign, so they must deliver the frame of the single
+ * FULL pass (every accepted step scanned, as the reference does, src/RayTraceGR.jl:488-490).  For built-in objects the bound is the
+ * library's; for user objects it is the source's rtgr_user_reach — and a reach function that is NOT an upper bound loses hits
+ * silently.  This traces the camera's canvas at ni x nj rays (<= 256 x 256; a coarse canvas of the same camera is the usual call)
+ * through both pass structures on device 0 of the context and compares: bit for bit for a built-in metric (with or without user
+ * objects), within the load-time probe's bars for a metric given as source.  RTGR_OK, or RTGR_ERR_BAD_ARG with the count of rays
+ * that differ in rtgr_last_error().  Blocking; a few milliseconds.  is_f32 must be 0 (Float32 runs one pass structure only). */
+int rtgr_scene_check(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, int is_f32);
 /* The EXEC-flip check.  ROCm 7.2's compiler can place a register copy or spill at the top of the FLOW block of a divergent if / else,
  * AHEAD of the instruction that switches EXEC to the `else` lanes; code of that shape computes wrong values in some lanes (DESIGN.md
  * §4.6: the Float64 FULL pass of a heavy metric was wrong from it in round 4).  rtgr_user_metric_compile / _build look for the shape

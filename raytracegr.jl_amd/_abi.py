@@ -76,7 +76,7 @@ EXPORTS = [
     "rtgr_eval_metric_f64", "rtgr_eval_metric_f32", "rtgr_eval_geodesic_f64", "rtgr_eval_geodesic_f32",
     "rtgr_eval_fastmath_f64", "rtgr_quantize_device_f64",
     "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded", "rtgr_code_object_audit", "rtgr_user_metric_build", "rtgr_listing_repair",
-    "rtgr_user_unit_compile", "rtgr_user_unit_build", "rtgr_user_unit_info",
+    "rtgr_user_unit_compile", "rtgr_user_unit_build", "rtgr_user_unit_info", "rtgr_scene_check",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -148,6 +148,7 @@ def _declare(lib):
     lib.rtgr_user_unit_compile.argtypes = [ctx, C.c_char_p, i32, P(rtgr_scene), P(u64)]
     lib.rtgr_user_unit_build.argtypes = [C.c_char_p, i32, P(rtgr_scene), C.c_char_p]
     lib.rtgr_user_unit_info.argtypes = [ctx, u64, P(rtgr_unit_info)]
+    lib.rtgr_scene_check.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, i32]
     for name in EXPORTS:
         if name != "rtgr_last_error":
             getattr(lib, name).restype = i32

@@ -138,6 +138,17 @@ def make_scene(metric, objs, ctx=None, units=True):
     return sc
 
 
+def check_scene(metric, objs, cam, ni=48, nj=48, opt=None, ctx=None):
+    """rtgr_scene_check: the FAR + NEAR passes of THIS scene must deliver the frame of the single FULL pass (every accepted step
+    scanned, as the reference does) — the check that catches a rtgr_user_reach that is not an upper bound.  `cam`: make_camera
+    arguments (dict) or an rtgr_camera.  Raises RtgrError naming the number of rays that differ; returns None when the frames agree."""
+    lib = _lib()
+    sc = make_scene(metric, objs, ctx)
+    camera = cam if isinstance(cam, rtgr_camera) else make_camera(**cam)
+    opt = opt or solver_defaults()
+    _abi.check(lib, lib.rtgr_scene_check(ctx, C.byref(sc), C.byref(opt), C.byref(camera), ni, nj, 0))
+
+
 def solver_defaults(dtype=np.float64, **over):
     """tol = eps(T)^(3/4), λ∈[0,100], hit threshold 0.01, miss colour (1,0,0)  (src/RayTraceGR.jl:485,:497,:519,:528).
     Pure constants — filled here so that building a solver struct does not need the GPU library."""
@@ -357,6 +368,6 @@ def example2(ni=200, nj=200, save=True, ctx=None):
 
 
 __all__ = ["D", "Metric", "UserMetric", "UserObjects", "UserObject", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
-           "make_scene", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
+           "make_scene", "check_scene", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
            "trace_rays", "trace_ray", "dmetric", "christoffel", "geodesic", "example1", "example2",
            "example1_scene", "example2_scene"]

@@ -1647,14 +1647,21 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 // A ~10 ms look at the fault's own symptom; a probe, not a proof (a unit wrong the same way in every pass goes through).
 template <class R> struct ProbeFrame { std::vector<R> rgb, se, lam; std::vector<uint8_t> status, hit; std::vector<uint32_t> na, nr; };
 template <class R>
-static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFrame<R>& f) {
-    constexpr uint64_t NI = 32, N = NI * NI;
+static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFrame<R>& f, const rtgr_solver* user_opt = nullptr,
+                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32) {
+    const uint64_t N = NI * NJ;
     rtgr_solver opt;
-    rtgr_solver_defaults(&opt, sizeof(R) == 4);
-    opt.max_steps = 4000;   // (bounds the probe on a metric this camera makes no sense for; such rays end with a status, identically)
     rtgr_camera cam;
-    std::memset(&cam, 0, sizeof cam);
-    cam.pos[1] = 4; cam.pos[2] = -2; cam.widthx[1] = 1; cam.widthy[3] = 1; cam.normal[2] = 1;
+    if (user_opt) opt = *user_opt;
+    else {
+        rtgr_solver_defaults(&opt, sizeof(R) == 4);
+        opt.max_steps = 4000;   // (bounds the probe on a metric this camera makes no sense for; such rays end with a status, identically)
+    }
+    if (user_cam) cam = *user_cam;
+    else {   // example2's camera, src/RayTraceGR.jl:588-593
+        std::memset(&cam, 0, sizeof cam);
+        cam.pos[1] = 4; cam.pos[2] = -2; cam.widthx[1] = 1; cam.widthy[3] = 1; cam.normal[2] = 1;
+    }
     DevBuf b;
     const size_t off_se = 3 * N * sizeof(R), off_lam = off_se + 8 * N * sizeof(R), off_na = off_lam + N * sizeof(R),
                  off_nr = off_na + N * 4, off_st = off_nr + N * 4, off_hit = off_st + N, total = off_hit + N;
@@ -1668,7 +1675,7 @@ static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFram
     out.n_reject = (uint32_t*)(base + off_nr); out.status = (uint8_t*)(base + off_st); out.hit = (uint8_t*)(base + off_hit);
     long saved;
     { std::lock_guard<std::mutex> lk(D.mu); saved = D.knobs.split; D.knobs.split = split; }
-    rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NI, 0, NI, (R*)base, &out, nullptr, nullptr);
+    rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
     { std::lock_guard<std::mutex> lk(D.mu); D.knobs.split = saved; }
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -1687,6 +1694,36 @@ static bool probe_same_bits(const ProbeFrame<R>& a, const ProbeFrame<R>& b) {
     auto eq = [](const auto& x, const auto& y) { return x.size() == y.size() && std::memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0; };
     return eq(a.rgb, b.rgb) && eq(a.se, b.se) && eq(a.lam, b.lam) && eq(a.na, b.na) && eq(a.nr, b.nr) && eq(a.status, b.status) && eq(a.hit, b.hit);
 }
+// the FULL pass's frame against the FAR + NEAR passes' of the same rays: true (and *why) when they disagree beyond what different
+// inlining of a user's own arithmetic explains — more than 2 % of the rays with another hit / status / step count (±2), or an end
+// state off by more than 1e-5 (relative) on a ray they agree on
+template <class R>
+static bool probe_disagree(const ProbeFrame<R>& full, const ProbeFrame<R>& pair, const char* whose, std::string* why) {
+    const size_t n = full.hit.size();
+    size_t other = 0;
+    double worst = 0;
+    for (size_t i = 0; i < n; i++) {
+        const long sa = (long)full.na[i] + full.nr[i], sb = (long)pair.na[i] + pair.nr[i];
+        if (full.hit[i] != pair.hit[i] || full.status[i] != pair.status[i] || std::labs(sa - sb) > 2) { other++; continue; }
+        for (int q = 0; q < 8; q++) {
+            const double x = full.se[8 * i + q], y = pair.se[8 * i + q];
+            if (x != x && y != y) continue;
+            const double e = std::fabs(x - y) / (1.0 + std::fabs(x));
+            if (!(e <= worst)) worst = e;   // (NaN on one side only: counted)
+        }
+    }
+    char buf[320];
+    if (other > std::max<size_t>(2, n / 50)) {
+        std::snprintf(buf, sizeof buf, "%s FULL pass and %s FAR + NEAR passes disagree on %zu of %zu rays (hit / status / step count)", whose, whose, other, n);
+        *why = buf; return true;
+    }
+    if (!(worst <= 1e-5)) {
+        std::snprintf(buf, sizeof buf, "%s FULL pass and %s FAR + NEAR passes end rays they agree on %.3g apart (relative; 1e-5 allowed)", whose, whose, worst);
+        *why = buf; return true;
+    }
+    return false;
+}
+
 static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
     rtgr_scene sc;
     std::memset(&sc, 0, sizeof sc);
@@ -1706,28 +1743,7 @@ static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
     if (has_pair) {
         for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 1, pair[k]))) return rc;
         if (!probe_same_bits(pair[0], pair[1])) { *why = "two runs of its Float64 FAR + NEAR passes over the same 32 x 32 probe frame differ"; return 1; }
-        const size_t n = full[0].hit.size();
-        size_t other = 0;
-        double worst = 0;
-        for (size_t i = 0; i < n; i++) {
-            const long sa = (long)full[0].na[i] + full[0].nr[i], sb = (long)pair[0].na[i] + pair[0].nr[i];
-            if (full[0].hit[i] != pair[0].hit[i] || full[0].status[i] != pair[0].status[i] || std::labs(sa - sb) > 2) { other++; continue; }
-            for (int q = 0; q < 8; q++) {
-                const double x = full[0].se[8 * i + q], y = pair[0].se[8 * i + q];
-                if (x != x && y != y) continue;
-                const double e = std::fabs(x - y) / (1.0 + std::fabs(x));
-                if (!(e <= worst)) worst = e;   // (NaN on one side only: counted)
-            }
-        }
-        char buf[256];
-        if (other > std::max<size_t>(2, n / 50)) {
-            std::snprintf(buf, sizeof buf, "its FULL pass and its FAR + NEAR passes disagree on %zu of %zu probe rays (hit / status / step count)", other, n);
-            *why = buf; return 1;
-        }
-        if (!(worst <= 1e-5)) {
-            std::snprintf(buf, sizeof buf, "its FULL pass and its FAR + NEAR passes end rays they agree on %.3g apart (relative; 1e-5 allowed)", worst);
-            *why = buf; return 1;
-        }
+        if (probe_disagree(full[0], pair[0], "its", why)) return 1;
     }
     if (U.full10_f32) {
         ProbeFrame<float> f32[2];
@@ -2030,6 +2046,41 @@ int rtgr_user_unit_build(const char* source, int stationary, const rtgr_scene* b
 }
 int rtgr_user_metric_build(const char* source, int stationary, const char* code_object_path) {
     return rtgr_user_unit_build(source, stationary, nullptr, code_object_path);
+}
+
+}  // extern "C"
+template <class R>
+static int scene_check(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, bool exact) {
+    ProbeFrame<R> full, pair;
+    int rc;
+    if ((rc = probe_trace<R>(D, *scene, 0, full, opt, cam, ni, nj))) return rc;
+    if ((rc = probe_trace<R>(D, *scene, 1, pair, opt, cam, ni, nj))) return rc;
+    std::string why;
+    if (exact) {
+        if (probe_same_bits(full, pair)) return RTGR_OK;
+        size_t other = 0;
+        for (size_t i = 0; i < full.hit.size(); i++) other += full.hit[i] != pair.hit[i] || full.status[i] != pair.status[i] || full.na[i] != pair.na[i];
+        why = "the FULL pass and the FAR + NEAR passes of this scene differ (" + std::to_string(other) + " of " + std::to_string(full.hit.size()) +
+              " rays with another hit / status / step count)";
+    } else if (!probe_disagree(full, pair, "the scene's", &why)) return RTGR_OK;
+    return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: " + why + " — a FAR pass that skips scans it must not skip: with user objects, "
+                                  "rtgr_user_reach is not an upper bound of how far rtgr_user_distance moves inside the box it is given");
+}
+extern "C" {
+
+int rtgr_scene_check(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, int is_f32) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!scene || !opt || !cam) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    if (ni == 0 || nj == 0 || ni > 256 || nj > 256) return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: a canvas of 1 .. 256 x 1 .. 256 rays");
+    if (is_f32) return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: Float32 scenes run ONE pass structure (the single FULL pass): nothing to compare");
+    DeviceCtx& D = *c->devs[0];
+    DeviceGuard guard(D.dev);
+    // bit for bit where every kernel is the library's own arithmetic (a built-in metric — closed form or generic —, with or without
+    // user objects: the same object functions are inlined into the same bodies); within the probe's bars for a metric given as source
+    const bool exact = (scene->metric & ~RTGR_METRIC_GENERIC) != RTGR_USER;
+    return scene_check<double>(D, scene, opt, cam, ni, nj, exact);
 }
 
 int rtgr_user_unit_info(rtgr_context* ctx, uint64_t id, rtgr_unit_info* info) {

@@ -62,7 +62,7 @@ _Static_assert(sizeof(pixel_f32) == 44 && offsetof(pixel_f32, normal) == 16 && o
 
 static const char* const BOUND[] = {"rtgr_create", "rtgr_destroy", "rtgr_context_devices", "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version",
                                     "rtgr_solver_defaults", "rtgr_trace_pixels_f64", "rtgr_trace_pixels_f32", "rtgr_trace_one_f64", "rtgr_trace_one_f32", "rtgr_trace_f64",
-                                    "rtgr_trace_sharded_f64", "rtgr_make_canvas_f64", "rtgr_user_metric_load", "rtgr_user_metric_compile",
+                                    "rtgr_trace_sharded_f64", "rtgr_make_canvas_f64", "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_unit_compile",
                                     "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", NULL};
 
 typedef int (*fn_defaults)(rtgr_solver*, int);

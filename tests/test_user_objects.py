@@ -332,3 +332,35 @@ def test_scenes_never_run_with_the_wrong_unit(lib):
     plain.obj[2].kind = 5
     with pytest.raises(abi.RtgrError, match="unknown object kind"):
         hip_trace(lib, plain, opt, 8, 8, cam=cam)
+
+
+@pytest.mark.gpu
+def test_a_reach_bound_that_lies_is_caught_by_the_scene_check(lib):
+    """rtgr_user_reach is the one piece of a user's source the library cannot verify by construction: the FAR pass skips the scan of a
+    step when no object can change sign within the bound, so a bound that is too small loses hits SILENTLY.  rtgr_scene_check traces
+    the caller's own scene through the single FULL pass and through FAR + NEAR and compares: a sound bound passes bit for bit, a bound
+    of zero ("nothing ever moves") is refused with the number of rays that differ, and so is a bound that forgets one object type."""
+    _, objs, cam = rt.example2_scene()
+    shapes = user_shapes()[1]
+    rt.check_scene(rt.kerr_schild, objs[:2] + shapes, cam)                              # examples/user_objects.py REACH: sound
+    rt.check_scene(rt.KerrSchild(1.0, 0.8), objs[:2] + shapes, cam)
+    rt.check_scene(rt.kerr_schild, objs, cam)                                           # a built-in scene passes too (the library's own bounds)
+    liar = rt.UserObjects(user_objects.SHAPES + """
+template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]) { return S(0); }
+""", name="shapes with a reach bound of zero")
+    lying = objs[:2] + [liar(o.type, o.params) for o in shapes]
+    with pytest.raises(abi.RtgrError, match=r"differ \(\d+ of 2304 rays.*rtgr_user_reach is not an upper bound"):
+        rt.check_scene(rt.kerr_schild, lying, cam)
+    half = rt.UserObjects(user_objects.SHAPES + user_objects.REACH.replace("if (type == 0u) {", "if (type == 0u) { return S(0);"),
+                          name="shapes whose torus claims never to move")
+    with pytest.raises(abi.RtgrError, match="rtgr_scene_check"):
+        rt.check_scene(rt.kerr_schild, objs[:2] + [half(o.type, o.params) for o in shapes], cam)
+    # (the lying unit itself loads and traces: its FULL pass is right, its FAR + NEAR frame is not — which is why the check exists)
+    from test_gpu_parity import hip_trace
+    sc = rt.make_scene(rt.kerr_schild, lying)
+    camera = rt.make_camera(**cam)
+    opt = rt.solver_defaults()
+    with abi.options(lib, split=0):
+        full = hip_trace(lib, sc, opt, 48, 48, cam=camera)
+    assert np.array_equal(full["hit"], O.trace(sc, opt, 48, 48, cam=camera)["hit"])
+    assert (hip_trace(lib, sc, opt, 48, 48, cam=camera)["hit"] != full["hit"]).sum() > 0

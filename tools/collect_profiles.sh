@@ -3,7 +3,7 @@
 # every BASELINE configuration that has a kernel of its own; then, locally, tools/merge_flops.py <round> writes
 # profiles/<round>/flops.json (keyed by the kernel-source hash) and row_checksums.json.
 #     usage (on the GPU box): tools/collect_profiles.sh r05 [a|b]      (two halves: one gpurun call is at most 20 minutes)
-R=${1:-r05}; PART=${2:-ab}
+R=${1:-r05}; PART=${2:-abc}
 if [[ $PART == *a* ]]; then
 tools/prof.sh ${R}_ks_ref0 --steps 3 --warmup 1 > /dev/null 2>&1; echo done ks_ref0
 tools/prof.sh ${R}_ks_true08 --steps 3 --warmup 1 --variant ks_true08 > /dev/null 2>&1; echo done ks_true08
@@ -15,4 +15,8 @@ tools/prof.sh ${R}_c5 --steps 2 --warmup 1 --variant ks_true0998_disk --size 819
 tools/prof.sh ${R}_generic --steps 3 --warmup 1 --rhs generic --size 2048 > /dev/null 2>&1; echo done generic
 tools/prof.sh ${R}_user_true08 --steps 3 --warmup 1 --rhs user --size 2048 --variant ks_true08 > /dev/null 2>&1; echo done user_true08
 tools/prof.sh ${R}_userks_true08 --steps 3 --warmup 1 --rhs user_ks --size 2048 --variant ks_true08 > /dev/null 2>&1; echo done userks_true08
+fi
+if [[ $PART == *c* ]]; then
+tools/prof.sh ${R}_user_sphere --steps 5 --warmup 1 --size 2048 --user-sphere > /dev/null 2>&1; echo done user_sphere "(example2 with its small sphere as a user-defined object: a unit of objects for the built-in metric)"
+tools/prof.sh ${R}_builtin_2048 --steps 5 --warmup 1 --size 2048 > /dev/null 2>&1; echo done builtin_2048 "(the same frame with the built-in sphere)"
 fi
