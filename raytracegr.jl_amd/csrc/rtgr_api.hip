@@ -353,6 +353,11 @@ static void scene_variant(const rtgr_scene* s, uint32_t* metric, bool* spin) {
     *spin = kind == RTGR_MINKOWSKI ? false : (generic ? true : s->a != 0.0);
 }
 
+// The load-time probe of a unit of OBJECTS traces a scene of built-in objects (it knows no parameters of the user's) and must still run
+// the UNIT's kernels, not the library's: while this is set on the calling thread, a scene that names a unit runs with it even though
+// nothing in the scene requires one.  (Everywhere else a built-in scene ignores rtgr_scene.user_metric, as it always has.)
+static thread_local bool tl_probe_forces_unit = false;
+
 template <class R>
 int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserModule** user) {
     if (!s) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
@@ -360,7 +365,7 @@ int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const
     *user = nullptr;
     if (s->nobj > RTGR_MAX_OBJECTS) return fail(RTGR_ERR_BAD_ARG, "too many objects");
     const bool user_metric = (s->metric & ~RTGR_METRIC_GENERIC) == RTGR_USER;
-    bool user_objects = false;
+    bool user_objects = tl_probe_forces_unit && s->user_metric != 0 && !user_metric;
     for (uint32_t o = 0; o < s->nobj; o++) user_objects = user_objects || s->obj[o].kind == RTGR_USER_OBJECT;
     if (user_metric || user_objects) {
         const char* what = user_metric ? "RTGR_USER" : "RTGR_USER_OBJECT";
@@ -1648,7 +1653,7 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 template <class R> struct ProbeFrame { std::vector<R> rgb, se, lam; std::vector<uint8_t> status, hit; std::vector<uint32_t> na, nr; };
 template <class R>
 static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFrame<R>& f, const rtgr_solver* user_opt = nullptr,
-                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32) {
+                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32, bool force_unit = false) {
     const uint64_t N = NI * NJ;
     rtgr_solver opt;
     rtgr_camera cam;
@@ -1675,7 +1680,9 @@ static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFram
     out.n_reject = (uint32_t*)(base + off_nr); out.status = (uint8_t*)(base + off_st); out.hit = (uint8_t*)(base + off_hit);
     long saved;
     { std::lock_guard<std::mutex> lk(D.mu); saved = D.knobs.split; D.knobs.split = split; }
+    tl_probe_forces_unit = force_unit;
     rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
+    tl_probe_forces_unit = false;
     { std::lock_guard<std::mutex> lk(D.mu); D.knobs.split = saved; }
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -1737,17 +1744,17 @@ static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
     sc.obj[2].kind = RTGR_SPHERE; sc.obj[2].p[1] = 4; sc.obj[2].p[4] = 1; sc.obj[2].p[8] = 0.5;
     int rc;
     ProbeFrame<double> full[2], pair[2];
-    for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 0, full[k]))) return rc;
+    for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 0, full[k], nullptr, nullptr, 32, 32, true))) return rc;
     if (!probe_same_bits(full[0], full[1])) { *why = "two runs of its Float64 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
     const bool has_pair = !(U.has_objects && !U.has_reach);
     if (has_pair) {
-        for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 1, pair[k]))) return rc;
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 1, pair[k], nullptr, nullptr, 32, 32, true))) return rc;
         if (!probe_same_bits(pair[0], pair[1])) { *why = "two runs of its Float64 FAR + NEAR passes over the same 32 x 32 probe frame differ"; return 1; }
         if (probe_disagree(full[0], pair[0], "its", why)) return 1;
     }
     if (U.full10_f32) {
         ProbeFrame<float> f32[2];
-        for (int k = 0; k < 2; k++) if ((rc = probe_trace<float>(D, sc, -1, f32[k]))) return rc;
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<float>(D, sc, -1, f32[k], nullptr, nullptr, 32, 32, true))) return rc;
         if (!probe_same_bits(f32[0], f32[1])) { *why = "two runs of its Float32 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
     }
     return RTGR_OK;
@@ -1777,6 +1784,9 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
     }
     std::lock_guard<std::mutex> load_lock(c->modules_mu);   // one load / unload at a time per context
     bool fresh = false;                                       // loaded by this call on at least one device (else: already resident)
+    // (a unit refused on device k — wrong ABI, missing kernel, HIP error — must not stay resident on devices 0 … k-1 of the context)
+    struct Rollback { rtgr_context* c; uint64_t id; bool* fresh; bool armed = true;
+                      ~Rollback() { if (armed && *fresh) { const std::string keep = rtgr_last_error(); (void)unload_locked(c, id); (void)fail(0, keep); } } } rollback{c, id, &fresh};
     for (auto& d : c->devs) {
         DeviceGuard guard(d->dev);
         bool same_phys = false;  // a logical duplicate of a device shares the module of its twin
@@ -1880,6 +1890,7 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
             for (auto& m : d->modules) if (m.id == id) m.probe_ok = true;
         }
     }
+    rollback.armed = false;
     if (id_out) *id_out = id;
     return RTGR_OK;
 }
