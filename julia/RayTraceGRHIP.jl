@@ -412,6 +412,25 @@ struct RayDetails{T}
 end
 
 """
+    check_scene(metric, objs, pos, widthx, widthy, normal; ni = 48, nj = 48, ctx = nothing)
+
+`rtgr_scene_check`: traces a coarse canvas of this camera through the single FULL pass (every accepted step scanned, as the
+reference's ContinuousCallback does, :488-490) and through the FAR + NEAR passes, and throws unless the two frames agree (bit for bit
+for a built-in metric).  The check to run once on a scene with `DeviceObject`s whose source brings a `rtgr_user_reach` bound: a bound
+that is too small loses hits silently, and this is what says so.
+"""
+function check_scene(metric, objs::Vector{RayTraceGR.Object{T}}, pos, widthx, widthy, normal; ni::Integer = 48, nj::Integer = 48,
+                     ctx = nothing) where {T<:Union{Float64,Float32}}
+    scene = scene_of(metric, objs, ctx)
+    scene === nothing && error("check_scene: this scene runs on the reference's CPU path (nothing to check)")
+    opt = solver_of(Float64)
+    cam = camera_of(pos, widthx, widthy, normal)
+    check(ccall((:rtgr_scene_check, librtgr), Cint, (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{RtgrCamera}, UInt64, UInt64, Cint),
+                handle(ctx), scene, opt, cam, ni, nj, 0))
+    nothing
+end
+
+"""
     render(metric, objs, pos, widthx, widthy, normal, ni, nj; T = Float64, ctx = nothing, details = false)
         -> (R, G, B)  or  ((R, G, B), RayDetails)
 

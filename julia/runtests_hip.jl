@@ -241,6 +241,8 @@ template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], con
     kerr = RayTraceGRHIP.KerrSchild(1.0, 0.8)
     @test maximum(maximum(abs.(RayTraceGRHIP.trace_rays(kerr, hip_objs, small).pixels[k].rgb -
                                RayTraceGR.trace_rays(kerr, cpu_objs, small).pixels[k].rgb)) for k in 1:576) <= 1e-6
+    # the source's reach bound against the single FULL pass, on this very scene (throws when the FAR pass would lose hits)
+    RayTraceGRHIP.check_scene(kerr_schild, hip_objs, pos, wx, wy, nrm)
     # an Object subtype WITHOUT device source still runs — on the reference's CPU path, as before
     @test RayTraceGRHIP.trace_rays(kerr_schild, cpu_objs, small).pixels[1].rgb == cpu.pixels[1].rgb
 end

@@ -283,3 +283,64 @@ def test_build_falls_back_to_the_listing_route_when_the_audit_finds_the_fault(tm
     answers.extend([(1, "x"), (1, "x")])
     with pytest.raises(RuntimeError, match="survive the listing route"):
         b.build(out=out, obj_dir=obj, verbose=False, force=True)
+
+
+def test_the_audit_survives_truncated_and_corrupted_files(tmp_path):
+    """rtgr_code_object_audit (and through it rtgr_user_metric_load) reads UNTRUSTED files: truncated images, section tables and
+    bundle entries whose offsets / sizes lie — including values near 2^64, where `off + size > bytes` wraps — must come
+    back as RTGR_ERR_BAD_ARG or a count, never as a crash.  Run in a child process so that a crash is a test failure, not the end
+    of the test run: 12 targeted corruptions of a real unit and of a real offload bundle + 300 seeded random ones."""
+    code = r'''
+import ctypes, os, random, struct, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "examples"))
+from __graft_entry__ import load_package
+rt = load_package()
+import user_metrics
+um = sys.modules[rt.__name__ + ".user_metric"]
+lib = rt._abi.load()
+good = open(um.compile_user_metric(user_metrics.SCHWARZSCHILD_ISOTROPIC, stationary=True), "rb").read()
+tmp = sys.argv[2]
+def audit(blob):
+    p = os.path.join(tmp, "case.bin")
+    open(p, "wb").write(blob)
+    n = ctypes.c_int32(-7); buf = ctypes.create_string_buffer(4096)
+    rc = lib.rtgr_code_object_audit(p.encode(), ctypes.byref(n), buf, 4096)
+    assert rc in (0, -1), rc
+    return rc, n.value
+assert audit(good) == (0, 0)
+U64 = 0xFFFFFFFFFFFFFFFF
+e_shoff, e_shnum, e_shstrndx = struct.unpack_from("<Q", good, 0x28)[0], struct.unpack_from("<H", good, 0x3C)[0], struct.unpack_from("<H", good, 0x3E)[0]
+cases = [good[:n] for n in (0, 1, 16, 63, 64, 200, e_shoff, e_shoff + 17, len(good) - 1)]
+def patch(off, fmt, val):
+    b = bytearray(good); struct.pack_into(fmt, b, off, val); return bytes(b)
+cases += [patch(0x28, "<Q", v) for v in (U64, U64 - 63, len(good) - 8, 1 << 63)]                       # e_shoff
+cases += [patch(0x3C, "<H", 0xFFFF), patch(0x3E, "<H", 0xFFFF), patch(0x3A, "<H", 1)]                   # e_shnum, e_shstrndx, e_shentsize
+for k in range(e_shnum):                                                                                # every section's offset / size
+    base = e_shoff + 64 * k
+    cases += [patch(base + 0x18, "<Q", U64 - 7), patch(base + 0x20, "<Q", U64), patch(base + 0x18, "<Q", len(good) - 3), patch(base + 0x00, "<I", 0xFFFFFFF0)]
+# an offload bundle around the good image, then with lying entries
+triple = b"hipv4-amdgcn-amd-amdhsa--gfx950"
+def bundle(off, size, tl=None, n=1):
+    head = b"__CLANG_OFFLOAD_BUNDLE__" + struct.pack("<Q", n) + struct.pack("<QQQ", off, size, len(triple) if tl is None else tl) + triple
+    return head + b"\0" * (4096 - len(head)) + good
+assert audit(bundle(4096, len(good))) == (0, 0)
+cases += [bundle(U64 - 5, 64), bundle(4096, U64), bundle(U64, U64), bundle(4096, len(good) + 1), bundle(4096, len(good), tl=U64), bundle(4096, len(good), tl=300),
+          bundle(4096, len(good), n=U64), bundle(1 << 62, 1 << 62)]
+rng = random.Random(5)
+for _ in range(300):
+    b = bytearray(good if rng.random() < 0.7 else bundle(4096, len(good)))
+    for _ in range(rng.randint(1, 6)):
+        at = rng.randrange(0, min(len(b), e_shoff + 64 * e_shnum if rng.random() < 0.5 else 4200))
+        b[at] = rng.randrange(256)
+    if rng.random() < 0.3:
+        b = b[:rng.randrange(1, len(b))]
+    cases.append(bytes(b))
+seen = {0: 0, -1: 0}
+for c in cases:
+    rc, n = audit(c)
+    seen[rc] += 1
+print("cases", len(cases), "ok", seen[0], "refused", seen[-1])
+'''
+    r = subprocess.run([sys.executable, "-c", code, ROOT, str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "cases" in r.stdout and "refused" in r.stdout
