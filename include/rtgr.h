@@ -208,7 +208,9 @@ int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len
  * bit —, and three that select another FORMULATION of the same algorithm, with results equal up to rounding: "tile" (1: the
  * simple tile-per-wave kernel), "pack" (Float32: 0 = one ray per lane, 1 = two rays per lane in packed arithmetic) and "packfar"
  * (Float32 experiment, default 0: 1 = the packed kernel without its scan as a FAR pass + the scalar NEAR pass; measured slower).
- * value -1 = automatic.  Initial values come from the environment variables RTGR_<NAME> read ONCE when the context is created. */
+ * value -1 = automatic.  Initial values come from the environment variables RTGR_<NAME> read ONCE when the context is created.
+ * Two options govern how run-time units are LOADED: "unit_audit" (default 1; 0 = skip the audit of the code object for the
+ * compiler's EXEC-flip fault) and "unit_probe" (default 1; 0 = skip the load-time probe) — test hooks, see rtgr_user_metric_load. */
 int rtgr_set_option(rtgr_context* ctx, const char* name, long value);
 int rtgr_get_option(rtgr_context* ctx, const char* name, long* value);
 
@@ -453,6 +455,14 @@ int rtgr_code_object_audit(const char* code_object_path, int* found, char* repor
  * repaired_path and *blocks = blocks rewritten (RTGR_ERR_BAD_ARG, nothing written, when a block is not of the form the rewrite is
  * proven for).  The same rule as raytracegr.jl_amd/isa_exec.py; the tests hold the two to the same answers. */
 int rtgr_listing_repair(const char* listing_path, const char* repaired_path, int* blocks);
+/* Every unit that rtgr_user_metric_load / _compile / rtgr_user_unit_compile brings in is checked THREE ways before a scene can use
+ * it: (1) ABI version and — when the builder recorded it — a hash of the device headers it was compiled against, which must be the
+ * one the library's own kernels were built from (the record layouts the kernels share are not part of this header and move
+ * without the ABI version moving); (2) the audit above, on bare code objects and on clang offload bundles alike; an image the
+ * audit cannot read is refused, a box without the disassembler loads unaudited; (3) a PROBE: the unit traces a fixed 32 x 32 frame
+ * through its single FULL pass and through its FAR + NEAR passes, twice each (Float32 FULL pass twice), and is refused
+ * (RTGR_ERR_BAD_ARG, nothing left resident) when two runs of one structure differ in any bit or the structures disagree — the
+ * symptoms of a mis-compiled unit, whatever the instruction shape (~10-70 ms). */
 /* 1 if module `id` is resident (id 0: any module), else 0 */
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id);
 

@@ -42,3 +42,29 @@ def test_assembly_inverts_the_split_with_padded_shares(ni, nj, ws, layout, plane
         parts.append(torch.cat([mine, pad], dim=1))
     got = sharded.assemble_rows(parts, ni, nj, ws, layout)
     assert torch.equal(got, full.reshape(planes, nj * ni))
+
+
+@settings(max_examples=100, deadline=None)
+@given(nj=st.integers(1, 200), ws=st.integers(1, 16), layout=st.sampled_from(["cyclic", "slab"]))
+def test_row_owner_is_the_rank_that_row_assignment_gives_the_row_to(nj, ws, layout):
+    """bench.py attributes a row whose checksum differs to the rank (or context device) that traced it: row_owner must be the inverse
+    of row_assignment for every row, rank count and layout."""
+    for r in range(ws):
+        j0, stride, nr = sharded.row_assignment(nj, ws, r, layout)
+        for j in (j0 + stride * np.arange(nr)):
+            assert sharded.row_owner(nj, ws, int(j), layout) == r
+
+
+def test_per_row_checksums_sum_to_the_frame_checksum_and_localise_a_wrong_row():
+    """the arithmetic of bench.py's frame / row checksums on a synthetic frame: int64 sums of the bit patterns (wrapping), one per
+    image row of the [3, ni * nj] planes (pixel i + j * ni); a change in one row moves that row's checksum only."""
+    ni, nj = 7, 5
+    rng = np.random.default_rng(3)
+    frame = torch.from_numpy(rng.normal(size=(3, ni * nj)))
+    bits = frame.contiguous().view(torch.int64)
+    rows = bits.view(3, nj, ni).sum(dim=(0, 2)).numpy()
+    assert (int(rows.sum()) - int(bits.sum().item())) % 2 ** 64 == 0
+    other = frame.clone()
+    other[1, 3 * ni + 2] += 1e-9            # plane 1, row 3, column 2
+    rows2 = other.contiguous().view(torch.int64).view(3, nj, ni).sum(dim=(0, 2)).numpy()
+    assert list(np.nonzero(rows != rows2)[0]) == [3]
