@@ -7,6 +7,8 @@
                                             #   in isotropic coordinates: a metric compiled at run time, UserMetric)
     python examples/render.py 4             # writes scenes/sphere4.png (the same scene around a Kerr hole, a = 0.8, in
                                             #   Boyer–Lindquist coordinates — user source with macos / matan2)
+    python examples/render.py 5             # writes scenes/sphere5.png (example2 with NEW Object subtypes — a torus and an
+                                            #   ellipsoid given as device source, UserObjects — where the small sphere was)
 
 The code below is what a user of RayTraceGR.jl writes, with `RayTraceGR.` replaced by the host mirror `rt.`.
 """
@@ -33,12 +35,17 @@ def main():
     frustum = rt.Plane(-20)                                                    # cut-off plane in the past
     sphere = rt.Sphere((0, 0 if which == 1 else 4, 0, 0), (1, 0, 0, 0), 0.5)   # the visible sphere
     objs = [caelum, frustum, sphere]
+    if which == 5:   # new subtypes of the reference's open `abstract type Object{T}` (distance / objcolor, src/RayTraceGR.jl:374-389)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import user_objects
+        shapes = rt.UserObjects(user_objects.SHAPES_WITH_REACH, name="torus + ellipsoid")
+        objs = [caelum, frustum, shapes(user_objects.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]), shapes(user_objects.ELLIPSOID, [3.3, 1.0, -0.8, 0.7, 0.5, 0.5])]
     pos = (0, 0 if which == 1 else 4, -2, 0)
     canvas = rt.make_canvas(metric, pos, (0, 1, 0, 0), (0, 0, 0, 1), (0, 0, 1, 0), ni, nj)
     canvas, info = rt.trace_rays(metric, objs, canvas, return_info=True)
     from raytracegr_jl_amd.png import write_png
     os.makedirs(rt.api.outdir, exist_ok=True)
-    file = os.path.join(rt.api.outdir, {1: "sphere.png", 2: "sphere2.png", 3: "sphere3.png", 4: "sphere4.png"}[which])
+    file = os.path.join(rt.api.outdir, {1: "sphere.png", 2: "sphere2.png", 3: "sphere3.png", 4: "sphere4.png", 5: "sphere5.png"}[which])
     write_png(file, canvas.image_u8())
     print(f'Output file is "{file}"  ({info["rays"]} rays, {info["accepted"] + info["rejected"]} RK step attempts)')
 

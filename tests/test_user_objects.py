@@ -364,3 +364,49 @@ template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], con
         full = hip_trace(lib, sc, opt, 48, 48, cam=camera)
     assert np.array_equal(full["hit"], O.trace(sc, opt, 48, 48, cam=camera)["hit"])
     assert (hip_trace(lib, sc, opt, 48, 48, cam=camera)["hit"] != full["hit"]).sum() > 0
+
+
+def _random_shapes_scene(seed):
+    """Seeded random scene with user objects among built-in ones: random Kerr–Schild variant (units for four metric variants), an
+    optional sky sphere, 2-6 objects drawn from {plane, sphere, disk, torus, ellipsoid} in random order with random parameters, random
+    camera and solver constants — the random-scene test of tests/test_gpu_parity.py with the two new Object subtypes in the mix."""
+    rng = np.random.default_rng(1000 + seed)
+    metric = [rt.kerr_schild, rt.KerrSchild(1.0, 0.6), rt.KerrSchild(0.7, 0.9, textbook=False), rt.KerrSchild(1.3, 0.0)][seed % 4]
+    fam = user_shapes()[0]
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -rng.uniform(9, 14))] if seed % 3 else []
+    n_user = 0
+    for k in range(rng.integers(2, 7)):
+        kind = rng.integers(0, 6) if (k or n_user) else 4          # (at least one user object per scene)
+        c = rng.normal(size=3) * 1.5 + np.array([4, 1, 0])
+        if kind == 0:
+            objs.append(rt.Plane(-rng.uniform(8, 30)))
+        elif kind == 1:
+            objs.append(rt.Sphere((0, *c), (1, 0, 0, 0), rng.uniform(0.2, 1.2)))
+        elif kind == 2:
+            objs.append(rt.Disk(rng.uniform(0.02, 0.2), rng.uniform(2.5, 4), rng.uniform(5, 8)))
+        elif kind in (3, 4):
+            objs.append(fam(user_objects.TORUS, [*c, rng.uniform(0.5, 1.4), rng.uniform(0.15, 0.4)]))
+            n_user += 1
+        else:
+            objs.append(fam(user_objects.ELLIPSOID, [*c, *rng.uniform(0.25, 1.0, size=3)]))
+            n_user += 1
+    pos = (0, 4 + rng.normal(), -3 + rng.normal(), rng.normal() * 0.5)
+    cam = rt.make_camera(pos, (0, 1, 0, 0), (0, 0, 0, 1), (0, 0.1 * rng.normal(), 1, 0.1 * rng.normal()))
+    opt = rt.solver_defaults(lambda1=float(rng.choice([100.0, 15.0])), reltol=float(rng.choice([2.0 ** -39, 1e-9])),
+                             hit_threshold=float(rng.choice([0.01, 0.05])), miss_rgb=(0.25, 0.5, 0.75), max_steps=5000)
+    return rt.make_scene(metric, objs), cam, opt, len(objs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_with_user_objects_match_the_oracle(lib, seed):
+    """The stated bounds of test_random_scenes_match_oracle (tests/test_gpu_parity.py: unfinished rays by count, <= 6 class flips,
+    <= 2 pixels over the 1e-6 wrap-aware RGB bar outside long orbits, step counts p99 <= 3) on scenes that mix the torus and the
+    ellipsoid with planes, spheres and disks — and, the reach bound coming from the source, the scene check on each of them."""
+    from test_gpu_parity import hip_trace, random_scene_violations
+    sc, cam, opt, nobj = _random_shapes_scene(seed)
+    gpu = hip_trace(lib, sc, opt, 40, 32, cam=cam)
+    ref = O.trace(sc, opt, 40, 32, cam=cam)
+    v = random_scene_violations(gpu, ref, sc, nobj)
+    assert not v, v
+    abi.check(lib, lib.rtgr_scene_check(None, C.byref(sc), C.byref(opt), C.byref(cam), 40, 32, 0))
