@@ -417,7 +417,10 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
  * objects may stand beside user objects in any order (:518-530's order rule applies to all).  Limits: the tile kernel
  * (option tile = 1) and the packed Float32 kernel know no user objects — scenes of a unit take the pipeline's scalar kernels;
  * the redshift output treats a user object's emitter as the static observer (as for planes and disks).
- * rtgr_user_metric_compile(ctx, source, stationary, id) == rtgr_user_unit_compile(ctx, source, stationary, NULL, id). */
+ * rtgr_user_metric_compile(ctx, source, stationary, id) == rtgr_user_unit_compile(ctx, source, stationary, NULL, id).
+ *   Environment: RTGR_UNIT_CACHE=<directory> (opt-in) keeps the code objects rtgr_user_unit_compile / rtgr_user_metric_compile build,
+ * keyed by source text + what they are built for + the device headers; a later process with the same inputs loads the file (audited
+ * and probed like any other) instead of compiling for seconds. */
 int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary, const rtgr_scene* built_for, uint64_t* id_out);
 /* ... the build step on its own (no GPU, no context): source -> code object file for rtgr_user_metric_load */
 int rtgr_user_unit_build(const char* source, int stationary, const rtgr_scene* built_for, const char* code_object_path);

@@ -2040,10 +2040,39 @@ int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary
     rtgr_context* c = nullptr;
     int rc = resolve_ctx(ctx, &c);
     if (rc) return rc;
+    // Opt-in disk cache for callers without a build system of their own (C, Julia): with RTGR_UNIT_CACHE=<directory> the code object
+    // of (source, what it is built for, the device headers) is kept there and a later process loads it in milliseconds instead of
+    // compiling for seconds.  The key covers everything the image depends on; the file is audited and probed at load like any other.
+    std::string cache_file;
+    if (const char* dir = std::getenv("RTGR_UNIT_CACHE")) if (*dir && source) {
+        UnitPlan P;
+        unsigned long long hh = 0;
+        if (plan_unit(source, stationary, built_for, &P) == RTGR_OK && header_hash_of(csrc_dir(), &hh) == RTGR_OK) {
+            std::string key = source;
+            for (const std::string& d : P.defines) key += "\n" + d;
+            key += "\n" + std::to_string(hh) + "\nabi " + std::to_string(RTGR_ABI_VERSION);
+            char name[64];
+            std::snprintf(name, sizeof name, "/unit_%016llx.hsaco", (unsigned long long)fnv1a(std::vector<char>(key.begin(), key.end())));
+            cache_file = std::string(dir) + name;
+            std::vector<char> image;
+            FILE* f = std::fopen(cache_file.c_str(), "rb");
+            if (f) {
+                std::fclose(f);
+                if (read_file(cache_file, image) == RTGR_OK && load_module_image(c, image, cache_file, id_out) == RTGR_OK) return RTGR_OK;
+                // (a stale or damaged file: fall through, rebuild and overwrite it)
+            }
+        }
+    }
     unit_build::Built built;
     if ((rc = build_unit_image(source, stationary, built_for, &built))) return rc;
     const std::vector<char> image(built.image.begin(), built.image.end());
-    return load_module_image(c, image, "compiled unit", id_out);   // (audited and probed there like any other image)
+    rc = load_module_image(c, image, "compiled unit", id_out);   // (audited and probed there like any other image)
+    if (rc == RTGR_OK && !cache_file.empty()) {
+        const std::string keep = rtgr_last_error();
+        (void)write_image(built, cache_file.c_str());             // best effort: an unwritable directory must not fail the compile
+        (void)fail(0, keep);
+    }
+    return rc;
 }
 int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
     return rtgr_user_unit_compile(ctx, source, stationary, nullptr, id_out);

@@ -410,3 +410,34 @@ def test_random_scenes_with_user_objects_match_the_oracle(lib, seed):
     v = random_scene_violations(gpu, ref, sc, nobj)
     assert not v, v
     abi.check(lib, lib.rtgr_scene_check(None, C.byref(sc), C.byref(opt), C.byref(cam), 40, 32, 0))
+
+
+@pytest.mark.gpu
+def test_in_process_units_can_be_kept_on_disk(lib, tmp_path, monkeypatch):
+    """RTGR_UNIT_CACHE (opt-in): the code object rtgr_user_unit_compile builds is kept under a key of everything it depends on, and the
+    same call in a later process — here: after unloading the unit — loads the file instead of compiling: same id, probed again, in a
+    fraction of the time; another source or another metric variant is another file."""
+    import time
+    monkeypatch.setenv("RTGR_UNIT_CACHE", str(tmp_path))
+    sc, cam = scene_variant("ks_true0_shapes", units=False)
+    src = (user_objects.SHAPES_WITH_REACH + "\n// cache test\n").encode()
+
+    def compile_once(scene):
+        mid = C.c_uint64(0)
+        t0 = time.perf_counter()
+        abi.check(lib, lib.rtgr_user_unit_compile(None, src, 0, C.byref(scene), C.byref(mid)))
+        return mid.value, time.perf_counter() - t0
+    first, t_build = compile_once(sc)
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 1 and files[0].startswith("unit_") and files[0].endswith(".hsaco")
+    abi.check(lib, lib.rtgr_user_metric_unload(None, first))
+    again, t_load = compile_once(sc)
+    assert again == first and um.unit_info(again)["probe_ok"] == 1 and t_load < 0.5 * t_build, (t_build, t_load)
+    other = abi.rtgr_scene.from_buffer_copy(sc)
+    other.a = 0.7                                                  # the a != 0 instantiation: another unit, another file
+    third, _ = compile_once(other)
+    assert third != first and len(os.listdir(tmp_path)) == 2
+    sc.user_metric = again
+    from test_gpu_parity import compare, hip_trace
+    opt = rt.solver_defaults()
+    compare(hip_trace(lib, sc, opt, 24, 24, cam=cam), O.trace(sc, opt, 24, 24, cam=cam), max_step_diff=1, sc=sc)
