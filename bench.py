@@ -873,12 +873,35 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     rt._abi.check(lib, lib.rtgr_timing_enable(None, 0, 0))
     att = (int(ctr[1]) + int(ctr[2])) / reps
     rays = n * n
+    # A render loop delivers frame after frame: with TWO frames in flight — frame k on stream A, frame k + 1 on stream B, each stream
+    # with the pipeline workspace the library keeps per stream — the thin end of one frame's passes overlaps the start of the next
+    # (what bench.py does at N > 1).  Small frames only (it is worth 0.4 % at 4096²); throughput, not latency.
+    two = None
+    if n * n <= (1 << 22) and not user_sphere:
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs2 = [{}, {}]
+        ctr2 = torch.zeros(8, dtype=torch.int64, device="cuda")
+        def frame(k):
+            with torch.cuda.stream(streams[k % 2]):
+                sharded.trace_rows_torch(sc, opt, cam, n, n, 0, 1, n, dtype=npdt, counters=ctr2, out=outs2[k % 2])
+        for k in range(4):
+            frame(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(2 * reps):
+            frame(k)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / (2 * reps)
+        two = {"ms_per_pass": dt2 * 1e3, "step_attempts_per_s": att / dt2, "over_single_stream": dt2 / dt,
+               "same_frame": bool(torch.equal(outs2[0]["rgb"], o["rgb"]) and torch.equal(outs2[1]["rgb"], o["rgb"]))}
     bits = o["rgb"].contiguous().view(torch.int64 if dtype == "f64" else torch.int32).to(torch.int64)
     _LAST_FRAME[0] = o["rgb"].clone() if user_sphere or keep_frame else None
     v = {"workload": f"{variant}, same camera, {n}x{n}, {dtype}, rhs {rhs}" + (", small sphere as a USER object" if user_sphere else ""),
          "size": n, "dtype": dtype, "rhs": rhs, "frame_checksum": int(bits.sum().item()),
          "ms_per_pass": dt * 1e3, "step_attempts_per_s": att / dt, "rays_per_s": rays / dt,
          "step_attempts_per_ray": att / rays, "rejected_per_pass": int(ctr[2]) // reps}
+    if two is not None:
+        v["two_frames_in_flight"] = two
     k_s = (float(kms[1]) + float(kms[3])) * 1e-3 / reps
     class _A:  # noqa: E701
         pass
