@@ -267,3 +267,62 @@ def test_runtests_hip_uses_only_what_the_stub_defines():
     for title in ('@testset "Minkowski metric"', '@testset "Kerr-Schild metric" for i in 1:7', '@testset "rays"',
                   '@testset "example1 / example2 == the committed PNGs"'):
         assert title in open(JLTESTS).read(), title
+
+
+# ---- a tokenizer-level check of the two Julia files (tests/julia_lint.py): what a parser or a first run would find ----------------
+# names the files take from Base / Core, StaticArrays, LinearAlgebra, Test-less Base utilities, and the reference's own exports
+# (src/RayTraceGR.jl: `export …` lines — SURVEY.md §2 lists them); everything else a function reads must be bound in the file
+JL_BASE = {"AbstractString", "Array", "Base", "C_NULL", "Cint", "Cstring", "Cvoid", "Dict", "ENV", "Float32", "Float64", "GC", "Int", "Integer",
+           "Matrix", "NTuple", "Ptr", "Real", "Ref", "String", "Tuple", "Type", "UInt32", "UInt64", "UInt8", "abs", "all", "any", "atan", "ccall",
+           "clamp", "close", "collect", "count", "dirname", "eltype", "eps", "error", "fieldcount", "fieldoffset", "finalizer", "get", "get!",
+           "hash", "include", "inv", "isbitstype", "isempty", "isnan", "isnothing", "joinpath", "length", "map", "max", "maximum", "mkpath", "mod",
+           "new", "ntuple", "permutedims", "pointer", "println", "reinterpret", "rm", "round", "similar", "size", "sizeof", "sqrt", "undef",
+           "unique", "unsafe_string", "zeros", "π"}
+JL_PACKAGES = {"SVector", "SMatrix", "SArray", "I", "RayTraceGR", "RayTraceGRHIP", "Images"}
+JL_REFERENCE_EXPORTS = {"Dual", "D", "minkowski", "kerr_schild", "dmetric", "christoffel", "Ray", "r2s", "s2r", "geodesic", "Object", "Plane",
+                        "Sphere", "min_distance", "Pixel", "Canvas", "make_canvas", "trace_rays"}
+
+
+def _lint(path_or_text, is_text=False):
+    import julia_lint as L
+    text = path_or_text if is_text else open(path_or_text).read()
+    toks = L.tokenize(text)
+    blocks = L.check_structure(toks)
+    known = JL_BASE | JL_PACKAGES | JL_REFERENCE_EXPORTS
+    return blocks, L.check_names(toks, known) + L.check_toplevel_names(toks, known)
+
+
+def test_julia_files_tokenize_nest_and_bind_every_name():
+    """julia/RayTraceGRHIP.jl and julia/runtests_hip.jl go through a tokenizer end to end (strings with interpolation, character
+    literals against the postfix transpose, nested comments), their brackets nest with the right kinds, every block has its `end`
+    (and `elseif` / `catch` stand in the right block), and every identifier a function body or a top-level statement reads is bound:
+    an argument, a local, a type parameter, a definition of the file, or a name Base / StaticArrays / the reference provides."""
+    for path, min_blocks in ((JL, 50), (JLTESTS, 12)):
+        blocks, unbound = _lint(path)
+        assert blocks >= min_blocks, (path, blocks)
+        assert not unbound, (path, sorted({(line, name) for _, line, name in unbound})[:20])
+
+
+def test_the_julia_checker_finds_what_a_parser_or_a_first_run_would():
+    """… and it is not a rubber stamp: the same files with one fault injected each — an unterminated string, brackets closed in the
+    wrong order, an `end` too many, an `elseif` spelled `else if`, a misspelled local variable, a misspelled function — are refused."""
+    import julia_lint as L
+    src = open(JL).read()
+    assert 'check(ccall((:rtgr_user_unit_compile, librtgr)' in src and "any(isnothing, po) && return nothing" in src
+    faults = {
+        "unterminated string": src.replace('const librtgr = get(ENV, "RTGR_LIB", "librtgr_hip.so")', 'const librtgr = get(ENV, "RTGR_LIB, "librtgr_hip.so")'),
+        "wrong bracket order": src.replace("any(isnothing, po) && return nothing", "any(isnothing, po] && return nothing"),
+        "an end too many": src.replace("ndevices(ctx) = Int(", "end\nndevices(ctx) = Int("),
+        "else if": src.replace("else\n            check(ccall((:rtgr_make_canvas_f32", "else if true\n            check(ccall((:rtgr_make_canvas_f32", 1),
+    }
+    for what, text in faults.items():
+        assert text != src, what
+        with pytest.raises(L.LintError):
+            L.check_structure(L.tokenize(text))
+    # names
+    for what, text, name in (("misspelled local", src.replace("any(isnothing, po) && return nothing", "any(isnothing, p0) && return nothing"), "p0"),
+                             ("misspelled function", src.replace("scene = scene_of(metric, objs, ctx)\n    scene === nothing && return RayTraceGR.trace_rays", "scene = scene_off(metric, objs, ctx)\n    scene === nothing && return RayTraceGR.trace_rays", 1), "scene_off"),
+                             ("misspelled constant", src.replace("pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECT, o.type, o.p)", "pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECTS, o.type, o.p)"), "RTGR_USER_OBJECTS")):
+        assert text != src, what
+        _, unbound = _lint(text, is_text=True)
+        assert name in {n for _, _, n in unbound}, (what, unbound[:5])
