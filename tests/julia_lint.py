@@ -205,17 +205,13 @@ def check_structure(tokens):
                 if stack and next(s[0] for s in reversed(stack) if s[0] in "([{") == "[":
                     continue                                       # a[end]: lastindex
                 raise LintError(f"line {t.line}: `end` inside ( ) or {{ }}")
-            if t.val == "struct" and k and toks[k - 1].kind == "kw" and toks[k - 1].val == "mutable":
-                pass
             if t.val == "type" and not (k and toks[k - 1].kind == "kw" and toks[k - 1].val in ("abstract", "primitive")):
                 continue
             if t.val == "type":
                 stack.append(("abstract type", t.line))
                 blocks += 1
                 continue
-            if t.val in OPENERS:
-                if t.val == "function" and k + 1 < len(toks) and False:
-                    pass
+            if t.val in OPENERS:                                   # (`mutable struct` is ONE block: `mutable` opens nothing)
                 stack.append((t.val, t.line))
                 blocks += 1
             elif t.val in ("elseif", "else"):
