@@ -352,6 +352,14 @@ int rtgr_eval_geodesic_f64(rtgr_context* ctx, const rtgr_scene* scene, const dou
                            double* ds /* n x 8 */);
 int rtgr_eval_geodesic_f32(rtgr_context* ctx, const rtgr_scene* scene, const float* s /* n x 8 */, uint64_t n, int path,
                            float* ds /* n x 8 */);
+/* objects and the colour rule at n points, on the device (host pointers): `distance(obj, x)` of every object of the scene in scene order
+ * (src/RayTraceGR.jl:377-419; user objects: the unit's rtgr_user_distance), `min_distance(objs, s)` (:433-441) and the colouring loop of
+ * trace_rays (:513-533: nearest object below opt->hit_threshold, objcolor x omin / length(objs), else opt->miss_rgb) evaluated at x as
+ * if a ray had ended there.  x: n x 4;  d: n x nobj;  dmin: n;  hit: n (omin, 0 = miss);  rgb: n x 3 (AoS).  Any output may be NULL. */
+int rtgr_eval_objects_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* x /* n x 4 */, uint64_t n,
+                          double* d, double* dmin, uint8_t* hit, double* rgb);
+int rtgr_eval_objects_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* x /* n x 4 */, uint64_t n,
+                          float* d, float* dmin, uint8_t* hit, float* rgb);
 /* the hot loop's reciprocal and reciprocal-square-root sequences (hardware seed + one third-order correction) on n
  * operands; either output may be NULL */
 int rtgr_eval_fastmath_f64(rtgr_context* ctx, const double* x, uint64_t n, double* rcp, double* rsq);

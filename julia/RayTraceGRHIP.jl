@@ -412,6 +412,37 @@ struct RayDetails{T}
 end
 
 """
+    eval_objects(metric, objs, xs::Vector{SVector{4,T}}; ctx = nothing) -> (d, dmin, hit, rgb)
+
+The object side of the path at the points `xs`, on the device (`rtgr_eval_objects_f64/_f32`): `d[o, p]` = `distance(objs[o], xs[p])`
+(:377-419; a `DeviceObject`: its unit's `rtgr_user_distance`), `dmin[p]` = `min_distance` (:433-441), and the colouring loop of
+`trace_rays` (:513-533) as if a ray had ended at `xs[p]`: `hit[p]` = the object's index (0: nothing within the threshold), `rgb[:, p]`.
+What `runtests_hip.jl` holds against the Julia methods of the same object, point by point.
+"""
+function eval_objects(metric, objs::Vector{RayTraceGR.Object{T}}, xs::Vector{SVector{4,T}}; ctx = nothing) where {T<:Union{Float64,Float32}}
+    scene = scene_of(metric, objs, ctx)
+    scene === nothing && error("eval_objects: this scene runs on the reference's CPU path")
+    opt = solver_of(T)
+    n = length(xs)
+    d = Matrix{T}(undef, max(length(objs), 1), n)        # C layout d[p * nobj + o]
+    dmin = Vector{T}(undef, n)
+    hit = Vector{UInt8}(undef, n)
+    rgb = Matrix{T}(undef, 3, n)                         # C layout rgb[3 p + c]
+    GC.@preserve xs d dmin hit rgb begin
+        if T === Float64
+            check(ccall((:rtgr_eval_objects_f64, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}, Ptr{Cvoid}),
+                        handle(ctx), scene, opt, pointer(xs), n, pointer(d), pointer(dmin), pointer(hit), pointer(rgb)))
+        else
+            check(ccall((:rtgr_eval_objects_f32, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Cvoid}, UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}, Ptr{Cvoid}),
+                        handle(ctx), scene, opt, pointer(xs), n, pointer(d), pointer(dmin), pointer(hit), pointer(rgb)))
+        end
+    end
+    d, dmin, hit, rgb
+end
+
+"""
     check_scene(metric, objs, pos, widthx, widthy, normal; ni = 48, nj = 48, ctx = nothing)
 
 `rtgr_scene_check`: traces a coarse canvas of this camera through the single FULL pass (every accepted step scanned, as the

@@ -241,6 +241,17 @@ template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], con
     kerr = RayTraceGRHIP.KerrSchild(1.0, 0.8)
     @test maximum(maximum(abs.(RayTraceGRHIP.trace_rays(kerr, hip_objs, small).pixels[k].rgb -
                                RayTraceGR.trace_rays(kerr, cpu_objs, small).pixels[k].rgb)) for k in 1:576) <= 1e-6
+    # the two methods pointwise: the unit's rtgr_user_distance / rtgr_user_objcolor against the Julia methods of the same Torus
+    xs = [SVector(0.0, 4.9, 0.0, 0.3), SVector(0.0, 4.0, 0.3, 0.7), SVector(-3.0, 2.0, 1.0, 0.5), SVector(-20.0, 0.0, 0.0, 0.0)]
+    d, dmin, hit, rgb = RayTraceGRHIP.eval_objects(kerr_schild, hip_objs, xs)
+    for p in 1:length(xs)
+        for o in 1:3
+            @test abs(d[o, p] - RayTraceGR.distance(cpu_objs[o], xs[p])) <= 1e-13 * (1 + abs(d[o, p]))
+        end
+        @test dmin[p] == minimum(d[:, p])
+    end
+    @test hit[1] == 3 && maximum(abs.(rgb[:, 1] - RayTraceGR.objcolor(cpu_objs[3], xs[1]))[[1, 3]]) <= 1e-12   # on the tube (G sits on a sawtooth jump there)
+    @test hit[4] == 2 && rgb[:, 4] == [0.0, 0.5, 0.0] .* (2 / 3)                                                  # on the plane
     # the source's reach bound against the single FULL pass, on this very scene (throws when the FAR pass would lose hits)
     RayTraceGRHIP.check_scene(kerr_schild, hip_objs, pos, wx, wy, nrm)
     # an Object subtype WITHOUT device source still runs — on the reference's CPU path, as before

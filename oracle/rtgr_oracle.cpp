@@ -789,6 +789,21 @@ int trace_impl(const rtgr_scene* sc, const rtgr_solver* opt, const T* state0, co
     return RTGR_OK;
 }
 
+// distance(obj, x) of every object, min_distance and the colour rule at n points: the checker of rtgr_eval_objects_f64 / _f32
+template <class T>
+int eval_objects_impl(const rtgr_scene* sc, const rtgr_solver* opt, const T* x, uint64_t n, T* d, T* dmin, uint8_t* hit, T* rgb) {
+    for (uint64_t p = 0; p < n; p++) {
+        const T* xp = x + 4 * p;
+        if (d) for (uint32_t o = 0; o < sc->nobj; o++) d[p * sc->nobj + o] = distance<T>(sc->obj[o], xp);   // :377-419
+        if (dmin) dmin[p] = min_distance<T>(*sc, xp);                                                        // :433-441
+        T col[3];
+        const uint8_t h = colour<T>(*sc, *opt, xp, col);                                                     // :513-533
+        if (hit) hit[p] = h;
+        if (rgb) for (int c = 0; c < 3; c++) rgb[3 * p + c] = col[c];
+    }
+    return 0;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -925,6 +940,13 @@ int rtgr_oracle_redshift_f64(const rtgr_scene* sc, const double* state0, const d
     }
     return RTGR_OK;
 }
+int rtgr_oracle_eval_objects_f64(const rtgr_scene* sc, const rtgr_solver* opt, const double* x, uint64_t n, double* d, double* dmin, uint8_t* hit, double* rgb) {
+    return eval_objects_impl<double>(sc, opt, x, n, d, dmin, hit, rgb);
+}
+int rtgr_oracle_eval_objects_f32(const rtgr_scene* sc, const rtgr_solver* opt, const float* x, uint64_t n, float* d, float* dmin, uint8_t* hit, float* rgb) {
+    return eval_objects_impl<float>(sc, opt, x, n, d, dmin, hit, rgb);
+}
+
 int rtgr_oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

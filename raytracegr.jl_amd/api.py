@@ -138,6 +138,22 @@ def make_scene(metric, objs, ctx=None, units=True):
     return sc
 
 
+def eval_objects(metric, objs, x, opt=None, dtype=np.float64, ctx=None):
+    """distance(obj, x) of every object, min_distance(objs, x) and the colouring rule of trace_rays at the points x [n, 4], on the
+    GPU (rtgr_eval_objects_*; src/RayTraceGR.jl:377-441, :513-533) -> dict(d [n, nobj], dmin [n], hit [n], rgb [n, 3])"""
+    lib = _lib()
+    sc = make_scene(metric, objs, ctx)
+    x = np.ascontiguousarray(x, dtype=dtype).reshape(-1, 4)
+    n = x.shape[0]
+    opt = opt or solver_defaults(dtype)
+    out = dict(d=np.zeros((n, max(sc.nobj, 1)), dtype), dmin=np.zeros(n, dtype), hit=np.zeros(n, np.uint8), rgb=np.zeros((n, 3), dtype))
+    fn = lib.rtgr_eval_objects_f64 if dtype == np.float64 else lib.rtgr_eval_objects_f32
+    _abi.check(lib, fn(ctx, C.byref(sc), C.byref(opt), x.ctypes.data, n, out["d"].ctypes.data, out["dmin"].ctypes.data,
+                       out["hit"].ctypes.data, out["rgb"].ctypes.data))
+    out["d"] = out["d"][:, :sc.nobj]
+    return out
+
+
 def check_scene(metric, objs, cam, ni=48, nj=48, opt=None, ctx=None):
     """rtgr_scene_check: the FAR + NEAR passes of THIS scene must deliver the frame of the single FULL pass (every accepted step
     scanned, as the reference does) — the check that catches a rtgr_user_reach that is not an upper bound.  `cam`: make_camera
@@ -368,6 +384,6 @@ def example2(ni=200, nj=200, save=True, ctx=None):
 
 
 __all__ = ["D", "Metric", "UserMetric", "UserObjects", "UserObject", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
-           "make_scene", "check_scene", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
+           "make_scene", "check_scene", "eval_objects", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
            "trace_rays", "trace_ray", "dmetric", "christoffel", "geodesic", "example1", "example2",
            "example1_scene", "example2_scene"]

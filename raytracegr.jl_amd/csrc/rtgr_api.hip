@@ -1583,7 +1583,54 @@ static int eval_geodesic_host(rtgr_context* ctx, const rtgr_scene* scene, const 
     HIP_TRY(hipMemcpy(ds, bo.p, n * 8 * sizeof(R), hipMemcpyDeviceToHost));
     return RTGR_OK;
 }
+template <class R>
+static int eval_objects_host(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const R* x, uint64_t n, R* d, R* dmin, uint8_t* hit, R* rgb) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!x) return fail(RTGR_ERR_BAD_ARG, "x is NULL");
+    if (n == 0) return RTGR_OK;
+    DeviceCtx& D = *c->devs[0];
+    DeviceGuard guard(D.dev);
+    std::lock_guard<std::mutex> lk(D.mu);
+    DevScene<R> sc;
+    DevSolver<R> so;
+    const UserModule* user = nullptr;
+    if ((rc = convert_scene<R>(D, scene, sc, &user))) return rc;
+    if ((rc = convert_solver<R>(opt, so))) return rc;
+    const size_t nd = (size_t)n * (sc.nobj ? sc.nobj : 1);
+    DevBuf bx, bd, bm, bh, bc;
+    if ((rc = bx.alloc(n * 4 * sizeof(R)))) return rc;
+    HIP_TRY(hipMemcpy(bx.p, x, n * 4 * sizeof(R), hipMemcpyHostToDevice));
+    if (d && (rc = bd.alloc(nd * sizeof(R)))) return rc;
+    if (dmin && (rc = bm.alloc(n * sizeof(R)))) return rc;
+    if (hit && (rc = bh.alloc(n))) return rc;
+    if (rgb && (rc = bc.alloc(n * 3 * sizeof(R)))) return rc;
+    if (user && user->has_objects) {   // the scene's unit knows its objects' methods: its kernel
+        hipFunction_t f = sizeof(R) == 8 ? user->eval_objects : user->eval_objects_f32;
+        if (!f) return fail(RTGR_ERR_BAD_ARG, "this unit carries no rtgr_user_eval_objects kernel (rebuild the unit)");
+        HIP_TRY(launch_module(f, (unsigned)((n + 255) / 256), 256, (hipStream_t) nullptr, sc, so, (const R*)bx.p, n, (R*)bd.p, (R*)bm.p, (uint8_t*)bh.p, (R*)bc.p));
+    } else if constexpr (sizeof(R) == 8) {
+        if ((rc = misc_eval_objects_f64(sc, so, (const double*)bx.p, n, (double*)bd.p, (double*)bm.p, (uint8_t*)bh.p, (double*)bc.p, nullptr))) return rc;
+    } else {
+        if ((rc = misc_eval_objects_f32(sc, so, (const float*)bx.p, n, (float*)bd.p, (float*)bm.p, (uint8_t*)bh.p, (float*)bc.p, nullptr))) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (d) HIP_TRY(hipMemcpy(d, bd.p, nd * sizeof(R), hipMemcpyDeviceToHost));
+    if (dmin) HIP_TRY(hipMemcpy(dmin, bm.p, n * sizeof(R), hipMemcpyDeviceToHost));
+    if (hit) HIP_TRY(hipMemcpy(hit, bh.p, n, hipMemcpyDeviceToHost));
+    if (rgb) HIP_TRY(hipMemcpy(rgb, bc.p, n * 3 * sizeof(R), hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
 extern "C" {
+int rtgr_eval_objects_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* x, uint64_t n, double* d, double* dmin,
+                          uint8_t* hit, double* rgb) {
+    return eval_objects_host<double>(ctx, scene, opt, x, n, d, dmin, hit, rgb);
+}
+int rtgr_eval_objects_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* x, uint64_t n, float* d, float* dmin,
+                          uint8_t* hit, float* rgb) {
+    return eval_objects_host<float>(ctx, scene, opt, x, n, d, dmin, hit, rgb);
+}
 int rtgr_eval_geodesic_f64(rtgr_context* ctx, const rtgr_scene* scene, const double* s, uint64_t n, int path, double* ds) {
     return eval_geodesic_host<double>(ctx, scene, s, n, path, ds);
 }
@@ -1853,6 +1900,7 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
             {&u.full10_f32, "rtgr_user_integrate_full10_f32", false}, {&u.fulln_f32, "rtgr_user_integrate_fulln_f32", false},
             {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false},
             {&u.resolve_f32, "rtgr_user_resolve_f32", false},
+            {&u.eval_objects, "rtgr_user_eval_objects", false}, {&u.eval_objects_f32, "rtgr_user_eval_objects_f32", false},
             {&u.eval_accel, "rtgr_user_eval_accel", false}, {&u.redshift, "rtgr_user_redshift", false},
             {&u.redshift_f32, "rtgr_user_redshift_f32", false}};
         for (auto& w : want)

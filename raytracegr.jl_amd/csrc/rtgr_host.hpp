@@ -90,6 +90,7 @@ struct UserModule {
     hipFunction_t full10_f32 = nullptr, fulln_f32 = nullptr, prepare_f32 = nullptr, canvas_f32 = nullptr;
     hipFunction_t redshift = nullptr, redshift_f32 = nullptr;   // optional (units built before round 3 have none)
     hipFunction_t resolve = nullptr, resolve_f32 = nullptr;     // the resolve kernel with the unit's objects (used when has_objects)
+    hipFunction_t eval_objects = nullptr, eval_objects_f32 = nullptr;   // rtgr_eval_objects_* with the unit's objects
     // what the unit was built for (rtgr_user_unit_desc): a scene runs with it only if its own variant is this one
     uint32_t metric = RTGR_USER;   // rtgr_metric (| RTGR_METRIC_GENERIC) of its kernels; RTGR_USER: a metric of its own
     bool spin = true;              // closed-form built-in kernels: the a != 0 instantiation
@@ -194,6 +195,10 @@ int misc_eval_metric_f64(const DevScene<double>& sc, const double* d_x, uint64_t
 int misc_eval_metric_f32(const DevScene<float>& sc, const float* d_x, uint64_t n, float* g, float* dg, float* Gam, hipStream_t st);
 int misc_eval_geodesic_f64(const DevScene<double>& sc, const double* d_s, uint64_t n, int path, double* d_ds, hipStream_t st);
 int misc_eval_geodesic_f32(const DevScene<float>& sc, const float* d_s, uint64_t n, int path, float* d_ds, hipStream_t st);
+int misc_eval_objects_f64(const DevScene<double>& sc, const DevSolver<double>& opt, const double* d_x, uint64_t n, double* d, double* dmin, uint8_t* hit,
+                          double* rgb, hipStream_t st);
+int misc_eval_objects_f32(const DevScene<float>& sc, const DevSolver<float>& opt, const float* d_x, uint64_t n, float* d, float* dmin, uint8_t* hit,
+                          float* rgb, hipStream_t st);
 int misc_eval_fastmath_f64(const double* d_x, uint64_t n, double* d_rcp, double* d_rsq, hipStream_t st);
 int misc_redshift_f64(const DevScene<double>& sc, const DevCamera<double>& cam, const double* d_state0, uint64_t ni, uint64_t nj,
                       uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const double* d_state_end,

@@ -318,6 +318,21 @@ RTGR_DEV uint8_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, co
     return (uint8_t)omin;
 }
 
+// parity hook rtgr_eval_objects_f64 / _f32: distance(obj, x) of every object (:377-419), min_distance (:433-441) and the colour rule
+// (:513-533) at one point per thread — a body function: a unit with user objects wraps it in a kernel of its own
+template <class R>
+RTGR_DEV void eval_objects_body(const DevScene<R>& sc, const DevSolver<R>& opt, const R* x, uint64_t n, R* d, R* dmin, uint8_t* hit, R* rgb) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const R xp[4] = {x[4 * p], x[4 * p + 1], x[4 * p + 2], x[4 * p + 3]};
+    if (d) for (uint32_t o = 0; o < sc.nobj; o++) d[p * sc.nobj + o] = obj_distance<R>(sc.obj[o], xp);
+    if (dmin) dmin[p] = min_distance<R>(sc, xp);
+    R col[3];
+    const uint8_t h = colour_pixel<R>(sc, opt, xp, col);
+    if (hit) hit[p] = h;
+    if (rgb) for (int c = 0; c < 3; c++) rgb[3 * p + c] = col[c];
+}
+
 // metric(x) with plain scalars (no duals): what make_canvas calls (:469)
 template <class R>
 RTGR_DEV void metric_plain(const DevScene<R>& sc, const R x[4], R g[4][4]) {

@@ -76,6 +76,11 @@ __global__ __launch_bounds__(256) void eval_geodesic_kernel(DevScene<R> sc, cons
     for (int c = 0; c < 8; c++) ds[8 * p + c] = so[c];
 }
 
+template <class R>
+__global__ __launch_bounds__(256) void eval_objects_kernel(DevScene<R> sc, DevSolver<R> opt, const R* x, uint64_t n, R* d, R* dmin, uint8_t* hit, R* rgb) {
+    eval_objects_body<R>(sc, opt, x, n, d, dmin, hit, rgb);
+}
+
 // the hot loop's reciprocal / reciprocal-square-root helpers (rtgr_physics.hpp: frcp, frsq), exposed so that their
 // accuracy claim (<= 1.5e-16 relative) is a test, not a comment
 __global__ __launch_bounds__(256) void eval_fastmath_kernel(const double* x, uint64_t n, double* rcp, double* rsq) {
@@ -146,6 +151,16 @@ int misc_eval_metric_f64(const DevScene<double>& sc, const double* d_x, uint64_t
 int misc_eval_metric_f32(const DevScene<float>& sc, const float* d_x, uint64_t n, float* g, float* dg, float* Gam, hipStream_t st) {
     hipLaunchKernelGGL(eval_metric_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, sc, d_x, n, g, dg, Gam);
     CHECK_LAUNCH();
+    return RTGR_OK;
+}
+int misc_eval_objects_f64(const DevScene<double>& sc, const DevSolver<double>& opt, const double* d_x, uint64_t n, double* d, double* dmin, uint8_t* hit,
+                          double* rgb, hipStream_t st) {
+    hipLaunchKernelGGL(eval_objects_kernel<double>, dim3(nblk(n)), dim3(256), 0, st, sc, opt, d_x, n, d, dmin, hit, rgb);
+    return RTGR_OK;
+}
+int misc_eval_objects_f32(const DevScene<float>& sc, const DevSolver<float>& opt, const float* d_x, uint64_t n, float* d, float* dmin, uint8_t* hit,
+                          float* rgb, hipStream_t st) {
+    hipLaunchKernelGGL(eval_objects_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, sc, opt, d_x, n, d, dmin, hit, rgb);
     return RTGR_OK;
 }
 int misc_eval_geodesic_f64(const DevScene<double>& sc, const double* d_s, uint64_t n, int path, double* d_ds, hipStream_t st) {

@@ -103,3 +103,16 @@ def image_u8(rgb, ni, nj):
     """rgb[3, ni*nj] (linear index i + j*ni) -> uint8 image[j, i, c] with N0f8 rounding."""
     a = np.rint(np.clip(rgb, 0, 1) * 255.0).astype(np.uint8).reshape(3, nj, ni)
     return np.ascontiguousarray(np.transpose(a, (1, 2, 0)))
+
+
+def eval_objects(scene, opt, x, dtype=np.float64):
+    """oracle twin of rtgr_eval_objects_*: dict(d [n, nobj], dmin [n], hit [n], rgb [n, 3])"""
+    x = np.ascontiguousarray(x, dtype).reshape(-1, 4)
+    n = x.shape[0]
+    out = dict(d=np.zeros((n, max(scene.nobj, 1)), dtype), dmin=np.zeros(n, dtype), hit=np.zeros(n, np.uint8), rgb=np.zeros((n, 3), dtype))
+    fn = lib().rtgr_oracle_eval_objects_f64 if dtype == np.float64 else lib().rtgr_oracle_eval_objects_f32
+    rc = fn(C.byref(scene), C.byref(opt), C.c_void_p(x.ctypes.data), C.c_uint64(n), C.c_void_p(out["d"].ctypes.data),
+            C.c_void_p(out["dmin"].ctypes.data), C.c_void_p(out["hit"].ctypes.data), C.c_void_p(out["rgb"].ctypes.data))
+    assert rc == 0
+    out["d"] = out["d"][:, :scene.nobj]
+    return out

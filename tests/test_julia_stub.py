@@ -275,7 +275,7 @@ def test_runtests_hip_uses_only_what_the_stub_defines():
 JL_BASE = {"AbstractString", "Array", "Base", "C_NULL", "Cint", "Cstring", "Cvoid", "Dict", "ENV", "Float32", "Float64", "GC", "Int", "Integer",
            "Matrix", "NTuple", "Ptr", "Real", "Ref", "String", "Tuple", "Type", "UInt32", "UInt64", "UInt8", "abs", "all", "any", "atan", "ccall",
            "clamp", "close", "collect", "count", "dirname", "eltype", "eps", "error", "fieldcount", "fieldoffset", "finalizer", "get", "get!",
-           "hash", "include", "inv", "isbitstype", "isempty", "isnan", "isnothing", "joinpath", "length", "map", "max", "maximum", "mkpath", "mod",
+           "hash", "include", "inv", "isbitstype", "minimum", "Vector", "isempty", "isnan", "isnothing", "joinpath", "length", "map", "max", "maximum", "mkpath", "mod",
            "new", "ntuple", "permutedims", "pointer", "println", "reinterpret", "rm", "round", "similar", "size", "sizeof", "sqrt", "undef",
            "unique", "unsafe_string", "zeros", "π"}
 JL_PACKAGES = {"SVector", "SMatrix", "SArray", "I", "RayTraceGR", "RayTraceGRHIP", "Images"}

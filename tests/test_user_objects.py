@@ -29,7 +29,7 @@ abi = rt._abi
 um = sys.modules[rt.__name__ + ".user_metric"]
 UNIT_KERNELS = ["rtgr_user_integrate_far", "rtgr_user_integrate_near", "rtgr_user_integrate_full10", "rtgr_user_integrate_fulln",
                 "rtgr_user_prepare", "rtgr_user_resolve", "rtgr_user_integrate_full10_f32", "rtgr_user_integrate_fulln_f32",
-                "rtgr_user_prepare_f32", "rtgr_user_resolve_f32"]
+                "rtgr_user_prepare_f32", "rtgr_user_resolve_f32", "rtgr_user_eval_objects", "rtgr_user_eval_objects_f32"]
 UNIT_GLOBALS = ["rtgr_user_abi_version", "rtgr_user_header_hash", "rtgr_user_unit_desc", "rtgr_user_far_waves", "rtgr_user_near_waves",
                 "rtgr_user_f32_waves"]
 METRIC_ONLY = ["rtgr_user_canvas", "rtgr_user_eval_metric", "rtgr_user_eval_geodesic", "rtgr_user_eval_accel"]
@@ -472,3 +472,57 @@ def test_full_size_frames_with_user_objects_have_the_size_independent_properties
     sharded.trace_rows_torch(sc, opt, cam, size, size, j0, js, nr, out=share)
     torch.cuda.synchronize()
     assert torch.equal(share["rgb"].view(3, nr, size), a["rgb"].view(3, size, size)[:, j0::js, :])
+
+
+def test_oracle_object_methods_known_answers():
+    """(CPU) distance / min_distance / the colour rule of the oracle at hand-computed points: the reference's Plane and Sphere
+    (src/RayTraceGR.jl:394-428), the inside-out sky, and the two user-object twins — zero ON the surface, the contract's signs, the
+    colour rule's `omin / length(objs)` scale (:530) and its miss colour (:528)."""
+    _, (torus, egg, _) = user_shapes()
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10), rt.Plane(-20), rt.Sphere((0, 4, 0, 0), (1, 0, 0, 0), 0.5), torus, egg]
+    sc = rt.make_scene(rt.minkowski, objs, units=False)
+    opt = rt.solver_defaults()
+    x = np.array([[-3.0, 4.0, 1.0, 0.0],       # above the small sphere: |Δ|² − R² = 1 − 1/4
+                  [-20.0, 0.0, 0.0, 0.0],      # ON the plane t = −20, inside the sky sphere: −(0 − 100) … sign(R) = −1
+                  [0.0, 4.9, 0.0, 0.3],        # on the torus' surface: top of the tube at ϱ = R
+                  [0.0, 4.0, 0.0, 0.0],        # the torus' centre hole: (0 − 0.9)² − 0.3² = 0.72
+                  [0.0, 3.3, 1.5, -0.8],       # on the ellipsoid: one semi-axis b = 0.5 along y
+                  [0.0, 3.3, 1.0, -0.8],       # the ellipsoid's centre: −1
+                  [0.0, 4.0, 0.0, 0.7]])       # above the small sphere, near nothing: a miss
+    r = O.eval_objects(sc, opt, x)
+    assert np.allclose(r["d"][0, :3], [100.0 - 17.0, 17.0, 0.75], atol=1e-13)
+    assert r["d"][1, 1] == 0.0 and np.isclose(r["d"][1, 0], 100.0) and r["hit"][1] == 2 and np.allclose(r["rgb"][1], np.array([0, 0.5, 0]) * 2 / 5)
+    assert abs(r["d"][2, 3]) < 1e-15 and np.isclose(r["d"][3, 3], 0.72) and abs(r["d"][4, 4]) < 1e-15 and np.isclose(r["d"][5, 4], -1.0)
+    assert r["hit"][2] == 4 and np.isclose(r["rgb"][2, 2], 0.5 * 4 / 5)                      # torus: blue = 1/2 x omin / nobj
+    v = r["rgb"][2, 1] * 5 / 4                                                                 # poloidal angle π/2 at the top of the tube:
+    assert min(v, 1.0 - v) < 1e-9                                                              # mod(6·(π/2)/π, 1) = mod(3, 1) — on the sawtooth's jump
+    assert r["hit"][5] == 5 and r["hit"][3] == 3                                               # (the torus' hole holds the small sphere's centre)
+    assert r["hit"][6] == 0 and np.allclose(r["rgb"][6], [1, 0, 0]) and r["dmin"][6] > 0.2     # nothing within the threshold: the miss colour (:528)
+    assert np.allclose(r["dmin"], r["d"].min(axis=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-13), (np.float32, 2e-5)])
+def test_object_methods_on_the_device_match_the_oracle_pointwise(lib, dtype, tol):
+    """rtgr_eval_objects_*: distance of every object, min_distance and the colour rule at 4096 random points, built-in objects through
+    the library's kernel and the user objects through their unit's, against the oracle — pointwise, not through a traced frame (the
+    a6 / a7 rows of SURVEY §8 the way rtgr_eval_metric / rtgr_eval_geodesic serve a2–a5)."""
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(-25, 2, (4096, 1)), rng.normal(size=(4096, 3)) * 2.5 + np.array([3.5, 0.5, 0.0])], axis=1)
+    _, (torus, egg, torus2) = user_shapes()
+    builtin = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -10), rt.Plane(-20), rt.Sphere((0, 4, 0, 0), (1, 0, 0, 0), 0.5), rt.Disk(0.05, 2.0, 4.0)]
+    opt = rt.solver_defaults(dtype, hit_threshold=0.05)
+    for metric, objs in ((rt.kerr_schild, builtin), (rt.kerr_schild, builtin[:2] + [torus, egg, torus2]), (rt.KerrSchild(1.0, 0.8), [egg, builtin[0], torus])):
+        got = rt.eval_objects(metric, objs, x, opt=opt, dtype=dtype)
+        sco = rt.make_scene(metric, objs, units=False)
+        ref = O.eval_objects(sco, opt, x, dtype=dtype)
+        scale = 1.0 + np.abs(ref["d"].astype(float))
+        assert (np.abs(got["d"].astype(float) - ref["d"]) / scale).max() <= tol
+        assert (np.abs(got["dmin"].astype(float) - ref["dmin"]) / (1.0 + np.abs(ref["dmin"].astype(float)))).max() <= tol
+        # the hit decision flips only where some distance sits within rounding of the threshold or of another object's; colours are
+        # compared where the decisions agree (wrap-aware: a sawtooth may sit on either side of its jump)
+        same = got["hit"] == ref["hit"]
+        assert same.mean() >= 0.999 and same.sum() > 4000 and (got["hit"] > 0).sum() > 50
+        dc = np.abs(got["rgb"][same].astype(float) - ref["rgb"][same])
+        per = np.where(got["hit"][same] > 0, got["hit"][same] / len(objs), 1.0)[:, None]
+        assert np.minimum(dc, np.abs(per - dc)).max() <= (1e-9 if dtype == np.float64 else 2e-3)
