@@ -432,6 +432,15 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
 int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary, const rtgr_scene* built_for, uint64_t* id_out);
 /* ... the build step on its own (no GPU, no context): source -> code object file for rtgr_user_metric_load */
 int rtgr_user_unit_build(const char* source, int stationary, const rtgr_scene* built_for, const char* code_object_path);
+/* Objects of SEVERAL sources in one scene (the reference puts any mix of Object subtypes into `objs`; compiled code holds a scene's
+ * objects in one unit): joins n object sources into ONE source text for rtgr_user_unit_compile / _build.  Source k, which defines
+ * ntypes[k] object types (tags 0 .. ntypes[k]-1), is wrapped in a namespace of its own; the joined text's methods dispatch on the tag:
+ * type t of source k is type ntypes[0] + ... + ntypes[k-1] + t of the joined text — the caller adds that base to obj[].type.  Where
+ * some sources bring rtgr_user_reach and others do not, the joined bound is +infinity for the types of the latter: every
+ * step of a scene that holds such an object is scanned (the NEAR pass), scenes without one keep the FAR pass's saving.  A metric's
+ * source is not joined: put it before the joined text, as with one family.  Text in, text out — no GPU, no context.
+ *   `out` may be NULL (then only *need, the length with its NUL, is written); a buffer shorter than *need is RTGR_ERR_BAD_ARG. */
+int rtgr_user_source_join(const char* const* sources, const uint32_t* ntypes, int n, char* out, uint64_t cap, uint64_t* need);
 /* What a resident unit was built for. */
 typedef struct rtgr_unit_info {
     uint32_t metric;       /* rtgr_metric (| RTGR_METRIC_GENERIC) its kernels are instantiated for; RTGR_USER: its own */

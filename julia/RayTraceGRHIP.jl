@@ -189,12 +189,16 @@ The reference's `Object{T}` is an open abstract type (src/RayTraceGR.jl:374-389)
 
 (optionally `rtgr_user_reach`: include/rtgr.h "user objects"), compiled at run time — together with the metric the objects are
 traced with — into the scene's unit (`rtgr_user_unit_compile`: one ccall, built in-process, no hipcc).  `type` tells the family's
-object types apart inside the source, `fields` (up to 9 numbers) are the object's parameters `p`.  All DeviceObjects of one `objs`
-vector share one family.  An object type WITHOUT device source still takes the reference's CPU path, as before.
+object types apart inside the source, `fields` (up to 9 numbers) are the object's parameters `p`.  DeviceObjects of SEVERAL families
+may stand in one `objs` vector when each family says how many types its source defines (`DeviceObjects(source, ntypes = 2)`): their
+sources are joined into one (`rtgr_user_source_join`: a namespace per family, type tags renumbered family after family in the order
+of first appearance).  An object type WITHOUT device source still takes the reference's CPU path, as before.
 """
 struct DeviceObjects
     source::String
+    ntypes::UInt32          # how many object types the source defines (0: not stated — enough as long as a scene uses one family)
 end
+DeviceObjects(source::AbstractString; ntypes::Integer = 0) = DeviceObjects(String(source), UInt32(ntypes))
 struct DeviceObject{T} <: RayTraceGR.Object{T}
     family::DeviceObjects
     type::UInt32
@@ -307,18 +311,42 @@ function unit_id(family::DeviceObjects, metric, scene::Ref{RtgrScene}, ctx)
     end
 end
 
+# the families of a scene as ONE family (rtgr_user_source_join) and the base each family's type tags move to
+const JOINED = Dict{Vector{DeviceObjects},DeviceObjects}()
+function join_families(fams::Vector{DeviceObjects})
+    all(f -> f.ntypes > 0, fams) ||
+        error("DeviceObjects of several families in one scene: say how many object types each source defines — DeviceObjects(source, ntypes = n)")
+    bases = UInt32[sum(UInt32[f.ntypes for f in fams[1:k-1]]; init = UInt32(0)) for k in 1:length(fams)]
+    joined = get!(JOINED, fams) do
+        srcs = Cstring[Base.unsafe_convert(Cstring, f.source) for f in fams]
+        nt = UInt32[f.ntypes for f in fams]
+        need = Ref{UInt64}(0)
+        GC.@preserve fams begin
+            check(ccall((:rtgr_user_source_join, librtgr), Cint, (Ptr{Cstring}, Ptr{UInt32}, Cint, Ptr{UInt8}, UInt64, Ptr{UInt64}),
+                        srcs, nt, length(fams), C_NULL, 0, need))
+            buf = Vector{UInt8}(undef, need[])
+            check(ccall((:rtgr_user_source_join, librtgr), Cint, (Ptr{Cstring}, Ptr{UInt32}, Cint, Ptr{UInt8}, UInt64, Ptr{UInt64}),
+                        srcs, nt, length(fams), buf, need[], need))
+        end
+        DeviceObjects(String(buf[1:end-1]), sum(nt))
+    end
+    joined, bases
+end
+
 function scene_of(metric, objs, ctx)
-    fams = unique(o.family for o in objs if o isa DeviceObject)
-    length(fams) > 1 && error("the DeviceObjects of one scene must come from one DeviceObjects source")
+    fams = unique(DeviceObjects[o.family for o in objs if o isa DeviceObject])
+    family, bases = length(fams) > 1 ? join_families(fams) : (isempty(fams) ? nothing : fams[1], UInt32[0])
     # (a DeviceMetric beside DeviceObjects lives in the objects' unit: its own module is not loaded)
     d = (!isempty(fams) && metric isa DeviceMetric) ? (RTGR_USER, metric.M, metric.a, UInt64(0)) : metric_desc(metric, ctx)
     (d === nothing || length(objs) > RTGR_MAX_OBJECTS) && return nothing
-    po = map(pack, objs)
+    po = map(objs) do o
+        o isa DeviceObject ? RtgrObject(RTGR_USER_OBJECT, o.type + bases[findfirst(==(o.family), fams)], o.p) : pack(o)
+    end
     any(isnothing, po) && return nothing
     packed = ntuple(i -> i <= length(po) ? po[i] : NOOBJ, RTGR_MAX_OBJECTS)
     scene = Ref(RtgrScene(d[1], length(objs), d[2], d[3], d[4], packed))
     isempty(fams) && return scene
-    Ref(RtgrScene(d[1], length(objs), d[2], d[3], unit_id(fams[1], metric, scene, ctx), packed))
+    Ref(RtgrScene(d[1], length(objs), d[2], d[3], unit_id(family, metric, scene, ctx), packed))
 end
 solver_of(::Type{T}) where {T} = begin
     opt = Ref{RtgrSolver}()

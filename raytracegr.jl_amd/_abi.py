@@ -77,7 +77,7 @@ EXPORTS = [
     "rtgr_eval_fastmath_f64", "rtgr_quantize_device_f64",
     "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded", "rtgr_code_object_audit", "rtgr_user_metric_build", "rtgr_listing_repair",
     "rtgr_user_unit_compile", "rtgr_user_unit_build", "rtgr_user_unit_info", "rtgr_scene_check",
-    "rtgr_eval_objects_f64", "rtgr_eval_objects_f32",
+    "rtgr_eval_objects_f64", "rtgr_eval_objects_f32", "rtgr_user_source_join",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -149,6 +149,7 @@ def _declare(lib):
     lib.rtgr_user_unit_compile.argtypes = [ctx, C.c_char_p, i32, P(rtgr_scene), P(u64)]
     lib.rtgr_user_unit_build.argtypes = [C.c_char_p, i32, P(rtgr_scene), C.c_char_p]
     lib.rtgr_user_unit_info.argtypes = [ctx, u64, P(rtgr_unit_info)]
+    lib.rtgr_user_source_join.argtypes = [P(C.c_char_p), P(C.c_uint32), i32, C.c_char_p, u64, P(u64)]
     for suf in ("f64", "f32"):
         getattr(lib, f"rtgr_eval_objects_{suf}").argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, u64, vp, vp, vp, vp]
     lib.rtgr_scene_check.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, i32]

@@ -113,16 +113,20 @@ def make_scene(metric, objs, ctx=None, units=True):
     if len(objs) > _abi.RTGR_MAX_OBJECTS:
         raise ValueError(f"at most {_abi.RTGR_MAX_OBJECTS} objects")
     # New Object subtypes (src/RayTraceGR.jl:374-389) come as a UserObjects family: its distance / objcolor methods are compiled
-    # into ONE unit together with the metric they are traced with (compiled code holds both in the same kernels), so all user
-    # objects of a scene belong to one family
-    families = {id(o.family): o.family for o in objs if isinstance(o, UserObject)}
+    # into ONE unit together with the metric they are traced with (compiled code holds both in the same kernels); the sources of
+    # several families are joined into one first (UserObjects.join: type tags renumbered family after family, in the order of
+    # first appearance in objs)
+    families = list({id(o.family): o.family for o in objs if isinstance(o, UserObject)}.values())
+    base = {id(f): 0 for f in families}
     if len(families) > 1:
-        raise ValueError("the user objects of one scene must come from one UserObjects source (a source may define several types)")
+        joined, bases = UserObjects.join(families)
+        base = {id(f): b for f, b in zip(families, bases)}
+        families = [joined]
     user_id = 0
     if not units:
         pass
     elif families:
-        user_id = next(iter(families.values())).unit_id(metric, ctx)
+        user_id = families[0].unit_id(metric, ctx)
     elif isinstance(metric, UserMetric):
         user_id = metric.module_id(ctx)
     sc = rtgr_scene()
@@ -131,7 +135,7 @@ def make_scene(metric, objs, ctx=None, units=True):
     sc.user_metric = user_id
     for o, obj in enumerate(objs):
         sc.obj[o].kind = obj.kind
-        sc.obj[o].type = getattr(obj, "type", 0)
+        sc.obj[o].type = getattr(obj, "type", 0) + (base[id(obj.family)] if isinstance(obj, UserObject) else 0)
         p = obj._pack()
         for q in range(9):
             sc.obj[o].p[q] = p[q]

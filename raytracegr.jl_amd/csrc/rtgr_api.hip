@@ -2136,6 +2136,55 @@ int rtgr_user_metric_build(const char* source, int stationary, const char* code_
     return rtgr_user_unit_build(source, stationary, nullptr, code_object_path);
 }
 
+// Several object families in one scene: compiled code holds a scene's objects in ONE unit, so their sources are joined into one —
+// each in a namespace of its own, under dispatchers on the (renumbered) type tag.  Text in, text out: no GPU, no context.
+int rtgr_user_source_join(const char* const* sources, const uint32_t* ntypes, int n, char* out, uint64_t cap, uint64_t* need) {
+    if (!sources || !ntypes || n < 1 || n > RTGR_MAX_OBJECTS)
+        return fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: 1.." + std::to_string(RTGR_MAX_OBJECTS) + " sources with their numbers of types");
+    std::string t = "// " + std::to_string(n) + " object families, joined by rtgr_user_source_join\n";
+    std::vector<uint32_t> base(n + 1, 0);
+    bool reach_any = false;
+    std::vector<bool> reach(n);
+    for (int k = 0; k < n; ++k) {
+        const char* src = sources[k];
+        const std::string who = "rtgr_user_source_join: source " + std::to_string(k);
+        if (!src) return fail(RTGR_ERR_BAD_ARG, who + " is NULL");
+        if (!std::strstr(src, "rtgr_user_distance") || !std::strstr(src, "rtgr_user_objcolor"))
+            return fail(RTGR_ERR_BAD_ARG, who + " must define rtgr_user_distance and rtgr_user_objcolor (the two methods of the reference's Object)");
+        if (std::strstr(src, "rtgr_user_metric") || std::strstr(src, "rtgr_user_ks"))
+            return fail(RTGR_ERR_BAD_ARG, who + " defines a metric: only object sources are joined (the metric's source is given beside the joined text)");
+        if (std::strstr(src, "rtgr_family_"))
+            return fail(RTGR_ERR_BAD_ARG, who + " is a joined source itself: join the original sources in one call");
+        if (ntypes[k] == 0) return fail(RTGR_ERR_BAD_ARG, who + ": number of object types is 0");
+        base[k + 1] = base[k] + ntypes[k];
+        reach[k] = std::strstr(src, "rtgr_user_reach") != nullptr;
+        reach_any = reach_any || reach[k];
+        t += "namespace rtgr_family_" + std::to_string(k) + " {\n#line 1 \"object family " + std::to_string(k) + "\"\n" + src + "\n}\n";
+    }
+    t += "#line 1 \"rtgr_user_source_join\"\n";
+    // family k's type t is the joined source's type base[k] + t; a tag past the last family's range goes to the last family
+    auto dispatch = [&](const std::string& head, const std::string& fn, const std::string& args, bool value, const std::vector<bool>* only) {
+        t += "template <class S> __device__ " + head + " {\n";
+        for (int k = 0; k < n; ++k) {
+            const std::string cond = k + 1 < n ? "    if (type < " + std::to_string(base[k + 1]) + "u) " : "    ";
+            const std::string call = "rtgr_family_" + std::to_string(k) + "::" + fn + "(type - " + std::to_string(base[k]) + "u, " + args + ")";
+            if (only && !(*only)[k]) t += cond + "return S(__builtin_huge_val());   // (this family brings no bound: never provably out of reach)\n";
+            else if (value) t += cond + "return " + call + ";\n";
+            else t += cond + "{ " + call + "; return; }\n";
+        }
+        t += "}\n";
+    };
+    dispatch("S rtgr_user_distance(unsigned type, const S x[4], const S p[9])", "rtgr_user_distance", "x, p", true, nullptr);
+    dispatch("void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3])", "rtgr_user_objcolor", "x, p, rgb", false, nullptr);
+    if (reach_any)
+        dispatch("S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4])", "rtgr_user_reach", "x, p, dl", true, &reach);
+    if (need) *need = t.size() + 1;
+    if (!out) return need ? RTGR_OK : fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: neither a buffer nor a place for the length");
+    if (cap < t.size() + 1) return fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: the buffer holds " + std::to_string(cap) + " bytes, the text needs " + std::to_string(t.size() + 1));
+    std::memcpy(out, t.c_str(), t.size() + 1);
+    return RTGR_OK;
+}
+
 }  // extern "C"
 template <class R>
 static int scene_check(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, bool exact) {

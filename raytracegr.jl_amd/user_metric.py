@@ -290,16 +290,48 @@ class UserObjects:
     The unit that carries the objects' kernels is built for the metric it is traced with (make_scene: one unit per (metric
     variant, source), cached on disk by content hash like user metrics)."""
 
-    def __init__(self, source, name="user_objects", jit=False):
+    def __init__(self, source, name="user_objects", jit=False, ntypes=None):
         if "rtgr_user_distance" not in source or "rtgr_user_objcolor" not in source:
             raise ValueError("the source must define rtgr_user_distance and rtgr_user_objcolor (the two methods of the reference's Object)")
         if "rtgr_user_metric" in source or "rtgr_user_ks" in source:
             raise ValueError("a UserObjects source defines objects only; give the metric as a UserMetric (make_scene joins the two sources)")
         self.source, self.name, self.jit = source, name, bool(jit)
+        self.ntypes = None if ntypes is None else int(ntypes)     # how many object types the source defines: needed to join families
         self._jit_ids = {}
 
     def __call__(self, type, params=()):
+        if self.ntypes is not None and not 0 <= int(type) < self.ntypes:
+            raise ValueError(f"{self.name} defines the object types 0..{self.ntypes - 1}, not {type}")
         return UserObject(self, type, params)
+
+    _joined = {}
+
+    @classmethod
+    def join(cls, families):
+        """Objects of several families in one scene: (joined family, type base of each family).  Compiled code holds a scene's
+        objects in one unit, so the sources become ONE source (rtgr_user_source_join: a namespace per family under dispatchers on
+        the renumbered type tag); make_scene does this by itself when the objects of a scene come from more than one family."""
+        import ctypes as C
+        families = list(families)
+        for f in families:
+            if f.ntypes is None:
+                raise ValueError(f"{f.name}: joining families needs the number of object types each source defines — UserObjects(source, ntypes=...)")
+        key = tuple((f.source, f.ntypes, f.jit) for f in families)
+        if key not in cls._joined:
+            lib = _abi.load()
+            srcs = (C.c_char_p * len(families))(*[f.source.encode() for f in families])
+            nt = (C.c_uint32 * len(families))(*[f.ntypes for f in families])
+            need = C.c_uint64(0)
+            _abi.check(lib, lib.rtgr_user_source_join(srcs, nt, len(families), None, 0, C.byref(need)))
+            buf = C.create_string_buffer(need.value)
+            _abi.check(lib, lib.rtgr_user_source_join(srcs, nt, len(families), buf, need.value, C.byref(need)))
+            cls._joined[key] = cls(buf.value.decode(), name="+".join(f.name for f in families), jit=any(f.jit for f in families),
+                                   ntypes=sum(f.ntypes for f in families))
+        bases, b = [], 0
+        for f in families:
+            bases.append(b)
+            b += f.ntypes
+        return cls._joined[key], bases
 
     def unit_id(self, metric, ctx=None):
         """id (in ctx) of the unit carrying this family's kernels for `metric` — a built-in Metric or a UserMetric, whose source

@@ -253,7 +253,12 @@ def test_user_objects_are_wired_to_the_abi():
     m = re.search(r"ccall\(\(:rtgr_user_unit_compile, librtgr\), Cint, \(Ctx, Cstring, Cint, Ptr\{RtgrScene\}, Ptr\{UInt64\}\),\s*"
                   r"handle\(ctx\), source, own && metric\.stationary, own \? C_NULL : scene, id\)", code)
     assert m, "unit_id must hand rtgr_user_unit_compile the scene the unit is meant for (C_NULL when the unit has a metric of its own)"
-    assert re.search(r"Ref\(RtgrScene\(d\[1\], length\(objs\), d\[2\], d\[3\], unit_id\(fams\[1\], metric, scene, ctx\), packed\)\)", code)
+    assert re.search(r"Ref\(RtgrScene\(d\[1\], length\(objs\), d\[2\], d\[3\], unit_id\(family, metric, scene, ctx\), packed\)\)", code)
+    # several families in one scene: joined by the library (one namespace per source), each object's tag moved by its family's base
+    assert {"join_families", "JOINED"} <= names
+    assert re.search(r"ccall\(\(:rtgr_user_source_join, librtgr\), Cint, \(Ptr\{Cstring\}, Ptr\{UInt32\}, Cint, Ptr\{UInt8\}, UInt64, Ptr\{UInt64\}\),\s*"
+                     r"srcs, nt, length\(fams\), buf, need\[\], need\)", code)
+    assert re.search(r"RtgrObject\(RTGR_USER_OBJECT, o\.type \+ bases\[findfirst\(==\(o\.family\), fams\)\], o\.p\)", code)
     assert "RayTraceGR.distance(o::DeviceObject{T}" in code and "RayTraceGR.objcolor(o::DeviceObject{T}" in code
 
 
@@ -275,7 +280,7 @@ def test_runtests_hip_uses_only_what_the_stub_defines():
 JL_BASE = {"AbstractString", "Array", "Base", "C_NULL", "Cint", "Cstring", "Cvoid", "Dict", "ENV", "Float32", "Float64", "GC", "Int", "Integer",
            "Matrix", "NTuple", "Ptr", "Real", "Ref", "String", "Tuple", "Type", "UInt32", "UInt64", "UInt8", "abs", "all", "any", "atan", "ccall",
            "clamp", "close", "collect", "count", "dirname", "eltype", "eps", "error", "fieldcount", "fieldoffset", "finalizer", "get", "get!",
-           "hash", "include", "inv", "isbitstype", "minimum", "Vector", "isempty", "isnan", "isnothing", "joinpath", "length", "map", "max", "maximum", "mkpath", "mod",
+           "hash", "include", "inv", "isbitstype", "minimum", "Vector", "sum", "findfirst", "ErrorException", "isempty", "isnan", "isnothing", "joinpath", "length", "map", "max", "maximum", "mkpath", "mod",
            "new", "ntuple", "permutedims", "pointer", "println", "reinterpret", "rm", "round", "similar", "size", "sizeof", "sqrt", "undef",
            "unique", "unsafe_string", "zeros", "π"}
 JL_PACKAGES = {"SVector", "SMatrix", "SArray", "I", "RayTraceGR", "RayTraceGRHIP", "Images"}

@@ -102,8 +102,65 @@ def test_scene_description_without_units_needs_neither_compiler_nor_gpu():
     assert [sc.obj[k].type for k in range(5)] == [0, 0, user_objects.TORUS, user_objects.ELLIPSOID, user_objects.TORUS]
     assert list(sc.obj[3].p)[:6] == [3.3, 1.0, -0.8, 0.7, 0.5, 0.5]
     fam_a, fam_b = rt.UserObjects(user_objects.SHAPES), rt.UserObjects(user_objects.SHAPES)
-    with pytest.raises(ValueError, match="one UserObjects source"):
+    with pytest.raises(ValueError, match="number of object types"):          # (two families: joined — which needs their type counts)
         rt.make_scene(rt.kerr_schild, [fam_a(0, [1, 2, 3, 1, 0.1]), fam_b(1, [0] * 6)], units=False)
+
+
+def _two_families(reach=(True, True), jit=False):
+    """Objects of TWO sources in one scene: the shapes of examples/user_objects.py and the reference's Sphere written as a user
+    object -> (joined scene objects after [sky, plane], the same with the built-in Sphere in place of the user one)"""
+    key = (tuple(reach), jit)
+    if key not in _TWO:
+        _TWO[key] = (rt.UserObjects(user_objects.SHAPES_WITH_REACH if reach[0] else user_objects.SHAPES, name="shapes", ntypes=2, jit=jit),
+                     rt.UserObjects(user_objects.SPHERE_AS_USER_OBJECT if reach[1] else user_objects.SPHERE_AS_USER_OBJECT.split(
+                         "template <class S> __device__ S rtgr_user_reach")[0], name="sphere", ntypes=1, jit=jit))
+    shapes, ball = _TWO[key]
+    pos, vel, radius = [0.0, 4.6, -0.9, 0.9], [1.0, 0.0, 0.0, 0.0], 0.35
+    joined = [shapes(user_objects.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]), ball(0, pos + vel + [radius]), shapes(user_objects.ELLIPSOID, [3.3, 1.0, -0.8, 0.7, 0.5, 0.5])]
+    return joined, [joined[0], rt.Sphere(pos, vel, radius), joined[2]]
+
+
+_TWO = {}
+
+
+def test_sources_of_several_families_join_into_one():
+    """rtgr_user_source_join: text in, text out (no GPU) — a namespace per family, dispatchers on the renumbered tag; make_scene
+    joins by itself and adds each family's base to its objects' types, in the order of first appearance."""
+    lib = abi.load()
+    joined, mixed = _two_families()
+    metric, objs, _ = rt.example2_scene()
+    sc = rt.make_scene(metric, objs[:2] + joined, units=False)
+    assert [sc.obj[k].kind for k in range(5)] == [abi.SPHERE, abi.PLANE] + [abi.USER_OBJECT] * 3
+    assert [sc.obj[k].type for k in range(5)] == [0, 0, 0, 2, 1]             # shapes: 0, 1; the sphere family's type 0 -> 2
+    sc = rt.make_scene(metric, objs[:2] + joined[1:], units=False)            # the sphere's family first: it takes base 0
+    assert [sc.obj[k].type for k in range(4)] == [0, 0, 0, 2]
+    fam, bases = rt.UserObjects.join([joined[0].family, joined[1].family])
+    assert bases == [0, 2] and fam.ntypes == 3 and rt.UserObjects.join([joined[0].family, joined[1].family])[0] is fam
+    assert fam.source.count("namespace rtgr_family_") == 2 and "rtgr_family_1::rtgr_user_reach(type - 2u, x, p, dl)" in fam.source
+    assert um.unit_defines(fam.source, False, (abi.KS_REF, False, False))[0][-2:] == ["-DRTGR_USER_OBJECTS=1", "-DRTGR_USER_REACH=1"]
+    # one family without a bound: its types are never provably out of reach; none with a bound: no reach function at all
+    half = rt.UserObjects.join([_two_families((False, True))[0][0].family, _two_families((False, True))[0][1].family])[0]
+    assert "if (type < 2u) return S(__builtin_huge_val());" in half.source and "rtgr_family_1::rtgr_user_reach" in half.source
+    none = rt.UserObjects.join([_two_families((False, False))[0][0].family, _two_families((False, False))[0][1].family])[0]
+    assert "rtgr_user_reach" not in none.source
+    with pytest.raises(ValueError, match="defines the object types 0..1"):
+        joined[0].family(2, [0] * 5)
+    # the C entry point's own refusals
+    need = C.c_uint64(0)
+
+    def join(srcs, nts, buf=None, cap=0):
+        a = (C.c_char_p * len(srcs))(*[None if t is None else t.encode() for t in srcs])
+        return lib.rtgr_user_source_join(a, (C.c_uint32 * len(nts))(*nts), len(srcs), buf, cap, C.byref(need))
+    assert join([user_objects.SHAPES, user_objects.SPHERE_AS_USER_OBJECT], [2, 1]) == 0 and need.value == len(half.source.encode()) + 1
+    small = C.create_string_buffer(16)
+    for bad, why in (((lambda: join([user_objects.SHAPES], [0])), "number of object types is 0"),
+                     ((lambda: join([user_metrics.KERR_BOYER_LINDQUIST], [1])), "must define rtgr_user_distance"),
+                     ((lambda: join([user_metrics.KERR_BOYER_LINDQUIST + user_objects.SHAPES], [2])), "defines a metric"),
+                     ((lambda: join([fam.source, user_objects.SHAPES], [3, 2])), "joined source itself"),
+                     ((lambda: join([user_objects.SHAPES, None], [2, 1])), "source 1 is NULL"),
+                     ((lambda: join([user_objects.SHAPES], [2], small, 16)), "the buffer holds 16 bytes")):
+        assert bad() == abi.ERR_BAD_ARG and why in lib.rtgr_last_error().decode(), (why, lib.rtgr_last_error())
+    assert lib.rtgr_user_source_join(None, None, 0, None, 0, None) == abi.ERR_BAD_ARG
 
 
 def test_oracle_twins_obey_the_distance_contract():
@@ -224,6 +281,68 @@ def test_a_unit_without_a_reach_bound_runs_the_full_pass_and_traces_the_same_fra
     abi.check(lib, lib.rtgr_timing_read(None, 0, C.byref(ms), C.byref(n)))
     lib.rtgr_timing_enable(None, 0, 0)
     assert n[1] >= 1 and n[3] == 0                                            # one main (FULL) pass, no NEAR pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric_name", ["ks_ref0", "ks_true08"])
+def test_objects_of_two_families_share_one_scene(lib, metric_name):
+    """The reference puts ANY mix of Object subtypes into `objs` (src/RayTraceGR.jl:483, :518-530).  Objects of two separately written
+    sources — the torus / ellipsoid family and the reference's own Sphere typed as a user object — in one scene: make_scene joins
+    the sources into one unit.  Against the oracle (which has the torus and ellipsoid twins and the built-in Sphere) at the
+    north-star bar; and, HIP against HIP, the SAME frame bit for bit as the scene with the built-in Sphere in the user sphere's
+    place (the joined unit calls the very functions each family's own unit does), FAR + NEAR == FULL, Float64 and Float32."""
+    from test_gpu_parity import compare, hip_trace
+    metric = {"ks_ref0": rt.kerr_schild, "ks_true08": rt.KerrSchild(1, 0.8)}[metric_name]
+    _, objs, cam = rt.example2_scene()
+    cam = rt.make_camera(**cam)
+    joined, mixed = _two_families()
+    sc_j, sc_m = rt.make_scene(metric, objs[:2] + joined), rt.make_scene(metric, objs[:2] + mixed)
+    assert sc_j.user_metric != sc_m.user_metric and [sc_j.obj[k].type for k in range(2, 5)] == [0, 2, 1]
+    assert _info(sc_j) == dict(_info(sc_m), **{k: _info(sc_j)[k] for k in ("far_waves", "near_waves", "f32_waves")})
+    assert _info(sc_j)["has_reach"] == 1 and _info(sc_j)["probe_ok"] == 1
+    opt = rt.solver_defaults()
+    ref = O.trace(rt.make_scene(metric, objs[:2] + mixed, units=False), opt, 64, 64, cam=cam)
+    assert set(np.unique(ref["hit"])) >= {1, 3, 4, 5}
+    got, same = hip_trace(lib, sc_j, opt, 64, 64, cam=cam), hip_trace(lib, sc_m, opt, 64, 64, cam=cam)
+    compare(got, ref, max_class_flips=0, max_step_diff=1, sc=sc_m)
+    with abi.options(lib, split=0):
+        full = hip_trace(lib, sc_j, opt, 64, 64, cam=cam)
+    for k in ("rgb", "hit", "status", "n_accept", "n_reject", "state_end", "lambda_end"):
+        assert np.array_equal(got[k], same[k], equal_nan=got[k].dtype.kind == "f"), (metric_name, k, "joined unit vs built-in sphere")
+        assert np.array_equal(got[k], full[k], equal_nan=got[k].dtype.kind == "f"), (metric_name, k, "FAR + NEAR vs FULL")
+    abi.check(lib, lib.rtgr_scene_check(None, C.byref(sc_j), C.byref(opt), C.byref(cam), 48, 48, 0))
+    opt32 = rt.solver_defaults(np.float32)
+    a, b = (hip_trace(lib, sc, opt32, 64, 64, cam=cam, dtype=np.float32) for sc in (sc_j, sc_m))
+    for k in ("rgb", "hit", "status", "n_accept", "n_reject"):
+        assert np.array_equal(a[k], b[k]), (metric_name, k, "Float32")
+    # pointwise: the joined dispatchers hand each type to its own family
+    x = np.array([[0.0, 4.9, 0.0, 0.3], [0.0, 4.6, -0.9, 1.25], [0.0, 3.3, 1.0, -0.3], [0.0, 4.6, -0.9, 0.9]])
+    dj, dm = rt.eval_objects(metric, objs[:2] + joined, x), rt.eval_objects(metric, objs[:2] + mixed, x)
+    for k in ("d", "dmin", "hit", "rgb"):
+        assert np.array_equal(dj[k], dm[k]), k
+    assert list(dj["hit"]) == [3, 4, 5, 0]
+
+
+@pytest.mark.gpu
+def test_a_family_without_a_bound_beside_one_with_a_bound(lib):
+    """Joined sources where only SOME bring rtgr_user_reach: the types of the others answer +infinity — a scene that holds such an
+    object scans every step (all rays take the NEAR pass), a scene of the same unit without one keeps the FAR pass; the frames are
+    those of the unit where every family has its bound."""
+    from test_gpu_parity import hip_trace
+    _, objs, cam = rt.example2_scene()
+    cam = rt.make_camera(**cam)
+    opt = rt.solver_defaults()
+    both, half = _two_families()[0], _two_families((False, True))[0]
+    sc_b, sc_h = rt.make_scene(rt.kerr_schild, objs[:2] + both), rt.make_scene(rt.kerr_schild, objs[:2] + half)
+    assert sc_b.user_metric != sc_h.user_metric and _info(sc_h)["has_reach"] == 1
+    a, b = hip_trace(lib, sc_b, opt, 48, 48, cam=cam), hip_trace(lib, sc_h, opt, 48, 48, cam=cam)
+    for k in ("rgb", "hit", "status", "n_accept", "n_reject", "state_end", "lambda_end"):
+        assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), k
+    # only the sphere (the family WITH a bound) on the scene, through the half-bounded unit: same frame as through the fully bounded one
+    sc_b1, sc_h1 = rt.make_scene(rt.kerr_schild, objs[:2] + both[1:2]), rt.make_scene(rt.kerr_schild, objs[:2] + half[1:2])
+    assert sc_b1.user_metric not in (sc_b.user_metric, sc_h.user_metric)      # (one family alone: its own unit, not the joined one)
+    a, b = hip_trace(lib, sc_b1, opt, 48, 48, cam=cam), hip_trace(lib, sc_h1, opt, 48, 48, cam=cam)
+    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["n_accept"], b["n_accept"])
 
 
 @pytest.mark.gpu
