@@ -316,7 +316,7 @@ def test_objects_of_two_families_share_one_scene(lib, metric_name):
     for k in ("rgb", "hit", "status", "n_accept", "n_reject"):
         assert np.array_equal(a[k], b[k]), (metric_name, k, "Float32")
     # pointwise: the joined dispatchers hand each type to its own family
-    x = np.array([[0.0, 4.9, 0.0, 0.3], [0.0, 4.6, -0.9, 1.25], [0.0, 3.3, 1.0, -0.3], [0.0, 4.6, -0.9, 0.9]])
+    x = np.array([[0.0, 4.9, 0.0, 0.3], [0.0, 4.6, -0.9, 1.25], [0.0, 3.3, 1.0, -0.3], [0.0, 4.0, 0.0, 0.7]])
     dj, dm = rt.eval_objects(metric, objs[:2] + joined, x), rt.eval_objects(metric, objs[:2] + mixed, x)
     for k in ("d", "dmin", "hit", "rgb"):
         assert np.array_equal(dj[k], dm[k]), k
