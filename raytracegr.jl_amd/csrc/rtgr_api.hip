@@ -357,6 +357,9 @@ static void scene_variant(const rtgr_scene* s, uint32_t* metric, bool* spin) {
 // the UNIT's kernels, not the library's: while this is set on the calling thread, a scene that names a unit runs with it even though
 // nothing in the scene requires one.  (Everywhere else a built-in scene ignores rtgr_scene.user_metric, as it always has.)
 static thread_local bool tl_probe_forces_unit = false;
+// … and the probe (and rtgr_scene_check) choose the pass structure of THEIR call without touching the device's `split` option, which
+// other threads' calls on the same device read: -2 = the option decides.
+static thread_local long tl_split_override = -2;
 
 template <class R>
 int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserModule** user) {
@@ -507,7 +510,7 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
     }
     StreamState* ss = nullptr;
     if ((rc = stream_state(D, st, &ss))) return rc;
-    LaunchEnv E{D, *ss, user, win ? win->after_setup : nullptr};
+    LaunchEnv E{D, *ss, user, win ? win->after_setup : nullptr, tl_split_override};
     rc = dispatch(E, A, generic, spin, st);
     if (rc) return rc;
     if (out && out->redshift) {   // one more kernel behind the pipeline: needs the end states and the hit map it wrote
@@ -1725,12 +1728,11 @@ static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFram
     std::memset(&out, 0, sizeof out);
     out.state_end = base + off_se; out.lambda_end = base + off_lam; out.n_accept = (uint32_t*)(base + off_na);
     out.n_reject = (uint32_t*)(base + off_nr); out.status = (uint8_t*)(base + off_st); out.hit = (uint8_t*)(base + off_hit);
-    long saved;
-    { std::lock_guard<std::mutex> lk(D.mu); saved = D.knobs.split; D.knobs.split = split; }
     tl_probe_forces_unit = force_unit;
+    tl_split_override = split;
     rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
     tl_probe_forces_unit = false;
-    { std::lock_guard<std::mutex> lk(D.mu); D.knobs.split = saved; }
+    tl_split_override = -2;
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     f.rgb.resize(3 * N); f.se.resize(8 * N); f.lam.resize(N); f.na.resize(N); f.nr.resize(N); f.status.resize(N); f.hit.resize(N);
@@ -1913,8 +1915,9 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
         d->modules.push_back(u);
         fresh = true;
     }
-    if (fresh && policy.unit_probe != 0) {
-        // one probe per physical device that now owns a copy of the module
+    if (policy.unit_probe != 0) {
+        // one probe per physical device that owns a copy of the module and has not probed it yet (a fresh copy — or one that was
+        // loaded earlier while the probe was switched off)
         std::vector<int> seen;
         for (auto& d : c->devs) {
             if (std::find(seen.begin(), seen.end(), d->dev) != seen.end()) continue;

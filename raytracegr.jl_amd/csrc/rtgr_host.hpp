@@ -164,6 +164,7 @@ struct LaunchEnv {
     StreamState& ss;
     const UserModule* user;  // the scene's unit (rtgr_scene.user_metric: RTGR_USER metric and / or RTGR_USER_OBJECT objects) or null
     hipEvent_t after_setup = nullptr;  // optional: recorded on the launch stream behind the ray set-up / queue-order kernels
+    long split = -2;                   // -2: the device's `split` option decides; else this call's own pass structure (the load-time probe, rtgr_scene_check)
 };
 
 size_t align256(size_t b);

@@ -253,7 +253,8 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     // (a user unit carries Float32 twins of the FULL pass only)
     // (… and a unit whose objects come without a reach bound has nothing to decide a hand-over by: every accepted step is
     //  scanned, as the reference does — the single FULL pass; include/rtgr.h "user objects")
-    bool split = (K.split >= 0 ? K.split != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
+    const long ksplit = E.split != -2 ? E.split : K.split;
+    bool split = (ksplit >= 0 ? ksplit != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
     if constexpr (USER) if (E.user->has_objects && !E.user->has_reach) split = false;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;

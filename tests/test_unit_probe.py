@@ -77,8 +77,13 @@ def test_probe_alone_refuses_a_unit_with_the_fault(lib, zoo_raw):
     with abi.options(lib, unit_audit=0, unit_probe=0):             # both checks off: it loads — that is what the options mean
         mid = um.load(raw)
         assert um.unit_info(mid)["probe_ok"] == 0
-        abi.check(lib, lib.rtgr_user_metric_unload(None, mid))
         um._ids.clear()
+    assert lib.rtgr_user_metric_loaded(None, mid) == 1
+    # asked for again with the probe back on: a resident copy that was never probed is probed NOW — refused, and gone
+    with abi.options(lib, unit_audit=0):
+        with pytest.raises(abi.RtgrError, match="refused by the load-time probe"):
+            um.load(raw)
+    um._ids.clear()
     assert lib.rtgr_user_metric_loaded(None, mid) == 0
 
 
