@@ -20,7 +20,8 @@ def lib():
         hdr = os.path.join(ROOT, "include", "rtgr.h")  # the oracle shares the product's struct layouts
         if (not os.path.exists(_ORACLE)) or os.path.getmtime(_ORACLE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-        _lib = C.CDLL(_ORACLE)
+        # (RTGR_ORACLE_LIB: another build of the same source — tools/sanitize_host.sh runs the CPU tests against an ASan / UBSan one)
+        _lib = C.CDLL(os.environ.get("RTGR_ORACLE_LIB") or _ORACLE)
     return _lib
 
 
