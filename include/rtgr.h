@@ -448,7 +448,7 @@ typedef struct rtgr_unit_info {
     uint32_t has_objects;  /* the source defined rtgr_user_distance / rtgr_user_objcolor                               */
     uint32_t has_reach;    /* ... and rtgr_user_reach: scenes with its objects run FAR + NEAR                          */
     uint32_t far_waves, near_waves, f32_waves; /* waves per SIMD its integrate passes were built for                  */
-    uint32_t probe_ok;     /* 1: the load-time probe ran (FULL == FAR + NEAR, twice each); 0: skipped (RTGR_UNIT_PROBE=0) */
+    uint32_t probe_ok;     /* 1: the load-time probe ran (FULL == FAR + NEAR, two schedules each); 0: skipped (unit_probe = 0) */
 } rtgr_unit_info;
 int rtgr_user_unit_info(rtgr_context* ctx, uint64_t id, rtgr_unit_info* info);
 /* The library's central schedule-invariance property, as a check a caller can run on ITS scene: the FAR + NEAR passes skip the
@@ -480,9 +480,10 @@ int rtgr_listing_repair(const char* listing_path, const char* repaired_path, int
  * one the library's own kernels were built from (the record layouts the kernels share are not part of this header and move
  * without the ABI version moving); (2) the audit above, on bare code objects and on clang offload bundles alike; an image the
  * audit cannot read is refused, a box without the disassembler loads unaudited; (3) a PROBE: the unit traces a fixed 32 x 32 frame
- * through its single FULL pass and through its FAR + NEAR passes, twice each (Float32 FULL pass twice), and is refused
- * (RTGR_ERR_BAD_ARG, nothing left resident) when two runs of one structure differ in any bit or the structures disagree — the
- * symptoms of a mis-compiled unit, whatever the instruction shape (~10-70 ms). */
+ * through its single FULL pass and through its FAR + NEAR passes, each under TWO schedules (sixteen waves with one ray per lane;
+ * three waves whose lanes refill from the queue — a ray's bits never depend on the schedule), the Float32 FULL pass likewise, and
+ * is refused (RTGR_ERR_BAD_ARG, nothing left resident) when the two schedules of one structure differ in any bit or the structures
+ * disagree — the symptoms of a mis-compiled unit, whatever the instruction shape (~10-130 ms). */
 /* 1 if module `id` is resident (id 0: any module), else 0 */
 int rtgr_user_metric_loaded(rtgr_context* ctx, uint64_t id);
 

@@ -36,13 +36,13 @@ int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------------------
 static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
                                          "far4", "rounds", "qchunk", "qchunk_near", "tile", "host_chunk",
-                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", nullptr};
+                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", "max_waves", nullptr};
 const char* const* knob_names() { return KNOB_NAMES; }
 long* knob_slot(Knobs& k, const char* name) {
     if (!name) return nullptr;
     long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
                      &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far, &k.peer, &k.pack, &k.packfar,
-                     &k.unit_probe, &k.unit_audit};
+                     &k.unit_probe, &k.unit_audit, &k.max_waves};
     for (int i = 0; KNOB_NAMES[i]; i++)
         if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
     return nullptr;
@@ -357,9 +357,9 @@ static void scene_variant(const rtgr_scene* s, uint32_t* metric, bool* spin) {
 // the UNIT's kernels, not the library's: while this is set on the calling thread, a scene that names a unit runs with it even though
 // nothing in the scene requires one.  (Everywhere else a built-in scene ignores rtgr_scene.user_metric, as it always has.)
 static thread_local bool tl_probe_forces_unit = false;
-// … and the probe (and rtgr_scene_check) choose the pass structure of THEIR call without touching the device's `split` option, which
-// other threads' calls on the same device read: -2 = the option decides.
-static thread_local long tl_split_override = -2;
+// … and the probe (and rtgr_scene_check) choose the launch options of THEIR calls — pass structure, queue order, grid size — without
+// touching the device's options, which other threads' calls on the same device read: null = the device's options decide.
+static thread_local const Knobs* tl_knobs_override = nullptr;
 
 template <class R>
 int convert_scene(const DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserModule** user) {
@@ -510,7 +510,7 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
     }
     StreamState* ss = nullptr;
     if ((rc = stream_state(D, st, &ss))) return rc;
-    LaunchEnv E{D, *ss, user, win ? win->after_setup : nullptr, tl_split_override};
+    LaunchEnv E{D, *ss, user, win ? win->after_setup : nullptr, tl_knobs_override};
     rc = dispatch(E, A, generic, spin, st);
     if (rc) return rc;
     if (out && out->redshift) {   // one more kernel behind the pipeline: needs the end states and the hit map it wrote
@@ -1694,8 +1694,9 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 // Round 4's compiler fault was a SILENT wrong answer that survived a round of green tests; its symptoms were
 // frames that differ from run to run and a single FULL pass that disagrees with the FAR + NEAR pair.  The textual audit knows one
 // shape of it.  This is the check that does not depend on the shape: a fresh unit traces a fixed 32 x 32 frame of example2's
-// camera and objects (src/RayTraceGR.jl:581-593) through both pass structures, twice each (and its Float32 FULL pass twice), and is
-// refused when (a) two runs of the same structure differ in ANY bit — every wave is independent of every other, so they must not —
+// camera and objects (src/RayTraceGR.jl:581-593) through both pass structures, each under two schedules (and its Float32 FULL pass
+// likewise), and is refused when (a) the two runs of one structure differ in ANY bit — a ray is independent of its lane, its wave
+// and its neighbours, so they must not —
 // or (b) the two structures disagree beyond what different inlining of the user's own arithmetic explains (the built-in kernels are
 // bit-identical between them; a user metric's products may contract differently in the FAR and the FULL kernel): more than 2 % of
 // the rays with another hit / status / step count (±2), or an end state off by more than 1e-5 (relative) on a ray they agree on.
@@ -1703,7 +1704,7 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id) {
 template <class R> struct ProbeFrame { std::vector<R> rgb, se, lam; std::vector<uint8_t> status, hit; std::vector<uint32_t> na, nr; };
 template <class R>
 static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFrame<R>& f, const rtgr_solver* user_opt = nullptr,
-                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32, bool force_unit = false) {
+                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32, bool force_unit = false, long max_waves = -1) {
     const uint64_t N = NI * NJ;
     rtgr_solver opt;
     rtgr_camera cam;
@@ -1728,11 +1729,15 @@ static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFram
     std::memset(&out, 0, sizeof out);
     out.state_end = base + off_se; out.lambda_end = base + off_lam; out.n_accept = (uint32_t*)(base + off_na);
     out.n_reject = (uint32_t*)(base + off_nr); out.status = (uint8_t*)(base + off_st); out.hit = (uint8_t*)(base + off_hit);
+    Knobs mine;                                       // this call's launch options: the device's, with the pass structure (and grid cap) asked for
+    { std::lock_guard<std::mutex> lk(D.mu); mine = D.knobs; }
+    mine.split = split;
+    mine.max_waves = max_waves;
     tl_probe_forces_unit = force_unit;
-    tl_split_override = split;
+    tl_knobs_override = &mine;
     rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
     tl_probe_forces_unit = false;
-    tl_split_override = -2;
+    tl_knobs_override = nullptr;
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     f.rgb.resize(3 * N); f.se.resize(8 * N); f.lam.resize(N); f.na.resize(N); f.nr.resize(N); f.status.resize(N); f.hit.resize(N);
@@ -1792,19 +1797,27 @@ static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
     sc.obj[1].kind = RTGR_PLANE;  sc.obj[1].p[0] = -20;
     sc.obj[2].kind = RTGR_SPHERE; sc.obj[2].p[1] = 4; sc.obj[2].p[4] = 1; sc.obj[2].p[8] = 0.5;
     int rc;
+    // The second run of each structure is scheduled DIFFERENTLY from the first: a grid of THREE waves over the 1024 rays instead of
+    // sixteen — the first run's lanes each trace one ray, the second run's refill from the queue about five times, with other
+    // neighbours in the wave every time.  A ray's arithmetic does not depend on which lane or wave carries it or on what its
+    // neighbours do (the library's scheduling options never change a bit: test_scheduling_knobs_do_not_change_results), so the two
+    // runs of a sound unit are bit-identical; code that executes part of a divergent branch for the wrong lanes — the fault — depends
+    // on exactly that.  (Until this change both runs had the same schedule and differed only through timing noise: a faulty unit could
+    // slip through when the noise was small.)
+    const long few = 3;
     ProbeFrame<double> full[2], pair[2];
-    for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 0, full[k], nullptr, nullptr, 32, 32, true))) return rc;
-    if (!probe_same_bits(full[0], full[1])) { *why = "two runs of its Float64 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
+    for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 0, full[k], nullptr, nullptr, 32, 32, true, k ? few : -1))) return rc;
+    if (!probe_same_bits(full[0], full[1])) { *why = "two differently scheduled runs of its Float64 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
     const bool has_pair = !(U.has_objects && !U.has_reach);
     if (has_pair) {
-        for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 1, pair[k], nullptr, nullptr, 32, 32, true))) return rc;
-        if (!probe_same_bits(pair[0], pair[1])) { *why = "two runs of its Float64 FAR + NEAR passes over the same 32 x 32 probe frame differ"; return 1; }
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 1, pair[k], nullptr, nullptr, 32, 32, true, k ? few : -1))) return rc;
+        if (!probe_same_bits(pair[0], pair[1])) { *why = "two differently scheduled runs of its Float64 FAR + NEAR passes over the same 32 x 32 probe frame differ"; return 1; }
         if (probe_disagree(full[0], pair[0], "its", why)) return 1;
     }
     if (U.full10_f32) {
         ProbeFrame<float> f32[2];
-        for (int k = 0; k < 2; k++) if ((rc = probe_trace<float>(D, sc, -1, f32[k], nullptr, nullptr, 32, 32, true))) return rc;
-        if (!probe_same_bits(f32[0], f32[1])) { *why = "two runs of its Float32 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<float>(D, sc, -1, f32[k], nullptr, nullptr, 32, 32, true, k ? few : -1))) return rc;
+        if (!probe_same_bits(f32[0], f32[1])) { *why = "two differently scheduled runs of its Float32 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
     }
     return RTGR_OK;
 }

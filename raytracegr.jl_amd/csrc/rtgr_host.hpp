@@ -69,6 +69,8 @@ struct Knobs {
     long peer = -1;               // multi-device gather (rtgr_trace_sharded_device_*): 0 = always stage the rows through pinned
                                   // host memory (the no-peer-access fallback, forced), 1 = peer copies or fail, -1 = peer copies
                                   // where rtgr_create could enable peer access, the fallback elsewhere
+    long max_waves = -1;          // cap of the integrate kernels' grid, in waves (the load-time probe: three waves over its 1024 rays make
+                                  // every lane refill many times; results never depend on it)
     long unit_probe = 1;          // run-time units: trace a small probe frame through both pass structures at load and refuse a unit
                                   // whose frames are irreproducible or disagree (rtgr_api.hip: probe_unit); 0 = skip
     long unit_audit = 1;          // … and audit the code object for the compiler's EXEC-flip fault before loading it; 0 = skip
@@ -164,7 +166,7 @@ struct LaunchEnv {
     StreamState& ss;
     const UserModule* user;  // the scene's unit (rtgr_scene.user_metric: RTGR_USER metric and / or RTGR_USER_OBJECT objects) or null
     hipEvent_t after_setup = nullptr;  // optional: recorded on the launch stream behind the ray set-up / queue-order kernels
-    long split = -2;                   // -2: the device's `split` option decides; else this call's own pass structure (the load-time probe, rtgr_scene_check)
+    const Knobs* knobs = nullptr;      // this call's own launch options (the load-time probe, rtgr_scene_check); null: the device's
 };
 
 size_t align256(size_t b);

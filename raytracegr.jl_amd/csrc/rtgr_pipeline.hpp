@@ -88,10 +88,11 @@ template <class R, int METRIC, bool SPIN>
 static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts10, bool split, uint64_t waves, hipStream_t st) {
     constexpr bool USER = (METRIC == RTGR_GENERIC_BASE + RTGR_USER);
     DeviceCtx& D = E.d;
-    const Knobs& K = D.knobs;
+    const Knobs& K = E.knobs ? *E.knobs : D.knobs;
     auto grid = [&](int per_simd) {
         const uint64_t per_cu = K.waves_per_cu > 0 ? (uint64_t)K.waves_per_cu : (uint64_t)(4 * per_simd);
-        const uint64_t resident = (uint64_t)D.num_cu * per_cu;
+        uint64_t resident = (uint64_t)D.num_cu * per_cu;
+        if (K.max_waves > 0 && (uint64_t)K.max_waves < resident) resident = (uint64_t)K.max_waves;
         return dim3((unsigned)(waves < resident ? waves : resident));
     };
     if (npts10 && split) {
@@ -219,7 +220,7 @@ template <class R, int METRIC, bool SPIN>
 static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     constexpr bool USER = (METRIC == RTGR_GENERIC_BASE + RTGR_USER);
     DeviceCtx& D = E.d;
-    const Knobs& K = D.knobs;
+    const Knobs& K = E.knobs ? *E.knobs : D.knobs;
     if constexpr (METRIC < RTGR_GENERIC_BASE) if (K.tile) {
         const uint64_t tiles = ((A.ni + 7) / 8) * ((A.nrows + 7) / 8);
         const uint64_t blocks = (tiles + 3) / 4;
@@ -253,8 +254,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     // (a user unit carries Float32 twins of the FULL pass only)
     // (… and a unit whose objects come without a reach bound has nothing to decide a hand-over by: every accepted step is
     //  scanned, as the reference does — the single FULL pass; include/rtgr.h "user objects")
-    const long ksplit = E.split != -2 ? E.split : K.split;
-    bool split = (ksplit >= 0 ? ksplit != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
+    bool split = (K.split >= 0 ? K.split != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
     if constexpr (USER) if (E.user->has_objects && !E.user->has_reach) split = false;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;

@@ -105,3 +105,50 @@ def test_a_unit_built_from_other_headers_is_refused(lib, tmp_path):
     unrecorded = _raw_unit(tmp_path, user_metrics.SCHWARZSCHILD_ISOTROPIC, "by_hand", header_hash=0)   # built by hand: ABI version only
     mid = um.load(unrecorded)
     assert um.unit_info(mid)["probe_ok"] == 1
+
+
+@pytest.mark.gpu
+def test_loading_and_probing_a_unit_does_not_disturb_frames_traced_meanwhile(lib):
+    """The probe picks the pass structure of ITS ten small traces per call (thread-local), not through the device's `split` option:
+    another host thread that traces a scene of another unit while units are loaded, probed and unloaded gets the same frame every
+    time, and the option is what it was."""
+    import ctypes as C
+    import threading
+
+    import numpy as np
+    from scenes import scene_variant
+    from test_gpu_parity import hip_trace
+    sc, cam = scene_variant("ks_ref0_shapes")
+    opt = rt.solver_defaults()
+    ref = hip_trace(lib, sc, opt, 48, 48, cam=cam)
+    split0 = C.c_long(0)
+    abi.check(lib, lib.rtgr_get_option(None, b"split", C.byref(split0)))
+    stop, errors, frames = threading.Event(), [], [0]
+
+    def tracer():
+        try:
+            while not stop.is_set():
+                got = hip_trace(lib, sc, opt, 48, 48, cam=cam)
+                for k in ("rgb", "hit", "n_accept", "n_reject"):
+                    assert np.array_equal(got[k], ref[k]), k
+                frames[0] += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=tracer)
+    th.start()
+    try:
+        path = um.compile_user_metric(user_metrics.SCHWARZSCHILD_ISOTROPIC, stationary=True)
+        for _ in range(3):
+            mid = um.load(path)
+            assert um.unit_info(mid)["probe_ok"] == 1
+            abi.check(lib, lib.rtgr_user_metric_unload(None, mid))
+            um._ids.clear()
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    assert frames[0] >= 3
+    now = C.c_long(0)
+    abi.check(lib, lib.rtgr_get_option(None, b"split", C.byref(now)))
+    assert now.value == split0.value

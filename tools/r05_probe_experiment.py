@@ -21,6 +21,7 @@ lib = abi.load()
 abi.check(lib, lib.rtgr_init(-1))
 out = os.path.join(ROOT, "gpurun_out", "r05", "probe")
 os.makedirs(out, exist_ok=True)
+REPEAT = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 hh = f"-DRTGR_HEADER_HASH={um._build.header_hash():#x}ull"
 for name, src in (("HELPER_ZOO", umx.HELPER_ZOO), ("KERR_BOYER_LINDQUIST", umx.KERR_BOYER_LINDQUIST)):
     with open(um.TEMPLATE) as fh:
@@ -43,6 +44,19 @@ for name, src in (("HELPER_ZOO", umx.HELPER_ZOO), ("KERR_BOYER_LINDQUIST", umx.K
             except abi.RtgrError as e:
                 verdict = "REFUSED: " + str(e).split("\n")[0][:230]
             print(f"{name} raw level {lvl}: audit finds {n_audit} block(s); load with unit_audit={audit_on}: {verdict}  [{time.time() - t:.2f} s]", flush=True)
+        if n_audit:   # how RELIABLY the probe alone refuses the faulty unit: REPEAT loads with the audit off, by the probe's reason
+            why = {}
+            for _ in range(REPEAT):
+                try:
+                    with abi.options(lib, unit_audit=0):
+                        mid = um.load(raw)
+                    lib.rtgr_user_metric_unload(None, mid)
+                    um._ids.clear()
+                    k = "LOADED (not refused)"
+                except abi.RtgrError as e:
+                    k = str(e).split("probe — ")[-1].split(" (the symptom")[0][:110]
+                why[k] = why.get(k, 0) + 1
+            print(f"{name} raw level {lvl}: {REPEAT} loads with the audit off: {why}", flush=True)
 # the repaired / sound units: probe cost
 for name, src, st in (("KERR_SCHILD", umx.KERR_SCHILD, True), ("KERR_SCHILD_KS", umx.KERR_SCHILD_KS, True), ("HELPER_ZOO (repaired)", umx.HELPER_ZOO, True),
                       ("KERR_BOYER_LINDQUIST (repaired)", umx.KERR_BOYER_LINDQUIST, True), ("EXPANDING_ISOTROPIC", umx.EXPANDING_ISOTROPIC, False)):

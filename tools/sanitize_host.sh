@@ -34,3 +34,4 @@ OTESTS="tests/test_oracle_golden.py tests/test_golden_fixtures.py tests/test_ref
 echo "== asan + ubsan: oracle/rtgr_oracle.cpp (g++), $OTESTS -m 'not gpu'" | tee -a "$LOG"
 (cd "$ROOT" && RTGR_ORACLE_LIB=$ROOT/oracle/_san/librtgr_oracle.so LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
    ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 python3 -m pytest $OTESTS -q -m "not gpu" 2>&1 | tail -n 4) | tee -a "$LOG"
+rm -rf "$ROOT/raytracegr.jl_amd/build/asan" "$ROOT/raytracegr.jl_amd/build/ubsan" "$ROOT/oracle/_san"   # (≈ 70 MB that would otherwise travel to the GPU box with every gpurun call)
