@@ -68,7 +68,7 @@ def test_bench_counts_its_own_flops_and_bytes():
     assert 500 < live["hbm_bytes_per_ray"] < 1500 and roof["traffic"] > 0
     # … and the profiler's own average kernel durations (one more child run, --kernel-trace --stats) agree with the HIP-event times
     assert len(live["rocprof_kernel_trace"]) == 2 and all(v["calls"] == 4 for v in live["rocprof_kernel_trace"].values())
-    assert 0.9 < roof["event_over_rocprof"] < 1.1
+    assert 0.85 < roof["event_over_rocprof"] < 1.15
     if "profile_flop_per_step_attempt" in roof:      # same sources profiled at 4096²: small launches idle a few more lanes
         assert 0.9 < roof["live_over_profile"] < 1.15
     off = _bench("--size", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--extras", "0")
@@ -127,7 +127,7 @@ def test_bench_two_rank_rehearsal_line_is_diagnosable():
     assert [p["rank"] for p in pr] == [0, 1] and sum(p["rays"] for p in pr) == 256 * 256
     assert sum(p["step_attempts"] for p in pr) == base["step_attempts_per_pass"]
     assert all(p["far_ms"] > 0 and p["near_ms"] > 0 and p["exchange_ms"] > 0 and p["wall_ms"] > 0 for p in pr)
-    assert 1.0 <= d["rank_imbalance"]["max_over_mean"] < 2.0
+    assert 1.0 <= d["rank_imbalance"]["max_over_mean"] < 4.0   # (two ranks time-share ONE GPU here: the bound only says the figure is sane)
     assert len(d["row_checksums_sha256"]) == 16 and "row_checksums" not in d          # the vector itself only on request
 
 
