@@ -40,6 +40,22 @@ def cache_dir():
     return d
 
 
+def prune_stale_units(verbose=False):
+    """Delete cached units that can no longer be named: a unit's file name hashes the template, the device headers and the listing
+    tool, so one built BEFORE the newest of those files was last written belongs to a hash nothing computes any more (each header
+    edit used to leave ~40 files, 8 MB, behind — all of which travel to the GPU box with every gpurun call).  -> files removed"""
+    newest = max(os.path.getmtime(f) for f in [TEMPLATE, _isa.__file__] + _HEADERS)
+    d, gone = cache_dir(), 0
+    for name in os.listdir(d):
+        f = os.path.join(d, name)
+        if os.path.isfile(f) and os.path.getmtime(f) < newest:
+            os.unlink(f)
+            gone += 1
+    if verbose and gone:
+        print(f"{d}: removed {gone} unit file(s) older than the current device headers")
+    return gone
+
+
 def _digest(source, extra_flags=()):
     h = hashlib.sha256()
     h.update(source.encode())
