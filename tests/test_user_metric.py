@@ -43,8 +43,15 @@ def test_bad_user_source_is_reported_not_swallowed():
     with pytest.raises(ValueError):
         um.compile_user_metric("int nothing_here;")
     bad = user_metrics.SCHWARZSCHILD_ISOTROPIC.replace("msqrt", "no_such_function")
-    with pytest.raises(RuntimeError, match="no_such_function"):
+    with pytest.raises(RuntimeError, match="no_such_function") as e:
         um.compile_user_metric(bad)
+    # the compiler's message carries the line of the USER's text (`#line 1 "user source"` ahead of it in the template), and the
+    # template's own numbering resumes behind it
+    at = 1 + bad.split("\n").index(next(l for l in bad.split("\n") if "no_such_function" in l))
+    assert f"user source:{at}:" in str(e.value), str(e.value)[:600]
+    tmpl = open(um.TEMPLATE).read().split("\n")
+    k = next(j for j, l in enumerate(tmpl) if l.startswith("#line") and "rtgr_user_unit.hip.in" in l)
+    assert tmpl[k] == f'#line {k + 2} "rtgr_user_unit.hip.in"' and tmpl[k - 1] == "@RTGR_USER_SOURCE@" and tmpl[k - 2] == '#line 1 "user source"'
 
 
 def test_in_process_build_needs_no_gpu_and_gives_a_sound_unit(tmp_path):
@@ -65,7 +72,7 @@ def test_in_process_build_needs_no_gpu_and_gives_a_sound_unit(tmp_path):
     bad = user_metrics.SCHWARZSCHILD_ISOTROPIC.replace("msqrt", "no_such_function")
     out = str(tmp_path / "bad.hsaco")
     assert lib.rtgr_user_metric_build(bad.encode(), 1, out.encode()) == abi.ERR_BAD_ARG
-    assert b"no_such_function" in lib.rtgr_last_error() and not os.path.exists(out)
+    assert b"no_such_function" in lib.rtgr_last_error() and b"user source:" in lib.rtgr_last_error() and not os.path.exists(out)
     assert lib.rtgr_user_metric_build(b"int nothing_here;", 0, out.encode()) == abi.ERR_BAD_ARG
 
 

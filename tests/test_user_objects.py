@@ -161,6 +161,13 @@ def test_sources_of_several_families_join_into_one():
                      ((lambda: join([user_objects.SHAPES], [2], small, 16)), "the buffer holds 16 bytes")):
         assert bad() == abi.ERR_BAD_ARG and why in lib.rtgr_last_error().decode(), (why, lib.rtgr_last_error())
     assert lib.rtgr_user_source_join(None, None, 0, None, 0, None) == abi.ERR_BAD_ARG
+    # a mistake in ONE family's text is reported with that family's name and its own line number (`#line` per namespace)
+    broken = rt.UserObjects(user_objects.SPHERE_AS_USER_OBJECT.replace("macos", "no_such_function"), name="broken", ntypes=1)
+    both = rt.UserObjects.join([joined[0].family, broken])[0]
+    at = 1 + broken.source.split("\n").index(next(l for l in broken.source.split("\n") if "no_such_function" in l))
+    with pytest.raises(RuntimeError, match="no_such_function") as e:
+        um.compile_user_metric(both.source, built_for=(abi.KS_REF, False, False))
+    assert f"object family 1:{at}:" in str(e.value), str(e.value)[:800]
 
 
 def test_oracle_twins_obey_the_distance_contract():

@@ -3,9 +3,8 @@
 # AddressSanitizer, then with UndefinedBehaviorSanitizer, on the HOST code only (-fno-gpu-sanitize), and the CPU tests that call into
 # the library run against each — the ISA audit on fuzzed code objects, the listing repair, the in-process unit build (hiprtc +
 # comgr), rtgr_user_source_join, the argument checks of every entry point.
-# Then the checker itself: oracle/rtgr_oracle.cpp built with g++ -fsanitize=address,undefined and the oracle's CPU tests (reference
-# goldens, committed fixtures, the reference's unit tests, identities, true geodesics) run against that build.
-#     usage: tools/sanitize_host.sh [log]          (≈ 15 min on 8 cores; builds under raytracegr.jl_amd/build/{asan,ubsan}/, oracle/_san/)
+# (The checker has the same run of its own: oracle/sanitize.sh.)
+#     usage: tools/sanitize_host.sh [log]          (≈ 10 min on 8 cores; builds under raytracegr.jl_amd/build/{asan,ubsan}/)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 LOG=${1:-$ROOT/profiles/r05/sanitize_host.log}
@@ -27,11 +26,4 @@ PY
   (cd "$ROOT" && RTGR_CSRC=$ROOT/raytracegr.jl_amd/csrc RTGR_LIB=$ROOT/raytracegr.jl_amd/build/$kind/librtgr_hip.so LD_PRELOAD=$RT \
      ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 python3 -m pytest $TESTS -q -m "not gpu" 2>&1 | tail -n 4) | tee -a "$LOG"
 done
-mkdir -p "$ROOT/oracle/_san"
-g++ -O1 -g -std=c++17 -fPIC -fopenmp -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-sanitize-recover=undefined \
-    -shared -o "$ROOT/oracle/_san/librtgr_oracle.so" "$ROOT/oracle/rtgr_oracle.cpp"
-OTESTS="tests/test_oracle_golden.py tests/test_golden_fixtures.py tests/test_reference_unit_tests.py tests/test_identities.py tests/test_truth.py tests/test_user_objects.py"
-echo "== asan + ubsan: oracle/rtgr_oracle.cpp (g++), $OTESTS -m 'not gpu'" | tee -a "$LOG"
-(cd "$ROOT" && RTGR_ORACLE_LIB=$ROOT/oracle/_san/librtgr_oracle.so LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-   ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 python3 -m pytest $OTESTS -q -m "not gpu" 2>&1 | tail -n 4) | tee -a "$LOG"
-rm -rf "$ROOT/raytracegr.jl_amd/build/asan" "$ROOT/raytracegr.jl_amd/build/ubsan" "$ROOT/oracle/_san"   # (≈ 70 MB that would otherwise travel to the GPU box with every gpurun call)
+rm -rf "$ROOT/raytracegr.jl_amd/build/asan" "$ROOT/raytracegr.jl_amd/build/ubsan"   # (≈ 70 MB that would otherwise travel to the GPU box with every gpurun call)
