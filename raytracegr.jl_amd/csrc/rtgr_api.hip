@@ -1733,11 +1733,12 @@ static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFram
     { std::lock_guard<std::mutex> lk(D.mu); mine = D.knobs; }
     mine.split = split;
     mine.max_waves = max_waves;
-    tl_probe_forces_unit = force_unit;
-    tl_knobs_override = &mine;
-    rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
-    tl_probe_forces_unit = false;
-    tl_knobs_override = nullptr;
+    {   // (the two thread-locals are cleared on every way out of the call, an exception from the allocator included)
+        struct Clear { ~Clear() { tl_probe_forces_unit = false; tl_knobs_override = nullptr; } } clear;
+        tl_probe_forces_unit = force_unit;
+        tl_knobs_override = &mine;
+        rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
+    }
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     f.rgb.resize(3 * N); f.se.resize(8 * N); f.lam.resize(N); f.na.resize(N); f.nr.resize(N); f.status.resize(N); f.hit.resize(N);
