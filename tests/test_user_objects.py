@@ -331,6 +331,24 @@ def test_objects_of_two_families_share_one_scene(lib, metric_name):
 
 
 @pytest.mark.gpu
+def test_joined_families_build_in_process_too(lib):
+    """The route a Julia or C caller takes (rtgr_user_unit_compile: hiprtc + comgr inside the library, no hipcc): the joined text —
+    namespaces, `#line` directives, dispatchers — compiles there as well, and traces the frame of the hipcc-built unit."""
+    from test_gpu_parity import hip_trace
+    _, objs, cam = rt.example2_scene()
+    cam = rt.make_camera(**cam)
+    opt = rt.solver_defaults()
+    sc_h = rt.make_scene(rt.kerr_schild, objs[:2] + _two_families()[0])
+    sc_j = rt.make_scene(rt.kerr_schild, objs[:2] + _two_families(jit=True)[0])
+    assert sc_h.user_metric != sc_j.user_metric and _info(sc_j)["has_reach"] == 1 and _info(sc_j)["probe_ok"] == 1
+    a, b = hip_trace(lib, sc_h, opt, 48, 48, cam=cam), hip_trace(lib, sc_j, opt, 48, 48, cam=cam)
+    for k in ("hit", "status", "n_accept", "n_reject"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.abs(a["rgb"] - b["rgb"]).max() <= 1e-12          # (two compilers' fusions of the same source: not bit for bit)
+    abi.check(lib, lib.rtgr_scene_check(None, C.byref(sc_j), C.byref(opt), C.byref(cam), 48, 48, 0))
+
+
+@pytest.mark.gpu
 def test_a_family_without_a_bound_beside_one_with_a_bound(lib):
     """Joined sources where only SOME bring rtgr_user_reach: the types of the others answer +infinity — a scene that holds such an
     object scans every step (all rays take the NEAR pass), a scene of the same unit without one keeps the FAR pass; the frames are
