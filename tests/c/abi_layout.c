@@ -20,6 +20,12 @@
  *                                   (M, a) in the scene, an RTGR_DISK object, the camera struct (rays generated on the device),
  *                                   rtgr_trace_f64 with an rtgr_ray_outputs block — 64 x 64; writes the three f64 RGB planes, then
  *                                   hit, status, n_accept, n_reject (compared with the oracle by the test)
+ *   abi_layout --render-user-objects <lib> out
+ *                                   the reference's SECOND extension point from plain C, no Python and no hipcc in the process: two
+ *                                   separately written object sources (a torus; the reference's Sphere as device source) joined by
+ *                                   rtgr_user_source_join, compiled IN-PROCESS by rtgr_user_unit_compile for example2's metric, the
+ *                                   unit's id put into the scene, rtgr_user_unit_info, rtgr_scene_check, rtgr_trace_f64 at 64 x 64
+ *                                   with an rtgr_ray_outputs block; same output format as --render-disk (compared with the oracle)
  */
 #include <dlfcn.h>
 #include <math.h>
@@ -63,7 +69,8 @@ _Static_assert(sizeof(pixel_f32) == 44 && offsetof(pixel_f32, normal) == 16 && o
 static const char* const BOUND[] = {"rtgr_create", "rtgr_destroy", "rtgr_context_devices", "rtgr_init", "rtgr_shutdown", "rtgr_last_error", "rtgr_abi_version",
                                     "rtgr_solver_defaults", "rtgr_trace_pixels_f64", "rtgr_trace_pixels_f32", "rtgr_trace_one_f64", "rtgr_trace_one_f32", "rtgr_trace_f64",
                                     "rtgr_trace_sharded_f64", "rtgr_make_canvas_f64", "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_unit_compile",
-                                    "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", NULL};
+                                    "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", "rtgr_user_source_join", "rtgr_user_unit_info", "rtgr_scene_check",
+                                    "rtgr_eval_objects_f64", "rtgr_eval_objects_f32", NULL};
 
 typedef int (*fn_defaults)(rtgr_solver*, int);
 typedef int (*fn_canvas)(rtgr_context*, const rtgr_scene*, const rtgr_camera*, uint64_t, uint64_t, uint64_t, uint64_t, double*);
@@ -76,8 +83,40 @@ typedef int (*fn_create)(const int*, int, rtgr_context**);
 typedef int (*fn_destroy)(rtgr_context*);
 typedef int (*fn_ndev)(rtgr_context*);
 
+typedef int (*fn_join)(const char* const*, const uint32_t*, int, char*, uint64_t, uint64_t*);
+typedef int (*fn_unit_compile)(rtgr_context*, const char*, int, const rtgr_scene*, uint64_t*);
+typedef int (*fn_unit_info)(rtgr_context*, uint64_t, rtgr_unit_info*);
+typedef int (*fn_scene_check)(rtgr_context*, const rtgr_scene*, const rtgr_solver*, const rtgr_camera*, uint64_t, uint64_t, int);
+
+/* two object families, written separately: `distance` and `objcolor` of a new Object subtype (src/RayTraceGR.jl:377-389) as device
+ * source — a torus around the z axis (p = centre, R, r), and the reference's own Sphere (:409-428; p = pos, vel, radius) */
+static const char* const TORUS_SRC =
+    "template <class S> __device__ S rtgr_user_distance(unsigned type, const S x[4], const S p[9]) {\n"
+    "    const S X = x[1] - p[0], Y = x[2] - p[1], Z = x[3] - p[2], w = msqrt(X * X + Y * Y) - p[3];\n"
+    "    return w * w + Z * Z - p[4] * p[4];\n"
+    "}\n"
+    "template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]) {\n"
+    "    const S pi = S(3.14159265358979323846264338327950288);\n"
+    "    const S X = x[1] - p[0], Y = x[2] - p[1], Z = x[3] - p[2], w = msqrt(X * X + Y * Y) - p[3];\n"
+    "    rgb[0] = mod1<S>(S(6) * matan2(Y, X) / pi); rgb[1] = mod1<S>(S(6) * matan2(Z, w) / pi); rgb[2] = S(0.5);\n"
+    "}\n"
+    "template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]) {\n"
+    "    const S X = x[1] - p[0], Y = x[2] - p[1], Z = x[3] - p[2], w = msqrt(X * X + Y * Y) - p[3], d = msqrt(dl[1] * dl[1] + dl[2] * dl[2]);\n"
+    "    return d * (S(2) * mabs(w) + d) + dl[3] * (S(2) * mabs(Z) + dl[3]);\n"
+    "}\n";
+static const char* const BALL_SRC =
+    "template <class S> __device__ S rtgr_user_distance(unsigned type, const S x[4], const S p[9]) {\n"
+    "    const S dx = x[1] - p[1], dy = x[2] - p[2], dz = x[3] - p[3], d = dx * dx + dy * dy + dz * dz - p[8] * p[8];\n"
+    "    return p[8] < S(0) ? -d : d;\n"
+    "}\n"
+    "template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]) {\n"
+    "    const S pi = S(3.14159265358979323846264338327950288);\n"
+    "    const S dx = x[1] - p[1], dy = x[2] - p[2], dz = x[3] - p[3], r = msqrt(dx * dx + dy * dy + dz * dz);\n"
+    "    rgb[0] = mod1<S>(S(12) * macos(dz / r) / pi); rgb[1] = mod1<S>(S(12) * matan2(dy, dx) / pi); rgb[2] = S(1);\n"
+    "}\n";                                  /* (no reach bound: its objects are scanned on every step) */
+
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render|--render-disk <lib> [out [ndev]]\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render|--render-disk|--render-user-objects <lib> [out [ndev]]\n"); return 2; }
     void* h = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
     for (int i = 0; BOUND[i]; i++)
@@ -136,6 +175,68 @@ int main(int argc, char** argv) {
         fclose(f);
         if (ctx && ((fn_destroy)dlsym(h, "rtgr_destroy"))(ctx)) return 16;
         printf("ok %llu rays %llu events\n", (unsigned long long)ctr.rays, (unsigned long long)ctr.events);
+        return 0;
+    }
+    if (strcmp(argv[1], "--render-user-objects") == 0) {
+        fn_trace trace = (fn_trace)dlsym(h, "rtgr_trace_f64");
+        fn_join join = (fn_join)dlsym(h, "rtgr_user_source_join");
+        fn_unit_compile compile = (fn_unit_compile)dlsym(h, "rtgr_user_unit_compile");
+        fn_unit_info info = (fn_unit_info)dlsym(h, "rtgr_user_unit_info");
+        fn_scene_check check = (fn_scene_check)dlsym(h, "rtgr_scene_check");
+        if (!trace || !join || !compile || !info || !check) return 4;
+        /* the two sources become one: torus = type 0 of family 0 -> 0, ball = type 0 of family 1 -> ntypes[0] + 0 = 1 */
+        const char* const srcs[2] = {TORUS_SRC, BALL_SRC};
+        const uint32_t ntypes[2] = {1, 1};
+        uint64_t need = 0;
+        if (join(srcs, ntypes, 2, NULL, 0, &need) || need == 0) { fprintf(stderr, "rtgr_user_source_join: %s\n", err()); return 20; }
+        char* joined = (char*)malloc(need);
+        if (join(srcs, ntypes, 2, joined, need, &need)) { fprintf(stderr, "rtgr_user_source_join: %s\n", err()); return 21; }
+        rtgr_scene sc;
+        memset(&sc, 0, sizeof sc);
+        sc.metric = RTGR_KS_REF; sc.M = 1.0; sc.a = 0.0; sc.nobj = 4;                        /* kerr_schild as written */
+        sc.obj[0].kind = RTGR_SPHERE; sc.obj[0].p[4] = 1.0; sc.obj[0].p[8] = -10.0;           /* caelum */
+        sc.obj[1].kind = RTGR_PLANE; sc.obj[1].p[0] = -20.0;                                   /* frustum */
+        sc.obj[2].kind = RTGR_USER_OBJECT; sc.obj[2].type = 0;                                 /* Torus(centre (4, 0, 0), R 0.9, r 0.3) */
+        sc.obj[2].p[0] = 4.0; sc.obj[2].p[3] = 0.9; sc.obj[2].p[4] = 0.3;
+        sc.obj[3].kind = RTGR_USER_OBJECT; sc.obj[3].type = ntypes[0] + 0;                     /* Ball(pos, vel, radius) */
+        sc.obj[3].p[1] = 4.6; sc.obj[3].p[2] = -0.9; sc.obj[3].p[3] = 0.9; sc.obj[3].p[4] = 1.0; sc.obj[3].p[8] = 0.35;
+        uint64_t id = 0;
+        if (compile(ctx, joined, 0, &sc /* built for THIS scene's metric variant */, &id) || id == 0) { fprintf(stderr, "rtgr_user_unit_compile: %s\n", err()); return 22; }
+        sc.user_metric = id;
+        rtgr_unit_info ui;
+        if (info(ctx, id, &ui) || ui.metric != RTGR_KS_REF || ui.spin != 0 || !ui.has_objects || !ui.has_reach || !ui.probe_ok) {
+            fprintf(stderr, "rtgr_user_unit_info: metric %u spin %u objects %u reach %u probe %u (%s)\n", ui.metric, ui.spin, ui.has_objects, ui.has_reach, ui.probe_ok, err());
+            return 23;
+        }
+        rtgr_camera cam;
+        memset(&cam, 0, sizeof cam);
+        cam.pos[1] = 4.0; cam.pos[2] = -2.0; cam.widthx[1] = 1.0; cam.widthy[3] = 1.0; cam.normal[2] = 1.0;
+        rtgr_solver opt;
+        if (defaults(&opt, 0)) return 5;
+        if (check(ctx, &sc, &opt, &cam, 48, 48, 0)) { fprintf(stderr, "rtgr_scene_check: %s\n", err()); return 24; }
+        const uint64_t ni = 64, nj = 64, n = ni * nj;
+        double* rgb = (double*)calloc(3 * n, sizeof(double));
+        uint8_t* hit = (uint8_t*)calloc(n, 1);
+        uint8_t* status = (uint8_t*)calloc(n, 1);
+        uint32_t* nacc = (uint32_t*)calloc(n, 4);
+        uint32_t* nrej = (uint32_t*)calloc(n, 4);
+        rtgr_ray_outputs outs;
+        memset(&outs, 0, sizeof outs);
+        outs.hit = hit; outs.status = status; outs.n_accept = nacc; outs.n_reject = nrej;
+        rtgr_counters ctr;
+        if (trace(ctx, &sc, &opt, NULL, &cam, ni, nj, 0, nj, rgb, &outs, &ctr)) { fprintf(stderr, "rtgr_trace_f64: %s\n", err()); return 7; }
+        if (ctr.rays != n) return 8;
+        sc.user_metric = 0;                  /* a scene with user objects and no unit is refused, not traced with something else */
+        if (trace(ctx, &sc, &opt, NULL, &cam, ni, nj, 0, nj, rgb, NULL, NULL) == 0) { fprintf(stderr, "a scene without its unit was traced\n"); return 25; }
+        FILE* f = fopen(argv[3], "wb");
+        if (!f) return 9;
+        fwrite(rgb, sizeof(double), 3 * n, f);
+        fwrite(hit, 1, n, f);
+        fwrite(status, 1, n, f);
+        fwrite(nacc, 4, n, f);
+        fwrite(nrej, 4, n, f);
+        fclose(f);
+        printf("ok %llu rays, unit %llx: far %u near %u f32 %u waves/SIMD\n", (unsigned long long)ctr.rays, (unsigned long long)id, ui.far_waves, ui.near_waves, ui.f32_waves);
         return 0;
     }
     /* example2(): src/RayTraceGR.jl:581-593 */

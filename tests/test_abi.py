@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -172,4 +173,41 @@ def test_c_caller_renders_the_kerr_disk_scene(lib, tmp_path, ndev):
     same = ~flips
     assert (status[same] == ref["status"][same]).all()
     assert np.abs((nacc + nrej).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))[same].max() <= 2
+    assert wrap_aware_rgb_err(rgb[:, same], ref["rgb"][:, same], hit[same], sc=sc) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_c_caller_compiles_and_traces_user_objects_of_two_sources(lib, tmp_path):
+    """The reference's second extension point from a plain C process — no Python, no torch-bundled HIP runtime, no hipcc: two object
+    sources joined (rtgr_user_source_join), the unit built in-process (rtgr_user_unit_compile: hiprtc + comgr resolved by the
+    library), audited and probed at load, the scene checked (rtgr_scene_check) and traced (rtgr_trace_f64) — against the oracle's
+    torus twin and the built-in Sphere in the ball's place.  What a Julia `trace_rays(kerr_schild, [caelum, frustum,
+    DeviceObject(torus…), DeviceObject(ball…)], canvas)` does, byte for byte."""
+    import subprocess
+    import oracle_lib as O
+    from scenes import wrap_aware_rgb_err
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import user_objects
+    exe = _build_c_caller(tmp_path)
+    out = str(tmp_path / "objs.bin")
+    res = subprocess.run([exe, "--render-user-objects", abi.LIB_PATH, out], capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stderr)
+    n = 64 * 64
+    raw = open(out, "rb").read()
+    rgb = np.frombuffer(raw, np.float64, 3 * n).reshape(3, n)
+    hit = np.frombuffer(raw, np.uint8, n, 24 * n)
+    status = np.frombuffer(raw, np.uint8, n, 25 * n)
+    nacc = np.frombuffer(raw, np.uint32, n, 26 * n)
+    nrej = np.frombuffer(raw, np.uint32, n, 30 * n)
+    _, objs, cam = rt.example2_scene()
+    shapes = rt.UserObjects(user_objects.SHAPES)
+    sc = rt.make_scene(rt.kerr_schild, objs[:2] + [shapes(user_objects.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]),
+                                                    rt.Sphere([0.0, 4.6, -0.9, 0.9], [1.0, 0.0, 0.0, 0.0], 0.35)], units=False)
+    ref = O.trace(sc, rt.solver_defaults(), 64, 64, cam=rt.make_camera(**cam))
+    flips = hit != ref["hit"]
+    assert int(flips.sum()) <= 2, int(flips.sum())     # (the ball's distance is written without the built-in's fused operations)
+    assert (hit == 3).sum() > 100 and (hit == 4).sum() > 30                                            # torus and ball in the picture
+    same = ~flips
+    assert (status[same] == ref["status"][same]).all()
+    assert np.abs((nacc + nrej).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))[same].max() <= 1
     assert wrap_aware_rgb_err(rgb[:, same], ref["rgb"][:, same], hit[same], sc=sc) <= 1e-6
