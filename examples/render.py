@@ -9,6 +9,8 @@
                                             #   Boyer–Lindquist coordinates — user source with macos / matan2)
     python examples/render.py 5             # writes scenes/sphere5.png (example2 with NEW Object subtypes — a torus and an
                                             #   ellipsoid given as device source, UserObjects — where the small sphere was)
+    python examples/render.py 6             # writes scenes/sphere6.png (objects of TWO separately written sources in one scene:
+                                            #   that torus and ellipsoid, and the reference's Sphere written as device source)
 
 The code below is what a user of RayTraceGR.jl writes, with `RayTraceGR.` replaced by the host mirror `rt.`.
 """
@@ -40,12 +42,19 @@ def main():
         import user_objects
         shapes = rt.UserObjects(user_objects.SHAPES_WITH_REACH, name="torus + ellipsoid")
         objs = [caelum, frustum, shapes(user_objects.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]), shapes(user_objects.ELLIPSOID, [3.3, 1.0, -0.8, 0.7, 0.5, 0.5])]
+    if which == 6:   # … of two families at once: make_scene joins the sources into one unit (each family says how many types it defines)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import user_objects
+        shapes = rt.UserObjects(user_objects.SHAPES_WITH_REACH, name="torus + ellipsoid", ntypes=2)
+        balls = rt.UserObjects(user_objects.SPHERE_AS_USER_OBJECT, name="sphere", ntypes=1)
+        objs = [caelum, frustum, shapes(user_objects.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]), balls(0, [0.0, 4.6, -0.9, 0.9, 1.0, 0.0, 0.0, 0.0, 0.35]),
+                shapes(user_objects.ELLIPSOID, [3.3, 1.0, -0.8, 0.7, 0.5, 0.5])]
     pos = (0, 0 if which == 1 else 4, -2, 0)
     canvas = rt.make_canvas(metric, pos, (0, 1, 0, 0), (0, 0, 0, 1), (0, 0, 1, 0), ni, nj)
     canvas, info = rt.trace_rays(metric, objs, canvas, return_info=True)
     from raytracegr_jl_amd.png import write_png
     os.makedirs(rt.api.outdir, exist_ok=True)
-    file = os.path.join(rt.api.outdir, {1: "sphere.png", 2: "sphere2.png", 3: "sphere3.png", 4: "sphere4.png", 5: "sphere5.png"}[which])
+    file = os.path.join(rt.api.outdir, {1: "sphere.png", 2: "sphere2.png", 3: "sphere3.png", 4: "sphere4.png", 5: "sphere5.png", 6: "sphere6.png"}[which])
     write_png(file, canvas.image_u8())
     print(f'Output file is "{file}"  ({info["rays"]} rays, {info["accepted"] + info["rejected"]} RK step attempts)')
 

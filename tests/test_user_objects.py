@@ -670,3 +670,27 @@ def test_object_methods_on_the_device_match_the_oracle_pointwise(lib, dtype, tol
         dc = np.abs(got["rgb"][same].astype(float) - ref["rgb"][same])
         per = np.where(got["hit"][same] > 0, got["hit"][same] / len(objs), 1.0)[:, None]
         assert np.minimum(dc, np.abs(per - dc)).max() <= (1e-9 if dtype == np.float64 else 2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [5, 6])
+def test_example_scripts_with_user_objects_write_the_oracles_image(lib, tmp_path, monkeypatch, which):
+    """examples/render.py 5 / 6 — what a user writes: new Object subtypes in `objs`, one family or two — end to end through make_canvas,
+    trace_rays and the PNG writer; the 8-bit image equals the oracle's of the same scene (a pixel or two may sit on a rounding edge)."""
+    import runpy
+    from raytracegr_jl_amd.png import read_png
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(sys, "argv", ["render.py", str(which), "64"])
+    runpy.run_path(os.path.join(ROOT, "examples", "render.py"), run_name="__main__")
+    img = read_png(str(tmp_path / "scenes" / f"sphere{which}.png"))
+    _, objs, cam = rt.example2_scene()
+    shapes = rt.UserObjects(user_objects.SHAPES)
+    mine = [shapes(user_objects.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]), shapes(user_objects.ELLIPSOID, [3.3, 1.0, -0.8, 0.7, 0.5, 0.5])]
+    if which == 6:
+        mine.insert(1, rt.Sphere([0.0, 4.6, -0.9, 0.9], [1.0, 0.0, 0.0, 0.0], 0.35))
+    ref = O.trace(rt.make_scene(rt.kerr_schild, objs[:2] + mine, units=False), rt.solver_defaults(), 64, 64, cam=rt.make_camera(**cam))
+    gold = O.image_u8(ref["rgb"], 64, 64)
+    assert img.shape == gold.shape == (64, 64, 3)
+    off = (np.abs(img.astype(int) - gold.astype(int)) > 1).any(axis=2)
+    assert int(off.sum()) <= 2, int(off.sum())
+    assert (ref["hit"] >= 3).sum() > 400                      # the new objects fill a good part of the frame
