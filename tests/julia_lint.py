@@ -514,3 +514,180 @@ def check_toplevel_names(tokens, known):
             if tok.val not in bound:
                 problems.append(("<top level>", tok.line, tok.val))
     return problems
+
+
+# ---- call arity: a call of a function the file defines must fit one of its methods' positional-argument counts ---------------------
+def _split_args(seq):
+    """tokens between a call's / header's parentheses -> (positional groups, keyword groups): split at depth-0 commas; everything after
+    a depth-0 `;` is keyword; in a CALL a group `name = value` is a keyword argument too (caller tells which by `is_call`)"""
+    groups, cur, d, after_semi, marks = [], [], 0, False, []
+    for t in seq:
+        if t.kind == "punct" and t.val in "([{":
+            d += 1
+        elif t.kind == "punct" and t.val in ")]}":
+            d -= 1
+        if d == 0 and t.kind == "punct" and t.val in ",;":
+            if cur:
+                groups.append(cur)
+                marks.append(after_semi)
+            cur = []
+            if t.val == ";":
+                after_semi = True
+            continue
+        cur.append(t)
+    if cur:
+        groups.append(cur)
+        marks.append(after_semi)
+    return [g for g, kw in zip(groups, marks) if not kw], [g for g, kw in zip(groups, marks) if kw]
+
+
+def _has_top_level(group, kind, val):
+    d = 0
+    for t in group:
+        if t.kind == "punct" and t.val in "([{":
+            d += 1
+        elif t.kind == "punct" and t.val in ")]}":
+            d -= 1
+        elif d == 0 and t.kind == kind and t.val == val:
+            return True
+    return False
+
+
+def _paren_group(toks, k):
+    """toks[k] is `(`: (tokens inside, index of the matching `)`)"""
+    d, j = 0, k
+    while j < len(toks):
+        if toks[j].kind == "punct" and toks[j].val in "([{":
+            d += 1
+        elif toks[j].kind == "punct" and toks[j].val in ")]}":
+            d -= 1
+            if d == 0:
+                return toks[k + 1:j], j
+        j += 1
+    raise LintError(f"line {toks[k].line}: unclosed (")
+
+
+def _skip_curly(toks, j):
+    if j < len(toks) and toks[j].kind == "punct" and toks[j].val == "{":
+        d = 0
+        while j < len(toks):
+            d += (toks[j].val == "{") - (toks[j].val == "}") if toks[j].kind == "punct" else 0
+            j += 1
+            if d == 0:
+                break
+    return j
+
+
+def method_arities(tokens):
+    """{name: [(min positional, max positional or None)]} for the functions a file defines under an UNQUALIFIED name (a method added
+    to another module's function — `Base.close(c) = …`, `RayTraceGR.distance(o, x) = …` — says nothing about that function's other
+    methods) and for its structs (the default constructor takes one argument per field)"""
+    toks, out, headers = _code(tokens), {}, []
+    for name, line, header, body in function_bodies(tokens):
+        headers.append(header)
+    lines = {}
+    for t in toks:
+        lines.setdefault(t.line, []).append(t)
+    inside_fn = set()
+    for _, _, header, body in function_bodies(tokens):
+        inside_fn |= {id(t) for t in body}
+    for ln, ts in lines.items():                                  # short forms at top level: `name(args) [where …] = …`
+        if ts[0].kind == "id" and id(ts[0]) not in inside_fn and len(ts) > 3:
+            j = _skip_curly(ts, 1)
+            if j < len(ts) and ts[j].kind == "punct" and ts[j].val == "(":
+                try:
+                    inner, close = _paren_group(ts, j)
+                except LintError:
+                    continue                                   # (the argument list continues on the next line: long enough to be a long form)
+                m = close + 1
+                if m < len(ts) and ts[m].kind == "op" and ts[m].val == "::":       # f(x)::T = …
+                    m += 2
+                    m = _skip_curly(ts, m)
+                if m < len(ts) and ts[m].kind == "kw" and ts[m].val == "where":
+                    m += 1
+                    m = _skip_curly(ts, m) if ts[m].kind == "punct" else m + 1
+                if m < len(ts) and ts[m].kind == "op" and ts[m].val == "=":
+                    headers.append(ts[:close + 1])
+    for header in headers:
+        if not header or header[0].kind != "id":
+            continue                                              # `function (m::K)(x)`: a callable object, no name to call
+        if len(header) > 1 and header[1].kind == "op" and header[1].val == ".":
+            continue                                              # Module.f: another module's function
+        j = _skip_curly(header, 1)
+        if j >= len(header) or not (header[j].kind == "punct" and header[j].val == "("):
+            continue
+        inner, _ = _paren_group(header, j)
+        pos, _ = _split_args(inner)
+        var = any(g[-1].kind == "op" and g[-1].val == "..." for g in pos)
+        need = sum(1 for g in pos if not _has_top_level(g, "op", "=") and not (g[-1].kind == "op" and g[-1].val == "..."))
+        out.setdefault(header[0].val, []).append((need, None if var else len(pos)))
+    k = 0
+    while k < len(toks):                                          # structs: one positional argument per field
+        t = toks[k]
+        if t.kind == "kw" and t.val == "struct":
+            name = toks[k + 1].val
+            depth, j, fields, bracket = 1, k + 2, 0, 0
+            while j < len(toks) and depth:
+                tt = toks[j]
+                if tt.kind == "punct" and tt.val in "([{":
+                    bracket += 1
+                elif tt.kind == "punct" and tt.val in ")]}":
+                    bracket -= 1
+                elif tt.kind == "kw" and tt.val in OPENERS and not bracket:
+                    depth += 1
+                elif tt.kind == "kw" and tt.val == "end" and not bracket:
+                    depth -= 1
+                elif depth == 1 and not bracket and tt.line != t.line and (tt.kind == "id" or (tt.kind == "kw" and tt.val == "type")):   # (`type` is a legal field name)
+                    # a field: an identifier that starts a statement (first of its line, or right behind a `;`)
+                    prev, nxt = toks[j - 1], toks[j + 1]
+                    starts = prev.line != tt.line or (prev.kind == "punct" and prev.val == ";")
+                    if starts and ((nxt.kind == "op" and nxt.val == "::") or nxt.line != tt.line or (nxt.kind == "punct" and nxt.val == ";")):
+                        fields += 1
+                j += 1
+            out.setdefault(name, []).append((fields, fields))
+            k = j
+            continue
+        k += 1
+    return out
+
+
+def check_arity(tokens, arities, qualifier=None):
+    """[(line, name, positional arguments given, what the definitions take)] for calls `name(…)` (or `qualifier.name(…)`) whose number
+    of positional arguments fits no method of `arities`.  Calls with a splat are skipped; a `do` block adds its function as first
+    argument; `name = value` inside the call's parentheses and everything behind `;` are keyword arguments."""
+    toks, problems = _code(tokens), []
+    defs = set()
+    for _, _, header, _ in function_bodies(tokens):
+        defs |= {id(t) for t in header}
+    k = 0
+    while k < len(toks):
+        t = toks[k]
+        if t.kind == "id" and t.val in arities and id(t) not in defs:
+            prev = toks[k - 1] if k else None
+            qualified = prev is not None and prev.kind == "op" and prev.val == "."
+            if qualified and not (qualifier and k >= 2 and toks[k - 2].kind == "id" and toks[k - 2].val == qualifier):
+                k += 1
+                continue                                          # x.name(…): a field or another module's function
+            if not qualified and qualifier:
+                k += 1
+                continue                                          # (checking a client file: only Module.name(…) is the module's)
+            j = _skip_curly(toks, k + 1)
+            if j < len(toks) and toks[j].kind == "punct" and toks[j].val == "(" and toks[j].line == t.line:
+                inner, close = _paren_group(toks, j)
+                after = toks[close + 1] if close + 1 < len(toks) else None
+                # a definition in short form is not a call: `name(args) [where …] =` at the start of a line
+                first_on_line = k == 0 or toks[k - 1].line != t.line
+                if first_on_line and after is not None and ((after.kind == "op" and after.val in ("=", "::")) or (after.kind == "kw" and after.val == "where")):
+                    k = close + 1
+                    continue
+                pos, _ = _split_args(inner)
+                if any(_has_top_level(g, "op", "...") for g in pos):
+                    k += 1
+                    continue
+                n = sum(1 for g in pos if not (_has_top_level(g, "op", "=") and g[0].kind == "id" and len(g) > 1 and g[1].kind == "op" and g[1].val == "="))
+                if after is not None and after.kind == "kw" and after.val == "do":
+                    n += 1
+                if not any(lo <= n and (hi is None or n <= hi) for lo, hi in arities[t.val]):
+                    problems.append((t.line, t.val, n, arities[t.val]))
+        k += 1
+    return problems

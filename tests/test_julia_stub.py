@@ -331,3 +331,46 @@ def test_the_julia_checker_finds_what_a_parser_or_a_first_run_would():
         assert text != src, what
         _, unbound = _lint(text, is_text=True)
         assert name in {n for _, _, n in unbound}, (what, unbound[:5])
+
+
+def test_calls_fit_the_methods_the_julia_files_define():
+    """Call ARITY, the mistake a first run finds first: every call of a function (or struct constructor) the module defines under an
+    unqualified name — inside the module, and as `RayTraceGRHIP.name(…)` in the test file — passes a number of positional arguments
+    that one of its methods takes (defaults and varargs counted, keyword arguments and `do` blocks told apart, splats skipped); the
+    same for the test file's own definitions.  And with one fault injected each — an argument dropped, one too many, a constructor
+    with a field forgotten — the check reports exactly that call."""
+    import julia_lint as L
+    src, tests = open(JL).read(), open(JLTESTS).read()
+    mod = L.tokenize(src)
+    arities = L.method_arities(mod)
+    assert len(arities) >= 40 and arities["unit_id"] == [(4, 4)] and arities["RtgrObject"] == [(3, 3)] and arities["RtgrCounters"] == [(8, 8)]
+    assert (0, 2) in arities["KerrSchild"] and (1, 1) in arities["DeviceObjects"] and (2, None) in arities["DeviceObject"]
+    assert L.check_arity(mod, arities) == []
+    tt = L.tokenize(tests)
+    assert L.check_arity(tt, arities, qualifier="RayTraceGRHIP") == []
+    assert L.check_arity(tt, L.method_arities(tt)) == []
+    for what, text, name, given in (
+            ("an argument dropped", src.replace("unit_id(family, metric, scene, ctx), packed))", "unit_id(family, metric, scene), packed))"), "unit_id", 3),
+            ("one too many", src.replace("cam = camera_of(pos, widthx, widthy, normal)", "cam = camera_of(pos, widthx, widthy, normal, ni)", 1), "camera_of", 5),
+            ("a field forgotten", src.replace("pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECT, o.type, o.p)", "pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECT, o.p)"), "RtgrObject", 2)):
+        assert text != src, what
+        found = L.check_arity(L.tokenize(text), arities)
+        assert [(n, g) for _, n, g, _ in found] == [(name, given)], (what, found)
+    # … and the calls of the REFERENCE's functions (signatures read off src/RayTraceGR.jl, cited by line): qualified in the module,
+    # qualified or plain (`using RayTraceGR`) in the test file
+    ref = {"minkowski": [(1, 1)], "kerr_schild": [(1, 1)],                 # :262, :274
+           "dmetric": [(2, 2)], "christoffel": [(2, 2)],                   # :302, :321
+           "Ray": [(2, 2)], "r2s": [(1, 1)], "s2r": [(1, 1)], "geodesic": [(3, 3)],    # :339-348, :358, :367
+           "distance": [(2, 2)], "objcolor": [(2, 2)], "min_distance": [(2, 2)],     # :384-389, :433
+           "Plane": [(1, 1)], "Sphere": [(3, 3)], "Pixel": [(3, 3)], "Canvas": [(1, 1)],   # :394, :409, :446, :453
+           "make_canvas": [(7, 7)], "trace_rays": [(3, 3)], "example1": [(0, 0)], "example2": [(0, 0)],   # :458, :483, :542, :578
+           "Dual": [(1, 2)]}                                               # :11-20
+    assert L.check_arity(mod, ref, qualifier="RayTraceGR") == []
+    assert L.check_arity(tt, ref, qualifier="RayTraceGR") == []
+    own = set(L.method_arities(tt))
+    assert L.check_arity(tt, {k: v for k, v in ref.items() if k not in own}) == []
+    worse = src.replace("return RayTraceGR.trace_rays(metric, objs, c)", "return RayTraceGR.trace_rays(metric, objs)", 1)
+    assert worse != src and [(n, g) for _, n, g, _ in L.check_arity(L.tokenize(worse), ref, qualifier="RayTraceGR")] == [("trace_rays", 2)]
+    bad = tests.replace("RayTraceGRHIP.eval_objects(kerr_schild, hip_objs, xs)", "RayTraceGRHIP.eval_objects(kerr_schild, hip_objs)")
+    assert bad != tests
+    assert [(n, g) for _, n, g, _ in L.check_arity(L.tokenize(bad), arities, qualifier="RayTraceGRHIP")] == [("eval_objects", 2)]
