@@ -691,3 +691,69 @@ def check_arity(tokens, arities, qualifier=None):
                     problems.append((t.line, t.val, n, arities[t.val]))
         k += 1
     return problems
+
+
+# ---- field access: `x.name` must name a field of SOME struct in sight (a misspelled field is a first-run error too) -----------------
+def struct_fields(tokens):
+    """{field names} of every struct the file defines"""
+    toks, out = _code(tokens), set()
+    k = 0
+    while k < len(toks):
+        t = toks[k]
+        if t.kind == "kw" and t.val == "struct":
+            depth, j, bracket = 1, k + 2, 0
+            while j < len(toks) and depth:
+                tt = toks[j]
+                if tt.kind == "punct" and tt.val in "([{":
+                    bracket += 1
+                elif tt.kind == "punct" and tt.val in ")]}":
+                    bracket -= 1
+                elif tt.kind == "kw" and tt.val in OPENERS and not bracket:
+                    depth += 1
+                elif tt.kind == "kw" and tt.val == "end" and not bracket:
+                    depth -= 1
+                elif depth == 1 and not bracket and tt.line != t.line and (tt.kind == "id" or (tt.kind == "kw" and tt.val == "type")):
+                    prev, nxt = toks[j - 1], toks[j + 1]
+                    starts = prev.line != tt.line or (prev.kind == "punct" and prev.val == ";")
+                    if starts and ((nxt.kind == "op" and nxt.val == "::") or nxt.line != tt.line or (nxt.kind == "punct" and nxt.val == ";")):
+                        out.add(tt.val)
+                j += 1
+            k = j
+            continue
+        k += 1
+    return out
+
+
+def check_fields(tokens, fields, modules):
+    """[(line, name)] of `x.name` accesses (x: an identifier that is no module, or the result of an index / call) whose `name` is no
+    field of any known struct.  `name(` directly behind the dot is a qualified call (Module.f(…)) and is skipped with its module."""
+    problems = []
+
+    def scan(toks):
+        for k, t in enumerate(toks):
+            if t.kind == "str":
+                for sub in t.val:
+                    scan(_code(sub))
+                continue
+            if not (t.kind == "op" and t.val == "." and 0 < k < len(toks) - 1):
+                continue
+            prev, nxt = toks[k - 1], toks[k + 1]
+            if not (nxt.kind == "id" or (nxt.kind == "kw" and nxt.val == "type")) or nxt.line != t.line:
+                continue                                          # broadcasting dot, `.+`, `f.(x)`
+            if prev.kind == "id":
+                if prev.val in modules:
+                    continue
+                # a chain Module.Sub.name: walk to the head
+                j, head = k - 1, prev
+                while j >= 2 and toks[j - 1].kind == "op" and toks[j - 1].val == "." and toks[j - 2].kind == "id":
+                    j -= 2
+                    head = toks[j]
+                if head.val in modules:
+                    continue
+            elif not (prev.kind == "punct" and prev.val in ")]"):
+                continue
+            if nxt.val not in fields:
+                problems.append((nxt.line, nxt.val))
+
+    scan(_code(tokens))
+    return problems

@@ -374,3 +374,22 @@ def test_calls_fit_the_methods_the_julia_files_define():
     bad = tests.replace("RayTraceGRHIP.eval_objects(kerr_schild, hip_objs, xs)", "RayTraceGRHIP.eval_objects(kerr_schild, hip_objs)")
     assert bad != tests
     assert [(n, g) for _, n, g, _ in L.check_arity(L.tokenize(bad), arities, qualifier="RayTraceGRHIP")] == [("eval_objects", 2)]
+
+
+def test_field_accesses_name_fields_that_exist():
+    """`x.name` (x a variable, an indexed value or a call's result — not a module) must name a field of some struct of the module, of
+    the test file or of the reference (Pixel, Canvas, Sphere, Plane, Ray, Dual: src/RayTraceGR.jl:11-14, :339-342, :394-413, :446-455);
+    a misspelled field is reported."""
+    import julia_lint as L
+    src, tests = open(JL).read(), open(JLTESTS).read()
+    mod, tt = L.tokenize(src), L.tokenize(tests)
+    fields = L.struct_fields(mod) | L.struct_fields(tt) | {"pos", "normal", "rgb", "pixels", "vel", "radius", "time", "x", "u", "val", "eps"}
+    assert {"user_metric", "ntypes", "state_end", "half_thickness", "type", "centre"} <= fields
+    modules = JL_PACKAGES | {"Base", "LinearAlgebra", "StaticArrays", "Test", "H"}
+    assert L.check_fields(mod, fields, modules) == [] and L.check_fields(tt, fields, modules) == []
+    n = len(re.findall(r"(?<![\w.])(?!RayTraceGR|RayTraceGRHIP|Base|Images)[a-z_]\w*\.[a-z_]\w*\b(?!\()", src))
+    assert n >= 60, n                                            # (the check has something to look at)
+    for what, text, name in (("a misspelled field", src.replace("pointer(det.state_end)", "pointer(det.sate_end)", 1), "sate_end"),
+                             ("a field of no struct", src.replace("o.type + bases[", "o.tag + bases[", 1), "tag")):
+        assert text != src, what
+        assert [f for _, f in L.check_fields(L.tokenize(text), fields, modules)] == [name], what
