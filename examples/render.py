@@ -50,6 +50,8 @@ def main():
         objs = [caelum, frustum, shapes(user_objects.TORUS, [4.0, 0.0, 0.0, 0.9, 0.3]), balls(0, [0.0, 4.6, -0.9, 0.9, 1.0, 0.0, 0.0, 0.0, 0.35]),
                 shapes(user_objects.ELLIPSOID, [3.3, 1.0, -0.8, 0.7, 0.5, 0.5])]
     pos = (0, 0 if which == 1 else 4, -2, 0)
+    if which in (5, 6):   # the sources bring a reach bound (it lets the FAR pass skip scans): once per scene, hold it against the single FULL pass
+        rt.check_scene(metric, objs, dict(pos=pos, widthx=(0, 1, 0, 0), widthy=(0, 0, 0, 1), normal=(0, 0, 1, 0)))
     canvas = rt.make_canvas(metric, pos, (0, 1, 0, 0), (0, 0, 0, 1), (0, 0, 1, 0), ni, nj)
     canvas, info = rt.trace_rays(metric, objs, canvas, return_info=True)
     from raytracegr_jl_amd.png import write_png
