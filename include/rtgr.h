@@ -428,7 +428,8 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
  * rtgr_user_metric_compile(ctx, source, stationary, id) == rtgr_user_unit_compile(ctx, source, stationary, NULL, id).
  *   Environment: RTGR_UNIT_CACHE=<directory> (opt-in) keeps the code objects rtgr_user_unit_compile / rtgr_user_metric_compile build,
  * keyed by source text + what they are built for + the device headers; a later process with the same inputs loads the file (audited
- * and probed like any other) instead of compiling for seconds. */
+ * and probed like any other) instead of compiling for seconds.  Within a process the same call again — same context, source,
+ * `stationary` and metric variant — is answered at once with the id it gave before, for as long as that unit is resident. */
 int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary, const rtgr_scene* built_for, uint64_t* id_out);
 /* ... the build step on its own (no GPU, no context): source -> code object file for rtgr_user_metric_load */
 int rtgr_user_unit_build(const char* source, int stationary, const rtgr_scene* built_for, const char* code_object_path);

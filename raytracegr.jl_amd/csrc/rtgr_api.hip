@@ -186,6 +186,10 @@ struct rtgr_context {
     std::vector<char> peer_ok;
     std::vector<std::string> peer_why;
     std::mutex modules_mu;   // run-time metric modules are loaded / unloaded on all devices under ONE lock
+    // rtgr_user_unit_compile: hash of (source, what it is built for, device headers) -> id of the unit it gave; the same call again is
+    // answered from here while that unit is resident (a C or Julia caller need not keep a table of its own to avoid a 5 s rebuild)
+    std::mutex compiled_mu;
+    std::unordered_map<uint64_t, uint64_t> compiled;
 };
 
 namespace {
@@ -2109,21 +2113,37 @@ int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary
     // of (source, what it is built for, the device headers) is kept there and a later process loads it in milliseconds instead of
     // compiling for seconds.  The key covers everything the image depends on; the file is audited and probed at load like any other.
     std::string cache_file;
-    if (const char* dir = std::getenv("RTGR_UNIT_CACHE")) if (*dir && source) {
+    uint64_t key_hash = 0;   // of everything the image depends on; 0: could not be formed (the build below says why)
+    if (source) {
         UnitPlan P;
         unsigned long long hh = 0;
         if (plan_unit(source, stationary, built_for, &P) == RTGR_OK && header_hash_of(csrc_dir(), &hh) == RTGR_OK) {
             std::string key = source;
             for (const std::string& d : P.defines) key += "\n" + d;
             key += "\n" + std::to_string(hh) + "\nabi " + std::to_string(RTGR_ABI_VERSION);
+            key_hash = fnv1a(std::vector<char>(key.begin(), key.end()));
+            if (!key_hash) key_hash = 1;
+        }
+    }
+    if (key_hash) {   // the same call again while its unit is resident: no compiler, no load
+        uint64_t known = 0;
+        { std::lock_guard<std::mutex> lk(c->compiled_mu); auto it = c->compiled.find(key_hash); if (it != c->compiled.end()) known = it->second; }
+        if (known && rtgr_user_metric_loaded(c, known) == 1) { if (id_out) *id_out = known; return RTGR_OK; }
+    }
+    auto remember = [&](int rc_) {
+        if (rc_ == RTGR_OK && key_hash && id_out) { std::lock_guard<std::mutex> lk(c->compiled_mu); c->compiled[key_hash] = *id_out; }
+        return rc_;
+    };
+    if (const char* dir = std::getenv("RTGR_UNIT_CACHE")) if (*dir && key_hash) {
+        {
             char name[64];
-            std::snprintf(name, sizeof name, "/unit_%016llx.hsaco", (unsigned long long)fnv1a(std::vector<char>(key.begin(), key.end())));
+            std::snprintf(name, sizeof name, "/unit_%016llx.hsaco", (unsigned long long)key_hash);
             cache_file = std::string(dir) + name;
             std::vector<char> image;
             FILE* f = std::fopen(cache_file.c_str(), "rb");
             if (f) {
                 std::fclose(f);
-                if (read_file(cache_file, image) == RTGR_OK && load_module_image(c, image, cache_file, id_out) == RTGR_OK) return RTGR_OK;
+                if (read_file(cache_file, image) == RTGR_OK && load_module_image(c, image, cache_file, id_out) == RTGR_OK) return remember(RTGR_OK);
                 // (a stale or damaged file: fall through, rebuild and overwrite it)
             }
         }
@@ -2137,7 +2157,7 @@ int rtgr_user_unit_compile(rtgr_context* ctx, const char* source, int stationary
         (void)write_image(built, cache_file.c_str());             // best effort: an unwritable directory must not fail the compile
         (void)fail(0, keep);
     }
-    return rc;
+    return remember(rc);
 }
 int rtgr_user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
     return rtgr_user_unit_compile(ctx, source, stationary, nullptr, id_out);

@@ -557,6 +557,34 @@ def test_random_scenes_with_user_objects_match_the_oracle(lib, seed):
 
 
 @pytest.mark.gpu
+def test_the_same_compile_call_again_is_answered_at_once(lib):
+    """rtgr_user_unit_compile remembers, per context, what it built: the same (source, stationary, metric variant) again returns the
+    id of the resident unit without a compiler run — a C or Julia caller need not keep a table of its own —; another variant is
+    another build; after an unload the call builds again."""
+    import time
+    src = user_objects.SHAPES.replace("S(6)", "S(5)").encode()                 # (a source no other test compiles in-process)
+    sc, _ = scene_variant("ks_ref0", units=False)
+    ids, secs = [], []
+    for _ in range(3):
+        t0 = time.time()
+        out = C.c_uint64(0)
+        abi.check(lib, lib.rtgr_user_unit_compile(None, src, 0, C.byref(sc), C.byref(out)))
+        ids.append(out.value)
+        secs.append(time.time() - t0)
+    assert ids[0] == ids[1] == ids[2] and secs[0] > 0.5 and max(secs[1:]) < 0.05, secs
+    other, _ = scene_variant("ks_true08", units=False)
+    out = C.c_uint64(0)
+    abi.check(lib, lib.rtgr_user_unit_compile(None, src, 0, C.byref(other), C.byref(out)))
+    assert out.value != ids[0]
+    abi.check(lib, lib.rtgr_user_metric_unload(None, ids[0]))
+    t0 = time.time()
+    abi.check(lib, lib.rtgr_user_unit_compile(None, src, 0, C.byref(sc), C.byref(out)))
+    assert out.value == ids[0] and time.time() - t0 > 0.5                      # not resident any more: built (and probed) again
+    for i in (ids[0], ):
+        abi.check(lib, lib.rtgr_user_metric_unload(None, i))
+
+
+@pytest.mark.gpu
 def test_in_process_units_can_be_kept_on_disk(lib, tmp_path, monkeypatch):
     """RTGR_UNIT_CACHE (opt-in): the code object rtgr_user_unit_compile builds is kept under a key of everything it depends on, and the
     same call in a later process — here: after unloading the unit — loads the file instead of compiling: same id, probed again, in a
