@@ -1,6 +1,6 @@
 """Run-time units are self-verifying at load (round-4 review item 2): the EXEC-flip fault of ROCm 7.2's compiler
 was a SILENT wrong answer.  Beside the textual audit of the code object there is a load-time PROBE that looks at the fault's own
-symptom — a 32 x 32 frame traced through the FULL pass and the FAR + NEAR passes, twice each — and needs no knowledge of the
+symptom — a 32 x 32 frame traced through the FULL pass and the FAR + NEAR passes, under two schedules each — and needs no knowledge of the
 instruction shape.  Here: a unit that carries the fault, with the audit switched off, must be refused by the probe alone; sound
 units pass it; a unit compiled from other device headers than the library's kernels is refused before it can overrun a workspace
 (ADVICE r4); an offload bundle — what a plain `hipcc --genco` writes — is audited like a bare code object."""
