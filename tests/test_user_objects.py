@@ -571,7 +571,7 @@ def test_the_same_compile_call_again_is_answered_at_once(lib):
         abi.check(lib, lib.rtgr_user_unit_compile(None, src, 0, C.byref(sc), C.byref(out)))
         ids.append(out.value)
         secs.append(time.time() - t0)
-    assert ids[0] == ids[1] == ids[2] and secs[0] > 0.5 and max(secs[1:]) < 0.05, secs
+    assert ids[0] == ids[1] == ids[2] and secs[0] > 0.5 and max(secs[1:]) < 0.25 * secs[0], secs
     other, _ = scene_variant("ks_true08", units=False)
     out = C.c_uint64(0)
     abi.check(lib, lib.rtgr_user_unit_compile(None, src, 0, C.byref(other), C.byref(out)))
