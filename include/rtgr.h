@@ -54,9 +54,14 @@ extern "C" {
  * the device-side record layout changed in round 4 (event-record tails, RecRef) without a bump — a unit built against the
  * older headers would have loaded and overrun the workspace.  Units also carry a hash of the device headers they were built
  * from (rtgr_user_header_hash), checked at load. */
-#define RTGR_ABI_VERSION 3
-#define RTGR_MAX_OBJECTS 16
+/* 4 (round 6): `objs::Vector{Object{T}}` has no length limit in the reference (src/RayTraceGR.jl:433-441, :483, :520-526) and has none
+ * here any more: rtgr_scene.objects (a caller array of any length) beside the 16 inline slots; rtgr_ray_outputs.hit32; frames in
+ * flight (rtgr_trace_frames_*); rtgr_scene_check runs by itself the first time a scene with user objects is traced. */
+#define RTGR_ABI_VERSION 4
+#define RTGR_MAX_OBJECTS 16         /* objects held INLINE in rtgr_scene.obj; a longer list goes through rtgr_scene.objects */
+#define RTGR_OBJECTS_LIMIT 1048576  /* sanity bound on rtgr_scene.nobj (2^20; the per-step cost is linear in it)            */
 #define RTGR_MAX_DEVICES 16
+#define RTGR_MAX_SOURCES 16         /* object sources rtgr_user_source_join joins in one call                               */
 
 /* ---- return codes -------------------------------------------------------------------------------------- */
 enum rtgr_status {
@@ -108,7 +113,7 @@ typedef struct rtgr_object {
 
 typedef struct rtgr_scene {
     uint32_t metric; /* rtgr_metric (| RTGR_METRIC_GENERIC) */
-    uint32_t nobj;   /* 0..RTGR_MAX_OBJECTS */
+    uint32_t nobj;   /* length of the object list: 0..RTGR_MAX_OBJECTS in obj[], or any number (<= RTGR_OBJECTS_LIMIT) in objects[] */
     double M;        /* mass  (reference: 1, :275) */
     double a;        /* spin  (reference: 0, :276) */
     uint64_t user_metric; /* id of the run-time compiled UNIT this scene is written for — the module that carries the kernels
@@ -116,6 +121,13 @@ typedef struct rtgr_scene {
                              (rtgr_user_metric_load / _compile, rtgr_user_unit_compile); a scene can never run with another
                              unit's kernels.  0: built-in metric and built-in objects only. */
     rtgr_object obj[RTGR_MAX_OBJECTS];
+    const rtgr_object* objects; /* NULL: the list is obj[0 .. nobj).  Otherwise the WHOLE list, nobj objects in the caller's (host)
+                             memory, and obj[] is not read — `objs::Vector{Object{T}}` of any length (src/RayTraceGR.jl:433-441, :483).
+                             Read during the call only, like every caller pointer.  On the device the first RTGR_MAX_OBJECTS
+                             objects travel in the kernels' argument block as before; the rest sit in a small device table the
+                             context keeps per distinct list (uploaded when a list is first seen — blocking, a few microseconds;
+                             a first sight during hipGraph capture is refused: trace the scene once before capturing).  Cost: the
+                             FAR pass's reach test and the NEAR pass's sample-point scan are linear in nobj. */
 } rtgr_scene;
 
 /* ---- solver constants (src/RayTraceGR.jl:485, :497, :510-511, :519, :528; OrdinaryDiffEq 5.38 defaults) -- */
@@ -164,7 +176,8 @@ typedef struct rtgr_ray_outputs {
     void* state_end;      /* n x 8 scalars (AoS)  — `sols.u[i]` (src/RayTraceGR.jl:516)                    */
     void* lambda_end;     /* n scalars            — `sol.t[end]` (:503)                                     */
     uint8_t* status;      /* n x rtgr_ray_status                                                            */
-    uint8_t* hit;         /* n: omin of the colouring rule (0 = miss, else 1-based object index, :518-526)  */
+    uint8_t* hit;         /* n: omin of the colouring rule (0 = miss, else 1-based object index, :518-526); scenes of
+                             more than 255 objects: RTGR_ERR_BAD_ARG, ask for hit32 instead                        */
     uint32_t* n_accept;   /* n: accepted steps per ray                                                      */
     uint32_t* n_reject;   /* n: rejected attempts per ray                                                   */
     void* redshift;       /* n scalars: g = (k.u_obs)/(k.u_emit), the frequency ratio observed/emitted of the light that
@@ -177,6 +190,7 @@ typedef struct rtgr_ray_outputs {
                              No reference counterpart (`vel` is stored and never used, :411, :416).  Every metric
                              (built-in, run-time compiled) and both scalar types, like `Sphere{T}` and the metric
                              argument of the reference (:409-413, :302-309); n scalars of the entry point's type. */
+    uint32_t* hit32;      /* n: omin as 32 bits — for object lists of any length (may be asked for beside `hit`)              */
 } rtgr_ray_outputs;
 
 /* ---- lifecycle --------------------------------------------------------------------------------------------- */

@@ -1,5 +1,5 @@
 # RayTraceGRHIP.jl — the reference-side binding a RayTraceGR.jl maintainer would add to route the hot path
-# (`trace_rays`, src/RayTraceGR.jl:482-536) through librtgr_hip.so (include/rtgr.h, ABI version 3).
+# (`trace_rays`, src/RayTraceGR.jl:482-536) through librtgr_hip.so (include/rtgr.h, ABI version 4).
 #
 # NOT EXECUTED IN THIS REPOSITORY: the build image has no Julia.  What stands in for running it:
 #   * tests/c/abi_layout.c — a compiled C caller that passes the same bytes this file would (structs by pointer, an
@@ -18,16 +18,18 @@
 # a maintainer can check with `[(fieldname(T,i), fieldoffset(T,i)) for i in 1:fieldcount(T)]`; runtests_hip.jl does):
 #
 #   RtgrObject       80   kind 0, type 4, p 8
-#   RtgrScene      1312   metric 0, nobj 4, M 8, a 16, user_metric 24, obj 32
+#   RtgrScene      1320   metric 0, nobj 4, M 8, a 16, user_metric 24, obj 32, objects 1312
 #   RtgrSolver       72   reltol 0, abstol 8, lambda0 16, lambda1 24, hit_threshold 32, miss_rgb 40, max_steps 64, interp_points 68
 #   RtgrCamera      128   pos 0, widthx 32, widthy 64, normal 96
 #   RtgrCounters     64   rays 0, accepted 8, rejected 16, rhs_evals 24, events 32, events_interior 40, not_finished 48, reserved 56
-#   RtgrRayOutputs   56   state_end 0, lambda_end 8, status 16, hit 24, n_accept 32, n_reject 40, redshift 48
+#   RtgrRayOutputs   64   state_end 0, lambda_end 8, status 16, hit 24, n_accept 32, n_reject 40, redshift 48, hit32 56
 #   Pixel{Float64}   88   pos 0, normal 32, rgb 64          (the reference's own type, src/RayTraceGR.jl:446-450)
 #   Pixel{Float32}   44   pos 0, normal 16, rgb 32
 #
 # It is a thin `ccall` layer; host code stays Julia, the metric/object/Pixel signatures of the reference are preserved,
-# and anything that cannot cross the C ABI (an arbitrary metric callable) falls back to the reference's own CPU path.
+# and anything that cannot cross the C ABI (an arbitrary metric callable, an Object subtype without device source, a scalar
+# type other than Float64 / Float32) falls back to the reference's own CPU path — never silently: every such return goes
+# through `cpu_fallback`, which emits one `@warn` naming the reason (a 3 ms frame and a 10 s one must not look alike).
 #
 # Every BASELINE.json configuration from Julia (INTEGRATION.md "Julia" has them spelled out):
 #   C1  example1()                                                      minkowski, 200², == scenes/sphere.png
@@ -41,7 +43,7 @@ using RayTraceGR
 using StaticArrays
 
 const librtgr = get(ENV, "RTGR_LIB", "librtgr_hip.so")
-const RTGR_MAX_OBJECTS = 16
+const RTGR_MAX_OBJECTS = 16      # objects held inline in RtgrScene.obj; a longer `objs` goes through RtgrScene.objects (any length)
 const Ctx = Ptr{Cvoid}          # rtgr_context*; C_NULL = the process's default context
 const D = RayTraceGR.D          # 4 (src/RayTraceGR.jl:253-254)
 
@@ -58,6 +60,7 @@ struct RtgrScene
     a::Float64
     user_metric::UInt64
     obj::NTuple{RTGR_MAX_OBJECTS,RtgrObject}
+    objects::Ptr{RtgrObject}    # C_NULL: the list is obj[1:nobj]; otherwise the WHOLE list, nobj objects — `objs` of any length (:433-441)
 end
 struct RtgrSolver
     reltol::Float64
@@ -87,6 +90,7 @@ struct RtgrRayOutputs          # optional per-ray outputs; C_NULL = not wanted
     n_accept::Ptr{UInt32}
     n_reject::Ptr{UInt32}
     redshift::Ptr{Cvoid}
+    hit32::Ptr{UInt32}          # omin as 32 bits: object lists beyond 255
 end
 
 # enum rtgr_metric / rtgr_object_kind / rtgr_ray_status of the header (tests/test_julia_stub.py compares the values)
@@ -108,6 +112,19 @@ const RTGR_RAY_NAN = UInt8(4)
 function check(rc)
     rc < 0 && error("librtgr_hip: ", unsafe_string(ccall((:rtgr_last_error, librtgr), Cstring, ())))
     rc
+end
+
+"""
+    cpu_fallback(what, why)
+
+Every place where a legal call of the reference cannot cross the C ABI and is handed to the reference's own CPU path goes through
+here: ONE `@warn` per distinct (entry point, reason) — the CPU path is ~3000 x slower than the device (profiles/r05/cpu_baseline_1024.json),
+and a first user must be able to tell the two apart by something better than the clock.  `ENV["RTGR_QUIET_FALLBACK"] = "1"` silences it.
+"""
+function cpu_fallback(what::AbstractString, why::AbstractString)
+    get(ENV, "RTGR_QUIET_FALLBACK", "0") == "1" ||
+        @warn "RayTraceGRHIP.$what: $why — running the reference's CPU path (RayTraceGR.$what), not the GPU" maxlog = 1 _id = Symbol(what, hash(why))
+    nothing
 end
 
 # ---- new scene vocabulary (SURVEY §8 f4): what BASELINE configs 2, 4 and 5 need and the reference does not have -------
@@ -297,18 +314,17 @@ metric_desc(m, ctx) = m === RayTraceGR.minkowski ? (RTGR_MINKOWSKI, 1.0, 0.0, UI
 # id of the unit that carries the kernels of `family`'s objects for the metric variant of `scene` (rtgr_user_unit_compile reads the
 # metric enum, the RTGR_METRIC_GENERIC flag and whether a != 0 off the scene; a DeviceMetric given as source is compiled into the
 # same unit) — built once per (context, source, metric variant)
-const UNIT_IDS = Dict{Tuple{Ctx,UInt64,UInt32,Bool},UInt64}()
-function unit_id(family::DeviceObjects, metric, scene::Ref{RtgrScene}, ctx)
+# (no table on this side: rtgr_user_unit_compile answers the same call again — same context, source, `stationary`, metric variant —
+#  at once with the id it gave before FOR AS LONG AS THAT UNIT IS RESIDENT, and builds and loads it again after an unload or a
+#  refusal by the load-time probe; a Dict here handed out dead ids, ADVICE r5)
+function unit_id(family::DeviceObjects, metric, scene, ctx)
     own = metric isa DeviceMetric
     own && isempty(metric.source) && error("DeviceObjects with a DeviceMetric: give the metric as source text too (the two share one unit)")
     source = own ? metric.source * "\n" * family.source : family.source
-    key = (handle(ctx), hash(source), scene[].metric, scene[].a != 0)
-    get!(UNIT_IDS, key) do
-        id = Ref{UInt64}(0)
-        check(ccall((:rtgr_user_unit_compile, librtgr), Cint, (Ctx, Cstring, Cint, Ptr{RtgrScene}, Ptr{UInt64}),
-                    handle(ctx), source, own && metric.stationary, own ? C_NULL : scene, id))
-        id[]
-    end
+    id = Ref{UInt64}(0)
+    check(ccall((:rtgr_user_unit_compile, librtgr), Cint, (Ctx, Cstring, Cint, Ptr{RtgrScene}, Ptr{UInt64}),
+                handle(ctx), source, own && metric.stationary, own ? C_NULL : scene, id))
+    id[]
 end
 
 # the families of a scene as ONE family (rtgr_user_source_join) and the base each family's type tags move to
@@ -333,20 +349,41 @@ function join_families(fams::Vector{DeviceObjects})
     joined, bases
 end
 
+"""
+    Scene
+
+An `rtgr_scene` ready for a `ccall`, together with what its pointers point to: `objs::Vector{Object{T}}` has no length limit in the
+reference (src/RayTraceGR.jl:433-441, :483), so a list beyond the 16 inline slots is handed over as an array (`rtgr_scene.objects`)
+that must outlive the call.  `ccall(..., (Ptr{RtgrScene}, ...), scene, ...)` roots this object for the duration of the call
+(`cconvert` returns it, `unsafe_convert` takes the pointer of the struct inside).
+"""
+mutable struct Scene
+    ref::Base.RefValue{RtgrScene}
+    list::Vector{RtgrObject}       # the packed objects when they travel as an array (empty otherwise)
+end
+Base.cconvert(::Type{Ptr{RtgrScene}}, s::Scene) = s
+Base.unsafe_convert(::Type{Ptr{RtgrScene}}, s::Scene) = Base.unsafe_convert(Ptr{RtgrScene}, s.ref)
+
+# (scene, nothing) or (nothing, why it cannot cross the C ABI)
 function scene_of(metric, objs, ctx)
     fams = unique(DeviceObjects[o.family for o in objs if o isa DeviceObject])
     family, bases = length(fams) > 1 ? join_families(fams) : (isempty(fams) ? nothing : fams[1], UInt32[0])
     # (a DeviceMetric beside DeviceObjects lives in the objects' unit: its own module is not loaded)
     d = (!isempty(fams) && metric isa DeviceMetric) ? (RTGR_USER, metric.M, metric.a, UInt64(0)) : metric_desc(metric, ctx)
-    (d === nothing || length(objs) > RTGR_MAX_OBJECTS) && return nothing
+    d === nothing && return nothing, "the metric `$(nameof(typeof(metric)))` is a Julia callable without a device counterpart " *
+                                     "(built-ins: minkowski, kerr_schild, KerrSchild(M, a); your own: DeviceMetric(source = ...))"
     po = map(objs) do o
         o isa DeviceObject ? RtgrObject(RTGR_USER_OBJECT, o.type + bases[findfirst(==(o.family), fams)], o.p) : pack(o)
     end
-    any(isnothing, po) && return nothing
-    packed = ntuple(i -> i <= length(po) ? po[i] : NOOBJ, RTGR_MAX_OBJECTS)
-    scene = Ref(RtgrScene(d[1], length(objs), d[2], d[3], d[4], packed))
-    isempty(fams) && return scene
-    Ref(RtgrScene(d[1], length(objs), d[2], d[3], unit_id(family, metric, scene, ctx), packed))
+    k = findfirst(isnothing, po)
+    k === nothing || return nothing, "objs[$k] is a `$(nameof(typeof(objs[k])))`: an Object subtype without device source " *
+                                     "(built-ins: Plane, Sphere, Disk; your own: DeviceObjects(source))"
+    list = length(po) > RTGR_MAX_OBJECTS ? RtgrObject[o for o in po] : RtgrObject[]
+    packed = ntuple(i -> (isempty(list) && i <= length(po)) ? po[i] : NOOBJ, RTGR_MAX_OBJECTS)
+    make(unit) = Scene(Ref(RtgrScene(d[1], length(objs), d[2], d[3], unit, packed, isempty(list) ? Ptr{RtgrObject}(C_NULL) : pointer(list))), list)
+    scene = make(d[4])
+    isempty(fams) && return scene, nothing
+    make(unit_id(family, metric, scene, ctx)), nothing
 end
 solver_of(::Type{T}) where {T} = begin
     opt = Ref{RtgrSolver}()
@@ -361,12 +398,15 @@ camera_of(pos, widthx, widthy, normal) =
 
 `RayTraceGR.make_canvas` (src/RayTraceGR.jl:457-478) on the device (`rtgr_make_canvas_f64/_f32`: metric at the pixel, `g⁻¹e_t`,
 normalisation — one thread per pixel), returned as the reference's own `Canvas{T}` of `Pixel{T}(x, u, zeros)` (:475).
-A metric that cannot cross the ABI falls back to the reference's function.
+A metric that cannot cross the ABI (or a scalar type other than Float64 / Float32) falls back to the reference's function, with a warning.
 """
 function make_canvas(metric, pos::SVector{4,T}, widthx::SVector{4,T}, widthy::SVector{4,T}, normal::SVector{4,T},
                      ni::Int, nj::Int; ctx = nothing) where {T<:Union{Float64,Float32}}
-    scene = scene_of(metric, RayTraceGR.Object{T}[], ctx)
-    scene === nothing && return RayTraceGR.make_canvas(metric, pos, widthx, widthy, normal, ni, nj)
+    scene, why = scene_of(metric, RayTraceGR.Object{T}[], ctx)
+    if scene === nothing
+        cpu_fallback("make_canvas", why)
+        return RayTraceGR.make_canvas(metric, pos, widthx, widthy, normal, ni, nj)
+    end
     cam = camera_of(pos, widthx, widthy, normal)
     st = Array{T}(undef, 8, ni, nj)                 # n x 8 ray states, pixel index i + j*ni (column-major pixels[i,j], :463-464)
     GC.@preserve st begin
@@ -388,6 +428,12 @@ function make_canvas(metric, pos::SVector{4,T}, widthx::SVector{4,T}, widthy::SV
     end
     RayTraceGR.Canvas{T}(pixels)
 end
+# `make_canvas` is generic in T (src/RayTraceGR.jl:457-462); the device computes in Float64 and Float32
+function make_canvas(metric, pos::SVector{4,T}, widthx::SVector{4,T}, widthy::SVector{4,T}, normal::SVector{4,T},
+                     ni::Int, nj::Int; ctx = nothing) where {T}
+    cpu_fallback("make_canvas", "the scalar type $T has no device arithmetic (Float64 and Float32 do)")
+    RayTraceGR.make_canvas(metric, pos, widthx, widthy, normal, ni, nj)
+end
 
 """
     trace_rays(metric, objs, c::Canvas{T}; ctx = nothing) -> Canvas{T},   T = Float64 | Float32
@@ -397,11 +443,21 @@ Drop-in for `RayTraceGR.trace_rays` (src/RayTraceGR.jl:483-484).  Passes `pointe
 filled (:532).  The tolerance is `eps(T)^(3/4)` as in the reference (:485).  `ctx = Context(0:7)`: all eight GPUs of a
 node work on the canvas (rows dealt cyclically); the result does not depend on the number of devices, bit for bit.
 `metric`: `minkowski`, `kerr_schild`, `KerrSchild(M, a)`, a `DeviceMetric`; anything else runs the reference's CPU path.
-`objs`: `Plane`, `Sphere`, `Disk`, `DeviceObject`s; any other `Object` subtype runs the reference's CPU path.
+`objs`: `Plane`, `Sphere`, `Disk`, `DeviceObject`s, in any number (the reference's `Vector{Object{T}}` has no length limit, :433-441,
+and neither has the device: the first 16 travel in the kernels' argument block, the rest in a device table; the per-step cost is
+linear in `length(objs)`); any other `Object` subtype runs the reference's CPU path.  Every fall-back says so once (`@warn`).
+
+Where parity ends: on rays that are CAPTURED with |u^t| ≳ 10⁶ the step sequence follows the rounding noise of the RHS formulation;
+the closed-form kernels (`kerr_schild`, `KerrSchild(M, a)`) then take up to 27 % fewer steps than the reference and end such rays with
+another status at the step cap (INTEGRATION.md "Where parity ends").  `KerrSchild(M, a; generic = true)` traces with the reference's
+own formulation of the RHS (0.82 of SURVEY §8(d)'s flop count executed, 1.18·10¹⁰ steps/s) and is the parity-first setting.
 """
 function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Canvas{T}; ctx = nothing) where {T<:Union{Float64,Float32}}
-    scene = scene_of(metric, objs, ctx)
-    scene === nothing && return RayTraceGR.trace_rays(metric, objs, c)        # arbitrary metric callable: reference CPU path
+    scene, why = scene_of(metric, objs, ctx)
+    if scene === nothing
+        cpu_fallback("trace_rays", why)
+        return RayTraceGR.trace_rays(metric, objs, c)
+    end
     opt = solver_of(T)
     ni, nj = size(c.pixels)
     out = similar(c.pixels)
@@ -419,6 +475,11 @@ function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Ca
     end
     RayTraceGR.Canvas{T}(out)
 end
+# `trace_rays` is generic in T (src/RayTraceGR.jl:483-485): any other scalar type is the reference's own business, loudly
+function trace_rays(metric, objs::Vector{RayTraceGR.Object{T}}, c::RayTraceGR.Canvas{T}; ctx = nothing) where {T}
+    cpu_fallback("trace_rays", "the scalar type $T has no device arithmetic (Float64 and Float32 do)")
+    RayTraceGR.trace_rays(metric, objs, c)
+end
 
 """
     RayDetails{T}
@@ -432,7 +493,7 @@ struct RayDetails{T}
     state_end::Array{T,3}
     lambda_end::Matrix{T}
     status::Matrix{UInt8}
-    hit::Matrix{UInt8}
+    hit::Matrix{UInt32}             # (rtgr_ray_outputs.hit32: `objs` may hold more than 255 objects)
     n_accept::Matrix{UInt32}
     n_reject::Matrix{UInt32}
     redshift::Matrix{T}
@@ -448,8 +509,9 @@ The object side of the path at the points `xs`, on the device (`rtgr_eval_object
 What `runtests_hip.jl` holds against the Julia methods of the same object, point by point.
 """
 function eval_objects(metric, objs::Vector{RayTraceGR.Object{T}}, xs::Vector{SVector{4,T}}; ctx = nothing) where {T<:Union{Float64,Float32}}
-    scene = scene_of(metric, objs, ctx)
-    scene === nothing && error("eval_objects: this scene runs on the reference's CPU path")
+    scene, why = scene_of(metric, objs, ctx)
+    scene === nothing && error("eval_objects: this scene runs on the reference's CPU path: ", why)
+    length(objs) <= 255 || error("eval_objects: `hit` is a byte per point (at most 255 objects)")
     opt = solver_of(T)
     n = length(xs)
     d = Matrix{T}(undef, max(length(objs), 1), n)        # C layout d[p * nobj + o]
@@ -480,8 +542,8 @@ that is too small loses hits silently, and this is what says so.
 """
 function check_scene(metric, objs::Vector{RayTraceGR.Object{T}}, pos, widthx, widthy, normal; ni::Integer = 48, nj::Integer = 48,
                      ctx = nothing) where {T<:Union{Float64,Float32}}
-    scene = scene_of(metric, objs, ctx)
-    scene === nothing && error("check_scene: this scene runs on the reference's CPU path (nothing to check)")
+    scene, why = scene_of(metric, objs, ctx)
+    scene === nothing && error("check_scene: this scene runs on the reference's CPU path (nothing to check): ", why)
     opt = solver_of(Float64)
     cam = camera_of(pos, widthx, widthy, normal)
     check(ccall((:rtgr_scene_check, librtgr), Cint, (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{RtgrCamera}, UInt64, UInt64, Cint),
@@ -499,19 +561,19 @@ This is the call for the big screens (4096², 8192²: 5.9 GB of pixels each way 
 """
 function render(metric, objs, pos, widthx, widthy, normal, ni::Integer, nj::Integer;
                 T::Type = Float64, ctx = nothing, details::Bool = false)
-    scene = scene_of(metric, objs, ctx)
-    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric and Plane / Sphere / Disk cross the C ABI")
+    scene, why = scene_of(metric, objs, ctx)
+    scene === nothing && error("render has no CPU counterpart in the reference (make_canvas + trace_rays are the reference's calls): ", why)
     opt = solver_of(T)
     cam = camera_of(pos, widthx, widthy, normal)
     rgb = Array{T}(undef, ni, nj, 3)                # plane-major: rgb[:, :, c] is plane c
     ctr = Ref{RtgrCounters}()
     det = details ? RayDetails{T}(Array{T}(undef, 8, ni, nj), Matrix{T}(undef, ni, nj), Matrix{UInt8}(undef, ni, nj),
-                                  Matrix{UInt8}(undef, ni, nj), Matrix{UInt32}(undef, ni, nj), Matrix{UInt32}(undef, ni, nj),
+                                  Matrix{UInt32}(undef, ni, nj), Matrix{UInt32}(undef, ni, nj), Matrix{UInt32}(undef, ni, nj),
                                   Matrix{T}(undef, ni, nj), RtgrCounters(0, 0, 0, 0, 0, 0, 0, 0)) : nothing
     GC.@preserve rgb det begin
-        outs = details ? Ref(RtgrRayOutputs(pointer(det.state_end), pointer(det.lambda_end), pointer(det.status), pointer(det.hit),
-                                            pointer(det.n_accept), pointer(det.n_reject), pointer(det.redshift))) :
-                         Ref(RtgrRayOutputs(C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+        outs = details ? Ref(RtgrRayOutputs(pointer(det.state_end), pointer(det.lambda_end), pointer(det.status), C_NULL,
+                                            pointer(det.n_accept), pointer(det.n_reject), pointer(det.redshift), pointer(det.hit))) :
+                         Ref(RtgrRayOutputs(C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
         if T === Float64
             check(ccall((:rtgr_trace_f64, librtgr), Cint,
                         (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, Ptr{Float64}, Ptr{RtgrCamera}, UInt64, UInt64, UInt64, UInt64,
@@ -536,8 +598,8 @@ Legacy single-pixel shape (test/runtests.jl:76).  `cb` is ignored: the callback 
 `ContinuousCallback(min_distance(objs, ·), terminate!)` (src/RayTraceGR.jl:488-490).
 """
 function trace_ray(metric, objs::Vector{RayTraceGR.Object{T}}, cb, p::RayTraceGR.Pixel{T}; ctx = nothing) where {T<:Union{Float64,Float32}}
-    scene = scene_of(metric, objs, ctx)
-    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric cross the C ABI")
+    scene, why = scene_of(metric, objs, ctx)
+    scene === nothing && error("trace_ray: ", why)
     opt = solver_of(T)
     pos, nrm = Ref(p.pos), Ref(p.normal)
     rgb = Ref(zeros(SVector{3,T})); se = Ref(zeros(SVector{8,T})); st = Ref{UInt8}(0)
@@ -565,8 +627,8 @@ end
 reversed, hence the `permutedims`.
 """
 function eval_metric(metric, x::SVector{4,T}, ctx) where {T<:Union{Float64,Float32}}
-    scene = scene_of(metric, RayTraceGR.Object{T}[], ctx)
-    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric cross the C ABI")
+    scene, why = scene_of(metric, RayTraceGR.Object{T}[], ctx)
+    scene === nothing && error("eval_metric: ", why)
     xs = collect(x)
     g = Array{T}(undef, 4, 4); dg = Array{T}(undef, 4, 4, 4); Γ = Array{T}(undef, 4, 4, 4)
     GC.@preserve xs g dg Γ begin
@@ -593,8 +655,8 @@ christoffel(metric, x; ctx = nothing) = eval_metric(metric, x, ctx)[3]
 formulation (duals → christoffel → contraction), `path = 2` exactly the function the production integrate loop calls.
 """
 function geodesic(s::SVector{8,T}, metric; ctx = nothing, path::Integer = 2) where {T<:Union{Float64,Float32}}
-    scene = scene_of(metric, RayTraceGR.Object{T}[], ctx)
-    scene === nothing && error("only minkowski / kerr_schild / KerrSchild / DeviceMetric cross the C ABI")
+    scene, why = scene_of(metric, RayTraceGR.Object{T}[], ctx)
+    scene === nothing && error("geodesic: ", why)
     si = collect(s); so = similar(si)
     GC.@preserve si so begin
         if T === Float64

@@ -470,12 +470,15 @@ inline void objcolor(const rtgr_object& o, const T pos[D], T col[3]) {
     col[0] = col[1] = col[2] = T(0);
 }
 
+// objs[o] of `objs::Vector{Object{T}}` (any length, :433-441, :483): the scene's inline slots, or the caller array rtgr_scene.objects
+inline const rtgr_object& object_of(const rtgr_scene& sc, uint32_t o) { return sc.objects ? sc.objects[o] : sc.obj[o]; }
+
 // min_distance(objs, s)                                                            src/RayTraceGR.jl:433-441
 template <class T>
 inline T min_distance(const rtgr_scene& sc, const T x[D]) {
     T dmin = std::numeric_limits<T>::infinity();
     for (uint32_t o = 0; o < sc.nobj; o++) {
-        T d = distance<T>(sc.obj[o], x);
+        T d = distance<T>(object_of(sc, o), x);
         dmin = (d < dmin || std::isnan(d)) ? d : dmin;  // Julia min() propagates NaN
     }
     return dmin;
@@ -735,28 +738,28 @@ RayResult solve_ray(const rtgr_scene& sc, const rtgr_solver& opt, const T s0[8],
 
 // colouring loop of trace_rays                                                     src/RayTraceGR.jl:513-533
 template <class T>
-inline uint8_t colour(const rtgr_scene& sc, const rtgr_solver& opt, const T x[D], T col[3]) {
+inline uint32_t colour(const rtgr_scene& sc, const rtgr_solver& opt, const T x[D], T col[3]) {
     uint32_t omin = 0;
     T dmin = T(opt.hit_threshold);                                                  // :519
     for (uint32_t o = 0; o < sc.nobj; o++) {                                        // :520-526
-        T d = distance<T>(sc.obj[o], x);
+        T d = distance<T>(object_of(sc, o), x);
         if (d < dmin) { omin = o + 1; dmin = d; }
     }
     if (omin == 0) {                                                                // :527-528
         for (int c = 0; c < 3; c++) col[c] = T(opt.miss_rgb[c]);
     } else {                                                                        // :530
-        objcolor<T>(sc.obj[omin - 1], x, col);
+        objcolor<T>(object_of(sc, omin - 1), x, col);
         T scale = T(omin) / T(sc.nobj);
         for (int c = 0; c < 3; c++) col[c] *= scale;
     }
-    return (uint8_t)omin;
+    return omin;
 }
 
 template <class T>
 int trace_impl(const rtgr_scene* sc, const rtgr_solver* opt, const T* state0, const rtgr_camera* cam, uint64_t ni,
                uint64_t nj, uint64_t j0, uint64_t j1, T* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr,
                int nthreads) {
-    if (!sc || !opt || !rgb || j1 <= j0 || j1 > nj || ni == 0 || sc->nobj > RTGR_MAX_OBJECTS) return RTGR_ERR_BAD_ARG;
+    if (!sc || !opt || !rgb || j1 <= j0 || j1 > nj || ni == 0 || (sc->nobj > RTGR_MAX_OBJECTS && !sc->objects)) return RTGR_ERR_BAD_ARG;
     if (!state0 && !cam) return RTGR_ERR_BAD_ARG;
     const uint64_t n = ni * (j1 - j0);
     uint64_t acc = 0, rej = 0, rhs = 0, ev = 0, evi = 0, nf = 0;
@@ -769,13 +772,14 @@ int trace_impl(const rtgr_scene* sc, const rtgr_solver* opt, const T* state0, co
         if (state0) for (int a = 0; a < 8; a++) s0[a] = state0[idx * 8 + a];
         else make_pixel<T>(*sc, *cam, ni, nj, (uint64_t)idx % ni, j0 + (uint64_t)idx / ni, s0);
         RayResult r = solve_ray<T>(*sc, *opt, s0, se, &lam);
-        uint8_t hit = colour<T>(*sc, *opt, se, col);
+        const uint32_t hit = colour<T>(*sc, *opt, se, col);
         for (int c = 0; c < 3; c++) rgb[(uint64_t)c * n + idx] = col[c];
         if (out) {
             if (out->state_end) for (int a = 0; a < 8; a++) ((T*)out->state_end)[idx * 8 + a] = se[a];
             if (out->lambda_end) ((T*)out->lambda_end)[idx] = lam;
             if (out->status) out->status[idx] = r.status;
-            if (out->hit) out->hit[idx] = hit;
+            if (out->hit) out->hit[idx] = (uint8_t)hit;
+            if (out->hit32) out->hit32[idx] = hit;
             if (out->n_accept) out->n_accept[idx] = r.nacc;
             if (out->n_reject) out->n_reject[idx] = r.nrej;
         }
@@ -794,11 +798,11 @@ template <class T>
 int eval_objects_impl(const rtgr_scene* sc, const rtgr_solver* opt, const T* x, uint64_t n, T* d, T* dmin, uint8_t* hit, T* rgb) {
     for (uint64_t p = 0; p < n; p++) {
         const T* xp = x + 4 * p;
-        if (d) for (uint32_t o = 0; o < sc->nobj; o++) d[p * sc->nobj + o] = distance<T>(sc->obj[o], xp);   // :377-419
+        if (d) for (uint32_t o = 0; o < sc->nobj; o++) d[p * sc->nobj + o] = distance<T>(object_of(*sc, o), xp);   // :377-419
         if (dmin) dmin[p] = min_distance<T>(*sc, xp);                                                        // :433-441
         T col[3];
-        const uint8_t h = colour<T>(*sc, *opt, xp, col);                                                     // :513-533
-        if (hit) hit[p] = h;
+        const uint32_t h = colour<T>(*sc, *opt, xp, col);                                                    // :513-533
+        if (hit) hit[p] = (uint8_t)h;
         if (rgb) for (int c = 0; c < 3; c++) rgb[3 * p + c] = col[c];
     }
     return 0;
@@ -927,7 +931,7 @@ int rtgr_oracle_redshift_f64(const rtgr_scene* sc, const double* state0, const d
         metric_eval<double, double>(*sc, state0 + 8 * i, g0);
         metric_eval<double, double>(*sc, state_end + 8 * i, ge);
         bool ok = observer(g0, uo);
-        const rtgr_object& ob = sc->obj[h - 1];
+        const rtgr_object& ob = object_of(*sc, h - 1);
         if (ob.kind == RTGR_SPHERE) {
             const double* v = ob.p + 4;
             const double v2 = dot(ge, v, v);

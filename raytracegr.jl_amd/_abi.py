@@ -7,9 +7,11 @@ from here).
 import ctypes as C
 import os
 
-RTGR_MAX_OBJECTS = 16
-RTGR_ABI_VERSION = 3
+RTGR_MAX_OBJECTS = 16          # objects held inline in rtgr_scene.obj; a longer list goes through rtgr_scene.objects
+RTGR_OBJECTS_LIMIT = 1 << 20
+RTGR_ABI_VERSION = 4
 RTGR_MAX_DEVICES = 16
+RTGR_MAX_SOURCES = 16
 
 # enum rtgr_metric
 MINKOWSKI, KS_REF, KS_TRUE, USER = 0, 1, 2, 3
@@ -28,7 +30,18 @@ class rtgr_object(C.Structure):
 
 class rtgr_scene(C.Structure):
     _fields_ = [("metric", C.c_uint32), ("nobj", C.c_uint32), ("M", C.c_double), ("a", C.c_double),
-                ("user_metric", C.c_uint64), ("obj", rtgr_object * RTGR_MAX_OBJECTS)]
+                ("user_metric", C.c_uint64), ("obj", rtgr_object * RTGR_MAX_OBJECTS), ("objects", C.POINTER(rtgr_object))]
+
+    def object(self, o):
+        """object o of the list, wherever it lives (the inline slots, or the caller array `objects`)"""
+        return self.objects[o] if self.objects else self.obj[o]
+
+    def clone(self):
+        """a copy that keeps the list of a long scene alive with it (the `objects` array is a Python object of its own)"""
+        c = type(self).from_buffer_copy(self)
+        if hasattr(self, "_keep"):
+            c._keep = self._keep
+        return c
 
 
 class rtgr_solver(C.Structure):
@@ -61,7 +74,8 @@ class rtgr_unit_info(C.Structure):
 
 class rtgr_ray_outputs(C.Structure):
     _fields_ = [("state_end", C.c_void_p), ("lambda_end", C.c_void_p), ("status", C.c_void_p),
-                ("hit", C.c_void_p), ("n_accept", C.c_void_p), ("n_reject", C.c_void_p), ("redshift", C.c_void_p)]
+                ("hit", C.c_void_p), ("n_accept", C.c_void_p), ("n_reject", C.c_void_p), ("redshift", C.c_void_p),
+                ("hit32", C.c_void_p)]
 
 
 # Every symbol include/rtgr.h declares (tests check the .so exports exactly this list).

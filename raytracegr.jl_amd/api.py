@@ -110,8 +110,8 @@ def make_scene(metric, objs, ctx=None, units=True):
             "a metric is one of the built-ins (minkowski, kerr_schild, KerrSchild(M,a)) or a UserMetric(source) "
             "compiled for the device; a Python callable cannot cross the C ABI (SURVEY §8b)")
     objs = list(objs)
-    if len(objs) > _abi.RTGR_MAX_OBJECTS:
-        raise ValueError(f"at most {_abi.RTGR_MAX_OBJECTS} objects")
+    if len(objs) > _abi.RTGR_OBJECTS_LIMIT:
+        raise ValueError(f"at most {_abi.RTGR_OBJECTS_LIMIT} objects")
     # New Object subtypes (src/RayTraceGR.jl:374-389) come as a UserObjects family: its distance / objcolor methods are compiled
     # into ONE unit together with the metric they are traced with (compiled code holds both in the same kernels); the sources of
     # several families are joined into one first (UserObjects.join: type tags renumbered family after family, in the order of
@@ -133,12 +133,18 @@ def make_scene(metric, objs, ctx=None, units=True):
     sc.metric = metric.kind | (_abi.METRIC_GENERIC if metric.generic else 0)
     sc.nobj, sc.M, sc.a = len(objs), metric.M, metric.a
     sc.user_metric = user_id
+    # `objs::Vector{Object{T}}` of any length (:433-441): up to RTGR_MAX_OBJECTS in the scene's inline slots, a longer list as one array
+    # behind rtgr_scene.objects (kept alive by the scene: sc._keep)
+    slots = sc.obj
+    if len(objs) > _abi.RTGR_MAX_OBJECTS:
+        slots = sc._keep = (_abi.rtgr_object * len(objs))()
+        sc.objects = C.cast(slots, C.POINTER(_abi.rtgr_object))
     for o, obj in enumerate(objs):
-        sc.obj[o].kind = obj.kind
-        sc.obj[o].type = getattr(obj, "type", 0) + (base[id(obj.family)] if isinstance(obj, UserObject) else 0)
+        slots[o].kind = obj.kind
+        slots[o].type = getattr(obj, "type", 0) + (base[id(obj.family)] if isinstance(obj, UserObject) else 0)
         p = obj._pack()
         for q in range(9):
-            sc.obj[o].p[q] = p[q]
+            slots[o].p[q] = p[q]
     return sc
 
 

@@ -3,7 +3,8 @@
     python raytracegr.jl_amd/build.py [--force] [--resource-usage] [--save-temps] [--via-listing] [-DNAME[=V] ...]
 
 The library is several translation units (csrc/tu_*.hip hold the kernels of one metric-variant group each,
-csrc/rtgr_misc.hip the small kernels, csrc/rtgr_api.hip the C ABI and no kernel at all); they are compiled in parallel
+csrc/rtgr_misc.hip the small kernels; the host side is kernel-free: csrc/rtgr_context.hip, rtgr_host_pipeline.hip, rtgr_sharded.hip,
+rtgr_hooks.hip, rtgr_units.hip and the extern "C" shims of csrc/rtgr_abi.hip — rtgr_internal.hpp says what is where); they are compiled in parallel
 into raytracegr.jl_amd/build/obj/ and linked with `hipcc -shared`.
 
 After linking, the library AUDITS the kernels embedded in it for the EXEC-flip fault of ROCm 7.2's compiler (DESIGN.md §4.6;
@@ -24,17 +25,19 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["tu_f64_ksref.hip", "tu_f64_kstrue.hip", "tu_f64_generic.hip", "tu_f64_mink.hip", "tu_f32_closed.hip",
-         "tu_f32_generic.hip", "rtgr_misc.hip", "rtgr_api.hip"]
+         "tu_f32_generic.hip", "rtgr_misc.hip", "rtgr_context.hip", "rtgr_host_pipeline.hip", "rtgr_sharded.hip", "rtgr_hooks.hip",
+         "rtgr_units.hip", "rtgr_abi.hip"]
 # the device-side headers: what the KERNELS are made of (bench.py keys its roofline profile on their hash)
 KERNEL_HEADERS = ["rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_packed_f32.hpp",
                   "rtgr_tsit5_tables.hpp"]
-HEADERS = KERNEL_HEADERS + ["rtgr_host.hpp", "rtgr_pipeline.hpp", "rtgr_isa_audit.hpp", "rtgr_isa_repair.hpp", "rtgr_unit_build.hpp"]
+HEADERS = KERNEL_HEADERS + ["rtgr_host.hpp", "rtgr_internal.hpp", "rtgr_pipeline.hpp", "rtgr_isa_audit.hpp", "rtgr_isa_repair.hpp", "rtgr_unit_build.hpp"]
 DEPS = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(HERE, "..", "include", "rtgr.h")]
 OUT = os.path.join(HERE, "librtgr_hip.so")
 OBJ = os.path.join(HERE, "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LLVM_BIN = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin")
-HOST_ONLY_UNITS = ("rtgr_api.hip",)   # no kernel in it: never needs the listing route
+# no kernel in them: they never need the listing route
+HOST_ONLY_UNITS = ("rtgr_context.hip", "rtgr_host_pipeline.hip", "rtgr_sharded.hip", "rtgr_hooks.hip", "rtgr_units.hip", "rtgr_abi.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -54,13 +57,13 @@ def kernel_source_hash(out=None):
     return h.hexdigest()[:16]
 
 
-# the headers a run-time unit is compiled against (user_metric._HEADERS, rtgr_api.hip header_hash_of: same files, same order)
+# the headers a run-time unit is compiled against (user_metric._HEADERS, rtgr_units.hip header_hash_of: same files, same order)
 UNIT_HEADERS = ["rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_tsit5_tables.hpp",
                 os.path.join("..", "..", "include", "rtgr.h")]
 
 
 def header_hash():
-    """FNV-1a (64 bit) over the device headers of run-time units: compiled into the library (-DRTGR_HEADER_HASH, rtgr_api.hip) and
+    """FNV-1a (64 bit) over the device headers of run-time units: compiled into the library (-DRTGR_HEADER_HASH, rtgr_units.hip) and
     into every unit (rtgr_user_header_hash); a unit built from other headers than the library's kernels is refused at load."""
     h = 1469598103934665603
     for f in UNIT_HEADERS:
@@ -153,7 +156,7 @@ def build(force=False, extra=(), verbose=True, out=OUT, obj_dir=OBJ, via_listing
             except RuntimeError as e:
                 return job, subprocess.CompletedProcess([], 1, "", str(e))
         cmd = [HIPCC] + FLAGS + list(extra) + ["-c", "-o", obj, src]
-        if os.path.basename(src) == "rtgr_api.hip":   # (depends on every header: rebuilt whenever the hash moves)
+        if os.path.basename(src) == "rtgr_units.hip":   # (depends on every header: rebuilt whenever the hash moves)
             cmd.insert(-4, f"-DRTGR_HEADER_HASH={header_hash():#x}ull")
         if verbose:
             print(" ".join(cmd), flush=True)

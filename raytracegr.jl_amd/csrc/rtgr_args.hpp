@@ -1,6 +1,6 @@
 // rtgr_args.hpp — plain-old-data shared by host and device code: device-side scene / solver / camera, the argument
 // blocks of the pipeline's kernels and the layout of the per-ray records in the workspace.  No device code here, so the
-// host-only translation units (rtgr_api.hip) can include it without instantiating kernels.
+// host-only translation units (rtgr_context.hip …) can include it without instantiating kernels.
 #pragma once
 #include <stdint.h>
 
@@ -15,12 +15,17 @@ struct DevObject {
     R p[9];
 };
 
+// The object list (src/RayTraceGR.jl:433-441: a Vector of any length).  The first RTGR_MAX_OBJECTS objects sit in the kernels' argument
+// block (scalar loads from the kernarg segment), the rest — rare — in a device table the context keeps per distinct list
+// (rtgr_context.hip: object_table); `more` is null when nobj <= RTGR_MAX_OBJECTS.  Kernels walk the list with for_each_object
+// (rtgr_physics.hpp), never by index.
 template <class R>
 struct DevScene {
     uint32_t metric;
     uint32_t nobj;
     R M, a;
     DevObject<R> obj[RTGR_MAX_OBJECTS];
+    const DevObject<R>* more;   // objects RTGR_MAX_OBJECTS .. nobj-1
 };
 
 template <class R>
@@ -63,6 +68,7 @@ struct TraceArgs {
     R* lambda_end;
     uint8_t* status;
     uint8_t* hit;
+    uint32_t* hit32;  // the same as 32 bits (object lists beyond 255)
     uint32_t* n_accept;
     uint32_t* n_reject;
     unsigned long long* counters;  // rtgr_counters or null
@@ -151,6 +157,7 @@ struct ResolveArgs {
     R* lambda_end;
     uint8_t* status;
     uint8_t* hit;
+    uint32_t* hit32;
     uint32_t* n_accept;
     uint32_t* n_reject;
 };

@@ -72,7 +72,7 @@ struct Knobs {
     long max_waves = -1;          // cap of the integrate kernels' grid, in waves (the load-time probe: three waves over its 1024 rays make
                                   // every lane refill many times; results never depend on it)
     long unit_probe = 1;          // run-time units: trace a small probe frame through both pass structures at load and refuse a unit
-                                  // whose frames are irreproducible or disagree (rtgr_api.hip: probe_unit); 0 = skip
+                                  // whose frames are irreproducible or disagree (rtgr_units.hip: probe_unit); 0 = skip
     long unit_audit = 1;          // … and audit the code object for the compiler's EXEC-flip fault before loading it; 0 = skip
                                   // (a test hook: the probe must catch a faulty unit on its own)
 };
@@ -97,10 +97,17 @@ struct UserModule {
     uint32_t metric = RTGR_USER;   // rtgr_metric (| RTGR_METRIC_GENERIC) of its kernels; RTGR_USER: a metric of its own
     bool spin = true;              // closed-form built-in kernels: the a != 0 instantiation
     bool has_metric = true, has_objects = false, has_reach = false;
-    bool probe_ok = false;         // the load-time probe ran and passed (rtgr_api.hip: probe_unit)
+    bool probe_ok = false;         // the load-time probe ran and passed (rtgr_units.hip: probe_unit)
 };
 
 struct TimedLaunch { hipEvent_t a, b; int which; };
+
+// Objects RTGR_MAX_OBJECTS .. nobj-1 of a scene whose list is longer than the kernels' argument block holds (DevScene::more): one
+// immutable device table per distinct (scalar type, list) a device has seen, found again by content.  Immutable, so a kernel in
+// flight — or a hipGraph captured earlier — never sees it change; freed by rtgr_trim / rtgr_destroy (or all at once, behind a
+// device synchronisation, when a caller has gone through OBJECT_TABLES_MAX distinct lists).
+struct ObjectTable { std::vector<char> content; void* dev = nullptr; };
+constexpr size_t OBJECT_TABLES_MAX = 512;
 
 // pipeline workspace of one (device, stream)
 struct StreamState {
@@ -110,7 +117,7 @@ struct StreamState {
     std::vector<void*> retired;           // superseded workspaces: kept alive for graphs captured earlier
 };
 
-struct Staging;  // host entry points (rtgr_api.hip)
+struct Staging;  // host entry points (rtgr_internal.hpp)
 
 struct DeviceCtx {
     int dev = -1;       // HIP device ordinal
@@ -119,6 +126,7 @@ struct DeviceCtx {
     std::mutex mu;      // held while a call enqueues its kernels: the enqueue sequences of two host threads never interleave
     std::unordered_map<hipStream_t, StreamState> streams;
     std::vector<UserModule> modules;
+    std::unordered_multimap<uint64_t, ObjectTable> object_tables;   // by FNV-1a of the content
     Knobs knobs;
     // optional per-kernel timing (bench.py's roofline leg): hipEvents around each kernel of the pipeline
     bool timing = false;
@@ -205,10 +213,10 @@ int misc_eval_objects_f32(const DevScene<float>& sc, const DevSolver<float>& opt
 int misc_eval_fastmath_f64(const double* d_x, uint64_t n, double* d_rcp, double* d_rsq, hipStream_t st);
 int misc_redshift_f64(const DevScene<double>& sc, const DevCamera<double>& cam, const double* d_state0, uint64_t ni, uint64_t nj,
                       uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const double* d_state_end,
-                      const uint8_t* d_hit, double* d_red, hipStream_t st);
+                      const uint8_t* d_hit, const uint32_t* d_hit32, double* d_red, hipStream_t st);
 int misc_redshift_f32(const DevScene<float>& sc, const DevCamera<float>& cam, const float* d_state0, uint64_t ni, uint64_t nj,
                       uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const float* d_state_end,
-                      const uint8_t* d_hit, float* d_red, hipStream_t st);
+                      const uint8_t* d_hit, const uint32_t* d_hit32, float* d_red, hipStream_t st);
 int misc_quantize(const double* d_rgb, uint64_t ni, uint64_t nj, uint8_t* d_img, hipStream_t st);
 // multi-device gather on device 0: rows of rank r (cyclic over nranks) back into place
 int misc_place_rows_f64(const double* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t planes,

@@ -279,18 +279,18 @@ RTGR_DEV R mod1(R x) {  // Julia mod(x, 1)
 }
 
 template <class R>
-RTGR_DEV uint8_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, const R x[4], R col[3]) {
+RTGR_DEV uint32_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, const R x[4], R col[3]) {
     uint32_t omin = 0;
     R dmin = opt.hit_threshold;                                                       // :519
-    for (uint32_t o = 0; o < sc.nobj; o++) {                                          // :520-526
-        const R d = obj_distance<R>(sc.obj[o], x);
+    for_each_object<R>(sc, [&](const DevObject<R>& o_, uint32_t o) {                  // :520-526
+        const R d = obj_distance<R>(o_, x);
         if (d < dmin) { omin = o + 1; dmin = d; }
-    }
+    });
     if (omin == 0) {                                                                  // :527-528
         col[0] = opt.miss_rgb[0]; col[1] = opt.miss_rgb[1]; col[2] = opt.miss_rgb[2];
         return 0;
     }
-    const DevObject<R>& ob = sc.obj[omin - 1];
+    const DevObject<R>& ob = object_at<R>(sc, omin - 1);
     const R pi = R(3.14159265358979323846264338327950288L);
     if (ob.kind == RTGR_PLANE) {                                                      // :402-404
         col[0] = R(0); col[1] = R(0.5); col[2] = R(0);
@@ -315,7 +315,7 @@ RTGR_DEV uint8_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, co
     }
     const R scale = R(omin) / R(sc.nobj);                                             // :530
     col[0] *= scale; col[1] *= scale; col[2] *= scale;
-    return (uint8_t)omin;
+    return omin;
 }
 
 // parity hook rtgr_eval_objects_f64 / _f32: distance(obj, x) of every object (:377-419), min_distance (:433-441) and the colour rule
@@ -325,11 +325,11 @@ RTGR_DEV void eval_objects_body(const DevScene<R>& sc, const DevSolver<R>& opt, 
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const R xp[4] = {x[4 * p], x[4 * p + 1], x[4 * p + 2], x[4 * p + 3]};
-    if (d) for (uint32_t o = 0; o < sc.nobj; o++) d[p * sc.nobj + o] = obj_distance<R>(sc.obj[o], xp);
+    if (d) for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) { d[p * sc.nobj + o] = obj_distance<R>(ob, xp); });
     if (dmin) dmin[p] = min_distance<R>(sc, xp);
     R col[3];
-    const uint8_t h = colour_pixel<R>(sc, opt, xp, col);
-    if (hit) hit[p] = h;
+    const uint32_t h = colour_pixel<R>(sc, opt, xp, col);
+    if (hit) hit[p] = (uint8_t)h;   // (the host side refuses `hit` for lists beyond 255 objects)
     if (rgb) for (int c = 0; c < 3; c++) rgb[3 * p + c] = col[c];
 }
 
@@ -431,12 +431,12 @@ RTGR_DEV R inner(const R g[4][4], const R a[4], const R b[4]) {
 // dispatches to the unit's rtgr_user_metric there)
 template <class R>
 RTGR_DEV void redshift_body(const DevScene<R>& sc, const DevCamera<R>& cam, const R* state0, uint64_t ni, uint64_t nj, uint64_t j0,
-                            uint64_t jstride, uint64_t n, uint64_t out_offset, const R* state_end, const uint8_t* hit, R* red) {
+                            uint64_t jstride, uint64_t n, uint64_t out_offset, const R* state_end, const uint8_t* hit, const uint32_t* hit32, R* red) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n) return;
     const uint64_t idx = out_offset + w;
     const R nan = R(__builtin_nan(""));
-    const uint32_t h = hit[idx];
+    const uint32_t h = hit32 ? hit32[idx] : (uint32_t)hit[idx];
     if (h == 0 || h > sc.nobj) { red[idx] = nan; return; }
     R s0[8], se[8];
     if (state0) for (int c = 0; c < 8; c++) s0[c] = state0[w * 8 + c];
@@ -447,7 +447,7 @@ RTGR_DEV void redshift_body(const DevScene<R>& sc, const DevCamera<R>& cam, cons
     metric_plain<R>(sc, s0, g0);
     static_observer<R>(g0, tobs, ok0);
     metric_plain<R>(sc, se, ge);
-    const DevObject<R>& ob = sc.obj[h - 1];
+    const DevObject<R>& ob = object_at<R>(sc, h - 1);
     if (ob.kind == RTGR_SPHERE) {
         const R v[4] = {ob.p[4], ob.p[5], ob.p[6], ob.p[7]};
         const R v2 = inner<R>(ge, v, v);

@@ -107,7 +107,7 @@ inline bool in_file(uint64_t off, uint64_t size, uint64_t bytes) { return off <=
 // number of FLOW blocks of `image` with vector instructions ahead of their EXEC flip (their description appended to *report);
 // NOT_UNDERSTOOD (-1) when the image is not an ELF64 code object with a .text section this code can walk, NO_DISASSEMBLER (-2) when
 // libamd_comgr is not on the box — the reason in *report.  The two are different findings: a box without the disassembler cannot
-// audit anything, a file that is not understood may be a container the runtime WOULD load (rtgr_api.hip: load_module_image).
+// audit anything, a file that is not understood may be a container the runtime WOULD load (rtgr_units.hip: load_module_image).
 constexpr int NOT_UNDERSTOOD = -1, NO_DISASSEMBLER = -2;
 inline int audit(const char* image, size_t bytes, std::string* report) {
     auto note = [&](const std::string& s) { if (report) *report += s; };

@@ -113,7 +113,8 @@ inline bool allocator_vector(const std::string& c) {
 }
 inline bool plain_salu(const std::string& c) {
     const std::string m = mnemonic(c);
-    return m == "s_mov_b32" || m == "s_mov_b64" || m == "s_nop" || m == "s_waitcnt";   // (s_waitcnt: no register operand, indifferent to EXEC)
+    // (s_movk_i32: a 16-bit constant into an SGPR, the same move as s_mov_b32 with a literal; s_waitcnt: no register operand, indifferent to EXEC)
+    return m == "s_mov_b32" || m == "s_mov_b64" || m == "s_movk_i32" || m == "s_nop" || m == "s_waitcnt";
 }
 
 struct Hit {

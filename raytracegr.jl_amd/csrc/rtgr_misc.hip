@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const T* part, uint64_t
 template <class R>
 __global__ __launch_bounds__(256) void redshift_kernel(DevScene<R> sc, DevCamera<R> cam, const R* state0, uint64_t ni, uint64_t nj,
                                                        uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset,
-                                                       const R* state_end, const uint8_t* hit, R* red) {
-    redshift_body<R>(sc, cam, state0, ni, nj, j0, jstride, n, out_offset, state_end, hit, red);
+                                                       const R* state_end, const uint8_t* hit, const uint32_t* hit32, R* red) {
+    redshift_body<R>(sc, cam, state0, ni, nj, j0, jstride, n, out_offset, state_end, hit, hit32, red);
 }
 
 #define CHECK_LAUNCH()                                     \
@@ -213,17 +213,17 @@ int misc_place_rows_u8(const uint8_t* d_part, uint64_t ni, uint64_t nj, uint64_t
 namespace rtgr {
 int misc_redshift_f64(const DevScene<double>& sc, const DevCamera<double>& cam, const double* d_state0, uint64_t ni, uint64_t nj,
                       uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const double* d_state_end,
-                      const uint8_t* d_hit, double* d_red, hipStream_t st) {
+                      const uint8_t* d_hit, const uint32_t* d_hit32, double* d_red, hipStream_t st) {
     hipLaunchKernelGGL(redshift_kernel<double>, dim3(nblk(n)), dim3(256), 0, st, sc, cam, d_state0, ni, nj, j0, jstride, n, out_offset,
-                       d_state_end, d_hit, d_red);
+                       d_state_end, d_hit, d_hit32, d_red);
     CHECK_LAUNCH();
     return RTGR_OK;
 }
 int misc_redshift_f32(const DevScene<float>& sc, const DevCamera<float>& cam, const float* d_state0, uint64_t ni, uint64_t nj,
                       uint64_t j0, uint64_t jstride, uint64_t n, uint64_t out_offset, const float* d_state_end,
-                      const uint8_t* d_hit, float* d_red, hipStream_t st) {
+                      const uint8_t* d_hit, const uint32_t* d_hit32, float* d_red, hipStream_t st) {
     hipLaunchKernelGGL(redshift_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, sc, cam, d_state0, ni, nj, j0, jstride, n, out_offset,
-                       d_state_end, d_hit, d_red);
+                       d_state_end, d_hit, d_hit32, d_red);
     CHECK_LAUNCH();
     return RTGR_OK;
 }

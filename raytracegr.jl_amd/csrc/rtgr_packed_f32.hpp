@@ -272,8 +272,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 dl[q] = h * rfma<V2>(h, a2, rabs<V2>(u[q]));
             }
             const float guard = 1.0f + 1e-6f;
-            for (uint32_t o = 0; o < A.sc.nobj; o++) {
-                const DevObject<float>& ob = A.sc.obj[o];
+            for_each_object<float>(A.sc, [&](const DevObject<float>& ob, uint32_t) {
                 V2 lhs, rhs;
                 if (ob.kind == RTGR_PLANE) {
                     lhs = rabs<V2>(x[0] - V2(ob.p[0]));
@@ -294,7 +293,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                 }
                 safe[0] = safe[0] && (lhs.x > rhs.x);
                 safe[1] = safe[1] && (lhs.y > rhs.y);
-            }
+            });
         }
         if (!FARP && any_accept) {
             if (want_state) {
@@ -343,7 +342,7 @@ RTGR_DEV void integrate2_body(const IntegrateArgs<float>& A) {
                             pos[j][q] = rfma<V2>(th, rfma<V2>(th, rfma<V2>(th, rfma<V2>(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
                     }
                 }
-                for (uint32_t o = 0; o < A.sc.nobj; o++) fold_distances2<3>(A.sc.obj[o], pos, dm);
+                for_each_object<float>(A.sc, [&](const DevObject<float>& ob, uint32_t) { fold_distances2<3>(ob, pos, dm); });
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     if (blk == 2 && j == 2) { nextc = dm[j]; continue; }

@@ -489,8 +489,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             }
                             bool safe = true;
                             const R guard = R(1) + R(1e-6);
-                            for (uint32_t o = 0; o < A.sc.nobj; o++) {
-                                const DevObject<R>& ob = A.sc.obj[o];
+                            for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t) {
                                 // (+ an absolute floor of a few hundred ulp of the operands: a distance that is itself
                                 //  rounding noise must go through the real scan)
                                 if (ob.kind == RTGR_PLANE) {
@@ -523,7 +522,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     //  terms by δ_ϱ <= δ_x + δ_y — not by their sum, which round 3 charged)
                                     safe = safe && (rabs(disk_distance_fast<R>(ob, px, py, x[3])) > guard * rmax(dl[3], dl[1] + dl[2]));
                                 }
-                            }
+                            });
                             if constexpr (MODE == MODE_FAR) hand_over = run && (!safe || (ps == R(0)));
                             else {
                                 need_scan = !safe || (ps == R(0));
@@ -590,7 +589,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     for (int q = 0; q < 4; q++)
                                         pos[j][q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
                                 }
-                                for (uint32_t o = 0; o < A.sc.nobj; o++) fold_distances<R, 5>(A.sc.obj[o], pos, dmin);
+                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t) { fold_distances<R, 5>(ob, pos, dmin); });
 #pragma unroll
                                 for (int j = 0; j < 5; j++) {
                                     const bool hit = (ps * dmin[j] < R(0)) && !found;
@@ -611,7 +610,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 dmin[3] = R(__builtin_huge_val());
 #pragma unroll
                                 for (int q = 0; q < 4; q++) pos[3][q] = xn[q];
-                                for (uint32_t o = 0; o < A.sc.nobj; o++) fold_distances<R, 4>(A.sc.obj[o], pos, dmin);
+                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t) { fold_distances<R, 4>(ob, pos, dmin); });
                                 nextc = dmin[3];
 #pragma unroll
                                 for (int j = 0; j < 3; j++) {
@@ -1117,7 +1116,7 @@ RTGR_DEV void resolve_body(const ResolveArgs<R>& A) {
             xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
     }
     R col[3];
-    const uint8_t hit = colour_pixel<R>(A.sc, A.opt, xe, col);
+    const uint32_t hit = colour_pixel<R>(A.sc, A.opt, xe, col);
     const uint64_t idx = A.offset + w;
     A.rgb[idx] = col[0];
     A.rgb[A.n_slab + idx] = col[1];
@@ -1142,7 +1141,8 @@ RTGR_DEV void resolve_body(const ResolveArgs<R>& A) {
     if (A.lambda_end) A.lambda_end[idx] = rfma(h, Theta, t);
 #endif
     if (A.status) A.status[idx] = (uint8_t)(mt[2] & 0xffu);
-    if (A.hit) A.hit[idx] = hit;
+    if (A.hit) A.hit[idx] = (uint8_t)hit;
+    if (A.hit32) A.hit32[idx] = hit;
     if (A.n_accept) A.n_accept[idx] = mt[0];
     if (A.n_reject) A.n_reject[idx] = mt[1];
 }

@@ -831,7 +831,7 @@ RTGR_DEV void christoffel_dev(const R g[4][4], const R dg[4][4][4], R Gam[4][4][
 //     template <class S> __device__ S    rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]);
 //     >= |distance(x') − distance(x)| for every x' with |x'_q − x_q| <= dl[q]
 // (include/rtgr.h "user objects").  The library's own kernels are compiled without them: a scene with an RTGR_USER_OBJECT
-// only ever runs with the kernels of its unit (convert_scene, rtgr_api.hip).
+// only ever runs with the kernels of its unit (convert_scene, rtgr_context.hip).
 #ifdef RTGR_USER_OBJECTS
 template <class S> __device__ S rtgr_user_distance(unsigned type, const S x[4], const S p[9]);
 template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3]);
@@ -864,7 +864,7 @@ RTGR_DEV R obj_distance(const DevObject<R>& o, const R pos[4]) {
 // objects by the sign at the step start and tests < 0 / <= 0; the minimum's sign is fixed by its members' signs).  The two
 // radial terms r_in − ϱ and ϱ − r_out are replaced by THEIR SIGNS, read off s = x² + y² without taking the root: the host
 // precomputes, in the device's scalar type, the band of s whose correctly rounded square root equals the radius
-// (p[3] = min{s : √s >= r_in}, p[4] = min{s : √s > r_in}, p[5], p[6] likewise for r_out; disk_sqrt_bands, rtgr_api.hip), so
+// (p[3] = min{s : √s >= r_in}, p[4] = min{s : √s > r_in}, p[5], p[6] likewise for r_out; disk_sqrt_band, rtgr_context.hip), so
 //     sign(r_in − RN(√s)) = +1 for s < p[3], 0 for p[3] <= s < p[4], −1 otherwise
 // EXACTLY — same sign, zero included, as obj_distance computes with its IEEE square root, for every s (√ is monotone and
 // correctly rounded).  Nine IEEE roots (~16 instructions each) per accepted NEAR step become compares and selects; the true
@@ -886,13 +886,33 @@ RTGR_DEV R disk_distance_fast(const DevObject<R>& o, R px, R py, R pz) {
     return rmax(rmax(rabs(pz) - o.p[0], o.p[1] - rc), rc - o.p[2]);
 }
 
+// The object list in order — f(object, index) —, as `for obj in objs` walks the reference's Vector (:434, :520): the first
+// RTGR_MAX_OBJECTS objects from the kernels' argument block (a wave-uniform index into the kernarg segment: scalar loads), the
+// rest of a longer list from the scene's device table (DevScene::more; the same wave-uniform walk over global memory).  The second
+// loop is cold code for every scene of up to RTGR_MAX_OBJECTS objects: never entered, and outside the hot loop's instruction
+// stream.
+template <class R, class F>
+RTGR_DEV void for_each_object(const DevScene<R>& sc, F&& f) {
+    const uint32_t n0 = sc.nobj < (uint32_t)RTGR_MAX_OBJECTS ? sc.nobj : (uint32_t)RTGR_MAX_OBJECTS;
+    for (uint32_t o = 0; o < n0; o++) f(sc.obj[o], o);
+    if (sc.nobj > (uint32_t)RTGR_MAX_OBJECTS) {
+        const DevObject<R>* __restrict__ more = sc.more;
+        for (uint32_t o = (uint32_t)RTGR_MAX_OBJECTS; o < sc.nobj; o++) f(more[o - (uint32_t)RTGR_MAX_OBJECTS], o);
+    }
+}
+// … and one object by (per-lane) index: `objs[omin]` (:530)
+template <class R>
+RTGR_DEV const DevObject<R>& object_at(const DevScene<R>& sc, uint32_t o) {
+    return o < (uint32_t)RTGR_MAX_OBJECTS ? sc.obj[o] : sc.more[o - (uint32_t)RTGR_MAX_OBJECTS];
+}
+
 template <class R>
 RTGR_DEV R min_distance(const DevScene<R>& sc, const R pos[4]) {                          // :433-441
     R dmin = R(__builtin_huge_val());
-    for (uint32_t o = 0; o < sc.nobj; o++) {
-        const R d = obj_distance<R>(sc.obj[o], pos);
+    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t) {
+        const R d = obj_distance<R>(ob, pos);
         dmin = (d < dmin || d != d) ? d : dmin;
-    }
+    });
     return dmin;
 }
 

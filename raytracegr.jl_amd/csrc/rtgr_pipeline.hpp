@@ -2,7 +2,7 @@
 //     reset -> prepare (camera ray, queue key, u̇(y0), initial dt) -> [order scan/scatter] -> integrate<FAR> -> integrate<NEAR>
 //     -> resolve
 // as templates over (scalar, metric variant, spin).  Each tu_*.hip instantiates the variants of its group, so the
-// library's translation units build in parallel and the C-ABI file (rtgr_api.hip) instantiates no kernel at all.
+// library's translation units build in parallel and the host units (rtgr_internal.hpp lists them) instantiate no kernel at all.
 //
 // Launch policy (Knobs, rtgr_host.hpp; "auto" decisions by launch size are documented where they are taken):
 //   waves_per_cu       resident waves per CU of the integrate kernel (auto = 4 x the instantiation's waves/SIMD)
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
             make_pixel<R>(A.sc, A.cam, A.ni, A.nj, i, A.j0 + jl * A.jstride, s0);
         }
         st = integrate_ray<R, METRIC, SPIN>(A.sc, A.opt, s0, se, lam);
-        const uint8_t hit = colour_pixel<R>(A.sc, A.opt, se, col);
+        const uint32_t hit = colour_pixel<R>(A.sc, A.opt, se, col);
         A.rgb[idx] = col[0];
         A.rgb[n + idx] = col[1];
         A.rgb[2 * n + idx] = col[2];
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
         }
         if (A.lambda_end) A.lambda_end[idx] = lam;
         if (A.status) A.status[idx] = st.status;
-        if (A.hit) A.hit[idx] = hit;
+        if (A.hit) A.hit[idx] = (uint8_t)hit;
+        if (A.hit32) A.hit32[idx] = hit;
         if (A.n_accept) A.n_accept[idx] = st.nacc;
         if (A.n_reject) A.n_reject[idx] = st.nrej;
         ev = (st.status == RTGR_RAY_EVENT);
@@ -310,7 +311,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
         ResolveArgs<R> RA;
         RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.hand = hand; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = A.out_offset + off;
         RA.n_slab = A.plane_stride ? A.plane_stride : n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
-        RA.status = A.status; RA.hit = A.hit; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
+        RA.status = A.status; RA.hit = A.hit; RA.hit32 = A.hit32; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
         {
             KernelTimer tm(D, st, 2);
             bool done = false;

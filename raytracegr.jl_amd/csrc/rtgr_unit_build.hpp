@@ -184,7 +184,7 @@ struct Built {
 
 // 0 = ok; 1 = the user's source does not compile (log in *why); 2 = anything else (*why)
 // `defines`: what the unit is made of (-DRTGR_USER_NE=3, -DRTGR_USER_KS=1, -DRTGR_USER_OBJECTS=1, -DRTGR_UNIT_BUILTIN_METRIC=…,
-// -DRTGR_HEADER_HASH=…: rtgr_api.hip plan_unit, the same rules as user_metric.py unit_defines)
+// -DRTGR_HEADER_HASH=…: rtgr_units.hip plan_unit, the same rules as user_metric.py unit_defines)
 inline int build(const std::string& unit, const std::string& include_dir, const std::vector<std::string>& defines, Built* out, std::string* why) {
     static std::mutex one_build_at_a_time;   // (the compiler libraries keep process-wide state; builds are seconds long and rare)
     std::lock_guard<std::mutex> lock(one_build_at_a_time);

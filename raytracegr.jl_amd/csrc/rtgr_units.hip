@@ -1,0 +1,649 @@
+// rtgr_units.hip — run-time compiled units (a metric, Object subtypes, or both, given as device source): in-process build
+// (rtgr_unit_build.hpp), the EXEC-flip audit (rtgr_isa_audit.hpp) and repair (rtgr_isa_repair.hpp), the load-time probe, loading
+// into every device of a context, the source joiner, and the scene check.  No kernel here: a unit's kernels come from
+// rtgr_user_unit.hip.in compiled with the caller's source.
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include "rtgr_internal.hpp"
+#include "rtgr_isa_audit.hpp"
+#include "rtgr_unit_build.hpp"
+
+namespace rtgr {
+
+// ---- run-time loaded units (metrics, objects) ------------------------------------------------------------------------------
+// drop unit `id` (0: all) from every device; the caller holds c->modules_mu
+int unload_locked(rtgr_context* c, uint64_t id) {
+    for (auto& d : c->devs) {
+        DeviceGuard guard(d->dev);
+        std::lock_guard<std::mutex> lk(d->mu);
+        bool any = false;
+        for (auto& m : d->modules) any = any || id == 0 || m.id == id;
+        if (!any) continue;
+        HIP_TRY(hipDeviceSynchronize());  // kernels of the module may still be in flight
+        for (size_t k = 0; k < d->modules.size();) {
+            if (id == 0 || d->modules[k].id == id) {
+                if (d->modules[k].owned) (void)hipModuleUnload(d->modules[k].module);
+                d->modules.erase(d->modules.begin() + (long)k);
+            } else k++;
+        }
+    }
+    return RTGR_OK;
+}
+int api::user_metric_unload(rtgr_context* ctx, uint64_t id) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> load_lock(c->modules_mu);
+    return unload_locked(c, id);
+}
+
+
+// ---- load-time probe of a unit ---------------------------------------------------------------------------------------------
+// Round 4's compiler fault was a SILENT wrong answer that survived a round of green tests; its symptoms were
+// frames that differ from run to run and a single FULL pass that disagrees with the FAR + NEAR pair.  The textual audit knows one
+// shape of it.  This is the check that does not depend on the shape: a fresh unit traces a fixed 32 x 32 frame of example2's
+// camera and objects (src/RayTraceGR.jl:581-593) through both pass structures, each under two schedules (and its Float32 FULL pass
+// likewise), and is refused when (a) the two runs of one structure differ in ANY bit — a ray is independent of its lane, its wave
+// and its neighbours, so they must not —
+// or (b) the two structures disagree beyond what different inlining of the user's own arithmetic explains (the built-in kernels are
+// bit-identical between them; a user metric's products may contract differently in the FAR and the FULL kernel): more than 2 % of
+// the rays with another hit / status / step count (±2), or an end state off by more than 1e-5 (relative) on a ray they agree on.
+// A ~10 ms look at the fault's own symptom; a probe, not a proof (a unit wrong the same way in every pass goes through).
+template <class R> struct ProbeFrame { std::vector<R> rgb, se, lam; std::vector<uint8_t> status; std::vector<uint32_t> hit, na, nr; };
+template <class R>
+static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFrame<R>& f, const rtgr_solver* user_opt = nullptr,
+                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32, bool force_unit = false, long max_waves = -1) {
+    const uint64_t N = NI * NJ;
+    rtgr_solver opt;
+    rtgr_camera cam;
+    if (user_opt) opt = *user_opt;
+    else {
+        rtgr_solver_defaults(&opt, sizeof(R) == 4);
+        opt.max_steps = 4000;   // (bounds the probe on a metric this camera makes no sense for; such rays end with a status, identically)
+    }
+    if (user_cam) cam = *user_cam;
+    else {   // example2's camera, src/RayTraceGR.jl:588-593
+        std::memset(&cam, 0, sizeof cam);
+        cam.pos[1] = 4; cam.pos[2] = -2; cam.widthx[1] = 1; cam.widthy[3] = 1; cam.normal[2] = 1;
+    }
+    DevBuf b;
+    const size_t off_se = 3 * N * sizeof(R), off_lam = off_se + 8 * N * sizeof(R), off_na = off_lam + N * sizeof(R),
+                 off_nr = off_na + N * 4, off_hit = off_nr + N * 4, off_st = off_hit + N * 4, total = off_st + N;
+    int rc;
+    if ((rc = b.alloc(total))) return rc;
+    char* base = (char*)b.p;
+    HIP_TRY(hipMemset(base, 0, total));
+    rtgr_ray_outputs out;
+    std::memset(&out, 0, sizeof out);
+    out.state_end = base + off_se; out.lambda_end = base + off_lam; out.n_accept = (uint32_t*)(base + off_na);
+    out.n_reject = (uint32_t*)(base + off_nr); out.status = (uint8_t*)(base + off_st); out.hit32 = (uint32_t*)(base + off_hit);
+    Knobs mine;                                       // this call's launch options: the device's, with the pass structure (and grid cap) asked for
+    { std::lock_guard<std::mutex> lk(D.mu); mine = D.knobs; }
+    mine.split = split;
+    mine.max_waves = max_waves;
+    {   // (the two thread-locals are cleared on every way out of the call, an exception from the allocator included)
+        struct Clear { ~Clear() { tl_probe_forces_unit = false; tl_knobs_override = nullptr; } } clear;
+        tl_probe_forces_unit = force_unit;
+        tl_knobs_override = &mine;
+        rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
+    }
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    f.rgb.resize(3 * N); f.se.resize(8 * N); f.lam.resize(N); f.na.resize(N); f.nr.resize(N); f.status.resize(N); f.hit.resize(N);
+    HIP_TRY(hipMemcpy(f.rgb.data(), base, off_se, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.se.data(), base + off_se, 8 * N * sizeof(R), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.lam.data(), base + off_lam, N * sizeof(R), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.na.data(), base + off_na, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.nr.data(), base + off_nr, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.status.data(), base + off_st, N, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.hit.data(), base + off_hit, N * 4, hipMemcpyDeviceToHost));
+    return RTGR_OK;
+}
+template <class R>
+static bool probe_same_bits(const ProbeFrame<R>& a, const ProbeFrame<R>& b) {
+    auto eq = [](const auto& x, const auto& y) { return x.size() == y.size() && std::memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0; };
+    return eq(a.rgb, b.rgb) && eq(a.se, b.se) && eq(a.lam, b.lam) && eq(a.na, b.na) && eq(a.nr, b.nr) && eq(a.status, b.status) && eq(a.hit, b.hit);
+}
+// the FULL pass's frame against the FAR + NEAR passes' of the same rays: true (and *why) when they disagree beyond what different
+// inlining of a user's own arithmetic explains — more than 2 % of the rays with another hit / status / step count (±2), or an end
+// state off by more than 1e-5 (relative) on a ray they agree on
+template <class R>
+static bool probe_disagree(const ProbeFrame<R>& full, const ProbeFrame<R>& pair, const char* whose, std::string* why) {
+    const size_t n = full.hit.size();
+    size_t other = 0;
+    double worst = 0;
+    for (size_t i = 0; i < n; i++) {
+        const long sa = (long)full.na[i] + full.nr[i], sb = (long)pair.na[i] + pair.nr[i];
+        if (full.hit[i] != pair.hit[i] || full.status[i] != pair.status[i] || std::labs(sa - sb) > 2) { other++; continue; }
+        for (int q = 0; q < 8; q++) {
+            const double x = full.se[8 * i + q], y = pair.se[8 * i + q];
+            if (x != x && y != y) continue;
+            const double e = std::fabs(x - y) / (1.0 + std::fabs(x));
+            if (!(e <= worst)) worst = e;   // (NaN on one side only: counted)
+        }
+    }
+    char buf[320];
+    if (other > std::max<size_t>(2, n / 50)) {
+        std::snprintf(buf, sizeof buf, "%s FULL pass and %s FAR + NEAR passes disagree on %zu of %zu rays (hit / status / step count)", whose, whose, other, n);
+        *why = buf; return true;
+    }
+    if (!(worst <= 1e-5)) {
+        std::snprintf(buf, sizeof buf, "%s FULL pass and %s FAR + NEAR passes end rays they agree on %.3g apart (relative; 1e-5 allowed)", whose, whose, worst);
+        *why = buf; return true;
+    }
+    return false;
+}
+
+static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
+    rtgr_scene sc;
+    std::memset(&sc, 0, sizeof sc);
+    sc.metric = U.has_metric ? (uint32_t)RTGR_USER : U.metric;
+    sc.M = 1.0;
+    sc.a = (!U.has_metric && U.spin && (U.metric & RTGR_METRIC_GENERIC) == 0) ? 0.5 : 0.0;
+    sc.user_metric = U.id;
+    sc.nobj = 3;                                                         // example2's objects, src/RayTraceGR.jl:582-586
+    sc.obj[0].kind = RTGR_SPHERE; sc.obj[0].p[4] = 1; sc.obj[0].p[8] = -10;
+    sc.obj[1].kind = RTGR_PLANE;  sc.obj[1].p[0] = -20;
+    sc.obj[2].kind = RTGR_SPHERE; sc.obj[2].p[1] = 4; sc.obj[2].p[4] = 1; sc.obj[2].p[8] = 0.5;
+    int rc;
+    // The second run of each structure is scheduled DIFFERENTLY from the first: a grid of THREE waves over the 1024 rays instead of
+    // sixteen — the first run's lanes each trace one ray, the second run's refill from the queue about five times, with other
+    // neighbours in the wave every time.  A ray's arithmetic does not depend on which lane or wave carries it or on what its
+    // neighbours do (the library's scheduling options never change a bit: test_scheduling_knobs_do_not_change_results), so the two
+    // runs of a sound unit are bit-identical; code that executes part of a divergent branch for the wrong lanes — the fault — depends
+    // on exactly that.  (Until this change both runs had the same schedule and differed only through timing noise: a faulty unit could
+    // slip through when the noise was small.)
+    const long few = 3;
+    ProbeFrame<double> full[2], pair[2];
+    for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 0, full[k], nullptr, nullptr, 32, 32, true, k ? few : -1))) return rc;
+    if (!probe_same_bits(full[0], full[1])) { *why = "two differently scheduled runs of its Float64 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
+    const bool has_pair = !(U.has_objects && !U.has_reach);
+    if (has_pair) {
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<double>(D, sc, 1, pair[k], nullptr, nullptr, 32, 32, true, k ? few : -1))) return rc;
+        if (!probe_same_bits(pair[0], pair[1])) { *why = "two differently scheduled runs of its Float64 FAR + NEAR passes over the same 32 x 32 probe frame differ"; return 1; }
+        if (probe_disagree(full[0], pair[0], "its", why)) return 1;
+    }
+    if (U.full10_f32) {
+        ProbeFrame<float> f32[2];
+        for (int k = 0; k < 2; k++) if ((rc = probe_trace<float>(D, sc, -1, f32[k], nullptr, nullptr, 32, 32, true, k ? few : -1))) return rc;
+        if (!probe_same_bits(f32[0], f32[1])) { *why = "two differently scheduled runs of its Float32 FULL pass over the same 32 x 32 probe frame differ"; return 1; }
+    }
+    return RTGR_OK;
+}
+
+#ifndef RTGR_HEADER_HASH
+#define RTGR_HEADER_HASH 0ull   // (build.py passes the FNV-1a of the device headers the library's kernels were built from)
+#endif
+
+// load a gfx950 code object image into every device of the context; its id is a hash of the image
+static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out) {
+    const uint64_t id = fnv1a(image);
+    const Knobs policy = [&] { std::lock_guard<std::mutex> lk(c->devs[0]->mu); return c->devs[0]->knobs; }();
+    if (policy.unit_audit != 0) {
+        // refuse code that carries the EXEC-flip fault of this LLVM (rtgr_isa_audit.hpp): a unit traced wrong from it in round 4.
+        // audit_any also unwraps the offload bundle a plain `hipcc --genco` writes (those were loaded unaudited).  A box
+        // without libamd_comgr cannot audit anything and loads the image as it is — the probe below still runs; a file the audit does
+        // not understand (a compressed bundle, say) that the runtime might load all the same is REFUSED, not waved through.
+        std::string report;
+        const int bad = isa_audit::audit_any(image.data(), image.size(), &report);
+        if (bad > 0)
+            return fail(RTGR_ERR_BAD_ARG, what + ": " + std::to_string(bad) + " FLOW block(s) with vector instructions ahead of the EXEC flip "
+                        "(a code-generation fault of the compiler, DESIGN.md §4.6; raytracegr.jl_amd/user_metric.py builds repaired units):\n" + report);
+        if (bad == isa_audit::NOT_UNDERSTOOD)
+            return fail(RTGR_ERR_BAD_ARG, what + ": cannot be audited (" + report + "): hand over a plain gfx950 code object "
+                        "(hipcc --genco --no-gpu-bundle-output) or an uncompressed offload bundle");
+    }
+    std::lock_guard<std::mutex> load_lock(c->modules_mu);   // one load / unload at a time per context
+    bool fresh = false;                                       // loaded by this call on at least one device (else: already resident)
+    // (a unit refused on device k — wrong ABI, missing kernel, HIP error — must not stay resident on devices 0 … k-1 of the context)
+    struct Rollback { rtgr_context* c; uint64_t id; bool* fresh; bool armed = true;
+                      ~Rollback() { if (armed && *fresh) { const std::string keep = rtgr_last_error(); (void)unload_locked(c, id); (void)fail(0, keep); } } } rollback{c, id, &fresh};
+    for (auto& d : c->devs) {
+        DeviceGuard guard(d->dev);
+        bool same_phys = false;  // a logical duplicate of a device shares the module of its twin
+        UserModule twin;
+        for (auto& o : c->devs)
+            if (o.get() != d.get() && o->dev == d->dev) {
+                std::lock_guard<std::mutex> lo(o->mu);   // (the twin's list is read under the twin's lock)
+                if (const UserModule* m = o->find_module(id)) { twin = *m; twin.owned = false; same_phys = true; break; }
+            }
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (d->find_module(id)) continue;
+        if (same_phys) { d->modules.push_back(twin); continue; }
+        UserModule u;
+        u.id = id;
+        hipError_t e = hipModuleLoadData(&u.module, image.data());
+        if (e != hipSuccess)
+            return fail(RTGR_ERR_HIP, std::string("hipModuleLoadData(") + what + "): " + hipGetErrorString(e));
+        auto bail = [&](const std::string& why) {
+            (void)hipModuleUnload(u.module);
+            return fail(RTGR_ERR_BAD_ARG, what + ": " + why);
+        };
+        {   // the unit must have been built against this library's headers
+            hipDeviceptr_t dptr = nullptr;
+            size_t bytes = 0;
+            unsigned ver = 0;
+            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_abi_version") != hipSuccess || bytes != sizeof ver)
+                return bail("not a run-time unit of this library (no rtgr_user_abi_version)");
+            if (hipMemcpyDtoH(&ver, dptr, sizeof ver) != hipSuccess) return bail("cannot read rtgr_user_abi_version");
+            if (ver != RTGR_ABI_VERSION)
+                return bail("built against ABI version " + std::to_string(ver) + ", this library is version " + std::to_string(RTGR_ABI_VERSION) + ": rebuild the unit");
+            // … the very headers: the record layouts and argument blocks the unit's kernels share with the library's are not part of
+            // the C ABI and change without its version moving (round 4's record overlay would have loaded an older unit and
+            // overrun the workspace).  0 on either side = not recorded (a unit built by hand, a library built without build.py).
+            unsigned long long hh = 0;
+            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_header_hash") == hipSuccess && bytes == sizeof hh &&
+                hipMemcpyDtoH(&hh, dptr, sizeof hh) == hipSuccess && hh != 0ull && RTGR_HEADER_HASH != 0ull && hh != RTGR_HEADER_HASH)
+                return bail("built from other device headers than this library's kernels (header hash differs): rebuild the unit");
+            // optional: the occupancies the unit's FAR / NEAR+FULL / Float32 passes were built for
+            struct { const char* name; unsigned* dst; } occ[] = {{"rtgr_user_far_waves", &u.far_waves}, {"rtgr_user_near_waves", &u.near_waves},
+                                                                {"rtgr_user_f32_waves", &u.f32_waves}};
+            for (auto& o : occ) {
+                unsigned fw = 0;
+                if (hipModuleGetGlobal(&dptr, &bytes, u.module, o.name) == hipSuccess && bytes == sizeof fw &&
+                    hipMemcpyDtoH(&fw, dptr, sizeof fw) == hipSuccess && fw >= 1 && fw <= 8) *o.dst = fw;
+            }
+            // what it was built for: {metric enum | generic flag, spin, metric of its own, objects, reach bound}
+            unsigned desc[8] = {0};
+            if (hipModuleGetGlobal(&dptr, &bytes, u.module, "rtgr_user_unit_desc") != hipSuccess || bytes != sizeof desc ||
+                hipMemcpyDtoH(desc, dptr, sizeof desc) != hipSuccess)
+                return bail("no rtgr_user_unit_desc (a unit of an older template): rebuild the unit");
+            u.metric = desc[0]; u.spin = desc[1] != 0; u.has_metric = desc[2] != 0; u.has_objects = desc[3] != 0; u.has_reach = desc[4] != 0;
+            if ((u.metric & ~RTGR_METRIC_GENERIC) > RTGR_USER || (u.has_metric != ((u.metric & ~RTGR_METRIC_GENERIC) == RTGR_USER)))
+                return bail("inconsistent rtgr_user_unit_desc");
+            if (!u.has_metric && !u.has_objects) return bail("the unit defines neither a metric nor objects");
+            (void)hipGetLastError();
+        }
+        const bool M = u.has_metric, O = u.has_objects;   // which kernels the unit must carry
+        struct { hipFunction_t* f; const char* name; bool required; } want[] = {
+            {&u.far, "rtgr_user_integrate_far", true},       {&u.near, "rtgr_user_integrate_near", true},
+            {&u.full10, "rtgr_user_integrate_full10", true}, {&u.fulln, "rtgr_user_integrate_fulln", true},
+            {&u.prepare, "rtgr_user_prepare", true},         {&u.resolve, "rtgr_user_resolve", O},
+            {&u.canvas, "rtgr_user_canvas", M},              {&u.eval_metric, "rtgr_user_eval_metric", M},
+            {&u.eval_geodesic, "rtgr_user_eval_geodesic", M},
+            {&u.full10_f32, "rtgr_user_integrate_full10_f32", false}, {&u.fulln_f32, "rtgr_user_integrate_fulln_f32", false},
+            {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false},
+            {&u.resolve_f32, "rtgr_user_resolve_f32", false},
+            {&u.eval_objects, "rtgr_user_eval_objects", false}, {&u.eval_objects_f32, "rtgr_user_eval_objects_f32", false},
+            {&u.eval_accel, "rtgr_user_eval_accel", false}, {&u.redshift, "rtgr_user_redshift", false},
+            {&u.redshift_f32, "rtgr_user_redshift_f32", false}};
+        for (auto& w : want)
+            if (hipModuleGetFunction(w.f, u.module, w.name) != hipSuccess) {
+                (void)hipGetLastError();
+                if (w.required) return bail(std::string("missing kernel ") + w.name);
+                *w.f = nullptr;
+            }
+        if (!u.prepare_f32 || !u.fulln_f32 || (O && !u.resolve_f32)) u.full10_f32 = nullptr;  // all or nothing
+        d->modules.push_back(u);
+        fresh = true;
+    }
+    if (policy.unit_probe != 0) {
+        // one probe per physical device that owns a copy of the module and has not probed it yet (a fresh copy — or one that was
+        // loaded earlier while the probe was switched off)
+        std::vector<int> seen;
+        for (auto& d : c->devs) {
+            if (std::find(seen.begin(), seen.end(), d->dev) != seen.end()) continue;
+            seen.push_back(d->dev);
+            UserModule u;
+            { std::lock_guard<std::mutex> lk(d->mu); const UserModule* m = d->find_module(id); if (!m) continue; u = *m; }
+            if (u.probe_ok) continue;
+            std::string why;
+            DeviceGuard guard(d->dev);
+            const int pr = probe_unit(*d, u, &why);
+            if (pr != RTGR_OK) {
+                const std::string msg = pr > 0 ? what + ": refused by the load-time probe — " + why +
+                                                 " (the symptom of a mis-compiled unit, DESIGN.md §4.6; option unit_probe = 0 skips the probe)"
+                                               : what + ": the load-time probe could not run: " + rtgr_last_error();
+                (void)unload_locked(c, id);
+                return fail(pr > 0 ? RTGR_ERR_BAD_ARG : pr, msg);
+            }
+        }
+        for (auto& d : c->devs) {
+            std::lock_guard<std::mutex> lk(d->mu);
+            for (auto& m : d->modules) if (m.id == id) m.probe_ok = true;
+        }
+    }
+    rollback.armed = false;
+    if (id_out) *id_out = id;
+    return RTGR_OK;
+}
+
+static int read_file(const std::string& path, std::vector<char>& out) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return fail(RTGR_ERR_BAD_ARG, "cannot open " + path);
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz <= 0) { std::fclose(f); return fail(RTGR_ERR_BAD_ARG, path + ": empty file"); }
+    out.resize((size_t)sz);
+    const size_t got = std::fread(out.data(), 1, (size_t)sz, f);
+    std::fclose(f);
+    if (got != (size_t)sz) return fail(RTGR_ERR_BAD_ARG, "short read on " + path);
+    return RTGR_OK;
+}
+
+// ---- in-process compilation (rtgr_unit_build.hpp: hiprtc + libamd_comgr, resolved lazily with dlopen) ------------------------------
+static std::string csrc_dir() {  // the device headers ship next to the library: <dir of librtgr_hip.so>/csrc (RTGR_CSRC overrides)
+    if (const char* e = std::getenv("RTGR_CSRC")) if (*e) return e;
+    Dl_info info;
+    if (dladdr((const void*)&rtgr_abi_version, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t s = p.rfind('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/csrc";
+    }
+    return "csrc";
+}
+
+
+int api::user_metric_load(rtgr_context* ctx, const char* code_object_path, uint64_t* id_out) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
+    std::vector<char> image;
+    if ((rc = read_file(code_object_path, image))) return rc;
+    return load_module_image(c, image, code_object_path, id_out);
+}
+
+int api::code_object_audit(const char* code_object_path, int* found, char* report, uint64_t report_len) {
+    if (!code_object_path || !*code_object_path || !found) return fail(RTGR_ERR_BAD_ARG, "code object path or found is NULL");
+    std::vector<char> image;
+    if (int rc = read_file(code_object_path, image)) return rc;
+    std::string text;
+    const int n = isa_audit::audit_any(image.data(), image.size(), &text);
+    if (n < 0) return fail(RTGR_ERR_BAD_ARG, std::string(code_object_path) + ": cannot be audited: " + text);
+    *found = n;
+    if (report && report_len) {
+        const size_t k = std::min<size_t>(text.size(), (size_t)report_len - 1);
+        std::memcpy(report, text.data(), k);
+        report[k] = 0;
+    }
+    return RTGR_OK;
+}
+
+// What a unit is made of, read off its source text and the scene it is meant for (the same rules as user_metric.py: unit_defines)
+struct UnitPlan { bool metric = false, ks_form = false, objects = false, reach = false; std::vector<std::string> defines; };
+static int plan_unit(const char* source, int stationary, const rtgr_scene* built_for, UnitPlan* P) {
+    if (!source) return fail(RTGR_ERR_BAD_ARG, "source is NULL");
+    P->ks_form = std::strstr(source, "rtgr_user_ks") != nullptr;
+    P->metric = P->ks_form || std::strstr(source, "rtgr_user_metric") != nullptr;
+    const bool dist = std::strstr(source, "rtgr_user_distance") != nullptr, colr = std::strstr(source, "rtgr_user_objcolor") != nullptr;
+    if (dist != colr)
+        return fail(RTGR_ERR_BAD_ARG, "objects need both methods of the reference's Object (src/RayTraceGR.jl:377-389): rtgr_user_distance AND rtgr_user_objcolor");
+    P->objects = dist;
+    P->reach = std::strstr(source, "rtgr_user_reach") != nullptr;
+    if (P->reach && !P->objects) return fail(RTGR_ERR_BAD_ARG, "rtgr_user_reach without rtgr_user_distance / rtgr_user_objcolor");
+    if (!P->metric && !P->objects)
+        return fail(RTGR_ERR_BAD_ARG, "the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
+                                      "double M, double a, S g[4][4])` (or, for a metric of Kerr-Schild form, rtgr_user_ks(const S "
+                                      "x[4], double M, double a, S& f, S k[3])) and / or the object methods rtgr_user_distance / rtgr_user_objcolor");
+    if (P->metric) {
+        if (built_for && (built_for->metric & ~RTGR_METRIC_GENERIC) != RTGR_USER)
+            return fail(RTGR_ERR_BAD_ARG, "the source defines a metric of its own, but built_for names a built-in one: pass NULL (or a RTGR_USER scene)");
+        if (stationary || P->ks_form) P->defines.push_back("-DRTGR_USER_NE=3");   // (Kerr–Schild form: stationary by contract)
+        if (P->ks_form) P->defines.push_back("-DRTGR_USER_KS=1");
+    } else {
+        if (!built_for || (built_for->metric & ~RTGR_METRIC_GENERIC) >= RTGR_USER)
+            return fail(RTGR_ERR_BAD_ARG, "a unit of objects alone is built for ONE built-in metric variant: pass the scene it is meant for as built_for "
+                                          "(its metric enum, RTGR_METRIC_GENERIC flag and whether a != 0 are read)");
+        uint32_t mv; bool sp;
+        scene_variant(built_for, &mv, &sp);
+        const bool generic = (mv & RTGR_METRIC_GENERIC) != 0;
+        P->defines.push_back("-DRTGR_UNIT_BUILTIN_METRIC=" + std::to_string(mv & ~RTGR_METRIC_GENERIC));
+        P->defines.push_back(std::string("-DRTGR_UNIT_GENERIC=") + (generic ? "1" : "0"));
+        P->defines.push_back(std::string("-DRTGR_UNIT_SPIN=") + ((sp && !generic) ? "1" : "0"));
+    }
+    if (P->objects) P->defines.push_back("-DRTGR_USER_OBJECTS=1");
+    if (P->reach) P->defines.push_back("-DRTGR_USER_REACH=1");
+    return RTGR_OK;
+}
+
+// FNV-1a over the device headers a unit is compiled against, in the order user_metric.py hashes them (header_hash): what a unit
+// records as rtgr_user_header_hash and load_module_image compares with the hash the library's own kernels were built from
+static int header_hash_of(const std::string& dir, unsigned long long* out) {
+    uint64_t h = 1469598103934665603ull;
+    for (const char* f : {"rtgr_args.hpp", "rtgr_physics.hpp", "rtgr_integrator.hpp", "rtgr_persistent.hpp", "rtgr_tsit5_tables.hpp", "../../include/rtgr.h"}) {
+        std::vector<char> b;
+        if (int rc = read_file(dir + "/" + f, b)) return rc;
+        for (char ch : b) { h ^= (unsigned char)ch; h *= 1099511628211ull; }
+    }
+    *out = h ? h : 1;
+    return RTGR_OK;
+}
+
+// source text -> the unit's code object, in-process (no GPU needed); RTGR_OK or a negative status with the reason as last error
+static int build_unit_image(const char* source, int stationary, const rtgr_scene* built_for, unit_build::Built* built) {
+    UnitPlan P;
+    if (int rc = plan_unit(source, stationary, built_for, &P)) return rc;
+    const std::string dir = csrc_dir();
+    std::vector<char> tmpl;
+    if (int rc = read_file(dir + "/rtgr_user_unit.hip.in", tmpl)) return rc;
+    std::string unit(tmpl.begin(), tmpl.end());
+    const std::string mark = "@RTGR_USER_SOURCE@";
+    const size_t at = unit.find(mark);
+    if (at == std::string::npos) return fail(RTGR_ERR_BAD_ARG, dir + "/rtgr_user_unit.hip.in: no " + mark);
+    unit.replace(at, mark.size(), source);
+    unsigned long long hh = 0;
+    if (int rc = header_hash_of(dir, &hh)) return rc;
+    char hbuf[64];
+    std::snprintf(hbuf, sizeof hbuf, "-DRTGR_HEADER_HASH=0x%llxull", hh);
+    P.defines.push_back(hbuf);
+    std::string why;
+    const int r = unit_build::build(unit, dir, P.defines, built, &why);
+    if (r == 1) return fail(RTGR_ERR_BAD_ARG, why);          // the user's source does not compile: the compiler's log
+    if (r != 0) return fail(RTGR_ERR_HIP, why);
+    return RTGR_OK;
+}
+static int write_image(const unit_build::Built& built, const char* code_object_path) {
+    const std::string tmp = std::string(code_object_path) + ".tmp" + std::to_string((long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(RTGR_ERR_BAD_ARG, "cannot write " + tmp);
+    const size_t put = std::fwrite(built.image.data(), 1, built.image.size(), f);
+    if (std::fclose(f) != 0 || put != built.image.size()) { std::remove(tmp.c_str()); return fail(RTGR_ERR_BAD_ARG, "short write on " + tmp); }
+    if (std::rename(tmp.c_str(), code_object_path) != 0) { std::remove(tmp.c_str()); return fail(RTGR_ERR_BAD_ARG, std::string("cannot rename to ") + code_object_path); }
+    return RTGR_OK;
+}
+
+int api::user_unit_compile(rtgr_context* ctx, const char* source, int stationary, const rtgr_scene* built_for, uint64_t* id_out) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    // Opt-in disk cache for callers without a build system of their own (C, Julia): with RTGR_UNIT_CACHE=<directory> the code object
+    // of (source, what it is built for, the device headers) is kept there and a later process loads it in milliseconds instead of
+    // compiling for seconds.  The key covers everything the image depends on; the file is audited and probed at load like any other.
+    std::string cache_file;
+    uint64_t key_hash = 0;   // of everything the image depends on; 0: could not be formed (the build below says why)
+    if (source) {
+        UnitPlan P;
+        unsigned long long hh = 0;
+        if (plan_unit(source, stationary, built_for, &P) == RTGR_OK && header_hash_of(csrc_dir(), &hh) == RTGR_OK) {
+            std::string key = source;
+            for (const std::string& d : P.defines) key += "\n" + d;
+            key += "\n" + std::to_string(hh) + "\nabi " + std::to_string(RTGR_ABI_VERSION);
+            key_hash = fnv1a(std::vector<char>(key.begin(), key.end()));
+            if (!key_hash) key_hash = 1;
+        }
+    }
+    if (key_hash) {   // the same call again while its unit is resident: no compiler, no load
+        uint64_t known = 0;
+        { std::lock_guard<std::mutex> lk(c->compiled_mu); auto it = c->compiled.find(key_hash); if (it != c->compiled.end()) known = it->second; }
+        if (known && rtgr_user_metric_loaded(c, known) == 1) { if (id_out) *id_out = known; return RTGR_OK; }
+    }
+    auto remember = [&](int rc_) {
+        if (rc_ == RTGR_OK && key_hash && id_out) { std::lock_guard<std::mutex> lk(c->compiled_mu); c->compiled[key_hash] = *id_out; }
+        return rc_;
+    };
+    if (const char* dir = std::getenv("RTGR_UNIT_CACHE")) if (*dir && key_hash) {
+        {
+            char name[64];
+            std::snprintf(name, sizeof name, "/unit_%016llx.hsaco", (unsigned long long)key_hash);
+            cache_file = std::string(dir) + name;
+            std::vector<char> image;
+            FILE* f = std::fopen(cache_file.c_str(), "rb");
+            if (f) {
+                std::fclose(f);
+                if (read_file(cache_file, image) == RTGR_OK && load_module_image(c, image, cache_file, id_out) == RTGR_OK) return remember(RTGR_OK);
+                // (a stale or damaged file: fall through, rebuild and overwrite it)
+            }
+        }
+    }
+    unit_build::Built built;
+    if ((rc = build_unit_image(source, stationary, built_for, &built))) return rc;
+    const std::vector<char> image(built.image.begin(), built.image.end());
+    rc = load_module_image(c, image, "compiled unit", id_out);   // (audited and probed there like any other image)
+    if (rc == RTGR_OK && !cache_file.empty()) {
+        const std::string keep = rtgr_last_error();
+        (void)write_image(built, cache_file.c_str());             // best effort: an unwritable directory must not fail the compile
+        (void)fail(0, keep);
+    }
+    return remember(rc);
+}
+int api::user_metric_compile(rtgr_context* ctx, const char* source, int stationary, uint64_t* id_out) {
+    return rtgr_user_unit_compile(ctx, source, stationary, nullptr, id_out);
+}
+
+int api::user_unit_build(const char* source, int stationary, const rtgr_scene* built_for, const char* code_object_path) {
+    if (!code_object_path || !*code_object_path) return fail(RTGR_ERR_BAD_ARG, "code object path is NULL or empty");
+    unit_build::Built built;
+    if (int rc = build_unit_image(source, stationary, built_for, &built)) return rc;
+    return write_image(built, code_object_path);
+}
+int api::user_metric_build(const char* source, int stationary, const char* code_object_path) {
+    return rtgr_user_unit_build(source, stationary, nullptr, code_object_path);
+}
+
+// Several object families in one scene: compiled code holds a scene's objects in ONE unit, so their sources are joined into one —
+// each in a namespace of its own, under dispatchers on the (renumbered) type tag.  Text in, text out: no GPU, no context.
+int api::user_source_join(const char* const* sources, const uint32_t* ntypes, int n, char* out, uint64_t cap, uint64_t* need) {
+    if (!sources || !ntypes || n < 1 || n > RTGR_MAX_SOURCES)
+        return fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: 1.." + std::to_string(RTGR_MAX_SOURCES) + " sources with their numbers of types");
+    std::string t = "// " + std::to_string(n) + " object families, joined by rtgr_user_source_join\n";
+    std::vector<uint32_t> base(n + 1, 0);
+    bool reach_any = false;
+    std::vector<bool> reach(n);
+    for (int k = 0; k < n; ++k) {
+        const char* src = sources[k];
+        const std::string who = "rtgr_user_source_join: source " + std::to_string(k);
+        if (!src) return fail(RTGR_ERR_BAD_ARG, who + " is NULL");
+        if (!std::strstr(src, "rtgr_user_distance") || !std::strstr(src, "rtgr_user_objcolor"))
+            return fail(RTGR_ERR_BAD_ARG, who + " must define rtgr_user_distance and rtgr_user_objcolor (the two methods of the reference's Object)");
+        if (std::strstr(src, "rtgr_user_metric") || std::strstr(src, "rtgr_user_ks"))
+            return fail(RTGR_ERR_BAD_ARG, who + " defines a metric: only object sources are joined (the metric's source is given beside the joined text)");
+        if (std::strstr(src, "rtgr_family_"))
+            return fail(RTGR_ERR_BAD_ARG, who + " is a joined source itself: join the original sources in one call");
+        if (ntypes[k] == 0) return fail(RTGR_ERR_BAD_ARG, who + ": number of object types is 0");
+        base[k + 1] = base[k] + ntypes[k];
+        reach[k] = std::strstr(src, "rtgr_user_reach") != nullptr;
+        reach_any = reach_any || reach[k];
+        t += "namespace rtgr_family_" + std::to_string(k) + " {\n#line 1 \"object family " + std::to_string(k) + "\"\n" + src + "\n}\n";
+    }
+    t += "#line 1 \"rtgr_user_source_join\"\n";
+    // family k's type t is the joined source's type base[k] + t; a tag past the last family's range goes to the last family
+    auto dispatch = [&](const std::string& head, const std::string& fn, const std::string& args, bool value, const std::vector<bool>* only) {
+        t += "template <class S> __device__ " + head + " {\n";
+        for (int k = 0; k < n; ++k) {
+            const std::string cond = k + 1 < n ? "    if (type < " + std::to_string(base[k + 1]) + "u) " : "    ";
+            const std::string call = "rtgr_family_" + std::to_string(k) + "::" + fn + "(type - " + std::to_string(base[k]) + "u, " + args + ")";
+            if (only && !(*only)[k]) t += cond + "return S(__builtin_huge_val());   // (this family brings no bound: never provably out of reach)\n";
+            else if (value) t += cond + "return " + call + ";\n";
+            else t += cond + "{ " + call + "; return; }\n";
+        }
+        t += "}\n";
+    };
+    dispatch("S rtgr_user_distance(unsigned type, const S x[4], const S p[9])", "rtgr_user_distance", "x, p", true, nullptr);
+    dispatch("void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3])", "rtgr_user_objcolor", "x, p, rgb", false, nullptr);
+    if (reach_any)
+        dispatch("S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4])", "rtgr_user_reach", "x, p, dl", true, &reach);
+    if (need) *need = t.size() + 1;
+    if (!out) return need ? RTGR_OK : fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: neither a buffer nor a place for the length");
+    if (cap < t.size() + 1) return fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: the buffer holds " + std::to_string(cap) + " bytes, the text needs " + std::to_string(t.size() + 1));
+    std::memcpy(out, t.c_str(), t.size() + 1);
+    return RTGR_OK;
+}
+
+template <class R>
+static int scene_check_frames(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, bool exact) {
+    ProbeFrame<R> full, pair;
+    int rc;
+    if ((rc = probe_trace<R>(D, *scene, 0, full, opt, cam, ni, nj))) return rc;
+    if ((rc = probe_trace<R>(D, *scene, 1, pair, opt, cam, ni, nj))) return rc;
+    std::string why;
+    if (exact) {
+        if (probe_same_bits(full, pair)) return RTGR_OK;
+        size_t other = 0;
+        for (size_t i = 0; i < full.hit.size(); i++) other += full.hit[i] != pair.hit[i] || full.status[i] != pair.status[i] || full.na[i] != pair.na[i];
+        why = "the FULL pass and the FAR + NEAR passes of this scene differ (" + std::to_string(other) + " of " + std::to_string(full.hit.size()) +
+              " rays with another hit / status / step count)";
+    } else if (!probe_disagree(full, pair, "the scene's", &why)) return RTGR_OK;
+    return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: " + why + " — a FAR pass that skips scans it must not skip: with user objects, "
+                                  "rtgr_user_reach is not an upper bound of how far rtgr_user_distance moves inside the box it is given");
+}
+
+int api::scene_check(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, int is_f32) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!scene || !opt || !cam) return fail(RTGR_ERR_BAD_ARG, "NULL argument");
+    if (ni == 0 || nj == 0 || ni > 256 || nj > 256) return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: a canvas of 1 .. 256 x 1 .. 256 rays");
+    if (is_f32) return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: Float32 scenes run ONE pass structure (the single FULL pass): nothing to compare");
+    DeviceCtx& D = *c->devs[0];
+    DeviceGuard guard(D.dev);
+    // bit for bit where every kernel is the library's own arithmetic (a built-in metric — closed form or generic —, with or without
+    // user objects: the same object functions are inlined into the same bodies); within the probe's bars for a metric given as source
+    const bool exact = (scene->metric & ~RTGR_METRIC_GENERIC) != RTGR_USER;
+    return scene_check_frames<double>(D, scene, opt, cam, ni, nj, exact);
+}
+
+int api::user_unit_info(rtgr_context* ctx, uint64_t id, rtgr_unit_info* info) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    if (!info) return fail(RTGR_ERR_BAD_ARG, "info is NULL");
+    DeviceCtx& d = *c->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    const UserModule* m = d.find_module(id);
+    if (!m) return fail(RTGR_ERR_BAD_ARG, "no such unit in this context");
+    std::memset(info, 0, sizeof *info);
+    info->metric = m->metric; info->spin = m->spin; info->has_objects = m->has_objects; info->has_reach = m->has_reach;
+    info->far_waves = m->far_waves; info->near_waves = m->near_waves; info->f32_waves = m->f32_waves; info->probe_ok = m->probe_ok;
+    return RTGR_OK;
+}
+
+int api::listing_repair(const char* listing_path, const char* repaired_path, int* blocks) {
+    if (!listing_path || !*listing_path || !blocks) return fail(RTGR_ERR_BAD_ARG, "listing path or blocks is NULL");
+    std::vector<char> text;
+    if (int rc = read_file(listing_path, text)) return rc;
+    std::vector<std::string> lines;
+    for (size_t p = 0; p <= text.size();) {
+        const auto e = std::find(text.begin() + (long)p, text.end(), '\n');
+        lines.emplace_back(text.begin() + (long)p, e);
+        if (e == text.end()) break;
+        p = (size_t)(e - text.begin()) + 1;
+    }
+    if (!repaired_path) { *blocks = (int)isa_repair::find(lines).size(); return RTGR_OK; }
+    std::string why;
+    const int n = isa_repair::repair(lines, &why);
+    if (n < 0) return fail(RTGR_ERR_BAD_ARG, std::string(listing_path) + ": " + why);
+    FILE* f = std::fopen(repaired_path, "wb");
+    if (!f) return fail(RTGR_ERR_BAD_ARG, std::string("cannot write ") + repaired_path);
+    for (size_t k = 0; k < lines.size(); k++) {
+        std::fwrite(lines[k].data(), 1, lines[k].size(), f);
+        if (k + 1 < lines.size()) std::fputc('\n', f);
+    }
+    if (std::fclose(f) != 0) return fail(RTGR_ERR_BAD_ARG, std::string("short write on ") + repaired_path);
+    *blocks = n;
+    return RTGR_OK;
+}
+
+int api::user_metric_loaded(rtgr_context* ctx, uint64_t id) {
+    rtgr_context* c = nullptr;
+    int rc = resolve_ctx(ctx, &c);
+    if (rc) return rc;
+    DeviceCtx& d = *c->devs[0];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (id == 0) return d.modules.empty() ? 0 : 1;
+    return d.find_module(id) ? 1 : 0;
+}
+
+}  // namespace rtgr

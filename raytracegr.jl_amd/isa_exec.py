@@ -50,7 +50,10 @@ LANE_SGPR_IO = ("v_readlane", "v_readfirstlane", "v_writelane")   # SGPR spill t
 BRANCH = re.compile(r"^(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc|s_call)")
 ALLOCATOR_VECTOR = re.compile(r"^(v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32|v_mov_b32(_e32)?|v_mov_b64(_e32)?|"
                               r"scratch_store_\w+|scratch_load_\w+)\s")
-PLAIN_SALU = re.compile(r"^(s_mov_b32|s_mov_b64|s_nop|s_waitcnt)\s")   # (s_waitcnt: no register operand, indifferent to EXEC)
+# (s_movk_i32: a 16-bit constant into an SGPR — the same move as s_mov_b32 with a literal, reads neither EXEC nor SCC; the compiler
+#  picks it for small constants such as scratch offsets: round 6's headers made one appear ahead of a flip.  s_waitcnt: no register
+#  operand, indifferent to EXEC)
+PLAIN_SALU = re.compile(r"^(s_mov_b32|s_mov_b64|s_movk_i32|s_nop|s_waitcnt)\s")
 
 
 class RepairError(RuntimeError):

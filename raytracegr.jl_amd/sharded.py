@@ -41,20 +41,24 @@ def trace_slab_torch(scene, opt, cam, ni, nj, j0, j1, device="cuda", dtype=np.fl
         if "rgb" not in res:
             res["rgb"] = torch.empty((3, n), dtype=td, device=dev)
         o = _abi.rtgr_ray_outputs()
+        # the hit map (omin, :518-526) is one byte per ray; an object list beyond 255 needs the 32-bit output (rtgr_ray_outputs.hit32)
+        wide = scene.nobj > 255
+        hit_dtype, hit_field = (torch.int32, "hit32") if wide else (torch.uint8, "hit")
         if hit_only:  # big frames: the hit map is one byte per ray, the other per-ray outputs are 85
             if "hit" not in res:
-                res["hit"] = torch.empty(n, dtype=torch.uint8, device=dev)
-            o.hit = res["hit"].data_ptr()
+                res["hit"] = torch.empty(n, dtype=hit_dtype, device=dev)
+            setattr(o, hit_field, res["hit"].data_ptr())
         if details:
             if "state_end" not in res:
                 res["state_end"] = torch.empty((n, 8), dtype=td, device=dev)
                 res["lambda_end"] = torch.empty(n, dtype=td, device=dev)
                 res["status"] = torch.empty(n, dtype=torch.uint8, device=dev)
-                res["hit"] = torch.empty(n, dtype=torch.uint8, device=dev)
+                res["hit"] = torch.empty(n, dtype=hit_dtype, device=dev)
                 res["n_accept"] = torch.empty(n, dtype=torch.int32, device=dev)
                 res["n_reject"] = torch.empty(n, dtype=torch.int32, device=dev)
-            for k in ("state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            for k in ("state_end", "lambda_end", "status", "n_accept", "n_reject"):
                 setattr(o, k, res[k].data_ptr())
+            setattr(o, hit_field, res["hit"].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
         fn = lib.rtgr_trace_device_f64 if dtype == np.float64 else lib.rtgr_trace_device_f32
         s0 = None

@@ -26,6 +26,12 @@
  *                                   rtgr_user_source_join, compiled IN-PROCESS by rtgr_user_unit_compile for example2's metric, the
  *                                   unit's id put into the scene, rtgr_user_unit_info, rtgr_scene_check, rtgr_trace_f64 at 64 x 64
  *                                   with an rtgr_ray_outputs block; same output format as --render-disk (compared with the oracle)
+ *   abi_layout --render-many <lib> out N
+ *                                   `objs::Vector{Object{T}}` of any length (src/RayTraceGR.jl:433-441) from plain C: N objects (sky, far
+ *                                   plane, N - 2 small spheres on a spiral around the hole) in a caller array behind rtgr_scene.objects
+ *                                   — what julia/RayTraceGRHIP.jl passes as `pointer(packed)` —, rtgr_trace_f64 at 48 x 48 with the
+ *                                   32-bit hit map (rtgr_ray_outputs.hit32); writes the RGB planes, hit32, status, n_accept, n_reject
+ *                                   and the N objects themselves (the test builds the oracle's scene from those bytes)
  */
 #include <dlfcn.h>
 #include <math.h>
@@ -39,9 +45,10 @@
 /* ---- the table (bytes) -------------------------------------------------------------------------------------------- */
 _Static_assert(sizeof(rtgr_object) == 80, "rtgr_object");
 _Static_assert(offsetof(rtgr_object, kind) == 0 && offsetof(rtgr_object, type) == 4 && offsetof(rtgr_object, p) == 8, "rtgr_object fields");
-_Static_assert(sizeof(rtgr_scene) == 1312, "rtgr_scene");
+_Static_assert(sizeof(rtgr_scene) == 1320, "rtgr_scene");
 _Static_assert(offsetof(rtgr_scene, metric) == 0 && offsetof(rtgr_scene, nobj) == 4 && offsetof(rtgr_scene, M) == 8 &&
-               offsetof(rtgr_scene, a) == 16 && offsetof(rtgr_scene, user_metric) == 24 && offsetof(rtgr_scene, obj) == 32, "rtgr_scene fields");
+               offsetof(rtgr_scene, a) == 16 && offsetof(rtgr_scene, user_metric) == 24 && offsetof(rtgr_scene, obj) == 32 &&
+               offsetof(rtgr_scene, objects) == 1312, "rtgr_scene fields");
 _Static_assert(sizeof(rtgr_solver) == 72, "rtgr_solver");
 _Static_assert(offsetof(rtgr_solver, reltol) == 0 && offsetof(rtgr_solver, abstol) == 8 && offsetof(rtgr_solver, lambda0) == 16 &&
                offsetof(rtgr_solver, lambda1) == 24 && offsetof(rtgr_solver, hit_threshold) == 32 &&
@@ -54,11 +61,11 @@ _Static_assert(sizeof(rtgr_counters) == 64, "rtgr_counters");
 _Static_assert(offsetof(rtgr_counters, rays) == 0 && offsetof(rtgr_counters, accepted) == 8 && offsetof(rtgr_counters, rejected) == 16 &&
                offsetof(rtgr_counters, rhs_evals) == 24 && offsetof(rtgr_counters, events) == 32 &&
                offsetof(rtgr_counters, events_interior) == 40 && offsetof(rtgr_counters, not_finished) == 48, "rtgr_counters fields");
-_Static_assert(sizeof(rtgr_ray_outputs) == 56, "rtgr_ray_outputs");
+_Static_assert(sizeof(rtgr_ray_outputs) == 64, "rtgr_ray_outputs");
 _Static_assert(offsetof(rtgr_ray_outputs, state_end) == 0 && offsetof(rtgr_ray_outputs, lambda_end) == 8 &&
                offsetof(rtgr_ray_outputs, status) == 16 && offsetof(rtgr_ray_outputs, hit) == 24 &&
                offsetof(rtgr_ray_outputs, n_accept) == 32 && offsetof(rtgr_ray_outputs, n_reject) == 40 &&
-               offsetof(rtgr_ray_outputs, redshift) == 48, "rtgr_ray_outputs fields");
+               offsetof(rtgr_ray_outputs, redshift) == 48 && offsetof(rtgr_ray_outputs, hit32) == 56, "rtgr_ray_outputs fields");
 
 /* Pixel{Float64} of the reference (src/RayTraceGR.jl:446-450): pos::SVector{4}, normal::SVector{4}, rgb::SVector{3} */
 typedef struct { double pos[4], normal[4], rgb[3]; } pixel_f64;
@@ -116,7 +123,7 @@ static const char* const BALL_SRC =
     "}\n";                                  /* (no reach bound: its objects are scanned on every step) */
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render|--render-disk|--render-user-objects <lib> [out [ndev]]\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: abi_layout --symbols|--render|--render-disk|--render-user-objects|--render-many <lib> [out [ndev | nobj]]\n"); return 2; }
     void* h = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
     for (int i = 0; BOUND[i]; i++)
@@ -133,7 +140,7 @@ int main(int argc, char** argv) {
     fn_one one = (fn_one)dlsym(h, "rtgr_trace_one_f64");
     fn_err err = (fn_err)dlsym(h, "rtgr_last_error");
     rtgr_context* ctx = NULL;   /* NULL = the process's default context (one device) */
-    const int ndev = argc > 4 ? atoi(argv[4]) : 0;
+    const int ndev = (argc > 4 && strcmp(argv[1], "--render-many") != 0) ? atoi(argv[4]) : 0;   /* (--render-many: argv[4] is the object count) */
     if (ndev > 0) {
         int ids[RTGR_MAX_DEVICES] = {0};
         if (ndev > RTGR_MAX_DEVICES) return 2;
@@ -175,6 +182,55 @@ int main(int argc, char** argv) {
         fclose(f);
         if (ctx && ((fn_destroy)dlsym(h, "rtgr_destroy"))(ctx)) return 16;
         printf("ok %llu rays %llu events\n", (unsigned long long)ctr.rays, (unsigned long long)ctr.events);
+        return 0;
+    }
+    if (strcmp(argv[1], "--render-many") == 0) {
+        if (argc < 5) return 2;
+        const uint32_t nobj = (uint32_t)atoi(argv[4]);
+        if (nobj < 3) return 2;
+        fn_trace trace = (fn_trace)dlsym(h, "rtgr_trace_f64");
+        rtgr_object* objs = (rtgr_object*)calloc(nobj, sizeof(rtgr_object));
+        objs[0].kind = RTGR_SPHERE; objs[0].p[4] = 1.0; objs[0].p[8] = -12.0;                  /* caelum */
+        objs[1].kind = RTGR_PLANE; objs[1].p[0] = -25.0;                                        /* frustum */
+        for (uint32_t k = 2; k < nobj; k++) {                                                   /* small spheres on a spiral around the hole */
+            const double t = 0.7 * (double)k, rad = 3.0 + 4.5 * (double)(k - 2) / (double)nobj;
+            objs[k].kind = RTGR_SPHERE;
+            objs[k].p[1] = rad * cos(t); objs[k].p[2] = rad * sin(t) + 1.5; objs[k].p[3] = 1.2 * sin(2.3 * t);
+            objs[k].p[4] = 1.0; objs[k].p[8] = 0.2 + 0.25 * fabs(sin(1.1 * t));
+        }
+        rtgr_scene sc;
+        memset(&sc, 0, sizeof sc);
+        sc.metric = RTGR_KS_REF; sc.M = 1.0; sc.a = 0.0;                                        /* kerr_schild as written */
+        sc.nobj = nobj; sc.objects = objs;                                                      /* the whole list; obj[] is not read */
+        rtgr_camera cam;
+        memset(&cam, 0, sizeof cam);
+        cam.pos[1] = 4.0; cam.pos[2] = -2.0; cam.widthx[1] = 1.0; cam.widthy[3] = 1.0; cam.normal[2] = 1.0;
+        rtgr_solver opt;
+        if (defaults(&opt, 0)) return 5;
+        const uint64_t ni = 48, nj = 48, n = ni * nj;
+        double* rgb = (double*)calloc(3 * n, sizeof(double));
+        uint32_t* hit32 = (uint32_t*)calloc(n, 4);
+        uint8_t* status = (uint8_t*)calloc(n, 1);
+        uint32_t* nacc = (uint32_t*)calloc(n, 4);
+        uint32_t* nrej = (uint32_t*)calloc(n, 4);
+        rtgr_ray_outputs outs;
+        memset(&outs, 0, sizeof outs);
+        outs.hit32 = hit32; outs.status = status; outs.n_accept = nacc; outs.n_reject = nrej;
+        rtgr_counters ctr;
+        if (trace(ctx, &sc, &opt, NULL, &cam, ni, nj, 0, nj, rgb, &outs, &ctr)) { fprintf(stderr, "rtgr_trace_f64: %s\n", err()); return 7; }
+        if (ctr.rays != n) return 8;
+        sc.objects = NULL;                   /* a list beyond the inline slots without the array is refused, not truncated */
+        if (nobj > RTGR_MAX_OBJECTS && trace(ctx, &sc, &opt, NULL, &cam, ni, nj, 0, nj, rgb, NULL, NULL) == 0) { fprintf(stderr, "a truncated list was traced\n"); return 26; }
+        FILE* f = fopen(argv[3], "wb");
+        if (!f) return 9;
+        fwrite(rgb, sizeof(double), 3 * n, f);
+        fwrite(hit32, 4, n, f);
+        fwrite(status, 1, n, f);
+        fwrite(nacc, 4, n, f);
+        fwrite(nrej, 4, n, f);
+        fwrite(objs, sizeof(rtgr_object), nobj, f);
+        fclose(f);
+        printf("ok %llu rays %u objects\n", (unsigned long long)ctr.rays, nobj);
         return 0;
     }
     if (strcmp(argv[1], "--render-user-objects") == 0) {

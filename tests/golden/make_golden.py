@@ -19,10 +19,11 @@ from scenes import scene_variant, rt  # noqa: E402
 
 VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk"]
 SHAPES = ["ks_ref0_shapes", "ks_true08_shapes", "mink_shapes"]   # user-defined Object subtypes (examples/user_objects.py; oracle twins)
+MANY = ["ks_ref0_many64", "ks_true08_many64"]                    # an object list beyond the 16 inline slots (rtgr_scene.objects)
 N = 32
 
 if __name__ == "__main__":
-    for name in (sys.argv[1:] or VARIANTS + SHAPES):
+    for name in (sys.argv[1:] or VARIANTS + SHAPES + MANY):
         sc, cam = scene_variant(name, units=False)
         r = O.trace(sc, rt.solver_defaults(), N, N, cam=cam)
         out = os.path.join(HERE, f"oracle_{name}_{N}.npz")

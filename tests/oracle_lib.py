@@ -25,14 +25,15 @@ def lib():
     return _lib
 
 
-def _outs(n, dtype, want):
+def _outs(n, dtype, want, wide=False):
+    """wide: the hit map as 32 bits (rtgr_ray_outputs.hit32) — object lists beyond 255"""
     o = abi.rtgr_ray_outputs()
     arrs = {}
     if want:
         arrs = dict(state_end=np.zeros((n, 8), dtype), lambda_end=np.zeros(n, dtype), status=np.zeros(n, np.uint8),
-                    hit=np.zeros(n, np.uint8), n_accept=np.zeros(n, np.uint32), n_reject=np.zeros(n, np.uint32))
+                    hit=np.zeros(n, np.uint32 if wide else np.uint8), n_accept=np.zeros(n, np.uint32), n_reject=np.zeros(n, np.uint32))
         for k, v in arrs.items():
-            setattr(o, k, v.ctypes.data)
+            setattr(o, "hit32" if (wide and k == "hit") else k, v.ctypes.data)
     return o, arrs
 
 
@@ -41,7 +42,7 @@ def trace(scene, opt, ni, nj, j0=0, j1=None, cam=None, state0=None, dtype=np.flo
     j1 = nj if j1 is None else j1
     n = ni * (j1 - j0)
     rgb = np.zeros((3, n), dtype)
-    o, arrs = _outs(n, dtype, details)
+    o, arrs = _outs(n, dtype, details, wide=scene.nobj > 255)
     ctr = abi.rtgr_counters()
     fn = lib().rtgr_oracle_trace_f64 if dtype == np.float64 else lib().rtgr_oracle_trace_f32
     s0 = None

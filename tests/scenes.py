@@ -31,10 +31,32 @@ def user_shapes(reach=True, jit=False):
 _FAMILIES = {}
 
 
+def many_objects(nobj, seed=7):
+    """`objs::Vector{Object{T}}` has no length limit in the reference (src/RayTraceGR.jl:433-441, :483, :520-526): example2's sky
+    sphere and far plane, then nobj - 2 seeded small spheres scattered around the hole (none contains example2's camera, none the
+    horizon).  The list's ORDER carries the colour scale omin / length(objs) (:530) and first-smaller-wins (:520-526)."""
+    rng = np.random.default_rng(seed)
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -12.0), rt.Plane(-25.0)]
+    cam = np.array([4.0, -2.0, 0.0])
+    while len(objs) < nobj:
+        d = rng.normal(size=3)
+        c = d / np.linalg.norm(d) * rng.uniform(2.8, 8.5) * np.array([1.0, 1.0, 0.6])
+        r = rng.uniform(0.15, 0.55)
+        if np.linalg.norm(c - cam) < r + 0.3 or np.linalg.norm(c) < 2.5 + r:
+            continue
+        objs.append(rt.Sphere((0, *c), (1, 0, 0, 0), r))
+    return objs
+
+
 def scene_variant(name, units=True, reach=True, jit=False):
     """BASELINE.json configs: 'ks_ref0' (example2 as written), 'ks_ref08', 'ks_true0', 'ks_true08', 'ks_true0998',
     'ks_true0998_disk' (config 5), 'mink' (example1).  '<variant>_shapes': the same with example2's small sphere replaced by two
     user-defined objects (user_shapes; units=False: a scene for the oracle — nothing is compiled or loaded)."""
+    if "_many" in name:   # '<variant>_many<N>': N objects (many_objects) in place of example2's three, same camera
+        base, n = name.split("_many")
+        metric = {"ks_ref0": rt.kerr_schild, "ks_true08": rt.KerrSchild(1, 0.8), "ks_ref0_generic": rt.KerrSchild(1, 0.0, textbook=False, generic=True),
+                  "mink": rt.minkowski}[base]
+        return rt.make_scene(metric, many_objects(int(n)), units=units), rt.make_camera(**rt.example2_scene()[2])
     if name.endswith("_shapes"):
         base = name[:-len("_shapes")]
         metric, objs, cam = rt.example1_scene() if base == "mink" else rt.example2_scene()
@@ -65,14 +87,14 @@ def circular_channels(hit, sc=None):
     circ = np.zeros((3, n), bool)
     kinds = np.full(n, rt._abi.SPHERE)
     if sc is not None:
-        table = np.array([0] + [sc.obj[o].kind for o in range(sc.nobj)])
+        table = np.array([0] + [sc.object(o).kind for o in range(sc.nobj)])
         kinds = table[np.minimum(hit, sc.nobj)]
     sph, dsk = (kinds == rt._abi.SPHERE) & (hit > 0), (kinds == rt._abi.DISK) & (hit > 0)
     circ[0] = sph
     circ[1] = sph | dsk
     circ[2] = dsk
     if sc is not None:   # the user objects of examples/user_objects.py: torus (type 0) R and G, ellipsoid (type 1) R and B
-        types = np.array([0] + [sc.obj[o].type for o in range(sc.nobj)])[np.minimum(hit, sc.nobj)]
+        types = np.array([0] + [sc.object(o).type for o in range(sc.nobj)])[np.minimum(hit, sc.nobj)]
         usr = (kinds == rt._abi.USER_OBJECT) & (hit > 0)
         circ[0] |= usr
         circ[1] |= usr & (types == 0)

@@ -39,13 +39,13 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_struct_sizes_match_the_header(lib):
-    # layouts in include/rtgr.h: object 8+72, scene 8+16+8+16*80, solver 8*8+8, camera 128, counters 64, outputs 56
+    # layouts in include/rtgr.h: object 8+72, scene 8+16+8+16*80+8, solver 8*8+8, camera 128, counters 64, outputs 64
     assert C.sizeof(abi.rtgr_object) == 80
-    assert C.sizeof(abi.rtgr_scene) == 32 + 16 * 80
+    assert C.sizeof(abi.rtgr_scene) == 32 + 16 * 80 + 8
     assert C.sizeof(abi.rtgr_solver) == 72
     assert C.sizeof(abi.rtgr_camera) == 128
     assert C.sizeof(abi.rtgr_counters) == 64
-    assert C.sizeof(abi.rtgr_ray_outputs) == 56
+    assert C.sizeof(abi.rtgr_ray_outputs) == 64
 
 
 def test_solver_defaults_are_the_reference_constants(lib):
@@ -118,10 +118,10 @@ def test_c_caller_layout_and_symbols(lib, tmp_path):
     assert sizes == {"scene": C.sizeof(abi.rtgr_scene), "solver": C.sizeof(abi.rtgr_solver), "camera": C.sizeof(abi.rtgr_camera),
                      "counters": C.sizeof(abi.rtgr_counters), "outputs": C.sizeof(abi.rtgr_ray_outputs),
                      "object": C.sizeof(abi.rtgr_object), "pixel": rt.pixel_dtype().itemsize}
-    assert abi.rtgr_scene.user_metric.offset == 24 and abi.rtgr_scene.obj.offset == 32
-    assert abi.rtgr_solver.max_steps.offset == 64 and abi.rtgr_ray_outputs.redshift.offset == 48
+    assert abi.rtgr_scene.user_metric.offset == 24 and abi.rtgr_scene.obj.offset == 32 and abi.rtgr_scene.objects.offset == 1312
+    assert abi.rtgr_solver.max_steps.offset == 64 and abi.rtgr_ray_outputs.redshift.offset == 48 and abi.rtgr_ray_outputs.hit32.offset == 56
     jl = open(os.path.join(ROOT, "julia", "RayTraceGRHIP.jl")).read()
-    for name, size in (("RtgrScene", 1312), ("RtgrSolver", 72), ("RtgrCamera", 128), ("RtgrRayOutputs", 56), (r"Pixel\{Float64\}", 88)):
+    for name, size in (("RtgrScene", 1320), ("RtgrSolver", 72), ("RtgrCamera", 128), ("RtgrRayOutputs", 64), (r"Pixel\{Float64\}", 88)):
         assert re.search(r"^#\s+" + name + r"\s+" + str(size) + r"\s", jl, re.M), name
 
 
@@ -170,6 +170,41 @@ def test_c_caller_renders_the_kerr_disk_scene(lib, tmp_path, ndev):
     flips = hit != ref["hit"]
     assert int(flips.sum()) <= 2, int(flips.sum())
     assert (hit == 3).sum() > 50                      # the disk is in the picture
+    same = ~flips
+    assert (status[same] == ref["status"][same]).all()
+    assert np.abs((nacc + nrej).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))[same].max() <= 2
+    assert wrap_aware_rgb_err(rgb[:, same], ref["rgb"][:, same], hit[same], sc=sc) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nobj", [16, 17, 40])
+def test_c_caller_traces_an_object_list_of_any_length(lib, tmp_path, nobj):
+    """`objs::Vector{Object{T}}` (src/RayTraceGR.jl:433-441, :483) from a plain C process: N objects in a caller array behind
+    rtgr_scene.objects — the bytes julia/RayTraceGRHIP.jl passes as `pointer(packed)` —, the 32-bit hit map; against the oracle on the
+    scene rebuilt from the objects the C program wrote.  16: the array route with a list the inline slots would hold; 17: one beyond."""
+    import subprocess
+    import oracle_lib as O
+    from scenes import wrap_aware_rgb_err
+    exe = _build_c_caller(tmp_path)
+    out = str(tmp_path / "many.bin")
+    res = subprocess.run([exe, "--render-many", abi.LIB_PATH, out, str(nobj)], capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stderr)
+    n = 48 * 48
+    raw = open(out, "rb").read()
+    rgb = np.frombuffer(raw, np.float64, 3 * n).reshape(3, n)
+    hit = np.frombuffer(raw, np.uint32, n, 24 * n)
+    status = np.frombuffer(raw, np.uint8, n, 28 * n)
+    nacc = np.frombuffer(raw, np.uint32, n, 29 * n)
+    nrej = np.frombuffer(raw, np.uint32, n, 33 * n)
+    arr = (abi.rtgr_object * nobj).from_buffer_copy(raw[37 * n:37 * n + 80 * nobj])
+    sc = rt.make_scene(rt.kerr_schild, [])
+    sc.nobj, sc._keep = nobj, arr
+    sc.objects = C.cast(arr, C.POINTER(abi.rtgr_object))
+    _, _, cam = rt.example2_scene()
+    ref = O.trace(sc, rt.solver_defaults(), 48, 48, cam=rt.make_camera(**cam))
+    flips = hit != ref["hit"]
+    assert int(flips.sum()) <= 4, int(flips.sum())
+    assert len(np.unique(hit)) >= 6 and (nobj <= 16 or hit.max() > 16)      # several spheres in view, some from beyond the inline slots
     same = ~flips
     assert (status[same] == ref["status"][same]).all()
     assert np.abs((nacc + nrej).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))[same].max() <= 2

@@ -12,7 +12,8 @@ from conftest import ROOT
 from scenes import rt, scene_variant
 
 VARIANTS = ["mink", "ks_ref0", "ks_ref08", "ks_true0", "ks_true08", "ks_true0998", "ks_true0998_disk",
-            "ks_ref0_shapes", "ks_true08_shapes", "mink_shapes"]   # *_shapes: user-defined Object subtypes (examples/user_objects.py)
+            "ks_ref0_shapes", "ks_true08_shapes", "mink_shapes",   # *_shapes: user-defined Object subtypes (examples/user_objects.py)
+            "ks_ref0_many64", "ks_true08_many64"]                  # 64 objects: a list beyond the 16 inline slots (src/RayTraceGR.jl:433-441)
 N = 32
 
 

@@ -32,7 +32,7 @@ def hip_trace(lib, sc, opt, ni, nj, j0=0, j1=None, cam=None, state0=None, dtype=
     j1 = nj if j1 is None else j1
     n = ni * (j1 - j0)
     rgb = np.zeros((3, n), dtype)
-    o, arrs = O._outs(n, dtype, True)
+    o, arrs = O._outs(n, dtype, True, wide=sc.nobj > 255)
     ctr = abi.rtgr_counters()
     fn = lib.rtgr_trace_f64 if dtype == np.float64 else lib.rtgr_trace_f32
     s0 = None
@@ -324,10 +324,10 @@ def test_bad_arguments_are_rejected(lib):
 
 
 def test_maximum_object_count_and_empty_scene(lib):
-    """The edges of the object list: RTGR_MAX_OBJECTS (16) objects — a ring of small spheres around the hole inside the sky
+    """The edges of the INLINE object list: RTGR_MAX_OBJECTS (16) objects — a ring of small spheres around the hole inside the sky
     sphere, the colour scale omin/length(objs) (src/RayTraceGR.jl:530) and first-smaller-wins (:520-526) over all of them —
-    against the oracle; one more than the maximum is refused; an EMPTY list means min_distance = +Inf (:433-441), no event,
-    every ray runs to λ1 and gets the miss colour (:527-528)."""
+    against the oracle; one more than the inline slots hold WITHOUT rtgr_scene.objects is refused (with it: the tests below); an
+    EMPTY list means min_distance = +Inf (:433-441), no event, every ray runs to λ1 and gets the miss colour (:527-528)."""
     _, _, cam = rt.example2_scene()
     cam = rt.make_camera(**cam)
     ring = [rt.Sphere((0, 4.5 * np.cos(t), 4.5 * np.sin(t), 0.6 * np.sin(3 * t)), (1, 0, 0, 0), 0.45)
@@ -344,8 +344,9 @@ def test_maximum_object_count_and_empty_scene(lib):
     sc.nobj = abi.RTGR_MAX_OBJECTS + 1
     rgb = np.zeros((3, 4))
     assert lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), 2, 2, 0, 2, rgb.ctypes.data, None, None) == abi.ERR_BAD_ARG
-    with pytest.raises(ValueError):
-        rt.make_scene(rt.kerr_schild, objs + [rt.Plane(-30.0)])
+    assert "rtgr_scene.objects" in lib.rtgr_last_error().decode()
+    sc17 = rt.make_scene(rt.kerr_schild, objs + [rt.Plane(-30.0)])      # the Python mirror hands a longer list over as an array
+    assert sc17.nobj == 17 and bool(sc17.objects) and sc17.object(16).kind == abi.PLANE
     empty = rt.make_scene(rt.KerrSchild(1.0, 0.5), [])
     opt15 = rt.solver_defaults(lambda1=15.0, miss_rgb=(0.25, 0.5, 0.75))
     g = hip_trace(lib, empty, opt15, 24, 24, cam=cam)
@@ -356,6 +357,66 @@ def test_maximum_object_count_and_empty_scene(lib):
     assert far.sum() > 300 and np.allclose(g["lambda_end"][far], 15.0)
     assert (g["rgb"] == np.array([[0.25], [0.5], [0.75]])).all()
     assert np.abs(g["state_end"][far] - r["state_end"][far]).max() < 1e-8
+
+
+@pytest.mark.parametrize("name,n,nobj", [("ks_ref0_many17", 40, 17), ("ks_ref0_many64", 64, 64), ("ks_true08_many64", 48, 64),
+                                         ("ks_ref0_generic_many33", 32, 33), ("mink_many20", 32, 20)])
+def test_object_lists_of_any_length_match_oracle(lib, name, n, nobj):
+    """`objs::Vector{Object{T}}` has no length limit in the reference (src/RayTraceGR.jl:433-441, :483; the colouring loop runs over
+    all of it, :520-526, and scales by its length, :530).  Lists beyond the 16 inline slots travel through rtgr_scene.objects: the
+    first 16 in the kernels' argument block, the rest in a device table (DevScene::more) — same walk, same order.  Against the oracle at
+    the north-star bar, for the closed-form a = 0 and a != 0 kernels, the generic dual-number kernels and flat space."""
+    sc, cam = scene_variant(name)
+    assert sc.nobj == nobj and bool(sc.objects)
+    opt = rt.solver_defaults()
+    g = hip_trace(lib, sc, opt, n, n, cam=cam)
+    r = O.trace(sc, opt, n, n, cam=cam)
+    assert (np.unique(r["hit"]) > abi.RTGR_MAX_OBJECTS).any() and (np.unique(r["hit"]) <= abi.RTGR_MAX_OBJECTS).any()   # hits on both sides of the 16
+    mink = name.startswith("mink")
+    compare(g, r, sc=sc, max_class_flips=40 if mink else 6, max_step_diff=4 if mink else 2)
+    assert g["counters"]["rays"] == n * n
+
+
+def test_a_short_list_through_the_objects_pointer_is_the_inline_list(lib):
+    """rtgr_scene.objects is only another way to hand the list over: example2's three objects as a caller array give the frame of the
+    inline slots bit for bit (and obj[] is not read: it holds garbage here)."""
+    sc, cam = example(2)
+    arr = (abi.rtgr_object * 3)(*[sc.obj[k] for k in range(3)])
+    via = sc.clone()
+    via.objects = C.cast(arr, C.POINTER(abi.rtgr_object))
+    for k in range(3):
+        via.obj[k].kind = 77
+    opt = rt.solver_defaults()
+    a = hip_trace(lib, sc, opt, 48, 48, cam=cam)
+    b = hip_trace(lib, via, opt, 48, 48, cam=cam)
+    for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_three_hundred_objects_and_the_wide_hit_map(lib):
+    """Beyond 255 objects omin (src/RayTraceGR.jl:518-526) does not fit the byte of rtgr_ray_outputs.hit: the call says so, and
+    hit32 carries it.  A 300-object list against the oracle (coarse canvas: the oracle pays 300 distances per callback evaluation)."""
+    sc, cam = scene_variant("ks_ref0_many300")
+    opt = rt.solver_defaults()
+    n = 24
+    rgb = np.zeros((3, n * n))
+    o = abi.rtgr_ray_outputs()
+    hit8 = np.zeros(n * n, np.uint8)
+    o.hit = hit8.ctypes.data
+    assert lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), n, n, 0, n, rgb.ctypes.data, C.byref(o), None) == abi.ERR_BAD_ARG
+    assert "hit32" in lib.rtgr_last_error().decode()
+    g = hip_trace(lib, sc, opt, n, n, cam=cam)
+    r = O.trace(sc, opt, n, n, cam=cam)
+    assert g["hit"].dtype == np.uint32 and int(r["hit"].max()) > 255
+    compare(g, r, sc=sc, max_class_flips=4, max_step_diff=2)
+    # the redshift output reads the hit map it is given: the wide one here
+    red = np.zeros(n * n)
+    se = np.zeros((n * n, 8))
+    h32 = np.zeros(n * n, np.uint32)
+    o = abi.rtgr_ray_outputs()
+    o.hit32, o.state_end, o.redshift = h32.ctypes.data, se.ctypes.data, red.ctypes.data
+    abi.check(lib, lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), n, n, 0, n, rgb.ctypes.data, C.byref(o), None))
+    assert np.array_equal(h32, g["hit"]) and np.isfinite(red[h32 > 2]).all() and np.isnan(red[h32 == 0]).all()
 
 
 def test_max_steps_status(lib):

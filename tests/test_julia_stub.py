@@ -246,14 +246,16 @@ def test_user_objects_are_wired_to_the_abi():
     rtgr_user_unit_compile with the scene as `built_for` (or C_NULL when a DeviceMetric's source is in the same unit); the unit's id
     lands in the scene; an object type without device source still yields `nothing` -> the reference's CPU path."""
     names, code = stub_definitions()
-    assert {"DeviceObjects", "DeviceObject", "unit_id", "UNIT_IDS"} <= names, names
+    assert {"DeviceObjects", "DeviceObject", "unit_id"} <= names, names
+    assert "UNIT_IDS" not in names    # (the library's own memo checks residency; a table on this side handed out dead ids, ADVICE r5)
     assert re.search(r"struct DeviceObject\{T\} <: RayTraceGR\.Object\{T\}", code)
     assert re.search(r"pack\(o::DeviceObject\)\s*=\s*RtgrObject\(RTGR_USER_OBJECT, o\.type, o\.p\)", code)
     assert re.search(r"pack\(o::RayTraceGR\.Object\)\s*=\s*nothing", code)
     m = re.search(r"ccall\(\(:rtgr_user_unit_compile, librtgr\), Cint, \(Ctx, Cstring, Cint, Ptr\{RtgrScene\}, Ptr\{UInt64\}\),\s*"
                   r"handle\(ctx\), source, own && metric\.stationary, own \? C_NULL : scene, id\)", code)
     assert m, "unit_id must hand rtgr_user_unit_compile the scene the unit is meant for (C_NULL when the unit has a metric of its own)"
-    assert re.search(r"Ref\(RtgrScene\(d\[1\], length\(objs\), d\[2\], d\[3\], unit_id\(family, metric, scene, ctx\), packed\)\)", code)
+    assert re.search(r"make\(unit_id\(family, metric, scene, ctx\)\), nothing", code)
+    assert re.search(r"make\(unit\) = Scene\(Ref\(RtgrScene\(d\[1\], length\(objs\), d\[2\], d\[3\], unit, packed, isempty\(list\) \? Ptr\{RtgrObject\}\(C_NULL\) : pointer\(list\)\)\), list\)", code)
     # several families in one scene: joined by the library (one namespace per source), each object's tag moved by its family's base
     assert {"join_families", "JOINED"} <= names
     assert re.search(r"ccall\(\(:rtgr_user_source_join, librtgr\), Cint, \(Ptr\{Cstring\}, Ptr\{UInt32\}, Cint, Ptr\{UInt8\}, UInt64, Ptr\{UInt64\}\),\s*"
@@ -282,7 +284,7 @@ JL_BASE = {"AbstractString", "Array", "Base", "C_NULL", "Cint", "Cstring", "Cvoi
            "clamp", "close", "collect", "count", "dirname", "eltype", "eps", "error", "fieldcount", "fieldoffset", "finalizer", "get", "get!",
            "hash", "include", "inv", "isbitstype", "minimum", "Vector", "sum", "findfirst", "ErrorException", "isempty", "isnan", "isnothing", "joinpath", "length", "map", "max", "maximum", "mkpath", "mod",
            "new", "ntuple", "permutedims", "pointer", "println", "reinterpret", "rm", "round", "similar", "size", "sizeof", "sqrt", "undef",
-           "unique", "unsafe_string", "zeros", "π"}
+           "unique", "unsafe_string", "zeros", "π", "Symbol", "nameof", "typeof", "findall", "string", "first", "last", "isa", "copy", "push!", "empty!", "haskey", "min", "cld", "fill", "view", "reshape", "Threads", "time_ns", "UInt", "Bool", "Nothing", "nothing", "pointer_from_objref", "append!", "iseven"}
 JL_PACKAGES = {"SVector", "SMatrix", "SArray", "I", "RayTraceGR", "RayTraceGRHIP", "Images"}
 JL_REFERENCE_EXPORTS = {"Dual", "D", "minkowski", "kerr_schild", "dmetric", "christoffel", "Ray", "r2s", "s2r", "geodesic", "Object", "Plane",
                         "Sphere", "min_distance", "Pixel", "Canvas", "make_canvas", "trace_rays"}
@@ -313,10 +315,10 @@ def test_the_julia_checker_finds_what_a_parser_or_a_first_run_would():
     wrong order, an `end` too many, an `elseif` spelled `else if`, a misspelled local variable, a misspelled function — are refused."""
     import julia_lint as L
     src = open(JL).read()
-    assert 'check(ccall((:rtgr_user_unit_compile, librtgr)' in src and "any(isnothing, po) && return nothing" in src
+    assert 'check(ccall((:rtgr_user_unit_compile, librtgr)' in src and "k = findfirst(isnothing, po)" in src
     faults = {
         "unterminated string": src.replace('const librtgr = get(ENV, "RTGR_LIB", "librtgr_hip.so")', 'const librtgr = get(ENV, "RTGR_LIB, "librtgr_hip.so")'),
-        "wrong bracket order": src.replace("any(isnothing, po) && return nothing", "any(isnothing, po] && return nothing"),
+        "wrong bracket order": src.replace("k = findfirst(isnothing, po)", "k = findfirst(isnothing, po]"),
         "an end too many": src.replace("ndevices(ctx) = Int(", "end\nndevices(ctx) = Int("),
         "else if": src.replace("else\n            check(ccall((:rtgr_make_canvas_f32", "else if true\n            check(ccall((:rtgr_make_canvas_f32", 1),
     }
@@ -325,8 +327,8 @@ def test_the_julia_checker_finds_what_a_parser_or_a_first_run_would():
         with pytest.raises(L.LintError):
             L.check_structure(L.tokenize(text))
     # names
-    for what, text, name in (("misspelled local", src.replace("any(isnothing, po) && return nothing", "any(isnothing, p0) && return nothing"), "p0"),
-                             ("misspelled function", src.replace("scene = scene_of(metric, objs, ctx)\n    scene === nothing && return RayTraceGR.trace_rays", "scene = scene_off(metric, objs, ctx)\n    scene === nothing && return RayTraceGR.trace_rays", 1), "scene_off"),
+    for what, text, name in (("misspelled local", src.replace("k = findfirst(isnothing, po)", "k = findfirst(isnothing, p0)"), "p0"),
+                             ("misspelled function", src.replace("scene, why = scene_of(metric, objs, ctx)\n    if scene === nothing\n        cpu_fallback(\"trace_rays\", why)", "scene, why = scene_off(metric, objs, ctx)\n    if scene === nothing\n        cpu_fallback(\"trace_rays\", why)", 1), "scene_off"),
                              ("misspelled constant", src.replace("pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECT, o.type, o.p)", "pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECTS, o.type, o.p)"), "RTGR_USER_OBJECTS")):
         assert text != src, what
         _, unbound = _lint(text, is_text=True)
@@ -350,7 +352,7 @@ def test_calls_fit_the_methods_the_julia_files_define():
     assert L.check_arity(tt, arities, qualifier="RayTraceGRHIP") == []
     assert L.check_arity(tt, L.method_arities(tt)) == []
     for what, text, name, given in (
-            ("an argument dropped", src.replace("unit_id(family, metric, scene, ctx), packed))", "unit_id(family, metric, scene), packed))"), "unit_id", 3),
+            ("an argument dropped", src.replace("make(unit_id(family, metric, scene, ctx)), nothing", "make(unit_id(family, metric, scene)), nothing"), "unit_id", 3),
             ("one too many", src.replace("cam = camera_of(pos, widthx, widthy, normal)", "cam = camera_of(pos, widthx, widthy, normal, ni)", 1), "camera_of", 5),
             ("a field forgotten", src.replace("pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECT, o.type, o.p)", "pack(o::DeviceObject) = RtgrObject(RTGR_USER_OBJECT, o.p)"), "RtgrObject", 2)):
         assert text != src, what
