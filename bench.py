@@ -32,6 +32,7 @@ import argparse
 import glob
 import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -97,6 +98,10 @@ def parse():
     ap.add_argument("--user-sphere", action="store_true",
                     help="example2's small sphere as a USER-DEFINED object of the same geometry (examples/user_objects.py "
                          "SPHERE_AS_USER_OBJECT through a run-time unit): what variants.user_sphere_* times, as a workload of its own")
+    ap.add_argument("--objects", type=int, default=3,
+                    help="length of the object list: example2's three objects plus N - 3 small spheres on a spiral around the hole (the "
+                         "reference's Vector{Object} has no length limit, src/RayTraceGR.jl:433-441; beyond 16 the list travels through "
+                         "rtgr_scene.objects) — what variants.objects16 / objects64 time, as a workload of its own")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one stream, trace and gather strictly in turn (no frames in flight)")
@@ -117,10 +122,19 @@ def parse():
 _USER_SPHERE = {}
 
 
-def build_scene(rt, variant, generic=False, user_sphere=False):
+def spiral_spheres(n):
+    """n small spheres (radius 0.2-0.45) on a spiral of radius 3-7.5 around the hole: the extra objects of --objects N"""
+    out = []
+    for k in range(n):
+        t, rad = 0.7 * (k + 2), 3.0 + 4.5 * k / max(n, 1)
+        out.append(((0.0, rad * math.cos(t), rad * math.sin(t) + 1.5, 1.2 * math.sin(2.3 * t)), 0.2 + 0.25 * abs(math.sin(1.1 * t))))
+    return out
+
+
+def build_scene(rt, variant, generic=False, user_sphere=False, nobj=3):
     """user_sphere: example2's small sphere typed as a USER object (examples/user_objects.py SPHERE_AS_USER_OBJECT: the same
     distance, colour rule and reach bound through the run-time unit's generic dispatch) — the frame is the same, the difference in
-    time is what a user-defined Object costs against a built-in one."""
+    time is what a user-defined Object costs against a built-in one.  nobj > 3: that many objects (spiral_spheres after example2's three)."""
     _, objs, cam = rt.example2_scene()
     if variant == "mink":
         metric, objs, cam = rt.example1_scene()
@@ -145,6 +159,8 @@ def build_scene(rt, variant, generic=False, user_sphere=False):
         if generic is True and variant != "mink":     # (the unit is built for the scene's metric variant)
             metric = rt.Metric(metric.kind, metric.M, metric.a, name=metric.__name__, generic=True)
             generic = False
+    if nobj > 3:
+        objs = list(objs) + [rt.Sphere(c, (1, 0, 0, 0), r) for c, r in spiral_spheres(nobj - 3)]
     sc = rt.make_scene(metric, objs)
     if generic and variant != "mink":
         sc.metric |= rt._abi.METRIC_GENERIC
@@ -290,8 +306,10 @@ def live_counters(a, log=None):
             out = os.path.join(work, name)
             cmd = [tool, "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "1", "--warmup", "0",
-                   "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"] + (["--user-sphere"] if getattr(a, "user_sphere", False) else [])
-            env = dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp")
+                   "--cpu-sample", "0", "--extras", "0", "--live-counters", "0", "--objects", str(getattr(a, "objects", 3))] + (["--user-sphere"] if getattr(a, "user_sphere", False) else [])
+            # (RTGR_UNIT_PROBE=0: the parent process probed the unit when it loaded it; in the counted child the load-time probe's
+            #  own rtgr_user_prepare* / integrate dispatches would be counted as passes of the workload — ADVICE r5)
+            env = dict(os.environ, RTGR_NO_COMPILE="1", RTGR_UNIT_PROBE="0", TMPDIR="/tmp")
             r = run_group(cmd, env, 150, f"--pmc {' '.join(counters)} ({a.variant} {a.size} {a.dtype} {a.rhs})")
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
@@ -315,6 +333,10 @@ def live_counters(a, log=None):
                         passes += 1      # the set-up kernel runs once per pass (one pipeline chunk: checked below)
             if passes < 1:
                 return None, f"no set-up kernel among the dispatches rocprofv3 recorded for {counters}"
+            # … and the divisor must be what the child says it ran (its timed, warm-up and allocation passes): a set-up kernel of
+            # anything else in the process — a probe, a scene check — would deflate every per-pass figure
+            if child.get("passes_in_process") not in (None, passes):
+                return None, f"{passes} set-up dispatches counted for {counters}, but the child ran {child['passes_in_process']} passes"
             for k, v in part.items():     # (the child runs its one timed pass plus the warm-up the bench always does)
                 tot[k] = v / passes
     except subprocess.TimeoutExpired:
@@ -357,8 +379,8 @@ def kernel_trace_pass(a, tool):
     try:
         cmd = [tool, "--kernel-trace", "--stats", "--output-format", "csv", "-d", work, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--size", str(a.size), "--variant", a.variant, "--dtype", a.dtype, "--rhs", a.rhs, "--steps", "3", "--warmup", "1",
-               "--cpu-sample", "0", "--extras", "0", "--live-counters", "0"] + (["--user-sphere"] if getattr(a, "user_sphere", False) else [])
-        r = run_group(cmd, dict(os.environ, RTGR_NO_COMPILE="1", TMPDIR="/tmp"), 150, f"--kernel-trace ({a.variant} {a.size} {a.dtype} {a.rhs})")
+               "--cpu-sample", "0", "--extras", "0", "--live-counters", "0", "--objects", str(getattr(a, "objects", 3))] + (["--user-sphere"] if getattr(a, "user_sphere", False) else [])
+        r = run_group(cmd, dict(os.environ, RTGR_NO_COMPILE="1", RTGR_UNIT_PROBE="0", TMPDIR="/tmp"), 150, f"--kernel-trace ({a.variant} {a.size} {a.dtype} {a.rhs})")
         if r.returncode != 0:
             return None
         out = {}
@@ -413,7 +435,7 @@ def main():
     abi = rt._abi
 
     failed, line = False, {}
-    a.rhs_key = a.rhs + ("+user_sphere" if a.user_sphere else "")   # (profile / checksum key: a unit's kernels are not the library's)
+    a.rhs_key = a.rhs + ("+user_sphere" if a.user_sphere else "") + (f"+objects{a.objects}" if a.objects != 3 else "")   # (profile / checksum key: another workload)
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -459,7 +481,7 @@ def main():
     if ws > 1:
         os.environ["RTGR_NO_COMPILE"] = "1"   # --rhs user on a cold cache: fail fast instead of N ranks starting hipcc
     npdt = np.float64 if a.dtype == "f64" else np.float32
-    scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user", "user_ks": "user_ks"}[a.rhs], user_sphere=a.user_sphere)
+    scene, cam = build_scene(rt, a.variant, {"closed": False, "generic": True, "user": "user", "user_ks": "user_ks"}[a.rhs], user_sphere=a.user_sphere, nobj=a.objects)
     opt = rt.solver_defaults(npdt)
     ni = nj = a.size
     # rows are dealt cyclically (rank r: rows r, r+N, …): contiguous slabs of a black-hole image are unbalanced
@@ -725,7 +747,7 @@ def main():
             roof["stale_profile"] = why
         name = C_name(lib)
         extras = {}
-        if a.extras and not multi and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64" and not a.user_sphere:
+        if a.extras and not multi and a.entry == "device" and a.rhs == "closed" and a.dtype == "f64" and not a.user_sphere and a.objects == 3:
             try:   # (outside the timed region; a failure here must not cost the headline line)
                 extras = run_extras(a, rt, host_pass, pixels_pass, dt / a.steps)
             except Exception as e:  # noqa: BLE001
@@ -743,6 +765,7 @@ def main():
                        "size": a.size, "variant": a.variant, "rhs": a.rhs_key, "entry": a.entry,
                        "parallelism": f"rows/{ws if a.entry == 'device' else len(ctx_ids)}"},
             "rays_per_s": rays / dt, "rays": rays // a.steps, "step_attempts_per_pass": attempts // a.steps,
+            "passes_in_process": a.warmup + extra_warm + a.steps,
             "accepted": acc // a.steps, "rejected": rej // a.steps, "rhs_evals_per_pass": nrhs // a.steps,
             "device": name, "roofline": roof, "cpu_baseline": cpu,
         }
@@ -843,7 +866,7 @@ def main():
 _LAST_FRAME = [None]
 
 
-def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, live_on=False, user_sphere=False, keep_frame=False):
+def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, live_on=False, user_sphere=False, keep_frame=False, nobj=3):
     """One BASELINE configuration outside the headline's timed region: `reps` device-resident frames (camera on the device,
     nothing over PCIe), wall time + the library's HIP-event kernel times, and the same executed-flop roofline as the headline's,
     from counters read by this run (live_counters(); Float64 configurations) or THIS configuration's profile entry
@@ -852,7 +875,7 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     import torch
     from raytracegr_jl_amd import sharded
     npdt = np.float64 if dtype == "f64" else np.float32
-    sc, cam = build_scene(rt, variant, {"closed": False, "generic": True}[rhs], user_sphere=user_sphere)
+    sc, cam = build_scene(rt, variant, {"closed": False, "generic": True}[rhs], user_sphere=user_sphere, nobj=nobj)
     opt = rt.solver_defaults(npdt)
     ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
     o = {}
@@ -896,7 +919,8 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
                "same_frame": bool(torch.equal(outs2[0]["rgb"], o["rgb"]) and torch.equal(outs2[1]["rgb"], o["rgb"]))}
     bits = o["rgb"].contiguous().view(torch.int64 if dtype == "f64" else torch.int32).to(torch.int64)
     _LAST_FRAME[0] = o["rgb"].clone() if user_sphere or keep_frame else None
-    v = {"workload": f"{variant}, same camera, {n}x{n}, {dtype}, rhs {rhs}" + (", small sphere as a USER object" if user_sphere else ""),
+    v = {"workload": f"{variant}, same camera, {n}x{n}, {dtype}, rhs {rhs}" + (", small sphere as a USER object" if user_sphere else "") +
+                     (f", {nobj} objects (example2's three + {nobj - 3} small spheres)" if nobj != 3 else ""),
          "size": n, "dtype": dtype, "rhs": rhs, "frame_checksum": int(bits.sum().item()),
          "ms_per_pass": dt * 1e3, "step_attempts_per_s": att / dt, "rays_per_s": rays / dt,
          "step_attempts_per_ray": att / rays, "rejected_per_pass": int(ctr[2]) // reps}
@@ -905,10 +929,12 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     k_s = (float(kms[1]) + float(kms[3])) * 1e-3 / reps
     class _A:  # noqa: E701
         pass
-    _A.variant, _A.dtype, _A.rhs, _A.size = variant, dtype, rhs, size
+    _A.variant, _A.dtype, _A.rhs, _A.size, _A.objects = variant, dtype, rhs, size, nobj
     prof, why = load_profile(_A)
     if user_sphere:     # (the unit's kernels are other kernels than the profiled ones: timing only)
         prof, why, live_on = None, "a run-time unit's kernels: no profile entry", False
+    if nobj != 3:       # (another workload than the profiled one: live counters or nothing)
+        prof, why = None, "another object list than the profiled workload's"
     live, why_not_live = live_counters(_A) if live_on else (None, "off")
     # Float32: the packed two-rays-per-lane kernel is priced against the fp32 VECTOR peak (v_pk_fma_f32), as asked
     peak = FP64_VALU_PEAK_TFLOPS if dtype == "f64" else F32_PACKED_VALU_PEAK_TFLOPS
@@ -1004,6 +1030,33 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
                     "reach bound of the source called from the unit's own set-up, FAR, NEAR and resolve kernels"}
     except Exception as e:  # noqa: BLE001
         ex["variants"]["user_sphere_ks_ref0_2048"] = {"error": repr(e)}
+    # What a LONGER OBJECT LIST costs (round-5 review item 1: `objs::Vector{Object{T}}` has no length limit, src/RayTraceGR.jl:433-441):
+    # example2 at 2048² with its three objects, with 16 (the kernels' argument block full) and with 64 (48 of them in the device
+    # table).  Per step every object costs one reach test in the FAR pass and nine distances in a scanned NEAR step; the slope is
+    # read off the hardware's instruction counter (SQ_INSTS_VALU per wave-step, live) and off the pass times.
+    try:
+        base = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2, live_on=bool(a.live_counters))
+        rows = {3: base}
+        for nobj in (16, 64):
+            rows[nobj] = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 6 if nobj == 16 else 3, 1, live_on=bool(a.live_counters), nobj=nobj)
+        for nobj in (16, 64):
+            r, b = rows[nobj], rows[3]
+            e = {"workload": r["workload"], "ms_per_pass": r["ms_per_pass"], "three_objects_ms_per_pass": b["ms_per_pass"],
+                 "over_three_objects": r["ms_per_pass"] / b["ms_per_pass"],
+                 "far_near_ms": [r["roofline"]["far_pass_ms_per_pass"], r["roofline"]["near_pass_ms_per_pass"]],
+                 "three_objects_far_near_ms": [b["roofline"]["far_pass_ms_per_pass"], b["roofline"]["near_pass_ms_per_pass"]],
+                 "step_attempts_per_ray": r["step_attempts_per_ray"], "step_attempts_per_s": r["step_attempts_per_s"],
+                 "frame_checksum": r["frame_checksum"]}
+            vr, vb = r["roofline"].get("valu_per_wave_step"), b["roofline"].get("valu_per_wave_step")
+            if vr and vb and r["roofline"].get("counters") == "live" and b["roofline"].get("counters") == "live":
+                e["valu_per_wave_step"] = vr
+                e["three_objects_valu_per_wave_step"] = vb
+                e["valu_per_wave_step_per_additional_sphere"] = (vr - vb) / (nobj - 3)
+                e["valu_note"] = ("SQ_INSTS_VALU of the integrate kernels (FAR + NEAR) per wave-step, counted live by this run; the slope is "
+                                  "the executed cost of one more sphere per step, both passes together (DESIGN.md §4.7 has the static split)")
+            ex["variants"][f"objects{nobj}_ks_ref0_2048"] = e
+    except Exception as e:  # noqa: BLE001
+        ex["variants"]["objects64_ks_ref0_2048"] = {"error": repr(e)}
     g = ex["variants"].get("generic_ks_ref0_4096", {}).get("roofline")
     if g:
         g["contract_8d_note"] = ("this kernel EXECUTES the reference formulation (4-wide duals through the metric, symmetric inverse, "

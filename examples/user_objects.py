@@ -54,6 +54,18 @@ template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], con
 
 SHAPES_WITH_REACH = SHAPES + REACH
 
+# … and a sample object per type for the library's load-time probe (include/rtgr.h "rtgr_user_sample"): about 0.5 across, around
+# (x, y, z) = (4, 0, 0) — where example2's small sphere stands.  With it a unit whose reach bound disagrees with its distance on
+# the samples does not even load; without it the automatic scene check of the first trace is what catches such a bound.
+SAMPLE = r'''
+template <class S> __device__ bool rtgr_user_sample(unsigned type, S p[9]) {
+    if (type == 0u) { p[0] = S(4.0); p[1] = S(0.0); p[2] = S(0.0); p[3] = S(0.32); p[4] = S(0.11); return true; }      // a small torus
+    if (type == 1u) { p[0] = S(3.9); p[1] = S(0.3); p[2] = S(0.35); p[3] = S(0.22); p[4] = S(0.15); p[5] = S(0.18); return true; }   // an egg beside it
+    return false;
+}
+'''
+SHAPES_WITH_REACH_AND_SAMPLES = SHAPES + REACH + SAMPLE
+
 # The reference's own Sphere (src/RayTraceGR.jl:409-428) typed as a USER object — same distance, same colour rule, and the reach
 # bound the library uses for its built-in sphere: what the generic dispatch of a user object costs against the built-in one is
 # the difference between two frames that are otherwise the same (bench.py: variants.user_sphere_*).  p = pos (4), vel (4), radius.

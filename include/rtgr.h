@@ -62,6 +62,7 @@ extern "C" {
 #define RTGR_OBJECTS_LIMIT 1048576  /* sanity bound on rtgr_scene.nobj (2^20; the per-step cost is linear in it)            */
 #define RTGR_MAX_DEVICES 16
 #define RTGR_MAX_SOURCES 16         /* object sources rtgr_user_source_join joins in one call                               */
+#define RTGR_MAX_SAMPLES 32         /* type tags 0 .. 31 of a unit are asked for a sample object (rtgr_user_sample)         */
 
 /* ---- return codes -------------------------------------------------------------------------------------- */
 enum rtgr_status {
@@ -223,6 +224,7 @@ int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len
  * simple tile-per-wave kernel), "pack" (Float32: 0 = one ray per lane, 1 = two rays per lane in packed arithmetic) and "packfar"
  * (Float32 experiment, default 0: 1 = the packed kernel without its scan as a FAR pass + the scalar NEAR pass; measured slower).
  * value -1 = automatic.  Initial values come from the environment variables RTGR_<NAME> read ONCE when the context is created.
+ * "scene_check" (default 1): the automatic first-trace check of scenes with user objects (see "user objects" below); 0 = off.
  * Two options govern how run-time units are LOADED: "unit_audit" (default 1; 0 = skip the audit of the code object for the
  * compiler's EXEC-flip fault) and "unit_probe" (default 1; 0 = skip the load-time probe) — test hooks, see rtgr_user_metric_load. */
 int rtgr_set_option(rtgr_context* ctx, const char* name, long value);
@@ -435,6 +437,16 @@ int rtgr_user_metric_unload(rtgr_context* ctx, uint64_t id); /* id 0: all */
  * = an upper bound of |distance(x') - distance(x)| over all x' with |x'_q - x_q| <= dl[q].  Without it ("rtgr_user_reach" does
  * not occur in the source) a user object is never provably out of reach and scenes of the unit run the single FULL pass
  * (every accepted step scanned, as the reference does): same results, the FAR pass's saving is lost.
+ *   Optional fourth function — a SAMPLE OBJECT per type for the library's own checks:
+ *     template <class S> __device__ bool rtgr_user_sample(unsigned type, S p[9]);
+ * = true with p filled for an object of `type` about 0.5 across placed around (x, y, z) = (4, 0, 0) — where example2's small sphere
+ * stands, in view of the probe's camera —, false for a type the source has none for.  With it the load-time probe (below) traces
+ * the unit's OWN objects through its FULL and FAR + NEAR passes, so a distance / reach pair that disagrees on the samples keeps the
+ * unit from loading at all; without it the probe's frame holds built-in objects only and a bad bound is left to the scene check.
+ *   Whether or not a source brings samples: the FIRST trace of every scene that holds user objects with a reach bound runs
+ * rtgr_scene_check's comparison by itself, on a coarse sample of that call's own rays (option "scene_check", default 1; a few
+ * milliseconds once per (unit, object list, metric parameters, solver constants, camera), answered from a table afterwards; not
+ * during hipGraph capture) — a reach function that is not an upper bound is refused with RTGR_ERR_BAD_ARG instead of losing hits.
  *   Scenes: obj[k].kind = RTGR_USER_OBJECT, .type, .p as the source expects; scene.user_metric = the unit's id.  Built-in
  * objects may stand beside user objects in any order (:518-530's order rule applies to all).  Limits: the tile kernel
  * (option tile = 1) and the packed Float32 kernel know no user objects — scenes of a unit take the pipeline's scalar kernels;

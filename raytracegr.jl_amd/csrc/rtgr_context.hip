@@ -21,13 +21,13 @@ int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------------------
 static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
                                          "far4", "rounds", "qchunk", "qchunk_near", "tile", "host_chunk",
-                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", "max_waves", nullptr};
+                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", "max_waves", "scene_check", nullptr};
 const char* const* knob_names() { return KNOB_NAMES; }
 long* knob_slot(Knobs& k, const char* name) {
     if (!name) return nullptr;
     long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
                      &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far, &k.peer, &k.pack, &k.packfar,
-                     &k.unit_probe, &k.unit_audit, &k.max_waves};
+                     &k.unit_probe, &k.unit_audit, &k.max_waves, &k.scene_check};
     for (int i = 0; KNOB_NAMES[i]; i++)
         if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
     return nullptr;
@@ -432,11 +432,13 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
                  rtgr_counters* d_counters, hipStream_t st, uint64_t jstride, uint64_t nrows_strided, const Window* win) {
     DeviceGuard guard(D.dev);
     if (!guard.ok) return fail(RTGR_ERR_HIP, "hipSetDevice failed");
+    int rc;
+    // a scene whose user objects bring their own reach bound is checked the first time it is seen (blocking, a few ms; takes D.mu itself)
+    if ((rc = auto_scene_check<R>(D, scene, opt, d_state0, cam, ni, nj, j0, j1, jstride, nrows_strided, st))) return rc;
     std::lock_guard<std::mutex> lk(D.mu);
     TraceArgs<R> A;
     std::memset(&A, 0, sizeof A);
     const UserModule* user = nullptr;
-    int rc;
     if ((rc = convert_scene<R>(D, scene, A.sc, &user, st))) return rc;
     if ((rc = convert_solver<R>(opt, A.opt))) return rc;
     if (!d_rgb) return fail(RTGR_ERR_BAD_ARG, "rgb is NULL");
@@ -476,7 +478,7 @@ int trace_device(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, 
     A.counters = (unsigned long long*)d_counters;
     const bool spin = scene->a != 0.0;
     const bool generic = ((scene->metric & RTGR_METRIC_GENERIC) != 0 && A.sc.metric != RTGR_MINKOWSKI) || A.sc.metric == RTGR_USER;
-    if (D.knobs.tile) {
+    if ((tl_knobs_override ? tl_knobs_override->tile : D.knobs.tile)) {   // (the probe and the scene check bring their own options: tile = 0)
         if (generic || user) return fail(RTGR_ERR_BAD_ARG, "RTGR_METRIC_GENERIC and run-time units need the persistent pipeline (option tile = 0)");
         if (win && (win->plane_stride || win->out_offset)) return fail(RTGR_ERR_BAD_ARG, "the tile kernel writes whole slabs only");
     }

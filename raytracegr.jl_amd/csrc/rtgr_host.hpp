@@ -75,6 +75,9 @@ struct Knobs {
                                   // whose frames are irreproducible or disagree (rtgr_units.hip: probe_unit); 0 = skip
     long unit_audit = 1;          // … and audit the code object for the compiler's EXEC-flip fault before loading it; 0 = skip
                                   // (a test hook: the probe must catch a faulty unit on its own)
+    long scene_check = 1;         // scenes whose USER OBJECTS bring their own reach bound: the first trace of each (unit, object list, metric
+                                  // parameters, solver, camera) runs rtgr_scene_check's comparison on a coarse sample of the call's own rays and
+                                  // refuses a scene whose FAR + NEAR passes lose what the FULL pass finds (rtgr_units.hip: auto_scene_check); 0 = off
 };
 const char* const* knob_names();  // NULL-terminated
 long* knob_slot(Knobs& k, const char* name);
@@ -93,6 +96,7 @@ struct UserModule {
     hipFunction_t redshift = nullptr, redshift_f32 = nullptr;   // optional (units built before round 3 have none)
     hipFunction_t resolve = nullptr, resolve_f32 = nullptr;     // the resolve kernel with the unit's objects (used when has_objects)
     hipFunction_t eval_objects = nullptr, eval_objects_f32 = nullptr;   // rtgr_eval_objects_* with the unit's objects
+    hipFunction_t samples = nullptr;   // optional: one sample object per type the source offers one for (rtgr_user_sample)
     // what the unit was built for (rtgr_user_unit_desc): a scene runs with it only if its own variant is this one
     uint32_t metric = RTGR_USER;   // rtgr_metric (| RTGR_METRIC_GENERIC) of its kernels; RTGR_USER: a metric of its own
     bool spin = true;              // closed-form built-in kernels: the a != 0 instantiation
@@ -127,6 +131,7 @@ struct DeviceCtx {
     std::unordered_map<hipStream_t, StreamState> streams;
     std::vector<UserModule> modules;
     std::unordered_multimap<uint64_t, ObjectTable> object_tables;   // by FNV-1a of the content
+    std::unordered_map<uint64_t, int> checked_scenes;                // auto_scene_check: key of a scene -> the verdict it got (RTGR_OK or the refusal)
     Knobs knobs;
     // optional per-kernel timing (bench.py's roofline leg): hipEvents around each kernel of the pipeline
     bool timing = false;

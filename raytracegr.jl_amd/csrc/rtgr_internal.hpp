@@ -159,6 +159,11 @@ int host_has_nan(const R* v, uint64_t count) {
 
 // ---- run-time units (rtgr_units.hip) ---------------------------------------------------------------------------------------------
 int unload_locked(rtgr_context* c, uint64_t id);   // drop unit `id` (0: all) from every device; the caller holds c->modules_mu
+// The scene check nobody has to remember: called by trace_device ahead of every enqueue, answers from the device's
+// table of checked scenes in all but the first call for a scene.  D.mu NOT held.
+template <class R>
+int auto_scene_check(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const R* d_state0, const rtgr_camera* cam,
+                     uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, uint64_t jstride, uint64_t nrows_strided, hipStream_t st);
 
 // ---- the entry points of include/rtgr.h, by the name behind the rtgr_ prefix (rtgr_abi.hip holds the extern "C" shims) ----------
 namespace api {

@@ -156,11 +156,13 @@ int misc_eval_metric_f32(const DevScene<float>& sc, const float* d_x, uint64_t n
 int misc_eval_objects_f64(const DevScene<double>& sc, const DevSolver<double>& opt, const double* d_x, uint64_t n, double* d, double* dmin, uint8_t* hit,
                           double* rgb, hipStream_t st) {
     hipLaunchKernelGGL(eval_objects_kernel<double>, dim3(nblk(n)), dim3(256), 0, st, sc, opt, d_x, n, d, dmin, hit, rgb);
+    CHECK_LAUNCH();
     return RTGR_OK;
 }
 int misc_eval_objects_f32(const DevScene<float>& sc, const DevSolver<float>& opt, const float* d_x, uint64_t n, float* d, float* dmin, uint8_t* hit,
                           float* rgb, hipStream_t st) {
     hipLaunchKernelGGL(eval_objects_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, sc, opt, d_x, n, d, dmin, hit, rgb);
+    CHECK_LAUNCH();
     return RTGR_OK;
 }
 int misc_eval_geodesic_f64(const DevScene<double>& sc, const double* d_s, uint64_t n, int path, double* d_ds, hipStream_t st) {

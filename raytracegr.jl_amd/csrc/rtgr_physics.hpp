@@ -838,6 +838,9 @@ template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4
 #ifdef RTGR_USER_REACH
 template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]);
 #endif
+#ifdef RTGR_USER_SAMPLE
+template <class S> __device__ bool rtgr_user_sample(unsigned type, S p[9]);   // optional: a sample object of `type` for the load-time probe
+#endif
 #endif
 
 template <class R>

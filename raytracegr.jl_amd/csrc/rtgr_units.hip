@@ -53,7 +53,8 @@ int api::user_metric_unload(rtgr_context* ctx, uint64_t id) {
 template <class R> struct ProbeFrame { std::vector<R> rgb, se, lam; std::vector<uint8_t> status; std::vector<uint32_t> hit, na, nr; };
 template <class R>
 static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFrame<R>& f, const rtgr_solver* user_opt = nullptr,
-                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32, bool force_unit = false, long max_waves = -1) {
+                       const rtgr_camera* user_cam = nullptr, uint64_t NI = 32, uint64_t NJ = 32, bool force_unit = false, long max_waves = -1,
+                       const R* d_state0 = nullptr /* device: NI x NJ ray states instead of a camera */) {
     const uint64_t N = NI * NJ;
     rtgr_solver opt;
     rtgr_camera cam;
@@ -82,11 +83,13 @@ static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFram
     { std::lock_guard<std::mutex> lk(D.mu); mine = D.knobs; }
     mine.split = split;
     mine.max_waves = max_waves;
+    mine.tile = 0;                                    // (the comparison is between the pipeline's pass structures: never the tile kernel)
+    mine.scene_check = 0;                             // (a check does not check itself)
     {   // (the two thread-locals are cleared on every way out of the call, an exception from the allocator included)
         struct Clear { ~Clear() { tl_probe_forces_unit = false; tl_knobs_override = nullptr; } } clear;
         tl_probe_forces_unit = force_unit;
         tl_knobs_override = &mine;
-        rc = trace_device<R>(D, &sc, &opt, (const R*)nullptr, &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
+        rc = trace_device<R>(D, &sc, &opt, d_state0, d_state0 ? nullptr : &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
     }
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -147,6 +150,34 @@ static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
     sc.obj[1].kind = RTGR_PLANE;  sc.obj[1].p[0] = -20;
     sc.obj[2].kind = RTGR_SPHERE; sc.obj[2].p[1] = 4; sc.obj[2].p[4] = 1; sc.obj[2].p[8] = 0.5;
     int rc;
+    if (U.has_objects && U.samples) {
+        // the source offers sample objects (rtgr_user_sample): they take the small sphere's place — up to 14 beside the sky and the
+        // far plane —, and the comparisons below then run through the unit's OWN distance / objcolor / reach functions: a reach bound
+        // that lies about a sample keeps the unit from loading
+        DevBuf b;
+        const size_t bytes = sizeof(unsigned) * (1 + RTGR_MAX_SAMPLES) + sizeof(double) * 9 * RTGR_MAX_SAMPLES + 8;
+        if ((rc = b.alloc(bytes))) return rc;
+        HIP_TRY(hipMemset(b.p, 0, bytes));
+        unsigned* d_count = (unsigned*)b.p;
+        unsigned* d_types = d_count + 1;
+        double* d_p = (double*)((char*)b.p + ((sizeof(unsigned) * (1 + RTGR_MAX_SAMPLES) + 7) & ~(size_t)7));
+        HIP_TRY(launch_module(U.samples, 1, 64, (hipStream_t) nullptr, d_count, d_types, d_p));
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<char> host(bytes);
+        HIP_TRY(hipMemcpy(host.data(), b.p, bytes, hipMemcpyDeviceToHost));
+        const unsigned count = *(const unsigned*)host.data();
+        const unsigned* types = (const unsigned*)host.data() + 1;
+        const double* ps = (const double*)(host.data() + ((const char*)d_p - (const char*)b.p));
+        if (count > 0 && count <= RTGR_MAX_SAMPLES) {
+            sc.nobj = 2;
+            for (unsigned k = 0; k < count && sc.nobj < RTGR_MAX_OBJECTS; k++) {
+                rtgr_object& o = sc.obj[sc.nobj++];
+                std::memset(&o, 0, sizeof o);
+                o.kind = RTGR_USER_OBJECT; o.type = types[k];
+                for (int q = 0; q < 9; q++) o.p[q] = ps[9 * k + q];
+            }
+        }
+    }
     // The second run of each structure is scheduled DIFFERENTLY from the first: a grid of THREE waves over the 1024 rays instead of
     // sixteen — the first run's lanes each trace one ray, the second run's refill from the queue about five times, with other
     // neighbours in the wave every time.  A ray's arithmetic does not depend on which lane or wave carries it or on what its
@@ -266,6 +297,7 @@ static int load_module_image(rtgr_context* c, const std::vector<char>& image, co
             {&u.prepare_f32, "rtgr_user_prepare_f32", false}, {&u.canvas_f32, "rtgr_user_canvas_f32", false},
             {&u.resolve_f32, "rtgr_user_resolve_f32", false},
             {&u.eval_objects, "rtgr_user_eval_objects", false}, {&u.eval_objects_f32, "rtgr_user_eval_objects_f32", false},
+            {&u.samples, "rtgr_user_samples", false},
             {&u.eval_accel, "rtgr_user_eval_accel", false}, {&u.redshift, "rtgr_user_redshift", false},
             {&u.redshift_f32, "rtgr_user_redshift_f32", false}};
         for (auto& w : want)
@@ -362,17 +394,44 @@ int api::code_object_audit(const char* code_object_path, int* found, char* repor
     return RTGR_OK;
 }
 
+// Does `source` declare or define the function `name`: the identifier followed by `(`, outside comments and string literals.  (A
+// comment that merely mentions rtgr_user_reach used to switch -DRTGR_USER_REACH=1 on, and the build then failed on an undefined
+// template; one that mentions rtgr_user_metric made an objects-only source a "metric" unit — ADVICE r5.)  The same rule as
+// user_metric.py: defines.
+static bool source_defines(const char* source, const char* name) {
+    const size_t n = std::strlen(name);
+    auto ident = [](char c) { return std::isalnum((unsigned char)c) || c == '_'; };
+    for (const char* p = source; *p;) {
+        if (p[0] == '/' && p[1] == '/') { while (*p && *p != '\n') p++; continue; }
+        if (p[0] == '/' && p[1] == '*') { p += 2; while (*p && !(p[0] == '*' && p[1] == '/')) p++; if (*p) p += 2; continue; }
+        if (*p == '"') { p++; while (*p && *p != '"' && *p != '\n') { if (*p == '\\' && p[1]) p++; p++; } if (*p) p++; continue; }
+        if (ident(*p)) {
+            const char* q = p;
+            while (ident(*q)) q++;
+            if ((size_t)(q - p) == n && std::strncmp(p, name, n) == 0) {
+                const char* r = q;
+                while (*r == ' ' || *r == '\t' || *r == '\n' || *r == '\r') r++;
+                if (*r == '(') return true;
+            }
+            p = q;
+            continue;
+        }
+        p++;
+    }
+    return false;
+}
+
 // What a unit is made of, read off its source text and the scene it is meant for (the same rules as user_metric.py: unit_defines)
 struct UnitPlan { bool metric = false, ks_form = false, objects = false, reach = false; std::vector<std::string> defines; };
 static int plan_unit(const char* source, int stationary, const rtgr_scene* built_for, UnitPlan* P) {
     if (!source) return fail(RTGR_ERR_BAD_ARG, "source is NULL");
-    P->ks_form = std::strstr(source, "rtgr_user_ks") != nullptr;
-    P->metric = P->ks_form || std::strstr(source, "rtgr_user_metric") != nullptr;
-    const bool dist = std::strstr(source, "rtgr_user_distance") != nullptr, colr = std::strstr(source, "rtgr_user_objcolor") != nullptr;
+    P->ks_form = source_defines(source, "rtgr_user_ks");
+    P->metric = P->ks_form || source_defines(source, "rtgr_user_metric");
+    const bool dist = source_defines(source, "rtgr_user_distance"), colr = source_defines(source, "rtgr_user_objcolor");
     if (dist != colr)
         return fail(RTGR_ERR_BAD_ARG, "objects need both methods of the reference's Object (src/RayTraceGR.jl:377-389): rtgr_user_distance AND rtgr_user_objcolor");
     P->objects = dist;
-    P->reach = std::strstr(source, "rtgr_user_reach") != nullptr;
+    P->reach = source_defines(source, "rtgr_user_reach");
     if (P->reach && !P->objects) return fail(RTGR_ERR_BAD_ARG, "rtgr_user_reach without rtgr_user_distance / rtgr_user_objcolor");
     if (!P->metric && !P->objects)
         return fail(RTGR_ERR_BAD_ARG, "the source must define `template <class S> __device__ void rtgr_user_metric(const S x[4], "
@@ -396,6 +455,7 @@ static int plan_unit(const char* source, int stationary, const rtgr_scene* built
     }
     if (P->objects) P->defines.push_back("-DRTGR_USER_OBJECTS=1");
     if (P->reach) P->defines.push_back("-DRTGR_USER_REACH=1");
+    if (P->objects && source_defines(source, "rtgr_user_sample")) P->defines.push_back("-DRTGR_USER_SAMPLE=1");
     return RTGR_OK;
 }
 
@@ -423,7 +483,15 @@ static int build_unit_image(const char* source, int stationary, const rtgr_scene
     const std::string mark = "@RTGR_USER_SOURCE@";
     const size_t at = unit.find(mark);
     if (at == std::string::npos) return fail(RTGR_ERR_BAD_ARG, dir + "/rtgr_user_unit.hip.in: no " + mark);
-    unit.replace(at, mark.size(), source);
+    {   // the `#line` directive behind the source names the TEMPLATE line that follows it: computed from where the directive stands
+        // (user_metric.py: paste_source does the same)
+        const std::string lmark = "@RTGR_TEMPLATE_LINE@";
+        const size_t la = unit.find(lmark);
+        if (la == std::string::npos) return fail(RTGR_ERR_BAD_ARG, dir + "/rtgr_user_unit.hip.in: no " + lmark);
+        const long line = 1 + (long)std::count(unit.begin(), unit.begin() + (long)la, '\n');   // 1-based line of the directive
+        unit.replace(la, lmark.size(), std::to_string(line + 1));
+    }
+    unit.replace(unit.find(mark), mark.size(), source);
     unsigned long long hh = 0;
     if (int rc = header_hash_of(dir, &hh)) return rc;
     char hbuf[64];
@@ -520,32 +588,35 @@ int api::user_source_join(const char* const* sources, const uint32_t* ntypes, in
         return fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: 1.." + std::to_string(RTGR_MAX_SOURCES) + " sources with their numbers of types");
     std::string t = "// " + std::to_string(n) + " object families, joined by rtgr_user_source_join\n";
     std::vector<uint32_t> base(n + 1, 0);
-    bool reach_any = false;
-    std::vector<bool> reach(n);
+    bool reach_any = false, sample_any = false;
+    std::vector<bool> reach(n), sample(n);
     for (int k = 0; k < n; ++k) {
         const char* src = sources[k];
         const std::string who = "rtgr_user_source_join: source " + std::to_string(k);
         if (!src) return fail(RTGR_ERR_BAD_ARG, who + " is NULL");
-        if (!std::strstr(src, "rtgr_user_distance") || !std::strstr(src, "rtgr_user_objcolor"))
+        if (!source_defines(src, "rtgr_user_distance") || !source_defines(src, "rtgr_user_objcolor"))
             return fail(RTGR_ERR_BAD_ARG, who + " must define rtgr_user_distance and rtgr_user_objcolor (the two methods of the reference's Object)");
-        if (std::strstr(src, "rtgr_user_metric") || std::strstr(src, "rtgr_user_ks"))
+        if (source_defines(src, "rtgr_user_metric") || source_defines(src, "rtgr_user_ks"))
             return fail(RTGR_ERR_BAD_ARG, who + " defines a metric: only object sources are joined (the metric's source is given beside the joined text)");
         if (std::strstr(src, "rtgr_family_"))
             return fail(RTGR_ERR_BAD_ARG, who + " is a joined source itself: join the original sources in one call");
         if (ntypes[k] == 0) return fail(RTGR_ERR_BAD_ARG, who + ": number of object types is 0");
         base[k + 1] = base[k] + ntypes[k];
-        reach[k] = std::strstr(src, "rtgr_user_reach") != nullptr;
+        reach[k] = source_defines(src, "rtgr_user_reach");
         reach_any = reach_any || reach[k];
+        sample[k] = source_defines(src, "rtgr_user_sample");
+        sample_any = sample_any || sample[k];
         t += "namespace rtgr_family_" + std::to_string(k) + " {\n#line 1 \"object family " + std::to_string(k) + "\"\n" + src + "\n}\n";
     }
     t += "#line 1 \"rtgr_user_source_join\"\n";
     // family k's type t is the joined source's type base[k] + t; a tag past the last family's range goes to the last family
-    auto dispatch = [&](const std::string& head, const std::string& fn, const std::string& args, bool value, const std::vector<bool>* only) {
+    auto dispatch = [&](const std::string& head, const std::string& fn, const std::string& args, bool value, const std::vector<bool>* only,
+                        const std::string& without = "return S(__builtin_huge_val());   // (this family brings no bound: never provably out of reach)") {
         t += "template <class S> __device__ " + head + " {\n";
         for (int k = 0; k < n; ++k) {
             const std::string cond = k + 1 < n ? "    if (type < " + std::to_string(base[k + 1]) + "u) " : "    ";
             const std::string call = "rtgr_family_" + std::to_string(k) + "::" + fn + "(type - " + std::to_string(base[k]) + "u, " + args + ")";
-            if (only && !(*only)[k]) t += cond + "return S(__builtin_huge_val());   // (this family brings no bound: never provably out of reach)\n";
+            if (only && !(*only)[k]) t += cond + without + "\n";
             else if (value) t += cond + "return " + call + ";\n";
             else t += cond + "{ " + call + "; return; }\n";
         }
@@ -555,6 +626,9 @@ int api::user_source_join(const char* const* sources, const uint32_t* ntypes, in
     dispatch("void rtgr_user_objcolor(unsigned type, const S x[4], const S p[9], S rgb[3])", "rtgr_user_objcolor", "x, p, rgb", false, nullptr);
     if (reach_any)
         dispatch("S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4])", "rtgr_user_reach", "x, p, dl", true, &reach);
+    if (sample_any) {   // (a type beyond the last family's own range asks that family, which says false)
+        dispatch("bool rtgr_user_sample(unsigned type, S p[9])", "rtgr_user_sample", "p", true, &sample, "return false;   // (this family offers no samples)");
+    }
     if (need) *need = t.size() + 1;
     if (!out) return need ? RTGR_OK : fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: neither a buffer nor a place for the length");
     if (cap < t.size() + 1) return fail(RTGR_ERR_BAD_ARG, "rtgr_user_source_join: the buffer holds " + std::to_string(cap) + " bytes, the text needs " + std::to_string(t.size() + 1));
@@ -562,12 +636,31 @@ int api::user_source_join(const char* const* sources, const uint32_t* ntypes, in
     return RTGR_OK;
 }
 
+// Can this scene run the FAR + NEAR pair at all?  Not with another number of sample points than the reference's 10 (the split kernels
+// are the 10-point instantiation), and not when its unit's objects come without a reach bound (such scenes run the single FULL pass).
+// RTGR_OK, or 1 with the reason: there is nothing to compare, and saying "the frames agree" would be a false all-clear.
+static int scene_has_pair(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, std::string* why) {
+    if (opt->interp_points != 10) { *why = "interp_points != 10: the scene runs the single FULL pass only"; return 1; }
+    const uint32_t kind = scene->metric & ~RTGR_METRIC_GENERIC;
+    bool user_objects = false;
+    const rtgr_object* objs = scene_objects(scene);
+    if (scene->nobj <= RTGR_MAX_OBJECTS || scene->objects)
+        for (uint32_t o = 0; o < scene->nobj; o++) user_objects = user_objects || objs[o].kind == RTGR_USER_OBJECT;
+    if (kind == RTGR_USER || user_objects) {
+        std::lock_guard<std::mutex> lk(D.mu);
+        const UserModule* U = D.find_module(scene->user_metric);
+        if (U && U->has_objects && !U->has_reach) { *why = "the unit's objects bring no rtgr_user_reach: the scene runs the single FULL pass only"; return 1; }
+    }
+    return RTGR_OK;
+}
+
 template <class R>
-static int scene_check_frames(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, bool exact) {
+static int scene_check_frames(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, bool exact,
+                              const R* d_state0 = nullptr) {
     ProbeFrame<R> full, pair;
     int rc;
-    if ((rc = probe_trace<R>(D, *scene, 0, full, opt, cam, ni, nj))) return rc;
-    if ((rc = probe_trace<R>(D, *scene, 1, pair, opt, cam, ni, nj))) return rc;
+    if ((rc = probe_trace<R>(D, *scene, 0, full, opt, cam, ni, nj, false, -1, d_state0))) return rc;
+    if ((rc = probe_trace<R>(D, *scene, 1, pair, opt, cam, ni, nj, false, -1, d_state0))) return rc;
     std::string why;
     if (exact) {
         if (probe_same_bits(full, pair)) return RTGR_OK;
@@ -579,6 +672,77 @@ static int scene_check_frames(DeviceCtx& D, const rtgr_scene* scene, const rtgr_
     return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: " + why + " — a FAR pass that skips scans it must not skip: with user objects, "
                                   "rtgr_user_reach is not an upper bound of how far rtgr_user_distance moves inside the box it is given");
 }
+
+// ---- the scene check nobody has to remember ------------------------------------------------------------------------------------------
+// A user object's reach bound is the one piece of a caller's source the library cannot verify by construction: a bound that is too small
+// makes the FAR pass skip scans it must not skip, and hits are lost without a word.  rtgr_scene_check catches it — if
+// it is called.  So trace_device calls this ahead of every enqueue: for a Float64 scene whose unit's objects bring a reach bound, the
+// FIRST trace of each (unit, object list, metric parameters, solver constants, camera) runs the check's comparison — single FULL pass
+// against FAR + NEAR, bit for bit for a built-in metric — on a coarse sample of the call's OWN rays (<= 48 x 48: a coarse canvas of
+// the call's camera, or every k-th of the caller's ray states), blocking, a few milliseconds; the verdict is kept per device and every
+// later call with the same scene is answered from the table.  Not run: during hipGraph capture (it synchronises), for scenes
+// without user objects (the built-in bounds are the library's own, held to the FULL pass by the tests), with option scene_check = 0.
+static thread_local bool tl_in_scene_check = false;
+template <class R>
+int auto_scene_check(DeviceCtx& D, const rtgr_scene* scene, const rtgr_solver* opt, const R* d_state0, const rtgr_camera* cam,
+                     uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, uint64_t jstride, uint64_t nrows_strided, hipStream_t st) {
+    if (sizeof(R) != 8 || tl_in_scene_check || tl_knobs_override || !scene || !opt || (!cam && !d_state0)) return RTGR_OK;
+    if (scene->user_metric == 0 || (scene->nobj > RTGR_MAX_OBJECTS && !scene->objects) || opt->interp_points != 10) return RTGR_OK;
+    const rtgr_object* objs = scene_objects(scene);
+    bool user_objects = false;
+    for (uint32_t o = 0; o < scene->nobj; o++) user_objects = user_objects || objs[o].kind == RTGR_USER_OBJECT;
+    if (!user_objects) return RTGR_OK;
+    uint64_t key = 0;
+    {
+        std::lock_guard<std::mutex> lk(D.mu);
+        if (D.knobs.scene_check == 0 || D.knobs.split == 0 || D.knobs.tile) return RTGR_OK;
+        const UserModule* U = D.find_module(scene->user_metric);
+        if (!U || !U->has_objects || !U->has_reach) return RTGR_OK;    // (no unit: convert_scene refuses the call; no bound: single FULL pass)
+        std::vector<char> k;
+        auto put = [&k](const void* p, size_t n) { k.insert(k.end(), (const char*)p, (const char*)p + n); };
+        put(&scene->metric, sizeof scene->metric); put(&scene->nobj, sizeof scene->nobj); put(&scene->M, sizeof scene->M);
+        put(&scene->a, sizeof scene->a); put(&scene->user_metric, sizeof scene->user_metric);
+        put(objs, (size_t)scene->nobj * sizeof(rtgr_object));
+        put(opt, sizeof *opt);
+        if (cam) put(cam, sizeof *cam);
+        key = fnv1a(k);
+        auto it = D.checked_scenes.find(key);
+        if (it != D.checked_scenes.end()) {
+            if (it->second == RTGR_OK) return RTGR_OK;
+            return fail(it->second, "this scene was refused by the automatic scene check when it was first traced (rtgr_scene_check says why; option scene_check = 0 switches the check off)");
+        }
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return RTGR_OK;   // (cannot synchronise: unchecked)
+    struct Flag { Flag() { tl_in_scene_check = true; } ~Flag() { tl_in_scene_check = false; } } flag;
+    const bool exact = (scene->metric & ~RTGR_METRIC_GENERIC) != RTGR_USER;
+    int rc;
+    if (!d_state0) {   // a coarse canvas of the call's own camera
+        const uint64_t cni = ni < 48 ? ni : 48, cnj = nj < 48 ? nj : 48;
+        rc = scene_check_frames<double>(D, scene, opt, cam, cni, cnj, exact);
+    } else {           // every k-th of the caller's ray states (they are the stream's to deliver: ordered behind what produces them)
+        const uint64_t nrows = nrows_strided ? nrows_strided : j1 - j0;
+        const uint64_t n = ni * nrows, m = n < 2304 ? n : 2304, step = n / m;
+        DevBuf sample;
+        if ((rc = sample.alloc(m * 8 * sizeof(R)))) return rc;
+        HIP_TRY(hipMemcpy2DAsync(sample.p, 8 * sizeof(R), d_state0, step * 8 * sizeof(R), 8 * sizeof(R), m, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        rc = scene_check_frames<double>(D, scene, opt, nullptr, m, 1, exact, (const double*)sample.p);
+    }
+    if (rc != RTGR_OK && rc != RTGR_ERR_BAD_ARG) return rc;   // (a HIP error is not a verdict on the scene)
+    if (rc != RTGR_OK) {
+        const std::string why = rtgr_last_error();
+        (void)fail(rc, why + " [found by the automatic check of a scene's first trace, on a coarse sample of the call's rays; option scene_check = 0 switches it off]");
+    }
+    std::lock_guard<std::mutex> lk(D.mu);
+    if (D.checked_scenes.size() > 4096) D.checked_scenes.clear();
+    D.checked_scenes[key] = rc;
+    return rc;
+}
+template int auto_scene_check<double>(DeviceCtx&, const rtgr_scene*, const rtgr_solver*, const double*, const rtgr_camera*, uint64_t, uint64_t, uint64_t, uint64_t,
+                                      uint64_t, uint64_t, hipStream_t);
+template int auto_scene_check<float>(DeviceCtx&, const rtgr_scene*, const rtgr_solver*, const float*, const rtgr_camera*, uint64_t, uint64_t, uint64_t, uint64_t,
+                                     uint64_t, uint64_t, hipStream_t);
 
 int api::scene_check(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, int is_f32) {
     rtgr_context* c = nullptr;
@@ -592,6 +756,8 @@ int api::scene_check(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solv
     // bit for bit where every kernel is the library's own arithmetic (a built-in metric — closed form or generic —, with or without
     // user objects: the same object functions are inlined into the same bodies); within the probe's bars for a metric given as source
     const bool exact = (scene->metric & ~RTGR_METRIC_GENERIC) != RTGR_USER;
+    std::string why;
+    if (scene_has_pair(D, scene, opt, &why)) return fail(RTGR_ERR_BAD_ARG, "rtgr_scene_check: nothing to compare — " + why);
     return scene_check_frames<double>(D, scene, opt, cam, ni, nj, exact);
 }
 

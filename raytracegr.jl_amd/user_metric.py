@@ -16,6 +16,7 @@ Code objects are cached by content hash (source + the headers they were built fr
 raytracegr.jl_amd/build/user/ (override: RTGR_USER_CACHE), so a metric is compiled once.
 """
 import hashlib
+import re
 import os
 import subprocess
 
@@ -40,19 +41,38 @@ def cache_dir():
     return d
 
 
+def _env_digest():
+    """what EVERY unit is built from besides its own source: the template, the device headers, the listing check / repair, the flags.
+    It leads a unit's file name (metric_<env>_<source>.hsaco), so the units of an earlier state of those files can be told by name."""
+    h = hashlib.sha256()
+    for f in [TEMPLATE, _isa.__file__] + _HEADERS:   # (the listing check / repair is part of how a unit is built)
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:8]
+
+
+# the files compile_user_metric writes into the cache directory: metric_<env 8 hex>_<source 20 hex> + .hip / .hsaco / .L<level>….s,
+# each possibly with a .tmp<pid> part while it is being written (and the names of earlier rounds, without the <env> part)
+_UNIT_FILE = re.compile(r"^metric_(?:([0-9a-f]{8})_)?[0-9a-f]{20}(?:\.L\d+)?(?:\.tmp\d+)?\.(?:hsaco|hip|s|o)(?:\.tmp\d+)?(?:\.o)?$")
+
+
 def prune_stale_units(verbose=False):
-    """Delete cached units that can no longer be named: a unit's file name hashes the template, the device headers and the listing
-    tool, so one built BEFORE the newest of those files was last written belongs to a hash nothing computes any more (each header
-    edit used to leave ~40 files, 8 MB, behind — all of which travel to the GPU box with every gpurun call).  -> files removed"""
-    newest = max(os.path.getmtime(f) for f in [TEMPLATE, _isa.__file__] + _HEADERS)
+    """Delete cached units that can no longer be named: a unit's file name leads with the digest of the template, the device headers
+    and the listing tool (_env_digest), so a file whose name carries ANOTHER digest belongs to a state of those files nothing computes
+    any more (each header edit used to leave ~40 files, 8 MB, behind — all of which travel to the GPU box with every gpurun call).
+    Decided by NAME and content hash only: files that are not units (RTGR_USER_CACHE may point at a shared directory) are never
+    touched, and neither a `touch` nor a `git checkout` makes a valid unit look stale.  -> files removed"""
+    cur = _env_digest()
     d, gone = cache_dir(), 0
     for name in os.listdir(d):
+        m = _UNIT_FILE.match(name)
         f = os.path.join(d, name)
-        if os.path.isfile(f) and os.path.getmtime(f) < newest:
+        if m and m.group(1) != cur and os.path.isfile(f):
             os.unlink(f)
             gone += 1
     if verbose and gone:
-        print(f"{d}: removed {gone} unit file(s) older than the current device headers")
+        print(f"{d}: removed {gone} unit file(s) built from other device headers than the current ones")
     return gone
 
 
@@ -60,19 +80,37 @@ def _digest(source, extra_flags=()):
     h = hashlib.sha256()
     h.update(source.encode())
     h.update(" ".join(extra_flags).encode())
-    for f in [TEMPLATE, _isa.__file__] + _HEADERS:   # (the listing check / repair is part of how a unit is built)
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
-    return h.hexdigest()[:20]
+    return _env_digest() + "_" + h.hexdigest()[:20]
+
+
+def _code_only(source):
+    """the source without its comments and string literals (what the compiler sees of it)"""
+    return re.sub(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\\n])*"', " ", source, flags=re.S)
+
+
+def defines(source, name):
+    """True when `source` declares or defines the function `name` — the identifier followed by `(`, outside comments.  (A comment
+    that merely mentions rtgr_user_reach used to switch -DRTGR_USER_REACH=1 on and the build then failed on an undefined template,
+    ADVICE r5.)  The same rule as rtgr_units.hip: source_defines."""
+    return re.search(r"(?<![A-Za-z0-9_])" + re.escape(name) + r"\s*\(", _code_only(source)) is not None
+
+
+def paste_source(template, source):
+    """the unit template with the caller's source in place.  The `#line` directive behind the source names the TEMPLATE line that
+    follows it — computed here from where the directive stands, not written into the template by hand (a hard-coded number drifted
+    with every edit of the template's header comment).  The same rule as rtgr_units.hip: build_unit_image."""
+    lines = template.split("\n")
+    at = next(i for i, l in enumerate(lines) if "@RTGR_TEMPLATE_LINE@" in l)
+    lines[at] = lines[at].replace("@RTGR_TEMPLATE_LINE@", str(at + 2))    # (the directive is line at + 1: the line after it is at + 2)
+    return "\n".join(lines).replace("@RTGR_USER_SOURCE@", source)
 
 
 def unit_defines(source, stationary=False, built_for=None):
-    """What a unit is made of, read off its source text and the metric variant it is meant for — the same rules as rtgr_api.hip:
+    """What a unit is made of, read off its source text and the metric variant it is meant for — the same rules as rtgr_units.hip:
     plan_unit.  built_for = (metric kind, generic, spin) of a built-in metric for a source that defines OBJECTS only."""
-    ks_form = "rtgr_user_ks" in source    # the metric given in Kerr–Schild form: f and k instead of the 16 entries
-    metric = ks_form or "rtgr_user_metric" in source
-    dist, colr = "rtgr_user_distance" in source, "rtgr_user_objcolor" in source
+    ks_form = defines(source, "rtgr_user_ks")    # the metric given in Kerr–Schild form: f and k instead of the 16 entries
+    metric = ks_form or defines(source, "rtgr_user_metric")
+    dist, colr = defines(source, "rtgr_user_distance"), defines(source, "rtgr_user_objcolor")
     if dist != colr:
         raise ValueError("objects need both methods of the reference's Object (src/RayTraceGR.jl:377-389): rtgr_user_distance AND rtgr_user_objcolor")
     if not metric and not dist:
@@ -98,9 +136,11 @@ def unit_defines(source, stationary=False, built_for=None):
         extra += [f"-DRTGR_UNIT_BUILTIN_METRIC={kind}", f"-DRTGR_UNIT_GENERIC={int(generic)}", f"-DRTGR_UNIT_SPIN={int(spin and not generic)}"]
     if dist:
         extra.append("-DRTGR_USER_OBJECTS=1")
-        if "rtgr_user_reach" in source:
+        if defines(source, "rtgr_user_reach"):
             extra.append("-DRTGR_USER_REACH=1")
-    elif "rtgr_user_reach" in source:
+        if defines(source, "rtgr_user_sample"):
+            extra.append("-DRTGR_USER_SAMPLE=1")
+    elif defines(source, "rtgr_user_reach"):
         raise ValueError("rtgr_user_reach without rtgr_user_distance / rtgr_user_objcolor")
     return extra, (stationary or ks_form) if metric else False
 
@@ -130,8 +170,7 @@ def compile_user_metric(source, verbose=False, stationary=False, built_for=None)
         build_in_process(source, tmp, stationary=bool(stat), built_for=built_for)
         os.replace(tmp, out)
         return out
-    with open(TEMPLATE) as fh:
-        unit = fh.read().replace("@RTGR_USER_SOURCE@", source)
+    unit = paste_source(open(TEMPLATE).read(), source)
     src = os.path.join(d, f"metric_{tag}.hip")
     tmp_src = src + f".tmp{os.getpid()}"   # concurrent ranks may generate the same unit: never expose a partial file
     with open(tmp_src, "w") as fh:
@@ -307,9 +346,9 @@ class UserObjects:
     variant, source), cached on disk by content hash like user metrics)."""
 
     def __init__(self, source, name="user_objects", jit=False, ntypes=None):
-        if "rtgr_user_distance" not in source or "rtgr_user_objcolor" not in source:
+        if not (defines(source, "rtgr_user_distance") and defines(source, "rtgr_user_objcolor")):
             raise ValueError("the source must define rtgr_user_distance and rtgr_user_objcolor (the two methods of the reference's Object)")
-        if "rtgr_user_metric" in source or "rtgr_user_ks" in source:
+        if defines(source, "rtgr_user_metric") or defines(source, "rtgr_user_ks"):
             raise ValueError("a UserObjects source defines objects only; give the metric as a UserMetric (make_scene joins the two sources)")
         self.source, self.name, self.jit = source, name, bool(jit)
         self.ntypes = None if ntypes is None else int(ntypes)     # how many object types the source defines: needed to join families

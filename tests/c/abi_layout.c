@@ -198,6 +198,8 @@ int main(int argc, char** argv) {
             objs[k].p[1] = rad * cos(t); objs[k].p[2] = rad * sin(t) + 1.5; objs[k].p[3] = 1.2 * sin(2.3 * t);
             objs[k].p[4] = 1.0; objs[k].p[8] = 0.2 + 0.25 * fabs(sin(1.1 * t));
         }
+        /* the last object stands in front of the camera: hits of the highest index, whatever the length of the list */
+        objs[nobj - 1].p[1] = 4.3; objs[nobj - 1].p[2] = 0.5; objs[nobj - 1].p[3] = 0.3; objs[nobj - 1].p[8] = 0.2;
         rtgr_scene sc;
         memset(&sc, 0, sizeof sc);
         sc.metric = RTGR_KS_REF; sc.M = 1.0; sc.a = 0.0;                                        /* kerr_schild as written */

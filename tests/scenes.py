@@ -45,6 +45,9 @@ def many_objects(nobj, seed=7):
         if np.linalg.norm(c - cam) < r + 0.3 or np.linalg.norm(c) < 2.5 + r:
             continue
         objs.append(rt.Sphere((0, *c), (1, 0, 0, 0), r))
+    # the LAST object of the list stands in front of example2's camera (inside its fan of rays, also along straight lines): whatever
+    # the length, the frame holds hits of the highest index — beyond the 16 inline slots for every list longer than that
+    objs[-1] = rt.Sphere((0, 4.3, 0.5, 0.3), (1, 0, 0, 0), 0.2)
     return objs
 
 

@@ -204,10 +204,13 @@ def test_c_caller_traces_an_object_list_of_any_length(lib, tmp_path, nobj):
     ref = O.trace(sc, rt.solver_defaults(), 48, 48, cam=rt.make_camera(**cam))
     flips = hit != ref["hit"]
     assert int(flips.sum()) <= 4, int(flips.sum())
-    assert len(np.unique(hit)) >= 6 and (nobj <= 16 or hit.max() > 16)      # several spheres in view, some from beyond the inline slots
+    assert len(np.unique(hit)) >= 6 and hit.max() == nobj                   # several spheres in view, the last of the list among them
     same = ~flips
     assert (status[same] == ref["status"][same]).all()
-    assert np.abs((nacc + nrej).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))[same].max() <= 2
+    sd = np.abs((nacc + nrej).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))
+    steps = (ref["n_accept"] + ref["n_reject"]).astype(np.int64)
+    bad = np.nonzero(same & (sd > np.maximum(2, steps * 15 // 1000)))[0]   # (captured rays, ~1300 steps until the far plane: counts within 1.5 %)
+    assert len(bad) == 0, [(int(k), int(hit[k]), int(status[k]), int(nacc[k] + nrej[k]), int(ref["n_accept"][k] + ref["n_reject"][k])) for k in bad[:8]]
     assert wrap_aware_rgb_err(rgb[:, same], ref["rgb"][:, same], hit[same], sc=sc) <= 1e-6
 
 

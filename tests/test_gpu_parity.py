@@ -45,14 +45,18 @@ def hip_trace(lib, sc, opt, ni, nj, j0=0, j1=None, cam=None, state0=None, dtype=
     return arrs
 
 
-def compare(gpu, ref, nobj=3, max_class_flips=0, max_step_diff=0, sc=None):
+def compare(gpu, ref, nobj=3, max_class_flips=0, max_step_diff=0, sc=None, rel_step_diff=0.0):
+    """rel_step_diff: the step counts of LONG rays — the captured ones that circle the hole for a thousand steps before the far plane ends
+    them — follow the RHS formulation's rounding noise (INTEGRATION.md "Where parity ends"): allowed max(max_step_diff, rel x steps)"""
     flips = gpu["hit"] != ref["hit"]
     assert int(flips.sum()) <= max_class_flips, f"{int(flips.sum())} hit-class flips"
     same = ~flips
     err = wrap_aware_rgb_err(gpu["rgb"][:, same], ref["rgb"][:, same], gpu["hit"][same], nobj, sc=sc)
     assert err <= RGB_TOL, err
-    sd = np.abs((gpu["n_accept"] + gpu["n_reject"]).astype(np.int64) - (ref["n_accept"] + ref["n_reject"]).astype(np.int64))
-    assert int(sd[same].max(initial=0)) <= max_step_diff, int(sd[same].max())
+    steps_ref = (ref["n_accept"] + ref["n_reject"]).astype(np.int64)
+    sd = np.abs((gpu["n_accept"] + gpu["n_reject"]).astype(np.int64) - steps_ref)
+    over = sd - np.maximum(max_step_diff, np.floor(rel_step_diff * steps_ref)).astype(np.int64)
+    assert int(over[same].max(initial=0)) <= 0, (int(sd[same].max()), int(steps_ref[same][np.argmax(over[same])]))
     assert (gpu["status"][same] == ref["status"][same]).all()
     return err, int(flips.sum())
 
@@ -371,9 +375,10 @@ def test_object_lists_of_any_length_match_oracle(lib, name, n, nobj):
     opt = rt.solver_defaults()
     g = hip_trace(lib, sc, opt, n, n, cam=cam)
     r = O.trace(sc, opt, n, n, cam=cam)
-    assert (np.unique(r["hit"]) > abi.RTGR_MAX_OBJECTS).any() and (np.unique(r["hit"]) <= abi.RTGR_MAX_OBJECTS).any()   # hits on both sides of the 16
+    assert int(r["hit"].max()) == nobj and (np.unique(r["hit"]) <= abi.RTGR_MAX_OBJECTS).any()   # hits on both sides of the 16 inline slots
     mink = name.startswith("mink")
-    compare(g, r, sc=sc, max_class_flips=40 if mink else 6, max_step_diff=4 if mink else 2)
+    # (the captured rays of these scenes circle the hole for ~1300 steps before the plane at t = -25 ends them: their counts are noise)
+    compare(g, r, sc=sc, max_class_flips=40 if mink else 6, max_step_diff=4 if mink else 2, rel_step_diff=0.015)
     assert g["counters"]["rays"] == n * n
 
 
@@ -408,7 +413,7 @@ def test_three_hundred_objects_and_the_wide_hit_map(lib):
     g = hip_trace(lib, sc, opt, n, n, cam=cam)
     r = O.trace(sc, opt, n, n, cam=cam)
     assert g["hit"].dtype == np.uint32 and int(r["hit"].max()) > 255
-    compare(g, r, sc=sc, max_class_flips=4, max_step_diff=2)
+    compare(g, r, sc=sc, max_class_flips=4, max_step_diff=2, rel_step_diff=0.015)
     # the redshift output reads the hit map it is given: the wide one here
     red = np.zeros(n * n)
     se = np.zeros((n * n, 8))

@@ -22,8 +22,7 @@ um = sys.modules[rt.__name__ + ".user_metric"]
 
 def _raw_unit(tmp_path, source, name, extra=(), bundle=False, header_hash=None):
     """the unit as plain `hipcc --genco` builds it: no listing check, no repair (what a C / Julia user with hipcc would hand over)"""
-    with open(um.TEMPLATE) as fh:
-        unit = fh.read().replace("@RTGR_USER_SOURCE@", source)
+    unit = um.paste_source(open(um.TEMPLATE).read(), source)
     hip, out = str(tmp_path / f"{name}.hip"), str(tmp_path / f"{name}.hsaco")
     with open(hip, "w") as fh:
         fh.write(unit)

@@ -49,9 +49,13 @@ def test_bad_user_source_is_reported_not_swallowed():
     # template's own numbering resumes behind it
     at = 1 + bad.split("\n").index(next(l for l in bad.split("\n") if "no_such_function" in l))
     assert f"user source:{at}:" in str(e.value), str(e.value)[:600]
-    tmpl = open(um.TEMPLATE).read().split("\n")
-    k = next(j for j, l in enumerate(tmpl) if l.startswith("#line") and "rtgr_user_unit.hip.in" in l)
-    assert tmpl[k] == f'#line {k + 2} "rtgr_user_unit.hip.in"' and tmpl[k - 1] == "@RTGR_USER_SOURCE@" and tmpl[k - 2] == '#line 1 "user source"'
+    # (the number is computed where the source is pasted — paste_source here, build_unit_image in the library — from where the
+    #  directive stands in the template: a hand-written one drifted with every edit of the template's header)
+    raw = open(um.TEMPLATE).read().split("\n")
+    k = next(j for j, l in enumerate(raw) if l.startswith("#line") and "rtgr_user_unit.hip.in" in l)
+    assert raw[k] == '#line @RTGR_TEMPLATE_LINE@ "rtgr_user_unit.hip.in"' and raw[k - 1] == "@RTGR_USER_SOURCE@" and raw[k - 2] == '#line 1 "user source"'
+    tmpl = um.paste_source(open(um.TEMPLATE).read(), "@RTGR_USER_SOURCE@").split("\n")
+    assert tmpl[k] == f'#line {k + 2} "rtgr_user_unit.hip.in"'
 
 
 def test_in_process_build_needs_no_gpu_and_gives_a_sound_unit(tmp_path):

@@ -483,7 +483,10 @@ def test_a_reach_bound_that_lies_is_caught_by_the_scene_check(lib):
     """rtgr_user_reach is the one piece of a user's source the library cannot verify by construction: the FAR pass skips the scan of a
     step when no object can change sign within the bound, so a bound that is too small loses hits SILENTLY.  rtgr_scene_check traces
     the caller's own scene through the single FULL pass and through FAR + NEAR and compares: a sound bound passes bit for bit, a bound
-    of zero ("nothing ever moves") is refused with the number of rays that differ, and so is a bound that forgets one object type."""
+    of zero ("nothing ever moves") is refused with the number of rays that differ, and so is a bound that forgets one object type.
+    Round 6: the comparison runs BY ITSELF the first time a scene with such objects is traced (rtgr_units.hip: auto_scene_check) —
+    the lying scene below is refused by a plain trace call, through the device entry and through the reference's own pixel array
+    alike, with nobody calling check_scene; option scene_check = 0 gives the old behaviour back (and shows what is lost)."""
     _, objs, cam = rt.example2_scene()
     shapes = user_shapes()[1]
     rt.check_scene(rt.kerr_schild, objs[:2] + shapes, cam)                              # examples/user_objects.py REACH: sound
@@ -499,15 +502,52 @@ template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], con
                           name="shapes whose torus claims never to move")
     with pytest.raises(abi.RtgrError, match="rtgr_scene_check"):
         rt.check_scene(rt.kerr_schild, objs[:2] + [half(o.type, o.params) for o in shapes], cam)
-    # (the lying unit itself loads and traces: its FULL pass is right, its FAR + NEAR frame is not — which is why the check exists)
+    # WITHOUT the caller's help: the lying unit loads (its probe frame holds built-in objects: the source offers no samples), and the
+    # first trace of the scene is refused by the automatic check — camera rays (device-side make_canvas) …
     from test_gpu_parity import hip_trace
     sc = rt.make_scene(rt.kerr_schild, lying)
     camera = rt.make_camera(**cam)
     opt = rt.solver_defaults()
-    with abi.options(lib, split=0):
-        full = hip_trace(lib, sc, opt, 48, 48, cam=camera)
-    assert np.array_equal(full["hit"], O.trace(sc, opt, 48, 48, cam=camera)["hit"])
-    assert (hip_trace(lib, sc, opt, 48, 48, cam=camera)["hit"] != full["hit"]).sum() > 0
+    with pytest.raises(abi.RtgrError, match=r"differ \(\d+ of \d+ rays.*rtgr_user_reach is not an upper bound.*automatic check"):
+        hip_trace(lib, sc, opt, 64, 64, cam=camera)
+    with pytest.raises(abi.RtgrError, match="refused by the automatic scene check when it was first traced"):   # … the second time from the table
+        hip_trace(lib, sc, opt, 64, 64, cam=camera)
+    # … and the reference's own call shape, trace_rays(metric, objs, canvas): ray states from the caller's Pixel array
+    canvas = rt.make_canvas(rt.kerr_schild, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], 64, 64)
+    opt9 = rt.solver_defaults(reltol=1e-9, abstol=1e-9)         # (other solver constants: another scene as far as the table goes)
+    with pytest.raises(abi.RtgrError, match="automatic check"):
+        rt.trace_rays(rt.kerr_schild, lying, canvas, opt=opt9)
+    # the sound scene goes through the same check and is traced (first call checked, second answered from the table)
+    sound = rt.make_scene(rt.kerr_schild, objs[:2] + shapes)
+    a = hip_trace(lib, sound, opt, 64, 64, cam=camera)
+    b = hip_trace(lib, sound, opt, 64, 64, cam=camera)
+    assert np.array_equal(a["rgb"], b["rgb"])
+    # scene_check = 0: the lying unit traces — its FULL pass is right, its FAR + NEAR frame is not, which is why the check exists
+    with abi.options(lib, scene_check=0):
+        with abi.options(lib, split=0):
+            full = hip_trace(lib, sc, opt, 48, 48, cam=camera)
+        assert np.array_equal(full["hit"], O.trace(sc, opt, 48, 48, cam=camera)["hit"])
+        assert (hip_trace(lib, sc, opt, 48, 48, cam=camera)["hit"] != full["hit"]).sum() > 0
+
+
+@pytest.mark.gpu
+def test_a_unit_whose_samples_expose_a_lying_bound_does_not_load(lib):
+    """The optional fourth function of an object source, rtgr_user_sample, hands the load-time probe one object per type: the probe's
+    FULL-against-FAR + NEAR comparison then runs through the unit's OWN distance and reach functions, and a bound that lies about a
+    sample keeps the unit from loading at all.  The sound source with samples loads (probe_ok) and traces the oracle's frame."""
+    _, objs, cam = rt.example2_scene()
+    good = rt.UserObjects(user_objects.SHAPES_WITH_REACH_AND_SAMPLES, name="shapes + reach + samples", jit=True)
+    sc = rt.make_scene(rt.kerr_schild, objs[:2] + [good(o.type, o.params) for o in user_shapes()[1]])
+    info = um.unit_info(sc.user_metric)
+    assert info["probe_ok"] == 1 and info["has_reach"] == 1
+    from test_gpu_parity import hip_trace, compare
+    camera, opt = rt.make_camera(**cam), rt.solver_defaults()
+    compare(hip_trace(lib, sc, opt, 48, 48, cam=camera), O.trace(sc, opt, 48, 48, cam=camera), sc=sc, max_class_flips=2, max_step_diff=2)
+    liar = rt.UserObjects(user_objects.SHAPES + """
+template <class S> __device__ S rtgr_user_reach(unsigned type, const S x[4], const S p[9], const S dl[4]) { return S(0); }
+""" + user_objects.SAMPLE, name="a reach bound of zero, with samples", jit=True)
+    with pytest.raises(abi.RtgrError, match="refused by the load-time probe.*FULL pass and its FAR \\+ NEAR passes"):
+        rt.make_scene(rt.kerr_schild, objs[:2] + [liar(o.type, o.params) for o in user_shapes()[1]])
 
 
 def _random_shapes_scene(seed):

@@ -24,8 +24,7 @@ os.makedirs(out, exist_ok=True)
 REPEAT = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 hh = f"-DRTGR_HEADER_HASH={um._build.header_hash():#x}ull"
 for name, src in (("HELPER_ZOO", umx.HELPER_ZOO), ("KERR_BOYER_LINDQUIST", umx.KERR_BOYER_LINDQUIST)):
-    with open(um.TEMPLATE) as fh:
-        unit = fh.read().replace("@RTGR_USER_SOURCE@", src)
+    unit = um.paste_source(open(um.TEMPLATE).read(), src)
     hip = os.path.join(out, name + ".hip")
     open(hip, "w").write(unit)
     for lvl, level in enumerate(um.LEVELS):
