@@ -307,6 +307,29 @@ int rtgr_trace_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr
 int rtgr_trace_pixels_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* pixels_in,
                           uint64_t ni, uint64_t nj, float* pixels_out, rtgr_counters* ctr);
 
+/* ---- several frames in one call, two in flight ------------------------------------------------------------------------
+ * AN EXTENSION: the reference renders one frame per call (example1 / example2, src/RayTraceGR.jl:560, :596).  A render loop delivers
+ * frame after frame, and every frame's pipeline ends thin (the last rays of the FAR pass, the long stayers of the NEAR pass, the
+ * last download); with two frames in flight the thin end of one overlaps the start of the next — 8-11 % per frame at 1024², 5 % for
+ * one GPU's share of a 4096² frame split eight ways.  A caller that owns two HIP streams gets that from the
+ * device entry points; these calls give it to the blocking ones: nframes frames of ONE scene and canvas size, frame k from cams[k]
+ * (rays generated on the device), or from state0s[k] (ni*nj x 8 ray states; state0s may be NULL, and so may single entries when cams
+ * is given), into rgb[k] (3 planes of ni*nj), outs[k] (outs may be NULL) and ctrs[k] (may be NULL).  The library alternates the
+ * frames between two pipelines of its own — staging buffers, streams and workspace each — on every device of the context (the rows of
+ * EVERY frame are dealt to all devices, as in rtgr_trace_f64).  Frame k's results are those of the single call, bit for bit.
+ * Blocking; returns the first failure with the frame's number in rtgr_last_error().  The _pixels twins take and fill the reference's
+ * own Array{Pixel{T},2} per frame, as rtgr_trace_pixels_f64 does. */
+int rtgr_trace_frames_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes, const rtgr_camera* cams,
+                          const double* const* state0s, uint64_t ni, uint64_t nj, double* const* rgb, const rtgr_ray_outputs* outs,
+                          rtgr_counters* ctrs);
+int rtgr_trace_frames_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes, const rtgr_camera* cams,
+                          const float* const* state0s, uint64_t ni, uint64_t nj, float* const* rgb, const rtgr_ray_outputs* outs,
+                          rtgr_counters* ctrs);
+int rtgr_trace_frames_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes,
+                                 const double* const* pixels_in, uint64_t ni, uint64_t nj, double* const* pixels_out, rtgr_counters* ctrs);
+int rtgr_trace_frames_pixels_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes,
+                                 const float* const* pixels_in, uint64_t ni, uint64_t nj, float* const* pixels_out, rtgr_counters* ctrs);
+
 /* Legacy single-ray shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:76): one pixel in, rgb out. */
 int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4],
                        const double normal[4], double rgb[3], double state_end[8], uint8_t* status);

@@ -592,6 +592,75 @@ function render(metric, objs, pos, widthx, widthy, normal, ni::Integer, nj::Inte
 end
 
 """
+    render_frames(metric, objs, cams, ni, nj; T = Float64, ctx = nothing) -> Vector{NTuple{3,Matrix{T}}}
+
+SEVERAL frames of one scene in ONE call (`rtgr_trace_frames_f64/_f32`), two in flight inside the library: frame `k` from the camera
+`cams[k] = (pos, widthx, widthy, normal)` (rays generated on the device), returned as its three `ni x nj` planes.  An extension — the
+reference renders one frame per call (`example1`, `example2`, src/RayTraceGR.jl:560, :596): a render loop's frames end thin (the last
+rays of a pass, the last download), and with two in flight the thin end of one overlaps the start of the next (8-11 % per frame at
+1024², INTEGRATION.md "Frames in flight").  Each frame is the frame `render` gives for that camera, bit for bit.
+"""
+function render_frames(metric, objs, cams::AbstractVector, ni::Integer, nj::Integer; T::Type = Float64, ctx = nothing)
+    scene, why = scene_of(metric, objs, ctx)
+    scene === nothing && error("render_frames has no CPU counterpart in the reference: ", why)
+    opt = solver_of(T)
+    K = length(cams)
+    packed = RtgrCamera[camera_of(c...)[] for c in cams]
+    rgb = [Array{T}(undef, ni, nj, 3) for _ in 1:K]      # plane-major, frame by frame
+    ptrs = Ptr{T}[pointer(a) for a in rgb]
+    ctrs = Vector{RtgrCounters}(undef, K)
+    GC.@preserve rgb begin
+        if T === Float64
+            check(ccall((:rtgr_trace_frames_f64, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, UInt32, Ptr{RtgrCamera}, Ptr{Ptr{Float64}}, UInt64, UInt64, Ptr{Ptr{Float64}},
+                         Ptr{RtgrRayOutputs}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, K, packed, C_NULL, ni, nj, ptrs, C_NULL, ctrs))
+        else
+            check(ccall((:rtgr_trace_frames_f32, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, UInt32, Ptr{RtgrCamera}, Ptr{Ptr{Float32}}, UInt64, UInt64, Ptr{Ptr{Float32}},
+                         Ptr{RtgrRayOutputs}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, K, packed, C_NULL, ni, nj, ptrs, C_NULL, ctrs))
+        end
+    end
+    [(a[:, :, 1], a[:, :, 2], a[:, :, 3]) for a in rgb]
+end
+
+"""
+    trace_rays_frames(metric, objs, canvases::Vector{Canvas{T}}; ctx = nothing) -> Vector{Canvas{T}}
+
+`trace_rays` over several canvases in one call, two in flight (`rtgr_trace_frames_pixels_f64/_f32`): each canvas's own `Pixel{T}`
+array goes across the ABI as in `trace_rays`, all of the same size.  Falls back — loudly — to a loop of the reference's `trace_rays`
+where the scene cannot cross the ABI.
+"""
+function trace_rays_frames(metric, objs::Vector{RayTraceGR.Object{T}}, canvases::Vector{RayTraceGR.Canvas{T}}; ctx = nothing) where {T<:Union{Float64,Float32}}
+    scene, why = scene_of(metric, objs, ctx)
+    if scene === nothing
+        cpu_fallback("trace_rays", why)
+        return [RayTraceGR.trace_rays(metric, objs, c) for c in canvases]
+    end
+    isempty(canvases) && return RayTraceGR.Canvas{T}[]
+    ni, nj = size(canvases[1].pixels)
+    all(c -> size(c.pixels) == (ni, nj), canvases) || error("trace_rays_frames: the canvases must have one size")
+    opt = solver_of(T)
+    outs = [similar(c.pixels) for c in canvases]
+    pin = Ptr{Cvoid}[pointer(c.pixels) for c in canvases]
+    pout = Ptr{Cvoid}[pointer(o) for o in outs]
+    ctrs = Vector{RtgrCounters}(undef, length(canvases))
+    GC.@preserve canvases outs begin
+        if T === Float64
+            check(ccall((:rtgr_trace_frames_pixels_f64, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, UInt32, Ptr{Ptr{Cvoid}}, UInt64, UInt64, Ptr{Ptr{Cvoid}}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, length(canvases), pin, ni, nj, pout, ctrs))
+        else
+            check(ccall((:rtgr_trace_frames_pixels_f32, librtgr), Cint,
+                        (Ctx, Ptr{RtgrScene}, Ptr{RtgrSolver}, UInt32, Ptr{Ptr{Cvoid}}, UInt64, UInt64, Ptr{Ptr{Cvoid}}, Ptr{RtgrCounters}),
+                        handle(ctx), scene, opt, length(canvases), pin, ni, nj, pout, ctrs))
+        end
+    end
+    [RayTraceGR.Canvas{T}(o) for o in outs]
+end
+
+"""
     trace_ray(metric, objs, cb, p::Pixel{T}; ctx = nothing) -> Pixel{T}
 
 Legacy single-pixel shape (test/runtests.jl:76).  `cb` is ignored: the callback is always

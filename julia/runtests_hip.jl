@@ -293,3 +293,40 @@ template <class S> __device__ void rtgr_user_objcolor(unsigned type, const S x[4
                                     RayTraceGRHIP.DeviceObject{Float64}(anon, 0, 0.0, 4.6, -0.9, 0.9, 1.0, 0.0, 0.0, 0.0, 0.35)], small)
     RayTraceGRHIP.check_scene(kerr_schild, hip_objs, pos, wx, wy, nrm)
 end
+
+# ---- round 6: what a legal call of the reference did differently until now ------------------------------------------------------------
+@testset "an object list of any length; loud fall-backs; frames in flight" begin
+    objs, pos, wx, wy, nrm = RayTraceGRHIP.example_scene(Float64, 2)
+    small = RayTraceGR.make_canvas(kerr_schild, pos, wx, wy, nrm, 24, 24)
+    # `objs::Vector{Object{T}}` has no length limit (src/RayTraceGR.jl:433-441): 40 objects — 24 of them beyond the inline slots of
+    # rtgr_scene — against the reference's own CPU path, the last one (in front of the camera) on screen with ITS colour scale 40 / 40
+    many = Object{Float64}[objs[1], objs[2]]
+    for k in 3:39
+        t = 0.7 * k
+        push!(many, Sphere{Float64}(SVector(0.0, (3 + 0.1 * k) * cos(t), (3 + 0.1 * k) * sin(t) + 1.5, 1.2 * sin(2.3 * t)), SVector(1.0, 0.0, 0.0, 0.0), 0.25))
+    end
+    push!(many, Sphere{Float64}(SVector(0.0, 4.3, 0.5, 0.3), SVector(1.0, 0.0, 0.0, 0.0), 0.2))
+    hip = RayTraceGRHIP.trace_rays(kerr_schild, many, small)
+    cpu = RayTraceGR.trace_rays(kerr_schild, many, small)
+    @test maximum(maximum(abs.(hip.pixels[k].rgb - cpu.pixels[k].rgb)) for k in 1:576) <= 1e-6
+    @test any(p.rgb[3] == 1.0 for p in hip.pixels)                      # the 40th object: blue = 1 x 40 / 40
+    planes, det = RayTraceGRHIP.render(kerr_schild, many, pos, wx, wy, nrm, 24, 24; details = true)
+    @test maximum(det.hit) == 40 && eltype(det.hit) == UInt32
+    # every fall-back to the CPU path says so, once: a closure metric, an Object subtype without device source, another scalar type
+    closure = x -> kerr_schild(x)
+    @test_logs (:warn, r"trace_rays: the metric .* running the reference's CPU path") RayTraceGRHIP.trace_rays(closure, objs, small)
+    cpu_only = Object{Float64}[objs[1], objs[2], Torus{Float64}(SVector(4.0, 0.0, 0.0), 0.9, 0.3)]
+    @test_logs (:warn, r"objs\[3\] is a `Torus`") RayTraceGRHIP.trace_rays(kerr_schild, cpu_only, small)
+    objs_big, pos_b, wx_b, wy_b, nrm_b = RayTraceGRHIP.example_scene(BigFloat, 2)
+    tiny = @test_logs (:warn, r"the scalar type BigFloat has no device arithmetic") RayTraceGRHIP.make_canvas(kerr_schild, pos_b, wx_b, wy_b, nrm_b, 2, 2)
+    @test eltype(tiny.pixels) == Pixel{BigFloat}
+    # several frames in one call, two in flight inside the library: each is the frame of the single call, bit for bit
+    cams = [(pos + SVector(0.0, 0.15 * k, -0.1 * k, 0.0), wx, wy, nrm) for k in 0:3]
+    frames = RayTraceGRHIP.render_frames(kerr_schild, objs, cams, 32, 24)
+    for k in 1:4
+        @test frames[k] == RayTraceGRHIP.render(kerr_schild, objs, cams[k]..., 32, 24)
+    end
+    canv = [RayTraceGR.make_canvas(kerr_schild, c..., 24, 24) for c in cams[1:3]]
+    both = RayTraceGRHIP.trace_rays_frames(kerr_schild, objs, canv)
+    @test all(both[k].pixels == RayTraceGRHIP.trace_rays(kerr_schild, objs, canv[k]).pixels for k in 1:3)
+end

@@ -92,6 +92,7 @@ EXPORTS = [
     "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_metric_unload", "rtgr_user_metric_loaded", "rtgr_code_object_audit", "rtgr_user_metric_build", "rtgr_listing_repair",
     "rtgr_user_unit_compile", "rtgr_user_unit_build", "rtgr_user_unit_info", "rtgr_scene_check",
     "rtgr_eval_objects_f64", "rtgr_eval_objects_f32", "rtgr_user_source_join",
+    "rtgr_trace_frames_f64", "rtgr_trace_frames_f32", "rtgr_trace_frames_pixels_f64", "rtgr_trace_frames_pixels_f32",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -145,6 +146,10 @@ def _declare(lib):
         f.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, u64, u64, vp, P(rtgr_counters)]
     for f in (lib.rtgr_trace_one_f64, lib.rtgr_trace_one_f32):
         f.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), vp, vp, vp, vp, vp]
+    for f in (lib.rtgr_trace_frames_f64, lib.rtgr_trace_frames_f32):     # (arrays of per-frame pointers: c_void_p arrays)
+        f.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), C.c_uint32, P(rtgr_camera), P(vp), u64, u64, P(vp), P(rtgr_ray_outputs), P(rtgr_counters)]
+    for f in (lib.rtgr_trace_frames_pixels_f64, lib.rtgr_trace_frames_pixels_f32):
+        f.argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), C.c_uint32, P(vp), u64, u64, P(vp), P(rtgr_counters)]
     for name in ("rtgr_trace_sharded_f64", "rtgr_trace_sharded_device_f64", "rtgr_trace_sharded_f32", "rtgr_trace_sharded_device_f32"):
         getattr(lib, name).argtypes = [ctx, P(rtgr_scene), P(rtgr_solver), P(rtgr_camera), u64, u64, vp,
                                        P(rtgr_ray_outputs), P(rtgr_counters)]

@@ -286,6 +286,33 @@ def trace_rays(metric, objs, c, opt=None, return_info=False, ctx=None):
     return (out, ctr.as_dict()) if return_info else out
 
 
+def trace_frames(metric, objs, cams, ni, nj, opt=None, dtype=np.float64, ctx=None, details=False):
+    """SEVERAL frames of one scene in one call, two in flight inside the library (rtgr_trace_frames_f64 / _f32) — an extension: the
+    reference renders one frame per call (src/RayTraceGR.jl:560, :596).  cams: a list of make_camera argument dicts (or rtgr_camera);
+    rays are generated on the device.  -> list of dict(rgb [3, ni*nj], counters (+ the per-ray outputs when details)), frame by frame:
+    each the result of the single call (rtgr_trace_f64), bit for bit."""
+    lib = _lib()
+    sc = make_scene(metric, objs, ctx)
+    opt = opt or solver_defaults(dtype)
+    K, n = len(cams), ni * nj
+    carr = (rtgr_camera * K)(*[c if isinstance(c, rtgr_camera) else make_camera(**c) for c in cams])
+    rgb = [np.zeros((3, n), dtype) for _ in range(K)]
+    ptrs = (C.c_void_p * K)(*[r.ctypes.data for r in rgb])
+    ctrs = (rtgr_counters * K)()
+    outs, per = None, [dict() for _ in range(K)]
+    if details:
+        outs = (rtgr_ray_outputs * K)()
+        wide = sc.nobj > 255
+        for k in range(K):
+            per[k] = dict(state_end=np.zeros((n, 8), dtype), lambda_end=np.zeros(n, dtype), status=np.zeros(n, np.uint8),
+                          hit=np.zeros(n, np.uint32 if wide else np.uint8), n_accept=np.zeros(n, np.uint32), n_reject=np.zeros(n, np.uint32))
+            for name, arr in per[k].items():
+                setattr(outs[k], "hit32" if (wide and name == "hit") else name, arr.ctypes.data)
+    fn = lib.rtgr_trace_frames_f64 if dtype == np.float64 else lib.rtgr_trace_frames_f32
+    _abi.check(lib, fn(ctx, C.byref(sc), C.byref(opt), K, carr, None, ni, nj, ptrs, outs, ctrs))
+    return [dict(per[k], rgb=rgb[k], counters=ctrs[k].as_dict()) for k in range(K)]
+
+
 def trace_ray(metric, objs, cb, p, opt=None, ctx=None):
     """Legacy single-pixel shape `trace_ray(metric, objs, cb, p)::Pixel` (test/runtests.jl:65-79).
     `cb` is accepted for signature parity and ignored: the callback is always
@@ -395,5 +422,5 @@ def example2(ni=200, nj=200, save=True, ctx=None):
 
 __all__ = ["D", "Metric", "UserMetric", "UserObjects", "UserObject", "minkowski", "kerr_schild", "KerrSchild", "Object", "Plane", "Sphere", "Disk",
            "make_scene", "check_scene", "eval_objects", "solver_defaults", "make_camera", "Pixel", "pixel_dtype", "Canvas", "make_canvas",
-           "trace_rays", "trace_ray", "dmetric", "christoffel", "geodesic", "example1", "example2",
+           "trace_rays", "trace_ray", "trace_frames", "dmetric", "christoffel", "geodesic", "example1", "example2",
            "example1_scene", "example2_scene"]

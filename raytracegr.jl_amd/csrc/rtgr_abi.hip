@@ -31,6 +31,10 @@ int rtgr_trace_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver
 int rtgr_trace_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* state0, const rtgr_camera* cam, uint64_t ni, uint64_t nj, uint64_t j0, uint64_t j1, float* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) { return rtgr::api::trace_f32(ctx, scene, opt, state0, cam, ni, nj, j0, j1, rgb, out, ctr); }
 int rtgr_trace_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double* pixels_in, uint64_t ni, uint64_t nj, double* pixels_out, rtgr_counters* ctr) { return rtgr::api::trace_pixels_f64(ctx, scene, opt, pixels_in, ni, nj, pixels_out, ctr); }
 int rtgr_trace_pixels_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float* pixels_in, uint64_t ni, uint64_t nj, float* pixels_out, rtgr_counters* ctr) { return rtgr::api::trace_pixels_f32(ctx, scene, opt, pixels_in, ni, nj, pixels_out, ctr); }
+int rtgr_trace_frames_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes, const rtgr_camera* cams, const double* const* state0s, uint64_t ni, uint64_t nj, double* const* rgb, const rtgr_ray_outputs* outs, rtgr_counters* ctrs) { return rtgr::api::trace_frames_f64(ctx, scene, opt, nframes, cams, state0s, ni, nj, rgb, outs, ctrs); }
+int rtgr_trace_frames_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes, const rtgr_camera* cams, const float* const* state0s, uint64_t ni, uint64_t nj, float* const* rgb, const rtgr_ray_outputs* outs, rtgr_counters* ctrs) { return rtgr::api::trace_frames_f32(ctx, scene, opt, nframes, cams, state0s, ni, nj, rgb, outs, ctrs); }
+int rtgr_trace_frames_pixels_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes, const double* const* pixels_in, uint64_t ni, uint64_t nj, double* const* pixels_out, rtgr_counters* ctrs) { return rtgr::api::trace_frames_pixels_f64(ctx, scene, opt, nframes, pixels_in, ni, nj, pixels_out, ctrs); }
+int rtgr_trace_frames_pixels_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, uint32_t nframes, const float* const* pixels_in, uint64_t ni, uint64_t nj, float* const* pixels_out, rtgr_counters* ctrs) { return rtgr::api::trace_frames_pixels_f32(ctx, scene, opt, nframes, pixels_in, ni, nj, pixels_out, ctrs); }
 int rtgr_trace_one_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const double pos[4], const double normal[4], double rgb[3], double state_end[8], uint8_t* status) { return rtgr::api::trace_one_f64(ctx, scene, opt, pos, normal, rgb, state_end, status); }
 int rtgr_trace_one_f32(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const float pos[4], const float normal[4], float rgb[3], float state_end[8], uint8_t* status) { return rtgr::api::trace_one_f32(ctx, scene, opt, pos, normal, rgb, state_end, status); }
 int rtgr_trace_sharded_f64(rtgr_context* ctx, const rtgr_scene* scene, const rtgr_solver* opt, const rtgr_camera* cam, uint64_t ni, uint64_t nj, double* rgb, const rtgr_ray_outputs* out, rtgr_counters* ctr) { return rtgr::api::trace_sharded_f64(ctx, scene, opt, cam, ni, nj, rgb, out, ctr); }

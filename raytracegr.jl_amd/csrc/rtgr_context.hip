@@ -130,16 +130,17 @@ std::mutex g_default_mu;
 rtgr_context* g_default = nullptr;
 const std::string& last_error_string() { return g_err; }
 
-int staging_of(DeviceCtx& d, Staging** out) {
-    if (!d.staging) {
+int staging_of(DeviceCtx& d, Staging** out, int slot) {
+    auto& mine = slot ? d.staging2 : d.staging;
+    if (!mine) {
         std::unique_ptr<Staging, void (*)(Staging*)> s(new Staging, staging_delete);
         HIP_TRY(hipStreamCreateWithFlags(&s->s_up, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&s->s_down, hipStreamNonBlocking));
         for (auto& e : s->ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        d.staging = std::move(s);
+        mine = std::move(s);
     }
-    *out = d.staging.get();
+    *out = mine.get();
     return RTGR_OK;
 }
 
@@ -156,7 +157,7 @@ void free_device_state(DeviceCtx& d, bool all) {
     }
     for (auto& kv : d.object_tables) (void)hipFree(kv.second.dev);   // (the device is idle: synchronised above)
     d.object_tables.clear();
-    if (all) d.staging.reset();   // (rtgr_trim releases the staging BUFFERS separately, under the staging's own mutex)
+    if (all) { d.staging.reset(); d.staging2.reset(); }   // (rtgr_trim releases the staging BUFFERS separately, under the staging's own mutex)
     if (all) {
         d.streams.clear();
         for (auto& m : d.modules) if (m.module && m.owned) (void)hipModuleUnload(m.module);
@@ -569,9 +570,10 @@ int api::trim(rtgr_context* ctx) {
         // Host-pointer calls hold Staging::mu for their whole duration and take D.mu inside it (to enqueue), so the staging
         // is trimmed FIRST and under its own mutex only (a call in flight finishes first, the next one re-allocates); the
         // struct itself — mutex, streams, events — goes with the context, never here.
-        Staging* s = nullptr;
-        { std::lock_guard<std::mutex> lk(d->mu); s = d->staging.get(); }
-        if (s) {
+        for (int slot = 0; slot < 2; slot++) {
+            Staging* s = nullptr;
+            { std::lock_guard<std::mutex> lk(d->mu); s = slot ? d->staging2.get() : d->staging.get(); }
+            if (!s) continue;
             DeviceGuard g(d->dev);
             std::lock_guard<std::mutex> ls(s->mu);
             (void)hipStreamSynchronize(s->s_up); (void)hipStreamSynchronize(s->s_comp); (void)hipStreamSynchronize(s->s_down);

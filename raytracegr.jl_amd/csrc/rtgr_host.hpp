@@ -139,7 +139,8 @@ struct DeviceCtx {
     double acc_ms[6] = {0, 0, 0, 0, 0, 0};       // summed durations since the last read: [0..3] rtgr_timing_read, [4..5] rtgr_timing_read_exchange
     uint64_t acc_n[6] = {0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> event_pool;
-    std::unique_ptr<Staging, void (*)(Staging*)> staging{nullptr, nullptr};
+    // the host-pointer entry points' pipelines: [0] every blocking call's; [1] the second frame in flight of rtgr_trace_frames_*
+    std::unique_ptr<Staging, void (*)(Staging*)> staging{nullptr, nullptr}, staging2{nullptr, nullptr};
 #ifdef RTGR_ROOT_STATS
     unsigned long long* dbg = nullptr;
 #endif

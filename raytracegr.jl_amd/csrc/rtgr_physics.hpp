@@ -898,10 +898,12 @@ template <class R, class F>
 RTGR_DEV void for_each_object(const DevScene<R>& sc, F&& f) {
     const uint32_t n0 = sc.nobj < (uint32_t)RTGR_MAX_OBJECTS ? sc.nobj : (uint32_t)RTGR_MAX_OBJECTS;
     for (uint32_t o = 0; o < n0; o++) f(sc.obj[o], o);
+#ifndef RTGR_INLINE_OBJECTS_ONLY   // (A/B builds: the loop as it was before lists could be longer — tools/launch_ab.py builds)
     if (sc.nobj > (uint32_t)RTGR_MAX_OBJECTS) {
         const DevObject<R>* __restrict__ more = sc.more;
         for (uint32_t o = (uint32_t)RTGR_MAX_OBJECTS; o < sc.nobj; o++) f(more[o - (uint32_t)RTGR_MAX_OBJECTS], o);
     }
+#endif
 }
 // … and one object by (per-lane) index: `objs[omin]` (:530)
 template <class R>

@@ -77,7 +77,8 @@ static const char* const BOUND[] = {"rtgr_create", "rtgr_destroy", "rtgr_context
                                     "rtgr_solver_defaults", "rtgr_trace_pixels_f64", "rtgr_trace_pixels_f32", "rtgr_trace_one_f64", "rtgr_trace_one_f32", "rtgr_trace_f64",
                                     "rtgr_trace_sharded_f64", "rtgr_make_canvas_f64", "rtgr_user_metric_load", "rtgr_user_metric_compile", "rtgr_user_unit_compile",
                                     "rtgr_eval_metric_f64", "rtgr_eval_geodesic_f64", "rtgr_user_source_join", "rtgr_user_unit_info", "rtgr_scene_check",
-                                    "rtgr_eval_objects_f64", "rtgr_eval_objects_f32", NULL};
+                                    "rtgr_eval_objects_f64", "rtgr_eval_objects_f32", "rtgr_trace_frames_f64", "rtgr_trace_frames_f32",
+                                    "rtgr_trace_frames_pixels_f64", "rtgr_trace_frames_pixels_f32", NULL};
 
 typedef int (*fn_defaults)(rtgr_solver*, int);
 typedef int (*fn_canvas)(rtgr_context*, const rtgr_scene*, const rtgr_camera*, uint64_t, uint64_t, uint64_t, uint64_t, double*);

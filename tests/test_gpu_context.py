@@ -631,3 +631,65 @@ def test_peer_table_and_exchange_timers(lib):
                 abi.check(lib, lib.rtgr_timing_enable(ctx, k, 0))
     finally:
         abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+def _cameras(k):
+    """k cameras on a short dolly around example2's: every frame another picture"""
+    _, _, cam = rt.example2_scene()
+    return [dict(cam, pos=(0, 4 + 0.15 * i, -2 - 0.1 * i, 0.05 * i)) for i in range(k)]
+
+
+@pytest.mark.parametrize("ndev", [0, 3])
+def test_frames_in_flight_are_the_single_frames(lib, ndev):
+    """rtgr_trace_frames_f64 / _f32: several frames of one scene in ONE blocking call, two in flight inside the library (two
+    pipelines per device: staging, streams, workspace) — what a caller with two HIP streams could always do, for the callers of the
+    blocking entry points (Julia, C).  No reference counterpart (example1 / example2 render one frame per call,
+    src/RayTraceGR.jl:560, :596).  Every frame — RGB and all per-ray outputs, counters — is the frame of the single call, bit for
+    bit; on the default context and on one of three (logical) devices, where the rows of EVERY frame are dealt to all devices."""
+    from test_gpu_parity import hip_trace
+    metric, objs, _ = rt.example2_scene(rt.KerrSchild(1.0, 0.8))
+    cams = _cameras(5)
+    ctx = abi.create_context(lib, _devices(ndev)) if ndev else None
+    try:
+        frames = rt.trace_frames(metric, objs, cams, 96, 80, ctx=ctx, details=True)
+        sc, opt = rt.make_scene(metric, objs), rt.solver_defaults()
+        for k, f in enumerate(frames):
+            single = hip_trace(lib, sc, opt, 96, 80, cam=rt.make_camera(**cams[k]))
+            for key in OUT_KEYS:
+                assert np.array_equal(f[key], single[key], equal_nan=True), (k, key)
+            assert f["counters"] == single["counters"], k
+        assert not np.array_equal(frames[0]["rgb"], frames[3]["rgb"])          # (the cameras differ: so do the frames)
+        # Float32, one frame (no second frame to overlap with: the plain call on the first pipeline)
+        f32 = rt.trace_frames(metric, objs, cams[:1], 64, 64, dtype=np.float32, ctx=ctx)[0]
+        s32 = hip_trace(lib, sc, rt.solver_defaults(np.float32), 64, 64, cam=rt.make_camera(**cams[0]), dtype=np.float32)
+        assert np.array_equal(f32["rgb"], s32["rgb"]) or ctx is not None     # (hip_trace runs on the default context: same bits there)
+    finally:
+        if ctx:
+            abi.check(lib, lib.rtgr_destroy(ctx))
+
+
+def test_frames_of_pixel_arrays_and_the_error_path(lib):
+    """The _pixels twin takes the reference's own Array{Pixel{T},2} per frame (src/RayTraceGR.jl:446-450, :532) — three canvases of three
+    cameras in one call equal three trace_rays calls; a frame with a NULL array is refused with its number before anything runs."""
+    metric, objs, _ = rt.example2_scene()
+    cams = _cameras(3)
+    sc, opt = rt.make_scene(metric, objs), rt.solver_defaults()
+    canv = [rt.make_canvas(metric, c["pos"], c["widthx"], c["widthy"], c["normal"], 72, 60) for c in cams]
+    want = [rt.trace_rays(metric, objs, c) for c in canv]
+    pin = [np.asfortranarray(c.pixels) for c in canv]
+    pout = [np.empty_like(p, order="F") for p in pin]
+    K = len(pin)
+    a_in = (C.c_void_p * K)(*[p.ctypes.data for p in pin])
+    a_out = (C.c_void_p * K)(*[p.ctypes.data for p in pout])
+    ctrs = (abi.rtgr_counters * K)()
+    abi.check(lib, lib.rtgr_trace_frames_pixels_f64(None, C.byref(sc), C.byref(opt), K, a_in, 72, 60, a_out, ctrs))
+    for k in range(K):
+        assert np.array_equal(pout[k]["rgb"], want[k].pixels["rgb"]) and np.array_equal(pout[k]["pos"], pin[k]["pos"]), k
+        assert ctrs[k].rays == 72 * 60
+    a_out[1] = None
+    assert lib.rtgr_trace_frames_pixels_f64(None, C.byref(sc), C.byref(opt), K, a_in, 72, 60, a_out, None) == abi.ERR_BAD_ARG
+    assert "frame 1" in lib.rtgr_last_error().decode()
+    rgb = np.zeros((3, 16))
+    one = (C.c_void_p * 1)(rgb.ctypes.data)
+    assert lib.rtgr_trace_frames_f64(None, C.byref(sc), C.byref(opt), 1, None, None, 4, 4, one, None, None) == abi.ERR_BAD_ARG   # neither cameras nor rays
+    assert lib.rtgr_trace_frames_f64(None, C.byref(sc), C.byref(opt), 0, None, None, 4, 4, one, None, None) == abi.ERR_BAD_ARG

@@ -284,7 +284,7 @@ JL_BASE = {"AbstractString", "Array", "Base", "C_NULL", "Cint", "Cstring", "Cvoi
            "clamp", "close", "collect", "count", "dirname", "eltype", "eps", "error", "fieldcount", "fieldoffset", "finalizer", "get", "get!",
            "hash", "include", "inv", "isbitstype", "minimum", "Vector", "sum", "findfirst", "ErrorException", "isempty", "isnan", "isnothing", "joinpath", "length", "map", "max", "maximum", "mkpath", "mod",
            "new", "ntuple", "permutedims", "pointer", "println", "reinterpret", "rm", "round", "similar", "size", "sizeof", "sqrt", "undef",
-           "unique", "unsafe_string", "zeros", "π", "Symbol", "nameof", "typeof", "findall", "string", "first", "last", "isa", "copy", "push!", "empty!", "haskey", "min", "cld", "fill", "view", "reshape", "Threads", "time_ns", "UInt", "Bool", "Nothing", "nothing", "pointer_from_objref", "append!", "iseven"}
+           "unique", "unsafe_string", "zeros", "π", "Symbol", "nameof", "typeof", "findall", "string", "first", "last", "isa", "copy", "push!", "empty!", "haskey", "min", "cld", "fill", "view", "reshape", "Threads", "time_ns", "UInt", "Bool", "Nothing", "nothing", "pointer_from_objref", "append!", "iseven", "cos", "sin", "BigFloat"}
 JL_PACKAGES = {"SVector", "SMatrix", "SArray", "I", "RayTraceGR", "RayTraceGRHIP", "Images"}
 JL_REFERENCE_EXPORTS = {"Dual", "D", "minkowski", "kerr_schild", "dmetric", "christoffel", "Ray", "r2s", "s2r", "geodesic", "Object", "Plane",
                         "Sphere", "min_distance", "Pixel", "Canvas", "make_canvas", "trace_rays"}
