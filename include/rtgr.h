@@ -218,7 +218,7 @@ int rtgr_solver_defaults(rtgr_solver* s, int is_f32);
 int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len, int* n_cu, int* clock_mhz, int* wavefront);
 
 /* Launch-policy options (experiments and schedule-invariance tests).  Names: "waves_per_cu", "waves_per_cu_near", "chunk",
- * "split", "order", "fair", "near_early", "far4", "rounds", "qchunk", "qchunk_near", "host_chunk", "peer" (multi-device gather:
+ * "split", "order", "fair", "near_early", "far4", "rounds", "handback_after", "qchunk", "qchunk_near", "host_chunk", "peer" (multi-device gather:
  * 0 = through the host, 1 = peer copies or fail) — these decide WHEN and WHERE a ray is integrated and never change a result
  * bit —, and three that select another FORMULATION of the same algorithm, with results equal up to rounding: "tile" (1: the
  * simple tile-per-wave kernel), "pack" (Float32: 0 = one ray per lane, 1 = two rays per lane in packed arithmetic) and "packfar"

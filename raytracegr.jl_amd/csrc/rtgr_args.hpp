@@ -93,6 +93,7 @@ struct IntegrateArgs {
     unsigned long long* ctrl;  // [0] ray queue head of the FULL / FAR pass, [1] queue head of the NEAR pass (per round)
     uint32_t pick_flag;     // passes that resume rays (NEAR, FAR of round >= 1): meta flag of the rays to pick up; 0 = camera rays
     uint32_t allow_handback;  // NEAR: hand a ray back to the next round's FAR pass once it has left every object's reach
+    uint32_t handback_after;  // … and has stayed this many accepted steps in the NEAR pass (0: any stay; round 6's "long stayers only")
     uint32_t queue_chunk;   // ray ids popped per atomic: <= RTGR_QUEUE_CHUNK, smaller when a wave gets few rays in total
     unsigned long long* counters;
     // prepare_kernel only: where the rays come from (state0 == null: the camera) and the ordering key outputs

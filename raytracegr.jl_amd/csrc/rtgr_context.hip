@@ -21,13 +21,13 @@ int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------------------
 static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
                                          "far4", "rounds", "qchunk", "qchunk_near", "tile", "host_chunk",
-                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", "max_waves", "scene_check", nullptr};
+                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", "max_waves", "scene_check", "handback_after", nullptr};
 const char* const* knob_names() { return KNOB_NAMES; }
 long* knob_slot(Knobs& k, const char* name) {
     if (!name) return nullptr;
     long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
                      &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far, &k.peer, &k.pack, &k.packfar,
-                     &k.unit_probe, &k.unit_audit, &k.max_waves, &k.scene_check};
+                     &k.unit_probe, &k.unit_audit, &k.max_waves, &k.scene_check, &k.handback_after};
     for (int i = 0; KNOB_NAMES[i]; i++)
         if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
     return nullptr;

@@ -58,6 +58,7 @@ struct Knobs {
     long near_early = 64;         // accepted steps at hand-over below which a ray goes on the NEAR pass's early list (0: no list)
     long far4 = -1;               // 0/1: force the 3- / 4-waves-per-SIMD a = 0 FAR instantiation (auto: by launch size)
     long rounds = 1;              // FAR/NEAR hand-back rounds (1..3)
+    long handback_after = 0;      // rounds > 1: the NEAR pass hands back only rays that have stayed this many accepted steps (experiment)
     long qchunk = -1;             // ray ids per queue atomic, FAR / FULL pass (auto)
     long qchunk_near = -1;        // ... NEAR pass (auto)
     long tile = 0;                // 1: the simple tile-per-wave kernel (RTGR_KERNEL=tile), an independent formulation

@@ -474,6 +474,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         // [budget: reach bound]
                     bool hand_over = false;
                     bool need_scan = true;  // NEAR: false when no lane of the wave can see a sign change in this step
+                    // NEAR: WHICH objects some lane of the wave may see change sign in this step — bit min(o, 63) of the mask, all ones for
+                    // the passes that do not test reach.  The scan below folds only those objects into the sample points' minima: an
+                    // object whose distance provably keeps its sign in this step, for every lane that takes part, cannot move the sign of
+                    // the minimum (a ray outside every object stays outside the ones it cannot reach), and the sign is all the scan reads.
+                    // With example2's three objects that saves little; with a list of 64 it is the difference between 9 x 64 distances
+                    // per scanned step and 9 x the one or two spheres a ray is passing (2048², 64 objects, NEAR pass
+                    // 65.9 -> see there).  Same results bit for bit: FULL == FAR + NEAR is under test with long lists too.
+                    unsigned long long scan_mask = ~0ull;
                     if constexpr (MODE == MODE_FAR || MODE == MODE_NEAR) {
                         if (EEst2 <= 1.0f) {
                             // ---- can ANY object's distance change sign anywhere in this step?  |x_q(θ) − x_q| <= δ_q for all
@@ -489,18 +497,24 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             }
                             bool safe = true;
                             const R guard = R(1) + R(1e-6);
-                            for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t) {
+                            if constexpr (MODE == MODE_NEAR) {
+                                // a lane INSIDE an object (ps < 0: the minimum is that object's negative distance and changes sign when
+                                // the ray leaves it), or without a sign yet (ps == 0), needs every object: no selection for this wave-step
+                                scan_mask = __ballot(run && !(ps > R(0))) != 0ull ? ~0ull : 0ull;
+                            }
+                            for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t o) {
+                                bool safe_o;
                                 // (+ an absolute floor of a few hundred ulp of the operands: a distance that is itself
                                 //  rounding noise must go through the real scan)
                                 if (ob.kind == RTGR_PLANE) {
-                                    safe = safe && (rabs(x[0] - ob.p[0]) > rfma(guard, dl[0], R(256) * eps * (rabs(x[0]) + rabs(ob.p[0]))));
+                                    safe_o = (rabs(x[0] - ob.p[0]) > rfma(guard, dl[0], R(256) * eps * (rabs(x[0]) + rabs(ob.p[0]))));
                                 } else if (ob.kind == RTGR_SPHERE) {
                                     const R X0 = x[1] - ob.p[1], X1 = x[2] - ob.p[2], X2 = x[3] - ob.p[3], Rr = ob.p[8];
                                     const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
                                     const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
                                                      rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
                                     const R mag = rabs(D0) + R(2) * Rr * Rr;  // >= |X|² + R²: the operands' magnitude, for the floor
-                                    safe = safe && (rabs(D0) > rfma(guard, B, R(256) * eps * mag));
+                                    safe_o = (rabs(D0) > rfma(guard, B, R(256) * eps * mag));
 #ifdef RTGR_USER_OBJECTS
                                 } else if (ob.kind == RTGR_USER_OBJECT) {
 #ifdef RTGR_USER_REACH
@@ -510,9 +524,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     const R gd[4] = {guard * dl[0], guard * dl[1], guard * dl[2], guard * dl[3]};
                                     const R du = rtgr_user_distance<R>(ob.type, x, ob.p);
                                     const R bu = rtgr_user_reach<R>(ob.type, x, ob.p, gd);
-                                    safe = safe && (rabs(du) > bu + R(256) * eps * (R(1) + rabs(du)));
+                                    safe_o = (rabs(du) > bu + R(256) * eps * (R(1) + rabs(du)));
 #else
-                                    safe = false;   // no bound given: never provably out of reach (such units run the FULL pass)
+                                    safe_o = false;   // no bound given: never provably out of reach (such units run the FULL pass)
 #endif
 #endif
                                 } else {
@@ -520,7 +534,11 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's root inside this branch
                                     // (a maximum of three terms moves by at most the LARGEST of their moves: |z| by δ_z, the two radial
                                     //  terms by δ_ϱ <= δ_x + δ_y — not by their sum, which round 3 charged)
-                                    safe = safe && (rabs(disk_distance_fast<R>(ob, px, py, x[3])) > guard * rmax(dl[3], dl[1] + dl[2]));
+                                    safe_o = (rabs(disk_distance_fast<R>(ob, px, py, x[3])) > guard * rmax(dl[3], dl[1] + dl[2]));
+                                }
+                                safe = safe && safe_o;
+                                if constexpr (MODE == MODE_NEAR) {
+                                    if (__ballot(run && !safe_o) != 0ull) scan_mask |= 1ull << (o < 63u ? o : 63u);
                                 }
                             });
                             if constexpr (MODE == MODE_FAR) hand_over = run && (!safe || (ps == R(0)));
@@ -532,7 +550,14 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         // NEAR pass: a ray stays here until it ends, also after it has left every object's reach; its
                         // wave then runs with few lanes (the longest stays are 150-370 steps), so the scan is skipped
                         // whenever NO active lane needs it — a wave-uniform decision, same results by the same bound.
-                        if constexpr (MODE == MODE_NEAR) need_scan = __ballot(run && (EEst2 <= 1.0f) && need_scan) != 0ull;
+                        if constexpr (MODE == MODE_NEAR) {
+                            need_scan = __ballot(run && (EEst2 <= 1.0f) && need_scan) != 0ull;
+                            // (the mask was formed under the EXEC of the lanes that accepted their step, the same value in each of them:
+                            //  read it from one of those — a lane that rejected still holds "every object", a superset and as correct —
+                            //  and make it wave-uniform for the compiler too, so that the scan's per-object branches are scalar)
+                            const unsigned long long m_acc = __ballot(EEst2 <= 1.0f);
+                            scan_mask = uniform64(__shfl(scan_mask, m_acc != 0ull ? (int)__builtin_ctzll(m_acc) : 0, 64));
+                        }
                     }
         // [budget: hand over]
                     if (hand_over) {
@@ -589,7 +614,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     for (int q = 0; q < 4; q++)
                                         pos[j][q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
                                 }
-                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t) { fold_distances<R, 5>(ob, pos, dmin); });
+                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t o) {
+                                    if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 5>(ob, pos, dmin);
+                                });
 #pragma unroll
                                 for (int j = 0; j < 5; j++) {
                                     const bool hit = (ps * dmin[j] < R(0)) && !found;
@@ -610,7 +637,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 dmin[3] = R(__builtin_huge_val());
 #pragma unroll
                                 for (int q = 0; q < 4; q++) pos[3][q] = xn[q];
-                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t) { fold_distances<R, 4>(ob, pos, dmin); });
+                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t o) {
+                                    if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 4>(ob, pos, dmin);
+                                });
                                 nextc = dmin[3];
 #pragma unroll
                                 for (int j = 0; j < 3; j++) {
@@ -651,7 +680,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             if (!(t < t1)) done = RTGR_RAY_LAMBDA1;
                             else if (nacc + nrej >= A.opt.max_steps) done = RTGR_RAY_MAXSTEPS;
                             else if (!(t + dt > t)) done = RTGR_RAY_DTMIN;
-                            else if (MODE == MODE_NEAR && A.allow_handback && safe_streak >= 2u) hand_back = true;
+                            else if (MODE == MODE_NEAR && A.allow_handback && safe_streak >= 2u && (nacc - nacc0) >= A.handback_after) hand_back = true;
                         }
                     } else {
                         nrej++;

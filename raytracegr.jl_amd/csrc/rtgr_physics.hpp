@@ -899,7 +899,7 @@ RTGR_DEV void for_each_object(const DevScene<R>& sc, F&& f) {
     const uint32_t n0 = sc.nobj < (uint32_t)RTGR_MAX_OBJECTS ? sc.nobj : (uint32_t)RTGR_MAX_OBJECTS;
     for (uint32_t o = 0; o < n0; o++) f(sc.obj[o], o);
 #ifndef RTGR_INLINE_OBJECTS_ONLY   // (A/B builds: the loop as it was before lists could be longer — tools/launch_ab.py builds)
-    if (sc.nobj > (uint32_t)RTGR_MAX_OBJECTS) {
+    if (__builtin_expect(sc.nobj > (uint32_t)RTGR_MAX_OBJECTS, 0)) {   // (laid out of line: 0.4-0.7 % of the 4096² frame when it sat in the hot loop's stream)
         const DevObject<R>* __restrict__ more = sc.more;
         for (uint32_t o = (uint32_t)RTGR_MAX_OBJECTS; o < sc.nobj; o++) f(more[o - (uint32_t)RTGR_MAX_OBJECTS], o);
     }

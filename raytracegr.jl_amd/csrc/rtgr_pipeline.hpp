@@ -131,6 +131,7 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
               } }
             P.pick_flag = META_HANDED;
             P.allow_handback = (r + 1 < rounds) ? 1u : 0u;
+            P.handback_after = (uint32_t)(K.handback_after > 0 ? K.handback_after : 0);
             {   // The NEAR pass visits EVERY ray id, and its rays last ~6 steps: all its waves pop at the same time and
                 // keep popping, so the device-scope atomic on the queue head (~90 M/s on one word) is what bounds it when
                 // the chunks are small — measured 0.8 ms for 2.1 M rays at 42 ids per pop (50 k atomics), also for a

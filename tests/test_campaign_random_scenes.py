@@ -65,3 +65,41 @@ def test_campaign_outlier_is_formulation_noise_not_a_device_error(lib, seed, gen
     worst = max(v_prod, key=v_prod.get)
     assert worst in v_tile, (worst, v_prod, v_tile)                 # the independent formulation breaks the SAME bound ...
     assert v_tile[worst] >= 0.5 * v_prod[worst], (v_prod, v_tile)   # ... by at least as much (two draws of one noise: factor 2)
+
+
+@pytest.mark.parametrize("seed", [246, 451])
+def test_where_parity_ends_and_what_the_generic_path_holds_there(lib, seed):
+    """INTEGRATION.md "Where parity ends", under test.  Two of the 14 outlier scenes of the 400-seed extension (profiles/r05/builtin_campaign.log,
+    gpurun_out/r05/outliers.log): Kerr–Schild, a late plane, reltol 1e-9 — rays that are CAPTURED hover above the horizon with
+    |u^t| growing to 1e7 and beyond before the plane ends them, and from |u^t| ~ 1e3 on the embedded error estimate is the rounding noise
+    of whichever formulation of the RHS produced it.  What holds there, measured and pinned:
+      * on the rays that stay signal-dominated (|u^t| < 1e3 at their end in the oracle) BOTH device formulations keep the library's
+        parity: same status, step counts within +-3 of the oracle's;
+      * on the noise-dominated rays the three formulations order as their cancellation predicts — oracle's as-written duals (noisiest:
+        most steps) >= device generic duals >= device closed form (fewest) — and the GENERIC path, the reference's own formulation and
+        the parity-first setting (`generic = true`), stays within 10 % of the oracle's mean step count where the closed form is up to 35 %
+        below it; end positions and colours of the rays all three finish still agree to 1e-6."""
+    sc0, cam, opt, nobj, closed, ref = _traces(lib, seed, False)
+    _, _, _, _, generic, _ = _traces(lib, seed, True)
+    steps = {k: (v["n_accept"] + v["n_reject"]).astype(np.int64) for k, v in (("oracle", ref), ("closed", closed), ("generic", generic))}
+    ut = np.abs(ref["state_end"][:, 4])
+    signal = ut < 1e3
+    noisy = ~signal
+    assert signal.sum() > 100 and noisy.sum() > 100, (int(signal.sum()), int(noisy.sum()))
+    for name, got in (("closed", closed), ("generic", generic)):
+        same_hit = got["hit"] == ref["hit"]
+        ok = signal & same_hit
+        assert (got["status"][ok] == ref["status"][ok]).all(), name
+        assert np.abs(steps[name] - steps["oracle"])[ok].max() <= 3, (name, int(np.abs(steps[name] - steps["oracle"])[ok].max()))
+        assert (signal & ~same_hit).sum() <= 6, name
+    mean = {k: float(v[noisy].mean()) for k, v in steps.items()}
+    print(f"seed {seed}: noise-dominated rays {int(noisy.sum())}, mean step attempts {mean}; at the step cap: oracle "
+          f"{int((ref['status'] == 2).sum())}, generic {int((generic['status'] == 2).sum())}, closed {int((closed['status'] == 2).sum())}")
+    assert mean["oracle"] >= mean["generic"] >= mean["closed"], mean
+    assert mean["generic"] >= 0.90 * mean["oracle"], mean                      # the parity-first setting: within 10 % where it is all noise
+    assert 0.60 * mean["oracle"] <= mean["closed"] < 0.97 * mean["oracle"], mean   # the closed form: fewer steps, as far as 35 % below
+    done = noisy & (ref["status"] == 0) & (generic["status"] == 0) & (closed["status"] == 0) & (ref["hit"] == generic["hit"]) & (ref["hit"] == closed["hit"])
+    assert done.sum() > 50
+    from scenes import wrap_aware_rgb_err
+    for got in (closed, generic):
+        assert wrap_aware_rgb_err(got["rgb"][:, done], ref["rgb"][:, done], ref["hit"][done], sc=sc0) <= 1e-6

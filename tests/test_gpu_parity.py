@@ -1109,8 +1109,10 @@ def test_hand_back_rounds_do_not_change_results(lib):
     a = hip_trace(lib, sc, opt, 96, 80, cam=cam)
     with abi.options(lib, rounds=2):
         b = hip_trace(lib, sc, opt, 96, 80, cam=cam)
+    with abi.options(lib, rounds=2, handback_after=32):      # round 6's experiment: only the rays that stay long in the NEAR pass go back
+        c = hip_trace(lib, sc, opt, 96, 80, cam=cam)
     for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
-        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
 
 
 def test_example_script_writes_the_golden_png(lib, tmp_path, monkeypatch):
