@@ -913,11 +913,23 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
     ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
     o = {}
     n = size
+    lib = rt._abi.load()
+    first_call_ms = None
+    if user_sphere:
+        # what the AUTOMATIC scene check costs: a scene whose user objects bring a reach bound is compared — FULL
+        # pass against FAR + NEAR on a coarse sample of the call's rays — the first time it is traced.  One pass with the check
+        # switched off (allocates the workspace, registers nothing), then the first checked pass, timed; the steady passes follow.
+        with rt._abi.options(lib, scene_check=0):
+            sharded.trace_rows_torch(sc, opt, cam, n, n, 0, 1, n, dtype=npdt, counters=ctr, out=o)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sharded.trace_rows_torch(sc, opt, cam, n, n, 0, 1, n, dtype=npdt, counters=ctr, out=o)
+        torch.cuda.synchronize()
+        first_call_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(warm):
         sharded.trace_rows_torch(sc, opt, cam, n, n, 0, 1, n, dtype=npdt, counters=ctr, out=o)
     torch.cuda.synchronize()
     ctr.zero_()
-    lib = rt._abi.load()
     rt._abi.check(lib, lib.rtgr_timing_enable(None, 0, 1))
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -959,6 +971,9 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
          "step_attempts_per_ray": att / rays, "rejected_per_pass": int(ctr[2]) // reps}
     if two is not None:
         v["two_frames_in_flight"] = two
+    if first_call_ms is not None:
+        v["first_checked_call_ms"] = first_call_ms
+        v["automatic_scene_check_ms"] = first_call_ms - dt * 1e3
     k_s = (float(kms[1]) + float(kms[3])) * 1e-3 / reps
     class _A:  # noqa: E701
         pass
@@ -1059,6 +1074,9 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
             "same_frame": bool(us["frame_checksum"] == bi["frame_checksum"]),
             "pixels_that_differ": int(((f_us != f_bi).any(dim=0)).sum().item()), "max_rgb_difference": float((f_us - f_bi).abs().max().item()),
             "step_attempts_per_s": us["step_attempts_per_s"],
+            "first_checked_call_ms": us.get("first_checked_call_ms"), "automatic_scene_check_ms": us.get("automatic_scene_check_ms"),
+            "scene_check_note": "the first trace of a scene whose user objects bring a reach bound runs rtgr_scene_check's comparison on a coarse "
+                                "sample of its rays (48 x 48 of the camera's canvas) before it is enqueued: first call = check + frame; every later call = frame",
             "note": "RTGR_USER_OBJECT through a run-time unit built for this scene's metric variant (rtgr_user_unit_compile): distance / objcolor / "
                     "reach bound of the source called from the unit's own set-up, FAR, NEAR and resolve kernels"}
     except Exception as e:  # noqa: BLE001

@@ -13,16 +13,25 @@ struct DevObject {
     uint32_t kind;
     uint32_t type;   // RTGR_USER_OBJECT: the caller's tag for rtgr_user_distance / rtgr_user_objcolor (rtgr_object.type)
     R p[9];
+    uint32_t orig;   // the object's index in the CALLER's list (the device list is regrouped: DevScene)
 };
 
 // The object list (src/RayTraceGR.jl:433-441: a Vector of any length).  The first RTGR_MAX_OBJECTS objects sit in the kernels' argument
 // block (scalar loads from the kernarg segment), the rest — rare — in a device table the context keeps per distinct list
-// (rtgr_context.hip: object_table); `more` is null when nobj <= RTGR_MAX_OBJECTS.  Kernels walk the list with for_each_object
-// (rtgr_physics.hpp), never by index.
+// (rtgr_context.hip: object_table); `more` is null when nobj <= RTGR_MAX_OBJECTS.  Kernels walk the list with for_each_object /
+// for_each_by_kind (rtgr_physics.hpp), never by index.
+// ORDER.  The caller's order matters to the colour rule only (first-smaller-wins and the scale omin / length(objs),
+// src/RayTraceGR.jl:520-530); the event condition is a minimum (:433-441) and the FAR pass's reach test a conjunction — neither
+// cares.  So the device list is REGROUPED by the host: the spheres first (nsph of them, in the caller's order), then everything else
+// (in the caller's order), each object carrying its original index (DevObject::orig), which the colour rule breaks ties by and
+// reports.  The integrate kernels then walk the spheres — all but two or three objects of any long list — in a loop of their own
+// with no dispatch on the kind: a third of the scalar instructions per object.
 template <class R>
 struct DevScene {
     uint32_t metric;
     uint32_t nobj;
+    uint32_t nsph;   // objects [0, nsph) of the regrouped list are RTGR_SPHEREs
+    uint32_t pad_;
     R M, a;
     DevObject<R> obj[RTGR_MAX_OBJECTS];
     const DevObject<R>* more;   // objects RTGR_MAX_OBJECTS .. nobj-1

@@ -374,11 +374,25 @@ int convert_scene(DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserM
     d.a = (R)s->a;
     int rc;
     const uint32_t n0 = s->nobj < (uint32_t)RTGR_MAX_OBJECTS ? s->nobj : (uint32_t)RTGR_MAX_OBJECTS;
-    for (uint32_t o = 0; o < n0; o++) if ((rc = convert_object<R>(objs[o], d.obj[o]))) return rc;
+    // the device list is REGROUPED (DevScene, rtgr_args.hpp): spheres first, then the rest, both in the caller's order, every object
+    // with its original index — the integrate kernels walk the spheres without a dispatch on the kind; the colour rule breaks ties
+    // by the original index and reports it, so no result depends on the regrouping
+    std::vector<uint32_t> order;
+    order.reserve(s->nobj);
+    for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind == RTGR_SPHERE) order.push_back(o);
+    d.nsph = (uint32_t)order.size();
+    for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind != RTGR_SPHERE) order.push_back(o);
+    for (uint32_t k = 0; k < n0; k++) {
+        if ((rc = convert_object<R>(objs[order[k]], d.obj[k]))) return rc;
+        d.obj[k].orig = order[k];
+    }
     if (s->nobj > n0) {   // the rest of a long list: a device table, shared by every call with the same list
         std::vector<char> content((size_t)(s->nobj - n0) * sizeof(DevObject<R>), 0);
         DevObject<R>* t = (DevObject<R>*)content.data();
-        for (uint32_t o = n0; o < s->nobj; o++) if ((rc = convert_object<R>(objs[o], t[o - n0]))) return rc;
+        for (uint32_t k = n0; k < s->nobj; k++) {
+            if ((rc = convert_object<R>(objs[order[k]], t[k - n0]))) return rc;
+            t[k - n0].orig = order[k];
+        }
         const void* dev = nullptr;
         if ((rc = object_table(D, content, st, &dev))) return rc;
         d.more = (const DevObject<R>*)dev;

@@ -280,17 +280,19 @@ RTGR_DEV R mod1(R x) {  // Julia mod(x, 1)
 
 template <class R>
 RTGR_DEV uint32_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, const R x[4], R col[3]) {
-    uint32_t omin = 0;
+    uint32_t omin = 0, pmin = 0;   // omin: 1-based index in the CALLER's list (what :518-530 calls omin); pmin: position in the device list
     R dmin = opt.hit_threshold;                                                       // :519
+    // (the device list is regrouped — spheres first, DevScene —: "the first object with the smallest distance wins" (:520-526) is
+    //  the smallest distance and, among equal ones, the smallest ORIGINAL index)
     for_each_object<R>(sc, [&](const DevObject<R>& o_, uint32_t o) {                  // :520-526
         const R d = obj_distance<R>(o_, x);
-        if (d < dmin) { omin = o + 1; dmin = d; }
+        if (d < dmin || (d == dmin && omin != 0u && o_.orig + 1u < omin)) { omin = o_.orig + 1u; pmin = o; dmin = d; }
     });
     if (omin == 0) {                                                                  // :527-528
         col[0] = opt.miss_rgb[0]; col[1] = opt.miss_rgb[1]; col[2] = opt.miss_rgb[2];
         return 0;
     }
-    const DevObject<R>& ob = object_at<R>(sc, omin - 1);
+    const DevObject<R>& ob = object_at<R>(sc, pmin);
     const R pi = R(3.14159265358979323846264338327950288L);
     if (ob.kind == RTGR_PLANE) {                                                      // :402-404
         col[0] = R(0); col[1] = R(0.5); col[2] = R(0);
@@ -325,7 +327,7 @@ RTGR_DEV void eval_objects_body(const DevScene<R>& sc, const DevSolver<R>& opt, 
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const R xp[4] = {x[4 * p], x[4 * p + 1], x[4 * p + 2], x[4 * p + 3]};
-    if (d) for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) { d[p * sc.nobj + o] = obj_distance<R>(ob, xp); });
+    if (d) for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t) { d[p * sc.nobj + ob.orig] = obj_distance<R>(ob, xp); });   // (scene order)
     if (dmin) dmin[p] = min_distance<R>(sc, xp);
     R col[3];
     const uint32_t h = colour_pixel<R>(sc, opt, xp, col);
@@ -447,7 +449,9 @@ RTGR_DEV void redshift_body(const DevScene<R>& sc, const DevCamera<R>& cam, cons
     metric_plain<R>(sc, s0, g0);
     static_observer<R>(g0, tobs, ok0);
     metric_plain<R>(sc, se, ge);
-    const DevObject<R>& ob = object_at<R>(sc, h - 1);
+    uint32_t pos = 0;                      // the hit map holds indices of the CALLER's list: find the object in the regrouped one
+    for_each_object<R>(sc, [&](const DevObject<R>& o_, uint32_t o) { if (o_.orig + 1u == h) pos = o; });
+    const DevObject<R>& ob = object_at<R>(sc, pos);
     if (ob.kind == RTGR_SPHERE) {
         const R v[4] = {ob.p[4], ob.p[5], ob.p[6], ob.p[7]};
         const R v2 = inner<R>(ge, v, v);

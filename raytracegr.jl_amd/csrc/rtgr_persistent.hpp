@@ -83,6 +83,26 @@ RTGR_DEV uint32_t mask_rank(unsigned long long mask, uint32_t lane) {
     return (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }
 
+// … of a SPHERE (the leading objects of the regrouped list, DevScene: no dispatch on the kind)
+template <class R, int P>
+RTGR_DEV void fold_sphere(const DevObject<R>& o, const R (&pos)[P][4], R (&dmin)[P]) {
+    const R cx = o.p[1], cy = o.p[2], cz = o.p[3], Rr = o.p[8];
+    const R nR2 = -Rr * Rr;
+    if (Rr < R(0)) {                                                                   // :415-419, sign(R) * (|x − c|² − R²)
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const R dx = pos[p][1] - cx, dy = pos[p][2] - cy, dz = pos[p][3] - cz;
+            dmin[p] = rmin(dmin[p], -rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, nR2))));
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const R dx = pos[p][1] - cx, dy = pos[p][2] - cy, dz = pos[p][3] - cz;
+            dmin[p] = rmin(dmin[p], rfma(dx, dx, rfma(dy, dy, rfma(dz, dz, nR2))));
+        }
+    }
+}
+
 // distances of one object at P sample positions folded into dmin[] (object-major: parameters fetched once)
 template <class R, int P>
 RTGR_DEV void fold_distances(const DevObject<R>& o, const R (&pos)[P][4], R (&dmin)[P]) {
@@ -502,19 +522,27 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 // the ray leaves it), or without a sign yet (ps == 0), needs every object: no selection for this wave-step
                                 scan_mask = __ballot(run && !(ps > R(0))) != 0ull ? ~0ull : 0ull;
                             }
-                            for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t o) {
+                            // (+ an absolute floor of a few hundred ulp of the operands: a distance that is itself rounding noise must go
+                            //  through the real scan)
+                            auto note = [&](bool safe_o, uint32_t o) {
+                                safe = safe && safe_o;
+                                if constexpr (MODE == MODE_NEAR) {
+                                    if (__ballot(run && !safe_o) != 0ull) scan_mask |= 1ull << (o < 63u ? o : 63u);
+                                }
+                            };
+                            for_each_by_kind<R>(A.sc,
+                              [&](const DevObject<R>& ob, uint32_t o) {   // the spheres of the list: no dispatch, one batch of scalar loads each
+                                const R X0 = x[1] - ob.p[1], X1 = x[2] - ob.p[2], X2 = x[3] - ob.p[3], Rr = ob.p[8];
+                                const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
+                                const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
+                                                 rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
+                                const R mag = rabs(D0) + R(2) * Rr * Rr;  // >= |X|² + R²: the operands' magnitude, for the floor
+                                note(rabs(D0) > rfma(guard, B, R(256) * eps * mag), o);
+                              },
+                              [&](const DevObject<R>& ob, uint32_t o) {   // everything else
                                 bool safe_o;
-                                // (+ an absolute floor of a few hundred ulp of the operands: a distance that is itself
-                                //  rounding noise must go through the real scan)
                                 if (ob.kind == RTGR_PLANE) {
                                     safe_o = (rabs(x[0] - ob.p[0]) > rfma(guard, dl[0], R(256) * eps * (rabs(x[0]) + rabs(ob.p[0]))));
-                                } else if (ob.kind == RTGR_SPHERE) {
-                                    const R X0 = x[1] - ob.p[1], X1 = x[2] - ob.p[2], X2 = x[3] - ob.p[3], Rr = ob.p[8];
-                                    const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
-                                    const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
-                                                     rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
-                                    const R mag = rabs(D0) + R(2) * Rr * Rr;  // >= |X|² + R²: the operands' magnitude, for the floor
-                                    safe_o = (rabs(D0) > rfma(guard, B, R(256) * eps * mag));
 #ifdef RTGR_USER_OBJECTS
                                 } else if (ob.kind == RTGR_USER_OBJECT) {
 #ifdef RTGR_USER_REACH
@@ -529,18 +557,15 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     safe_o = false;   // no bound given: never provably out of reach (such units run the FULL pass)
 #endif
 #endif
-                                } else {
+                                } else {   // RTGR_DISK
                                     R px = x[1], py = x[2];
                                     asm volatile("" : "+v"(px), "+v"(py));  // keep the disk's root inside this branch
                                     // (a maximum of three terms moves by at most the LARGEST of their moves: |z| by δ_z, the two radial
                                     //  terms by δ_ϱ <= δ_x + δ_y — not by their sum, which round 3 charged)
                                     safe_o = (rabs(disk_distance_fast<R>(ob, px, py, x[3])) > guard * rmax(dl[3], dl[1] + dl[2]));
                                 }
-                                safe = safe && safe_o;
-                                if constexpr (MODE == MODE_NEAR) {
-                                    if (__ballot(run && !safe_o) != 0ull) scan_mask |= 1ull << (o < 63u ? o : 63u);
-                                }
-                            });
+                                note(safe_o, o);
+                              });
                             if constexpr (MODE == MODE_FAR) hand_over = run && (!safe || (ps == R(0)));
                             else {
                                 need_scan = !safe || (ps == R(0));
@@ -614,9 +639,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     for (int q = 0; q < 4; q++)
                                         pos[j][q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
                                 }
-                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t o) {
-                                    if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 5>(ob, pos, dmin);
-                                });
+                                for_each_by_kind<R>(A.sc,
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_sphere<R, 5>(ob, pos, dmin); },
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 5>(ob, pos, dmin); });
 #pragma unroll
                                 for (int j = 0; j < 5; j++) {
                                     const bool hit = (ps * dmin[j] < R(0)) && !found;
@@ -637,9 +662,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 dmin[3] = R(__builtin_huge_val());
 #pragma unroll
                                 for (int q = 0; q < 4; q++) pos[3][q] = xn[q];
-                                for_each_object<R>(A.sc, [&](const DevObject<R>& ob, uint32_t o) {
-                                    if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 4>(ob, pos, dmin);
-                                });
+                                for_each_by_kind<R>(A.sc,
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_sphere<R, 4>(ob, pos, dmin); },
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 4>(ob, pos, dmin); });
                                 nextc = dmin[3];
 #pragma unroll
                                 for (int j = 0; j < 3; j++) {

@@ -900,12 +900,38 @@ RTGR_DEV void for_each_object(const DevScene<R>& sc, F&& f) {
     for (uint32_t o = 0; o < n0; o++) f(sc.obj[o], o);
 #ifndef RTGR_INLINE_OBJECTS_ONLY   // (A/B builds: the loop as it was before lists could be longer — tools/launch_ab.py builds)
     if (__builtin_expect(sc.nobj > (uint32_t)RTGR_MAX_OBJECTS, 0)) {   // (laid out of line: 0.4-0.7 % of the 4096² frame when it sat in the hot loop's stream)
-        const DevObject<R>* __restrict__ more = sc.more;
-        for (uint32_t o = (uint32_t)RTGR_MAX_OBJECTS; o < sc.nobj; o++) f(more[o - (uint32_t)RTGR_MAX_OBJECTS], o);
+        // The table is read-only for the kernel's lifetime and walked with a wave-uniform index: through the CONSTANT address space
+        // its loads are scalar loads (s_load, the scalar cache — what the kernarg-resident objects get), not vector loads of one
+        // address by 64 lanes with a vector-memory round trip ahead of every object's arithmetic (measured at 64 objects, 2048²:
+        // the table walked with global_load cost the frame 3 x what its instruction count explains — DESIGN.md §4.7).
+        typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
+        const ConstTable more = (ConstTable)(unsigned long long)sc.more;
+        for (uint32_t o = (uint32_t)RTGR_MAX_OBJECTS; o < sc.nobj; o++)
+            f(*(const DevObject<R>*)(more + (o - (uint32_t)RTGR_MAX_OBJECTS)), o);
     }
 #endif
 }
-// … and one object by (per-lane) index: `objs[omin]` (:530)
+// The same walk with the spheres — objects [0, nsph) of the regrouped list (DevScene) — handed to a function of their own:
+// fs(sphere, position) needs no dispatch on the kind, fo(object, position) is the general one.  For consumers that do not care
+// about the order (the reach test's conjunction, the minima of the sample-point scan).
+template <class R, class FS, class FO>
+RTGR_DEV void for_each_by_kind(const DevScene<R>& sc, FS&& fs, FO&& fo) {
+    const uint32_t n0 = sc.nobj < (uint32_t)RTGR_MAX_OBJECTS ? sc.nobj : (uint32_t)RTGR_MAX_OBJECTS;
+    const uint32_t s0 = sc.nsph < n0 ? sc.nsph : n0;
+    for (uint32_t o = 0; o < s0; o++) fs(sc.obj[o], o);
+    for (uint32_t o = s0; o < n0; o++) fo(sc.obj[o], o);
+#ifndef RTGR_INLINE_OBJECTS_ONLY
+    if (__builtin_expect(sc.nobj > (uint32_t)RTGR_MAX_OBJECTS, 0)) {
+        typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
+        const ConstTable more = (ConstTable)(unsigned long long)sc.more;
+        const uint32_t s1 = sc.nsph < sc.nobj ? sc.nsph : sc.nobj;
+        for (uint32_t o = (uint32_t)RTGR_MAX_OBJECTS; o < s1; o++) fs(*(const DevObject<R>*)(more + (o - (uint32_t)RTGR_MAX_OBJECTS)), o);
+        for (uint32_t o = s1 > (uint32_t)RTGR_MAX_OBJECTS ? s1 : (uint32_t)RTGR_MAX_OBJECTS; o < sc.nobj; o++)
+            fo(*(const DevObject<R>*)(more + (o - (uint32_t)RTGR_MAX_OBJECTS)), o);
+    }
+#endif
+}
+// … and one object by (per-lane) POSITION in the regrouped list
 template <class R>
 RTGR_DEV const DevObject<R>& object_at(const DevScene<R>& sc, uint32_t o) {
     return o < (uint32_t)RTGR_MAX_OBJECTS ? sc.obj[o] : sc.more[o - (uint32_t)RTGR_MAX_OBJECTS];

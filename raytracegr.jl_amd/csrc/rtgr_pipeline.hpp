@@ -102,7 +102,14 @@ static int launch_integrate(LaunchEnv& E, const IntegrateArgs<R>& IA, bool npts1
         // hands rays that have left every object's reach back, and a second FAR + NEAR round carries them on — the
         // extra passes' own start-up and tails cost more than the NEAR tail they remove.  Each pass has its own queue
         // head (ctrl[0..7]).
-        int rounds = (int)K.rounds;
+        // … EXCEPT for long object lists (round 6): with tens of small objects along its path a ray is handed to the NEAR pass early and
+        // would stay there — two waves per SIMD, every step a candidate for the scan — for the rest of its life; a second round takes
+        // it back once it has left every reach.  Measured on example2 + N − 3 small spheres at 2048² (profiles/r06/
+        // objects_cost_rounds_sweep.log; one / two rounds): 24 objects 41.9 / 42.1 ms, 32: 53.6 / 48.1, 48: 72.5 / 59.3, 64: 82.7 / 64.1,
+        // 96: 102.4 / 88.0, 128: 88.1 / 83.8, 192: 124.1 / 123.0, 256: 169.2 / 187.7 (every ray is near something all the time); with
+        // a = 0.8: 32: 50.0 / 52.2, 64: 59.0 / 58.8, 128: 95.4 / 83.0.  Automatic: two rounds for lists of 32 to 199 objects — a rule
+        // read off one family of scenes; option `rounds` overrides it either way, and no choice changes a result bit.
+        int rounds = K.rounds > 0 ? (int)K.rounds : ((IA.sc.nobj >= 32u && IA.sc.nobj < 200u) ? 2 : 1);
         rounds = rounds < 1 ? 1 : (rounds > 3 ? 3 : rounds);  // 2 queue heads per round; slot 6 is the early-list cursor
         IntegrateArgs<R> P = IA;
         for (int r = 0; r < rounds; r++) {

@@ -380,6 +380,13 @@ def test_object_lists_of_any_length_match_oracle(lib, name, n, nobj):
     # (the captured rays of these scenes circle the hole for ~1300 steps before the plane at t = -25 ends them: their counts are noise)
     compare(g, r, sc=sc, max_class_flips=40 if mink else 6, max_step_diff=4 if mink else 2, rel_step_diff=0.015)
     assert g["counters"]["rays"] == n * n
+    # … and every pass structure of the library delivers the same bits for a long list too: the default (two hand-back rounds from
+    # 32 objects on), one round, three, and the single FULL pass that scans every accepted step as the reference does
+    for knobs in (dict(rounds=1), dict(rounds=3), dict(split=0)):
+        with abi.options(lib, **knobs):
+            other = hip_trace(lib, sc, opt, n, n, cam=cam)
+        for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            assert np.array_equal(g[k], other[k], equal_nan=True), (knobs, k)
 
 
 def test_a_short_list_through_the_objects_pointer_is_the_inline_list(lib):
