@@ -271,7 +271,7 @@ def run_group(cmd, env, timeout, what):
     return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 
-def live_counters(a, log=None):
+def live_counters(a, log=None, only_flop=False):
     """Executed flops and HBM bytes of ONE pass of this workload, hardware-counted here and now: bench.py re-run (one pass, no
     extras, no CPU leg) under `rocprofv3 --pmc` in child processes — the arithmetic counters, FETCH_SIZE and WRITE_SIZE each in a
     run of its own, never combined with a trace (MI355X_MICROARCH.md's recipe).  Returns (dict, None) or (None, why).  Children
@@ -298,6 +298,8 @@ def live_counters(a, log=None):
     flop_set = ([f"SQ_INSTS_VALU_FMA_{sfx}", f"SQ_INSTS_VALU_MUL_{sfx}", f"SQ_INSTS_VALU_ADD_{sfx}", "SQ_INSTS_VALU"] if a.dtype == "f64"
                 else ["SQ_INSTS_VALU_FLOPS_FP32", "SQ_INSTS_VALU"])
     sets = {"flop": flop_set, "fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"]}
+    if only_flop:      # (the objects16 / objects64 variants want the instruction counts only: one child instead of four)
+        sets = {"flop": flop_set}
     work = tempfile.mkdtemp(prefix="rtgr_pmc_", dir="/tmp")
     tot, attempts, rays = {}, None, None
     t0 = time.time()
@@ -351,13 +353,13 @@ def live_counters(a, log=None):
     flops_lane = tot.get("SQ_INSTS_VALU_FLOPS_FP32", 0.0) if a.dtype == "f32" else (2 * fma + mul + add)
     if flops_lane <= 0 or not attempts:
         return None, f"counters came back empty: {tot}"
-    trace = kernel_trace_pass(a, tool)     # (best effort: the kernels' average durations as rocprofv3 itself reports them)
+    trace = None if only_flop else kernel_trace_pass(a, tool)     # (best effort: the kernels' average durations as rocprofv3 itself reports them)
     return {"flop_per_step_attempt": 64.0 * flops_lane / attempts,
             "flop_counter": "64 x SQ_INSTS_VALU_FLOPS_FP32 (counts packed instructions in full)" if a.dtype == "f32" else "64 x (2 FMA + MUL + ADD) of SQ_INSTS_VALU_*_F64",
             "valu_per_wave_step": tot.get("SQ_INSTS_VALU", 0.0) / (attempts / 64.0),
             "fma_mul_add_per_wave_step": [fma / (attempts / 64.0), mul / (attempts / 64.0), add / (attempts / 64.0)] if a.dtype == "f64" else None,
             # FETCH_SIZE / WRITE_SIZE count KB; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes on gfx950
-            "hbm_bytes_per_ray": (2 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / rays,
+            "hbm_bytes_per_ray": None if only_flop else (2 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / rays,
             "hbm_note": "2 x FETCH_SIZE + WRITE_SIZE over the library's pipeline kernels (KB x 1024), per pass, per ray",
             "step_attempts_counted": attempts, "seconds": round(time.time() - t0, 1),
             "rocprof_kernel_trace": trace,
@@ -983,7 +985,7 @@ def time_variant(rt, variant, size, dtype="f64", rhs="closed", reps=3, warm=1, l
         prof, why, live_on = None, "a run-time unit's kernels: no profile entry", False
     if nobj != 3:       # (another workload than the profiled one: live counters or nothing)
         prof, why = None, "another object list than the profiled workload's"
-    live, why_not_live = live_counters(_A) if live_on else (None, "off")
+    live, why_not_live = live_counters(_A, only_flop=(nobj != 3)) if live_on else (None, "off")
     # Float32: the packed two-rays-per-lane kernel is priced against the fp32 VECTOR peak (v_pk_fma_f32), as asked
     peak = FP64_VALU_PEAK_TFLOPS if dtype == "f64" else F32_PACKED_VALU_PEAK_TFLOPS
     r = {"bound": "valu_f64" if dtype == "f64" else "valu_f32_packed", "peak": peak, "unit": "TFLOP/s", "kernel_ms_per_pass": k_s * 1e3,
@@ -1086,7 +1088,14 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
     # table).  Per step every object costs one reach test in the FAR pass and nine distances in a scanned NEAR step; the slope is
     # read off the hardware's instruction counter (SQ_INSTS_VALU per wave-step, live) and off the pass times.
     try:
-        base = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2, live_on=bool(a.live_counters))
+        base = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2, live_on=False)
+        if a.live_counters:    # (the three-object frame's instruction count at THIS size, one counter pass)
+            class _B:  # noqa: E701
+                pass
+            _B.variant, _B.dtype, _B.rhs, _B.size, _B.objects = "ks_ref0", "f64", "closed", 2048, 3
+            lv, _ = live_counters(_B, only_flop=True)
+            if lv:
+                base["roofline"]["valu_per_wave_step"], base["roofline"]["counters"] = lv["valu_per_wave_step"], "live"
         rows = {3: base}
         for nobj in (16, 64):
             rows[nobj] = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 6 if nobj == 16 else 3, 1, live_on=bool(a.live_counters), nobj=nobj)
