@@ -536,7 +536,18 @@ int api::user_unit_compile(rtgr_context* ctx, const char* source, int stationary
     if (key_hash) {   // the same call again while its unit is resident: no compiler, no load
         uint64_t known = 0;
         { std::lock_guard<std::mutex> lk(c->compiled_mu); auto it = c->compiled.find(key_hash); if (it != c->compiled.end()) known = it->second; }
-        if (known && rtgr_user_metric_loaded(c, known) == 1) { if (id_out) *id_out = known; return RTGR_OK; }
+        if (known && rtgr_user_metric_loaded(c, known) == 1) {
+            // (… unless that copy was loaded while the probe was switched off and the probe is on now: then it goes through
+            //  load_module_image again, which finds it resident and probes it — ADVICE r5)
+            bool unprobed = false;
+            {
+                DeviceCtx& d0 = *c->devs[0];
+                std::lock_guard<std::mutex> lk(d0.mu);
+                const UserModule* m = d0.find_module(known);
+                unprobed = d0.knobs.unit_probe != 0 && m && !m->probe_ok;
+            }
+            if (!unprobed) { if (id_out) *id_out = known; return RTGR_OK; }
+        }
     }
     auto remember = [&](int rc_) {
         if (rc_ == RTGR_OK && key_hash && id_out) { std::lock_guard<std::mutex> lk(c->compiled_mu); c->compiled[key_hash] = *id_out; }

@@ -65,6 +65,50 @@ def test_what_a_unit_is_made_of_is_read_off_its_source():
         rt.UserObjects("int nothing_here;")
 
 
+def test_a_comment_that_mentions_a_function_does_not_define_it(tmp_path):
+    """What a unit is made of is read off the source's CODE — an identifier followed by `(`, outside comments and string literals — by
+    the Python mirror (`defines`) and by the library (`source_defines`, through rtgr_user_unit_build) alike.  A comment that mentions
+    rtgr_user_reach used to switch -DRTGR_USER_REACH=1 on (the build then failed on an undefined template); one that mentions
+    rtgr_user_metric made an objects-only source a "metric" unit.  … and rtgr_user_sample is detected the same way."""
+    chatty = ("// a torus and an egg; no rtgr_user_reach( bound ) here, and nothing like rtgr_user_metric(x) either\n"
+              "/* rtgr_user_ks(x, M, a, f, k) would be another way to give a metric */\n" + user_objects.SHAPES +
+              '\n// const char* note = "rtgr_user_sample(type, p)";\n')
+    d, st = um.unit_defines(chatty, built_for=(abi.KS_REF, False, False))
+    assert d == ["-DRTGR_UNIT_BUILTIN_METRIC=1", "-DRTGR_UNIT_GENERIC=0", "-DRTGR_UNIT_SPIN=0", "-DRTGR_USER_OBJECTS=1"] and not st
+    assert um.defines(user_objects.SHAPES_WITH_REACH_AND_SAMPLES, "rtgr_user_sample") and not um.defines(chatty, "rtgr_user_sample")
+    d, _ = um.unit_defines(user_objects.SHAPES_WITH_REACH_AND_SAMPLES, built_for=(abi.KS_REF, False, False))
+    assert d[-3:] == ["-DRTGR_USER_OBJECTS=1", "-DRTGR_USER_REACH=1", "-DRTGR_USER_SAMPLE=1"]
+    rt.UserObjects(chatty, name="chatty", jit=True)         # (constructing it checks the same thing: objects only, both methods)
+    # the library's own reading of the same text: built_for is REQUIRED (objects only) and the unit builds — no reach bound switched on
+    lib = abi.load()
+    sc = rt.make_scene(rt.kerr_schild, [], units=False)
+    out = str(tmp_path / "chatty.hsaco")
+    assert lib.rtgr_user_unit_build(chatty.encode(), 0, None, out.encode()) == abi.ERR_BAD_ARG and b"built_for" in lib.rtgr_last_error()
+    abi.check(lib, lib.rtgr_user_unit_build(chatty.encode(), 0, C.byref(sc), out.encode()))
+    syms = _symbols(out)
+    assert "rtgr_user_resolve" in syms and "rtgr_user_samples" not in syms
+    out2 = str(tmp_path / "samples.hsaco")
+    abi.check(lib, lib.rtgr_user_unit_build(user_objects.SHAPES_WITH_REACH_AND_SAMPLES.encode(), 0, C.byref(sc), out2.encode()))
+    assert "rtgr_user_samples" in _symbols(out2)
+
+
+def test_pruning_the_unit_cache_touches_units_only(tmp_path, monkeypatch):
+    """prune_stale_units decides by NAME and content digest: a cache directory shared with other files (RTGR_USER_CACHE=/tmp …) keeps
+    them, a unit of the current device headers survives a `touch` of the headers' mtimes, and units named after another state of the
+    headers — or in the naming of earlier rounds — go (the rule used to be "every file older than the newest header")."""
+    import os
+    import time
+    monkeypatch.setenv("RTGR_USER_CACHE", str(tmp_path))
+    cur = um._env_digest()
+    keep = [tmp_path / "notes.txt", tmp_path / "metric_notes.hsaco", tmp_path / f"metric_{cur}_{'a' * 20}.hsaco", tmp_path / f"metric_{cur}_{'b' * 20}.hip"]
+    gone = [tmp_path / f"metric_{'0' * 8}_{'a' * 20}.hsaco", tmp_path / f"metric_{'c' * 20}.hsaco", tmp_path / f"metric_{'0' * 8}_{'d' * 20}.L1.tmp123.s"]
+    for f in keep + gone:
+        f.write_text("x")
+        os.utime(f, (time.time() - 10 ** 7, time.time() - 10 ** 7))          # all of them OLDER than every header
+    assert um.prune_stale_units() == len(gone)
+    assert all(f.exists() for f in keep) and not any(f.exists() for f in gone)
+
+
 @pytest.mark.parametrize("route", ["hipcc", "in-process"])
 def test_object_units_build_on_cpu_with_every_kernel(route, tmp_path):
     """A unit of objects for a built-in metric variant carries the integrate / set-up / RESOLVE kernels (Float64 and Float32) and none

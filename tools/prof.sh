@@ -8,6 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 python3 $R/bench.py --cpu-sample 0 --extras 0 --emit-row-checksums "$@" > $OUT/bench_plain.log 2>&1
 export RTGR_NO_COMPILE=1   # (--rhs user: the plain run above has filled the cache; never start hipcc under the profiler)
+export RTGR_UNIT_PROBE=0   # (… and probed the unit: under the profiler the probe's small frames would be counted as dispatches of the workload)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --cpu-sample 0 --extras 0 "$@" > $OUT/bench_trace.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SMEM" \
