@@ -238,7 +238,7 @@ def _assemble(asm, out):
             os.unlink(obj)
 
 
-MAX_SCRATCH = 64   # bytes per lane; == RTGR_USER_MAX_SCRATCH of rtgr_api.hip
+MAX_SCRATCH = 64   # bytes per lane; == RTGR_USER_MAX_SCRATCH of rtgr_unit_build.hpp
 # (generic-RHS kernels | closed-form kernels of a built-in metric in a unit of objects: whichever the unit instantiates reads its own)
 LEVELS = [[], ["-DRTGR_WAVES_PER_SIMD_GENERIC=1", "-DRTGR_WAVES_PER_SIMD_GENERIC_F32=2",
                "-DRTGR_WAVES_PER_SIMD_FAR=2", "-DRTGR_WAVES_PER_SIMD=1", "-DRTGR_WAVES_PER_SIMD_F32=2"],

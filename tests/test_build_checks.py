@@ -258,7 +258,7 @@ def test_a_library_unit_built_through_its_listing_is_the_same_code(tmp_path):
 
 def test_build_falls_back_to_the_listing_route_when_the_audit_finds_the_fault(tmp_path):
     """The driver logic with stand-in tools (every tool just creates its output file): a post-link audit that reports the fault makes
-    build() compile the kernel units again through compile_via_listing — not the kernel-free rtgr_api.hip — and link again; an
+    build() compile the kernel units again through compile_via_listing — not the kernel-free host units (rtgr_context.hip …) — and link again; an
     audit that still reports it after that is an error."""
     b = _build_module("rtgr_build_t3")
     log = tmp_path / "calls.log"
@@ -278,7 +278,7 @@ def test_build_falls_back_to_the_listing_route_when_the_audit_finds_the_fault(tm
     links = [c for c in calls if " -shared " in c and c.startswith("hipcc")]
     device_listings = [c for c in calls if "--cuda-device-only" in c]
     assert len(links) == 2 and len(device_listings) == len(b.UNITS) - len(b.HOST_ONLY_UNITS)
-    assert not any("rtgr_api.hip" in c for c in device_listings) and answers == []
+    assert not any(h in c for c in device_listings for h in b.HOST_ONLY_UNITS) and answers == []
     assert sum(1 for c in calls if c.startswith("clang-offload-bundler")) == len(device_listings)
     answers.extend([(1, "x"), (1, "x")])
     with pytest.raises(RuntimeError, match="survive the listing route"):

@@ -658,6 +658,30 @@ def test_f32_crops_of_the_spinning_variants_match_f32_oracle(lib, name):
     assert gpu["counters"]["rays"] == 64 * 64 and gpu["counters"]["events"] >= 0.99 * ref["counters"]["events"]
 
 
+@pytest.mark.parametrize("name,nobj", [("ks_ref0_many64", 64), ("ks_true08_many64", 64)])
+def test_f32_long_object_lists_match_f32_oracle(lib, name, nobj):
+    """The object table in Float32 (DevObject<float>; scalar kernel and the packed two-rays-per-lane kernel, which walks the
+    list once per half): a 64-object list against the Float32 oracle at the Float32 bars above, hits on both sides of the
+    16 inline slots, and the two kernels against each other at the bars of the test below."""
+    sc, cam = scene_variant(name)
+    assert sc.nobj == nobj
+    opt = rt.solver_defaults(np.float32)
+    ref = O.trace(sc, opt, 48, 48, cam=cam, dtype=np.float32)
+    assert int(ref["hit"].max()) == nobj and (np.unique(ref["hit"]) <= abi.RTGR_MAX_OBJECTS).any()
+    got = {}
+    for pk in (0, 1):
+        with abi.options(lib, pack=pk):
+            gpu = got[pk] = hip_trace(lib, sc, opt, 48, 48, cam=cam, dtype=np.float32)
+        flips = gpu["hit"] != ref["hit"]
+        # (64 small spheres: ~10 x the silhouette length of example2's scene per pixel of canvas, and Float32 decides a
+        # silhouette pixel either way — the flip bar scales with it)
+        assert flips.mean() <= 4 * F32_FLIP_FRAC, (pk, flips.mean())
+        same = ~flips
+        assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same], sc=sc) < F32_RGB_TOL
+        assert gpu["counters"]["rays"] == 48 * 48
+    assert (got[0]["hit"] != got[1]["hit"]).sum() <= 12
+
+
 @pytest.mark.parametrize("name", ["mink", "ks_ref0", "ks_ref08", "ks_true08", "ks_true0998_disk"])
 def test_f32_packed_two_rays_per_lane_kernel_equals_the_scalar_kernel(lib, name):
     """The Float32 FULL pass exists twice: one ray per lane (integrate_body<float>) and two rays per lane in packed f32
