@@ -31,11 +31,22 @@ struct DevScene {
     uint32_t metric;
     uint32_t nobj;
     uint32_t nsph;   // objects [0, nsph) of the regrouped list are RTGR_SPHEREs
-    uint32_t pad_;
+    uint32_t ngroups;   // > 0: the spheres [nloose, nsph) are laid out group by group (see below); 0: no groups
     R M, a;
     DevObject<R> obj[RTGR_MAX_OBJECTS];
-    const DevObject<R>* more;   // objects RTGR_MAX_OBJECTS .. nobj-1
+    const DevObject<R>* more;   // objects RTGR_MAX_OBJECTS .. nobj-1 (the table holds the WHOLE list: table = more - RTGR_MAX_OBJECTS)
+    uint32_t nloose;    // (ngroups > 0) spheres [0, nloose) belong to no group
+    uint32_t pad_;
 };
+// GROUPS (long lists: DESIGN.md §4.7).  The FAR pass's reach test asks of every object, every step, "can this step reach you?"; of a
+// list of 64 small spheres the answer is no for all but one or two.  The host therefore sorts the spheres of a long list into groups of
+// up to RTGR_GROUP_MAX neighbours (median splits of their centres: rtgr_context.hip) and gives every group a bounding sphere; a step
+// that provably stays outside a group's bounding sphere cannot change the sign of any member's distance, and the members are only
+// asked when some lane of the wave cannot prove that.  A group is a DevObject in sphere form — p[1..3] the centre, p[8] the radius,
+// `type` the position of its first member in the device list, `orig` their number — and the groups follow the objects in the table:
+// groups = table + nobj.  Same results bit for bit with and without (the bound is a bound; FULL == FAR + NEAR is under test with
+// grouped lists); option groups = 0 switches them off (A/B, tests).
+#define RTGR_GROUP_MAX 8
 
 template <class R>
 struct DevSolver {
@@ -159,6 +170,7 @@ struct ResolveArgs {
     const R* hand;     // … and heads (the rays' hand-over lines, stride HAND_W)
     const uint32_t* meta;
     int recw;
+    uint32_t select;   // 1: lists beyond the argument block are narrowed per wave to the objects a ray's last step can meet (select_objects)
     uint64_t n;        // rays in this chunk
     uint64_t offset;   // first ray of the chunk in the caller's slab
     uint64_t n_slab;   // rays in the slab (plane stride of rgb)

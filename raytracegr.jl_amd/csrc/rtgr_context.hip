@@ -21,13 +21,13 @@ int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------------------
 static const char* const KNOB_NAMES[] = {"waves_per_cu", "waves_per_cu_near", "chunk", "split", "order", "fair", "near_early",
                                          "far4", "rounds", "qchunk", "qchunk_near", "tile", "host_chunk",
-                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", "max_waves", "scene_check", "handback_after", nullptr};
+                                         "dbg_pass_far", "peer", "pack", "packfar", "unit_probe", "unit_audit", "max_waves", "scene_check", "handback_after", "groups", nullptr};
 const char* const* knob_names() { return KNOB_NAMES; }
 long* knob_slot(Knobs& k, const char* name) {
     if (!name) return nullptr;
     long* slots[] = {&k.waves_per_cu, &k.waves_per_cu_near, &k.chunk, &k.split, &k.order, &k.fair, &k.near_early,
                      &k.far4, &k.rounds, &k.qchunk, &k.qchunk_near, &k.tile, &k.host_chunk, &k.dbg_pass_far, &k.peer, &k.pack, &k.packfar,
-                     &k.unit_probe, &k.unit_audit, &k.max_waves, &k.scene_check, &k.handback_after};
+                     &k.unit_probe, &k.unit_audit, &k.max_waves, &k.scene_check, &k.handback_after, &k.groups};
     for (int i = 0; KNOB_NAMES[i]; i++)
         if (std::strcmp(KNOB_NAMES[i], name) == 0) return slots[i];
     return nullptr;
@@ -331,6 +331,80 @@ static int object_table(DeviceCtx& D, const std::vector<char>& content, hipStrea
     return RTGR_OK;
 }
 
+// ---- groups of a long list's spheres (DevScene, rtgr_args.hpp: GROUPS) ------------------------------------------------------------
+struct SphereGroup { uint32_t first, count; };   // positions in the device list
+// `order` holds the spheres in the caller's order; on return: [0, *nloose) the spheres that join no group, then the groups' members,
+// group by group (`groups`: their positions).  Groups are the leaves of median splits of the centres along the widest axis — a k-d
+// tree's leaves, <= RTGR_GROUP_MAX members each; a sphere much larger than the list's typical one (a sky sphere around the scene) would
+// make its group's bounding sphere as large as itself and stays loose.  Lists with fewer than two full groups, or with a non-finite
+// centre or radius among the spheres, get no groups.  Deterministic: ties are broken by the caller's index.
+static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order, uint32_t* nloose, std::vector<SphereGroup>& groups) {
+    *nloose = 0;
+    groups.clear();
+    const size_t n = order.size();
+    if (n < 2 * (size_t)RTGR_GROUP_MAX) return;
+    std::vector<double> radii(n);
+    for (size_t k = 0; k < n; k++) {
+        const rtgr_object& o = objs[order[k]];
+        if (!std::isfinite(o.p[1]) || !std::isfinite(o.p[2]) || !std::isfinite(o.p[3]) || !std::isfinite(o.p[8])) return;
+        radii[k] = std::fabs(o.p[8]);
+    }
+    std::vector<double> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const double big = 4.0 * sorted[n / 2];
+    std::vector<uint32_t> loose, rest;
+    for (size_t k = 0; k < n; k++) (radii[k] > big ? loose : rest).push_back(order[k]);
+    if (rest.size() < 2 * (size_t)RTGR_GROUP_MAX) return;
+    std::vector<std::pair<size_t, size_t>> todo{{0, rest.size()}}, leaves;
+    while (!todo.empty()) {
+        const auto [lo, hi] = todo.back();
+        todo.pop_back();
+        if (hi - lo <= (size_t)RTGR_GROUP_MAX) { leaves.push_back({lo, hi}); continue; }
+        double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        for (size_t k = lo; k < hi; k++)
+            for (int q = 0; q < 3; q++) { mn[q] = std::min(mn[q], objs[rest[k]].p[1 + q]); mx[q] = std::max(mx[q], objs[rest[k]].p[1 + q]); }
+        int ax = 0;
+        for (int q = 1; q < 3; q++) if (mx[q] - mn[q] > mx[ax] - mn[ax]) ax = q;
+        const size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(rest.begin() + lo, rest.begin() + mid, rest.begin() + hi, [&](uint32_t a, uint32_t b) {
+            const double ca = objs[a].p[1 + ax], cb = objs[b].p[1 + ax];
+            return ca < cb || (ca == cb && a < b);
+        });
+        todo.push_back({mid, hi});
+        todo.push_back({lo, mid});
+    }
+    std::sort(leaves.begin(), leaves.end());
+    for (auto& lf : leaves) std::sort(rest.begin() + lf.first, rest.begin() + lf.second);   // (members in the caller's order)
+    *nloose = (uint32_t)loose.size();
+    order = loose;
+    order.insert(order.end(), rest.begin(), rest.end());
+    for (auto& lf : leaves) groups.push_back({(uint32_t)(loose.size() + lf.first), (uint32_t)(lf.second - lf.first)});
+}
+// … and a group's bounding sphere from its members AS THE KERNELS SEE THEM (the scalar type's values): centre = the middle of the
+// centres' box, radius = max (|c_i − C| + |r_i|), evaluated in double and rounded UP into R with a margin of 64 ulp — what the reach
+// test's argument needs is containment, not tightness.
+template <class R>
+static void bounding_sphere(const DevObject<R>* t, const SphereGroup& g, DevObject<R>& out) {
+    double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (uint32_t k = g.first; k < g.first + g.count; k++)
+        for (int q = 0; q < 3; q++) { mn[q] = std::min(mn[q], (double)t[k].p[1 + q]); mx[q] = std::max(mx[q], (double)t[k].p[1 + q]); }
+    std::memset(&out, 0, sizeof out);
+    out.kind = RTGR_SPHERE;
+    out.type = g.first;
+    out.orig = g.count;
+    for (int q = 0; q < 3; q++) out.p[1 + q] = (R)(0.5 * mn[q] + 0.5 * mx[q]);
+    double rad = 0;
+    for (uint32_t k = g.first; k < g.first + g.count; k++) {
+        double d2 = 0;
+        for (int q = 0; q < 3; q++) { const double e = (double)t[k].p[1 + q] - (double)out.p[1 + q]; d2 += e * e; }
+        rad = std::max(rad, std::sqrt(d2) + std::fabs((double)t[k].p[8]));
+    }
+    rad = rad * (1.0 + 64.0 * (double)std::numeric_limits<R>::epsilon()) + (double)std::numeric_limits<R>::min();
+    R r = (R)rad;
+    if ((double)r < rad) r = std::nextafter(r, std::numeric_limits<R>::infinity());
+    out.p[8] = r;
+}
+
 template <class R>
 int convert_scene(DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserModule** user, hipStream_t st) {
     if (!s) return fail(RTGR_ERR_BAD_ARG, "scene is NULL");
@@ -381,21 +455,27 @@ int convert_scene(DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserM
     order.reserve(s->nobj);
     for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind == RTGR_SPHERE) order.push_back(o);
     d.nsph = (uint32_t)order.size();
+    // … and the spheres of a LONG list in groups of neighbours (DevScene: GROUPS)
+    std::vector<SphereGroup> groups;
+    if (s->nobj > n0 && (tl_knobs_override ? tl_knobs_override->groups : D.knobs.groups))
+        group_spheres(objs, order, &d.nloose, groups);
     for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind != RTGR_SPHERE) order.push_back(o);
     for (uint32_t k = 0; k < n0; k++) {
         if ((rc = convert_object<R>(objs[order[k]], d.obj[k]))) return rc;
         d.obj[k].orig = order[k];
     }
-    if (s->nobj > n0) {   // the rest of a long list: a device table, shared by every call with the same list
-        std::vector<char> content((size_t)(s->nobj - n0) * sizeof(DevObject<R>), 0);
+    if (s->nobj > n0) {   // a long list: a device table of ALL of it (+ its groups), shared by every call with the same list
+        std::vector<char> content((size_t)(s->nobj + groups.size()) * sizeof(DevObject<R>), 0);
         DevObject<R>* t = (DevObject<R>*)content.data();
-        for (uint32_t k = n0; k < s->nobj; k++) {
-            if ((rc = convert_object<R>(objs[order[k]], t[k - n0]))) return rc;
-            t[k - n0].orig = order[k];
+        for (uint32_t k = 0; k < s->nobj; k++) {
+            if ((rc = convert_object<R>(objs[order[k]], t[k]))) return rc;
+            t[k].orig = order[k];
         }
+        for (size_t g = 0; g < groups.size(); g++) bounding_sphere<R>(t, groups[g], t[s->nobj + g]);
+        d.ngroups = (uint32_t)groups.size();
         const void* dev = nullptr;
         if ((rc = object_table(D, content, st, &dev))) return rc;
-        d.more = (const DevObject<R>*)dev;
+        d.more = (const DevObject<R>*)dev + n0;
     }
     return RTGR_OK;
 }
@@ -761,6 +841,34 @@ int api::trace_rows_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const
 }
 
 }  // namespace rtgr
+
+// A test hook, not part of include/rtgr.h (tests/test_host_logic.py; host code only — runs without a GPU): how convert_scene lays a
+// list's SPHERES out — `order` (n entries: indices into objs, loose spheres first, then the groups' members), the number of loose
+// ones, and per group {centre x, y, z, radius, first position, count} as the kernels of the scalar type get them.  objs[] must all be
+// RTGR_SPHEREs.  Returns the number of groups (0: the list gets none), or -1 when `cap` groups do not hold them.
+extern "C" int rtgr_testhook_group_spheres(const rtgr_object* objs, uint32_t n, int is_f32, uint32_t* order_out, uint32_t* nloose,
+                                           double* groups_out, uint32_t cap) {
+    using namespace rtgr;
+    std::vector<uint32_t> order(n);
+    for (uint32_t k = 0; k < n; k++) order[k] = k;
+    std::vector<SphereGroup> groups;
+    group_spheres(objs, order, nloose, groups);
+    for (uint32_t k = 0; k < n; k++) order_out[k] = order[k];
+    if (groups.size() > cap) return -1;
+    auto fill = [&](auto zero) {
+        typedef decltype(zero) R;
+        std::vector<DevObject<R>> t(n);
+        for (uint32_t k = 0; k < n; k++) (void)convert_object<R>(objs[order[k]], t[k]);
+        for (size_t g = 0; g < groups.size(); g++) {
+            DevObject<R> G;
+            bounding_sphere<R>(t.data(), groups[g], G);
+            double* o = groups_out + 6 * g;
+            o[0] = (double)G.p[1]; o[1] = (double)G.p[2]; o[2] = (double)G.p[3]; o[3] = (double)G.p[8]; o[4] = G.type; o[5] = G.orig;
+        }
+    };
+    if (is_f32) fill(0.0f); else fill(0.0);
+    return (int)groups.size();
+}
 
 #ifdef RTGR_ROOT_STATS
 // (debug builds export two symbols that are not part of include/rtgr.h)

@@ -278,13 +278,14 @@ RTGR_DEV R mod1(R x) {  // Julia mod(x, 1)
     return r >= R(1) ? R(0) : r;
 }
 
-template <class R>
-RTGR_DEV uint32_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, const R x[4], R col[3]) {
+template <class R, bool SEL = false>
+RTGR_DEV uint32_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, const R x[4], R col[3], ObjSel sel = ObjSel{}) {
     uint32_t omin = 0, pmin = 0;   // omin: 1-based index in the CALLER's list (what :518-530 calls omin); pmin: position in the device list
     R dmin = opt.hit_threshold;                                                       // :519
     // (the device list is regrouped — spheres first, DevScene —: "the first object with the smallest distance wins" (:520-526) is
     //  the smallest distance and, among equal ones, the smallest ORIGINAL index)
     for_each_object<R>(sc, [&](const DevObject<R>& o_, uint32_t o) {                  // :520-526
+        if constexpr (SEL) { if (!sel.has(o)) return; }   // (left out: provably farther than the nearest object, select_objects)
         const R d = obj_distance<R>(o_, x);
         if (d < dmin || (d == dmin && omin != 0u && o_.orig + 1u < omin)) { omin = o_.orig + 1u; pmin = o; dmin = d; }
     });

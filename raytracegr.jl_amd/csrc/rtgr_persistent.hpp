@@ -184,6 +184,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
     const int npts = (int)A.opt.interp_points;
     const R eps = sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7);
     const R t1_snap = uniform_(t1 - R(16) * eps * rmaxabs<R>(t0, t1));   // below this λ the snap-to-λ1 test cannot hold
+    // (the NEAR pass's scan mask, below: one bit per 2^mask_shift neighbours of the device list — one per object up to 64 objects)
+    const uint32_t mask_shift = A.sc.nobj > 64u ? 32u - (uint32_t)__builtin_clz((A.sc.nobj - 1u) >> 6) : 0u;
 
     int state = L_FREE;
     bool exhausted = false;
@@ -494,8 +496,10 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
         // [budget: reach bound]
                     bool hand_over = false;
                     bool need_scan = true;  // NEAR: false when no lane of the wave can see a sign change in this step
-                    // NEAR: WHICH objects some lane of the wave may see change sign in this step — bit min(o, 63) of the mask, all ones for
-                    // the passes that do not test reach.  The scan below folds only those objects into the sample points' minima: an
+                    // NEAR: WHICH objects some lane of the wave may see change sign in this step — bit o >> mask_shift of the mask (one
+                    // bit per object up to 64 objects; beyond, one per 2, 4, … neighbours of the device list, which the groups of a long
+                    // list have made neighbours in space: a bit drags in what the ray is passing anyway), all ones for the passes that
+                    // do not test reach.  The scan below folds only those objects into the sample points' minima: an
                     // object whose distance provably keeps its sign in this step, for every lane that takes part, cannot move the sign of
                     // the minimum (a ray outside every object stays outside the ones it cannot reach), and the sign is all the scan reads.
                     // With example2's three objects that saves little; with a list of 64 it is the difference between 9 x 64 distances
@@ -527,17 +531,33 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             auto note = [&](bool safe_o, uint32_t o) {
                                 safe = safe && safe_o;
                                 if constexpr (MODE == MODE_NEAR) {
-                                    if (__ballot(run && !safe_o) != 0ull) scan_mask |= 1ull << (o < 63u ? o : 63u);
+                                    if (__ballot(run && !safe_o) != 0ull) scan_mask |= 1ull << (o >> mask_shift);
                                 }
                             };
-                            for_each_by_kind<R>(A.sc,
+                            // (a lane that has ruled a whole GROUP of spheres out — see below — has ruled its members out: what the
+                            //  members' own tests say for that lane, asked because another lane needs them, does not count)
+                            bool group_out = false;
+                            for_each_within_reach<R>(A.sc,
+                              [&](const DevObject<R>& G) -> bool {        // a group of a long list (DevScene): its bounding sphere
+                                // OUTSIDE the bounding sphere now, and for the whole step (the sphere test below without the absolute
+                                // value): then outside every member, by at least the same margin, for the whole step — no member's
+                                // distance changes sign.  The floor keeps that margin above the rounding noise of the members' own
+                                // distances (|X_g| − R_g > 64 eps (|X_g| + R_g), the noise is a few eps of |X_i| + R_i <= |X_g| + 2 R_g).
+                                const R X0 = x[1] - G.p[1], X1 = x[2] - G.p[2], X2 = x[3] - G.p[3], Rr = G.p[8];
+                                const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
+                                const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
+                                                 rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
+                                const R mag = rabs(D0) + R(2) * Rr * Rr;
+                                group_out = D0 > rfma(guard, B, R(256) * eps * mag);
+                                return __ballot(run && !group_out) != 0ull;
+                              },
                               [&](const DevObject<R>& ob, uint32_t o) {   // the spheres of the list: no dispatch, one batch of scalar loads each
                                 const R X0 = x[1] - ob.p[1], X1 = x[2] - ob.p[2], X2 = x[3] - ob.p[3], Rr = ob.p[8];
                                 const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
                                 const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
                                                  rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
                                 const R mag = rabs(D0) + R(2) * Rr * Rr;  // >= |X|² + R²: the operands' magnitude, for the floor
-                                note(rabs(D0) > rfma(guard, B, R(256) * eps * mag), o);
+                                note(group_out || rabs(D0) > rfma(guard, B, R(256) * eps * mag), o);
                               },
                               [&](const DevObject<R>& ob, uint32_t o) {   // everything else
                                 bool safe_o;
@@ -640,8 +660,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                         pos[j][q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
                                 }
                                 for_each_by_kind<R>(A.sc,
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_sphere<R, 5>(ob, pos, dmin); },
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 5>(ob, pos, dmin); });
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_sphere<R, 5>(ob, pos, dmin); },
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_distances<R, 5>(ob, pos, dmin); });
 #pragma unroll
                                 for (int j = 0; j < 5; j++) {
                                     const bool hit = (ps * dmin[j] < R(0)) && !found;
@@ -663,8 +683,8 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
 #pragma unroll
                                 for (int q = 0; q < 4; q++) pos[3][q] = xn[q];
                                 for_each_by_kind<R>(A.sc,
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_sphere<R, 4>(ob, pos, dmin); },
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o < 63u ? o : 63u)) & 1ull) fold_distances<R, 4>(ob, pos, dmin); });
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_sphere<R, 4>(ob, pos, dmin); },
+                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_distances<R, 4>(ob, pos, dmin); });
                                 nextc = dmin[3];
 #pragma unroll
                                 for (int j = 0; j < 3; j++) {
@@ -1048,12 +1068,77 @@ static __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t
 // ---------------------------------------------------------------------------------------------------------------------
 // resolve kernel: one thread per ray — root of cond(x(θ)) on [0, top], end state, colouring rule, stores
 // ---------------------------------------------------------------------------------------------------------------------
-template <class R>
-RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th) {
+template <class R, bool SEL = false>
+RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th, ObjSel sel = ObjSel{}) {
     R x[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) x[q] = rfma(th, rfma(th, rfma(th, rfma(th, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
-    return min_distance<R>(sc, x);
+    return min_distance<R, SEL>(sc, x, sel);
+}
+
+// LONG LISTS.  The root-find below evaluates the condition — the minimum over ALL objects' distances (:433-441) — some ten times per
+// event, and the colour rule once more: with N objects, ~10 N distances per ray, of which all but one or two are of objects nowhere
+// near the step the event lies in.  For a list beyond the argument block the wave first narrows the list down: over the event's step
+// every object's distance stays within d_i(0) ± B_i (the bounds of the FAR pass's reach test, from the box |x_q(θ) − x_q(0)| <= δ_q,
+// θ in [0, top], that the step's polynomial spans), so the minimum never exceeds U = min_i (d_i(0) + B_i), and an object with
+// d_i(0) − B_i > U is never the minimum — neither its value nor its index can enter a result, at any θ of the bracket.  The objects
+// that SOME lane of the wave cannot leave out form the selection (one bit per object up to 64, per 2^shift neighbours beyond); the
+// rays of a wave are neighbours on the canvas, so the selection is a handful of objects.  Same frame bit for bit (under test with
+// option groups = 0, which switches this off too).  Guards as in the reach test: 1e-6 relative on the bound, a floor of 256 ulp of the
+// operands' magnitude; a NaN anywhere keeps the object in.
+template <class R>
+RTGR_DEV void distance_bounds(const DevObject<R>& ob, const R x[4], const R dl[4], R* lower, R* upper) {
+    const R eps = sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7);
+    const R guard = R(1) + R(1e-6);
+    R d0, B, mag;
+    if (ob.kind == RTGR_SPHERE) {
+        const R X0 = x[1] - ob.p[1], X1 = x[2] - ob.p[2], X2 = x[3] - ob.p[3], Rr = ob.p[8];
+        const R D0 = rfma(X0, X0, rfma(X1, X1, rfma(X2, X2, -Rr * Rr)));
+        B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]), rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
+        mag = rabs(D0) + R(2) * Rr * Rr;
+        d0 = Rr < R(0) ? -D0 : D0;
+    } else if (ob.kind == RTGR_PLANE) {
+        d0 = x[0] - ob.p[0];
+        B = dl[0];
+        mag = rabs(x[0]) + rabs(ob.p[0]);
+#ifdef RTGR_USER_OBJECTS
+    } else if (ob.kind == RTGR_USER_OBJECT) {
+#ifdef RTGR_USER_REACH
+        const R gd[4] = {guard * dl[0], guard * dl[1], guard * dl[2], guard * dl[3]};
+        d0 = rtgr_user_distance<R>(ob.type, x, ob.p);
+        B = rtgr_user_reach<R>(ob.type, x, ob.p, gd);
+        mag = R(1) + rabs(d0);
+#else
+        d0 = R(0); B = R(__builtin_huge_val()); mag = R(0);   // no bound given: always in, never bounds the minimum
+#endif
+#endif
+    } else {   // RTGR_DISK: a maximum of three terms moves by at most the largest of their moves
+        d0 = obj_distance<R>(ob, x);
+        B = rmax(dl[3], dl[1] + dl[2]);
+        mag = rabs(d0) + rabs(x[1]) + rabs(x[2]) + rabs(x[3]) + rabs(ob.p[2]);
+    }
+    const R w = rfma(guard, B, R(256) * eps * mag);
+    *lower = d0 - w;
+    *upper = d0 + w;
+}
+template <class R>
+RTGR_DEV ObjSel select_objects(const DevScene<R>& sc, const R x0[4], const R c[4][4], R top, bool event) {
+    ObjSel sel{0ull, objsel_shift(sc.nobj)};
+    R dl[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) dl[q] = top * rfma(top, rfma(top, rfma(top, rabs(c[3][q]), rabs(c[2][q])), rabs(c[1][q])), rabs(c[0][q]));
+    R U = R(__builtin_huge_val());
+    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t) {
+        R lo, up;
+        distance_bounds<R>(ob, x0, dl, &lo, &up);
+        U = up < U ? up : U;
+    });
+    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) {
+        R lo, up;
+        distance_bounds<R>(ob, x0, dl, &lo, &up);
+        if (__ballot(event && !(lo > U)) != 0ull) sel.mask |= 1ull << (o >> sel.shift);
+    });
+    return sel;
 }
 
 // Bracketed root of g(θ) = ps·cond(x(θ)) on [0, top], g(0) > 0 >= g(top).  Ridders' method: every iterate stays inside
@@ -1063,11 +1148,11 @@ RTGR_DEV R cond_poly(const DevScene<R>& sc, const R x0[4], const R c[4][4], R th
 // up to a few ulp (a 512-ulp window, 1e-13 in θ, for the rays whose distance is too noisy for that).  If the probes fail
 // (estimate was off) the loop simply continues on the tightened bracket; the bisection point `mid` guarantees progress.
 // -DRTGR_ROOT_STATS builds report the iteration count of every ray through lambda_end.
-template <class R>
-RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R ps, R top, int* iters = nullptr) {
+template <class R, bool SEL = false>
+RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R ps, R top, int* iters = nullptr, ObjSel sel = ObjSel{}) {
     R lo = R(0), hi = top;
-    R fhi = cond_poly<R>(sc, x0, c, hi) * ps;
-    R flo = cond_poly<R>(sc, x0, c, R(0)) * ps;
+    R fhi = cond_poly<R, SEL>(sc, x0, c, hi, sel) * ps;
+    R flo = cond_poly<R, SEL>(sc, x0, c, R(0), sel) * ps;
     R result = R(0);
     bool done = false;
     if (fhi == R(0)) { result = hi; done = true; }
@@ -1081,7 +1166,7 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
         if (!(width > R(2) * eps * hi) || !(mid > lo && mid < hi)) {
             result = lo; done = true;
         } else {
-            const R fm = cond_poly<R>(sc, x0, c, mid) * ps;
+            const R fm = cond_poly<R, SEL>(sc, x0, c, mid, sel) * ps;
             const R rad = rfma(fm, fm, -flo * fhi);  // > 0 since flo > 0 > fhi
             // Ridders' estimate.  When one end of the bracket already sits on the root (|g(lo)| ~ 1e-17 after a lucky
             // iterate) the formula returns that end itself: the point to EVALUATE is then the midpoint (progress), but the
@@ -1091,7 +1176,7 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
             const bool inside = xr > lo && xr < hi;
             const R x4 = inside ? xr : mid;
             const R est = inside ? xr : (xr <= lo ? lo : (xr >= hi ? hi : mid));
-            const R f4 = (x4 == mid) ? fm : cond_poly<R>(sc, x0, c, x4) * ps;
+            const R f4 = (x4 == mid) ? fm : cond_poly<R, SEL>(sc, x0, c, x4, sel) * ps;
             // An exact zero is common (a plane at a representable time makes g vanish on a whole ulp-interval of θ):
             // "directly at zero" is an accepted result, so stop there.
             if (fm == R(0)) { result = mid; done = true; }
@@ -1120,8 +1205,8 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
                 for (int pass = 0; pass < 2 && !done; pass++) {
                     const R wd = (pass == 0 ? R(16) : R(512)) * eps;
                     const R pm = rmax(rfma(-wd, scale, est), lo), pp = rmin(rfma(wd, scale, est), hi);
-                    const R fpm = (pm > lo) ? cond_poly<R>(sc, x0, c, pm) * ps : flo;
-                    const R fpp = (pp < hi) ? cond_poly<R>(sc, x0, c, pp) * ps : fhi;
+                    const R fpm = (pm > lo) ? cond_poly<R, SEL>(sc, x0, c, pm, sel) * ps : flo;
+                    const R fpp = (pp < hi) ? cond_poly<R, SEL>(sc, x0, c, pp, sel) * ps : fhi;
                     if (!(fpm < R(0)) && !(fpp > R(0))) {
                         result = pm; done = true;  // the sign change (or an exact zero at pm) is inside [pm, pp]
                     } else if (fpp == R(0)) {
@@ -1141,36 +1226,14 @@ RTGR_DEV R event_root(const DevScene<R>& sc, const R x0[4], const R c[4][4], R p
 #ifdef RTGR_ROOT_STATS
 #define RTGR_ROOT_STATS_ARG , &root_iters
 #else
-#define RTGR_ROOT_STATS_ARG
+#define RTGR_ROOT_STATS_ARG , nullptr
 #endif
 
-// (a body function: a unit with user objects wraps it in a resolve kernel of its own — the root-find evaluates the objects'
-//  distances and the colour rule their objcolor)
+// the stores of one resolved ray
 template <class R>
-RTGR_DEV void resolve_body(const ResolveArgs<R>& A) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= A.n) return;
-    const RecRef<const R> rec{A.hand + w * HAND_W, A.rec + w * (uint64_t)A.recw};
-    R x0[4], xe[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) xe[q] = x0[q] = rec[REC_X + q];
-    const R ps = rec[REC_PS], top = rec[REC_TOP], t = rec[REC_T], h = rec[REC_H];
-    R Theta = R(0);
-    int root_iters = 0;
+RTGR_DEV void resolve_store(const ResolveArgs<R>& A, uint64_t w, const RecRef<const R>& rec, const R xe[4], R Theta, R t, R h, const R col[3],
+                            uint32_t hit, R ps, int root_iters) {
     (void)root_iters;
-    if (ps != R(0)) {  // an event: the polynomial part of the record is valid
-        R c[4][4];
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) c[m][q] = rec[REC_C + 4 * m + q];
-        Theta = event_root<R>(A.sc, x0, c, ps, top RTGR_ROOT_STATS_ARG);
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
-    }
-    R col[3];
-    const uint32_t hit = colour_pixel<R>(A.sc, A.opt, xe, col);
     const uint64_t idx = A.offset + w;
     A.rgb[idx] = col[0];
     A.rgb[A.n_slab + idx] = col[1];
@@ -1199,6 +1262,71 @@ RTGR_DEV void resolve_body(const ResolveArgs<R>& A) {
     if (A.hit32) A.hit32[idx] = hit;
     if (A.n_accept) A.n_accept[idx] = mt[0];
     if (A.n_reject) A.n_reject[idx] = mt[1];
+}
+template <class R> RTGR_DEV void resolve_body_selected(const ResolveArgs<R>& A);
+
+// (a body function: a unit with user objects wraps it in a resolve kernel of its own — the root-find evaluates the objects'
+//  distances and the colour rule their objcolor)
+template <class R>
+RTGR_DEV void resolve_body(const ResolveArgs<R>& A) {
+    if (__builtin_expect(A.select != 0u && A.sc.nobj > (uint32_t)RTGR_MAX_OBJECTS && A.n != 0, 0)) { resolve_body_selected<R>(A); return; }
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= A.n) return;
+    const RecRef<const R> rec{A.hand + w * HAND_W, A.rec + w * (uint64_t)A.recw};
+    R x0[4], xe[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) xe[q] = x0[q] = rec[REC_X + q];
+    const R ps = rec[REC_PS], top = rec[REC_TOP], t = rec[REC_T], h = rec[REC_H];
+    R Theta = R(0);
+    int root_iters = 0;
+    (void)root_iters;
+    if (ps != R(0)) {  // an event: the polynomial part of the record is valid
+        R c[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[m][q] = rec[REC_C + 4 * m + q];
+        Theta = event_root<R>(A.sc, x0, c, ps, top RTGR_ROOT_STATS_ARG);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
+    }
+    R col[3];
+    const uint32_t hit = colour_pixel<R>(A.sc, A.opt, xe, col);
+    resolve_store<R>(A, w, rec, xe, Theta, t, h, col, hit, ps, root_iters);
+}
+// … and the same with the list narrowed down first (select_objects): lists beyond the argument block
+template <class R>
+RTGR_DEV void resolve_body_selected(const ResolveArgs<R>& A) {
+    const uint64_t w0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = w0 < A.n;
+    const uint64_t w = live ? w0 : A.n - 1;   // (every lane of the wave takes part in the selection's ballots; the spare ones repeat the last ray, silently)
+    const RecRef<const R> rec{A.hand + w * HAND_W, A.rec + w * (uint64_t)A.recw};
+    R x0[4], xe[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) xe[q] = x0[q] = rec[REC_X + q];
+    const R ps = rec[REC_PS], top = rec[REC_TOP], t = rec[REC_T], h = rec[REC_H];
+    R Theta = R(0);
+    int root_iters = 0;
+    (void)root_iters;
+    const bool event = ps != R(0);
+    R c[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[m][q] = event ? rec[REC_C + 4 * m + q] : R(0);
+    ObjSel sel = select_objects<R>(A.sc, x0, c, event ? top : R(0), event);
+    if (event) {
+        Theta = event_root<R, true>(A.sc, x0, c, ps, top RTGR_ROOT_STATS_ARG, sel);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
+    }
+    // (a ray without an event is coloured where it stopped: nothing is known about that point — every object is asked)
+    if (__ballot(!event) != 0ull) sel.mask = ~0ull;
+    R col[3];
+    const uint32_t hit = colour_pixel<R, true>(A.sc, A.opt, xe, col, sel);
+    if (live) resolve_store<R>(A, w, rec, xe, Theta, t, h, col, hit, ps, root_iters);
 }
 template <class R>
 __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs<R> A) {

@@ -931,16 +931,53 @@ RTGR_DEV void for_each_by_kind(const DevScene<R>& sc, FS&& fs, FO&& fo) {
     }
 #endif
 }
+// The reach test's walk (rtgr_persistent.hpp): as for_each_by_kind, but a list with GROUPS (DevScene, rtgr_args.hpp) is walked group
+// by group — fg(group) -> wave-uniform "some lane cannot rule this group out"; only then its members are handed to fs.  The whole
+// walk of a grouped list reads the device table (scalar loads through the constant address space, as above) and is cold code for
+// every list without groups.
+template <class R, class FG, class FS, class FO>
+RTGR_DEV void for_each_within_reach(const DevScene<R>& sc, FG&& fg, FS&& fs, FO&& fo) {
+#ifndef RTGR_INLINE_OBJECTS_ONLY
+    if (__builtin_expect(sc.ngroups != 0u, 0)) {
+        typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
+        const ConstTable table = (ConstTable)(unsigned long long)(sc.more - (uint32_t)RTGR_MAX_OBJECTS);
+        const ConstTable groups = table + sc.nobj;
+        for (uint32_t o = 0; o < sc.nloose; o++) fs(*(const DevObject<R>*)(table + o), o);
+        for (uint32_t g = 0; g < sc.ngroups; g++) {
+            const DevObject<R>& G = *(const DevObject<R>*)(groups + g);
+            if (fg(G)) {
+                const uint32_t o1 = G.type + G.orig;
+                for (uint32_t o = G.type; o < o1; o++) fs(*(const DevObject<R>*)(table + o), o);
+            }
+        }
+        for (uint32_t o = sc.nsph; o < sc.nobj; o++) fo(*(const DevObject<R>*)(table + o), o);
+        return;
+    }
+#endif
+    for_each_by_kind<R>(sc, fs, fo);
+}
 // … and one object by (per-lane) POSITION in the regrouped list
 template <class R>
 RTGR_DEV const DevObject<R>& object_at(const DevScene<R>& sc, uint32_t o) {
     return o < (uint32_t)RTGR_MAX_OBJECTS ? sc.obj[o] : sc.more[o - (uint32_t)RTGR_MAX_OBJECTS];
 }
 
-template <class R>
-RTGR_DEV R min_distance(const DevScene<R>& sc, const R pos[4]) {                          // :433-441
+// A SELECTION of the list's objects (the resolve kernel, rtgr_persistent.hpp: select_objects): bit o >> shift of the mask says
+// whether object o (position in the device list) takes part.  Only ever used to leave out objects that provably cannot be the minimum.
+struct ObjSel {
+    unsigned long long mask;
+    uint32_t shift;
+    RTGR_DEV bool has(uint32_t o) const { return ((mask >> (o >> shift)) & 1ull) != 0ull; }
+};
+RTGR_DEV uint32_t objsel_shift(uint32_t nobj) {   // the smallest shift with (nobj − 1) >> shift <= 63
+    return nobj > 64u ? 32u - (uint32_t)__builtin_clz((nobj - 1u) >> 6) : 0u;
+}
+
+template <class R, bool SEL = false>
+RTGR_DEV R min_distance(const DevScene<R>& sc, const R pos[4], ObjSel sel = ObjSel{}) {   // :433-441
     R dmin = R(__builtin_huge_val());
-    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t) {
+    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) {
+        if constexpr (SEL) { if (!sel.has(o)) return; }
         const R d = obj_distance<R>(ob, pos);
         dmin = (d < dmin || d != d) ? d : dmin;
     });

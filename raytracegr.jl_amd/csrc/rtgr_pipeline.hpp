@@ -317,7 +317,7 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
         rc = launch_integrate<R, METRIC, SPIN>(E, IA, A.opt.interp_points == 10, split, (m + 63) / 64, st);
         if (rc) return rc;
         ResolveArgs<R> RA;
-        RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.hand = hand; RA.meta = meta; RA.recw = recw; RA.n = m; RA.offset = A.out_offset + off;
+        RA.sc = A.sc; RA.opt = A.opt; RA.rec = rec; RA.hand = hand; RA.meta = meta; RA.recw = recw; RA.select = K.groups ? 1u : 0u; RA.n = m; RA.offset = A.out_offset + off;
         RA.n_slab = A.plane_stride ? A.plane_stride : n; RA.rgb = A.rgb; RA.state_end = A.state_end; RA.lambda_end = A.lambda_end;
         RA.status = A.status; RA.hit = A.hit; RA.hit32 = A.hit32; RA.n_accept = A.n_accept; RA.n_reject = A.n_reject;
         {

@@ -105,7 +105,7 @@ def circular_channels(hit, sc=None):
     return circ
 
 
-def wrap_aware_rgb_err(a, b, hit, nobj=3, sc=None):
+def wrap_aware_rgb_err(a, b, hit, nobj=3, sc=None, per_pixel=False):
     """L∞ distance between RGB planes a, b [3, n], evaluated modulo the sawtooth of objcolor (src/RayTraceGR.jl:427) on the
     channels that carry one (circular_channels): there the circular distance has period omin/nobj; every other channel is
     compared plainly.  Pass the scene when it may hold a disk."""
@@ -115,4 +115,4 @@ def wrap_aware_rgb_err(a, b, hit, nobj=3, sc=None):
     per = (hit.astype(np.float64) / max(nobj, 1))[None, :]
     per = np.where(per > 0, per, 1.0)
     dc = np.where(circular_channels(hit, sc), np.minimum(d, np.abs(per - d)), d)
-    return dc.max(initial=0.0)
+    return dc.max(axis=0) if per_pixel else dc.max(initial=0.0)

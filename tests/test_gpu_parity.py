@@ -382,7 +382,36 @@ def test_object_lists_of_any_length_match_oracle(lib, name, n, nobj):
     assert g["counters"]["rays"] == n * n
     # … and every pass structure of the library delivers the same bits for a long list too: the default (two hand-back rounds from
     # 32 objects on), one round, three, and the single FULL pass that scans every accepted step as the reference does
-    for knobs in (dict(rounds=1), dict(rounds=3), dict(split=0)):
+    # … and with every object asked every step instead of the groups' bounding spheres first (lists of >= 16 small spheres get groups)
+    for knobs in (dict(rounds=1), dict(rounds=3), dict(split=0), dict(groups=0), dict(groups=0, rounds=1)):
+        with abi.options(lib, **knobs):
+            other = hip_trace(lib, sc, opt, n, n, cam=cam)
+        for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            assert np.array_equal(g[k], other[k], equal_nan=True), (knobs, k)
+
+
+@pytest.mark.parametrize("metric", ["ks_ref0", "ks_true08"])
+@pytest.mark.parametrize("seed,nsph,spread,rmax", [(1, 40, 6.0, 0.5), (2, 150, 7.0, 0.3), (3, 90, 3.5, 0.8), (4, 200, 9.0, 0.12)])
+def test_grouped_lists_give_the_frame_of_the_full_scan(lib, metric, seed, nsph, spread, rmax):
+    """The groups of a long list (DevScene, rtgr_args.hpp) only ever SKIP questions whose answer is known: seeded clouds of 40-200
+    spheres — sparse, dense and overlapping, tiny — give, bit for bit, the frame of the pass structure that asks nothing in advance
+    (split = 0: every accepted step scanned against every object, as the reference does), and of the reach test without groups."""
+    rng = np.random.default_rng(seed)
+    objs = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -14.0), rt.Plane(-30.0)]
+    camera = np.array([4.0, -2.0, 0.0])
+    while len(objs) < nsph + 2:
+        c = rng.normal(size=3) * spread / 1.7
+        r = rng.uniform(0.05, rmax)
+        if np.linalg.norm(c - camera) < r + 0.3 or np.linalg.norm(c) < 2.3 + r:
+            continue
+        objs.append(rt.Sphere((0, *c), (1, 0, 0, 0), r))
+    m = {"ks_ref0": rt.kerr_schild, "ks_true08": rt.KerrSchild(1, 0.8)}[metric]
+    sc, cam = rt.make_scene(m, objs), rt.make_camera(**rt.example2_scene()[2])
+    opt = rt.solver_defaults()
+    n = 56
+    g = hip_trace(lib, sc, opt, n, n, cam=cam)
+    assert len(np.unique(g["hit"])) > 8 and g["counters"]["rays"] == n * n
+    for knobs in (dict(split=0), dict(groups=0)):
         with abi.options(lib, **knobs):
             other = hip_trace(lib, sc, opt, n, n, cam=cam)
         for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
@@ -676,8 +705,13 @@ def test_f32_long_object_lists_match_f32_oracle(lib, name, nobj):
         # (64 small spheres: ~10 x the silhouette length of example2's scene per pixel of canvas, and Float32 decides a
         # silhouette pixel either way — the flip bar scales with it)
         assert flips.mean() <= 4 * F32_FLIP_FRAC, (pk, flips.mean())
-        same = ~flips
-        assert wrap_aware_rgb_err(gpu["rgb"][:, same].astype(float), ref["rgb"][:, same].astype(float), gpu["hit"][same], sc=sc) < F32_RGB_TOL
+        # (rays that circle the hole before they reach the sky amplify Float32's rounding: their landing point — same object, other
+        #  colour — is each solution's own, INTEGRATION.md "Where parity ends"; the bar is for rays of ordinary length, nearly all)
+        plain = ~flips & ((ref["n_accept"] + ref["n_reject"]) < 150)
+        assert plain.mean() > 0.85
+        err = wrap_aware_rgb_err(gpu["rgb"][:, plain].astype(float), ref["rgb"][:, plain].astype(float), gpu["hit"][plain], sc=sc, per_pixel=True)
+        # (… and a pixel whose ray grazes one of the 62 small spheres lands elsewhere on it: a handful)
+        assert (err >= F32_RGB_TOL).sum() <= 6, (pk, np.sort(err)[-8:])
         assert gpu["counters"]["rays"] == 48 * 48
     assert (got[0]["hit"] != got[1]["hit"]).sum() <= 12
 

@@ -68,3 +68,74 @@ def test_per_row_checksums_sum_to_the_frame_checksum_and_localise_a_wrong_row():
     other[1, 3 * ni + 2] += 1e-9            # plane 1, row 3, column 2
     rows2 = other.contiguous().view(torch.int64).view(3, nj, ni).sum(dim=(0, 2)).numpy()
     assert list(np.nonzero(rows != rows2)[0]) == [3]
+
+
+# ---- the groups of a long list's spheres (rtgr_context.hip: group_spheres / bounding_sphere; DevScene in rtgr_args.hpp) -------------
+def _group(spheres, f32=False):
+    """spheres: (n, 4) array of centre x, y, z and radius -> (order, nloose, groups[ng, 6]) through the library's test hook"""
+    import ctypes as C
+    from raytracegr_jl_amd import _abi as abi
+    lib = abi.load()
+    n = len(spheres)
+    objs = (abi.rtgr_object * n)()
+    for k, (x, y, z, r) in enumerate(spheres):
+        objs[k].kind = abi.SPHERE
+        objs[k].p[1], objs[k].p[2], objs[k].p[3], objs[k].p[8] = x, y, z, r
+    order = np.zeros(n, np.uint32)
+    nloose = C.c_uint32(0)
+    groups = np.zeros((n + 1, 6))
+    fn = lib.rtgr_testhook_group_spheres
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(abi.rtgr_object), C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32]
+    ng = fn(objs, n, int(f32), order.ctypes.data, C.byref(nloose), groups.ctypes.data, n + 1)
+    assert ng >= 0
+    return order, nloose.value, groups[:ng]
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(16, 400), st.integers(0, 2**31 - 1), st.booleans(), st.sampled_from(["cloud", "line", "same", "wide_radii"]))
+def test_groups_of_a_long_list_contain_their_members(n, seed, f32, shape):
+    """What the FAR pass's group test rests on: the groups' member ranges tile the spheres behind the loose ones, no sphere is lost or
+    listed twice, and every member — as the kernels of the scalar type see it — lies INSIDE its group's bounding sphere
+    (|c_i − C| + r_i <= R_g, evaluated in extended precision); groups hold 1..RTGR_GROUP_MAX members; the layout is a function of
+    the list alone."""
+    rng = np.random.default_rng(seed)
+    c = {"cloud": rng.normal(size=(n, 3)) * 5, "line": np.outer(rng.uniform(-8, 8, n), [1.0, 0.5, 0.0]),
+         "same": np.zeros((n, 3)) + 1.25, "wide_radii": rng.uniform(-6, 6, (n, 3))}[shape]
+    r = np.exp(rng.uniform(-4, 2, n)) if shape == "wide_radii" else rng.uniform(0.05, 0.5, n)
+    sph = np.column_stack([c, r])
+    order, nloose, groups = _group(sph, f32)
+    assert sorted(order.tolist()) == list(range(n))
+    if len(groups) == 0:
+        assert nloose == 0 and order.tolist() == list(range(n))
+        return
+    pos = nloose
+    ty = np.float32 if f32 else np.float64
+    seen = sph[order].astype(ty).astype(np.longdouble)      # the members as the kernels get them
+    for cx, cy, cz, rg, first, count in groups:
+        assert first == pos and 1 <= count <= 8
+        m = seen[int(first):int(first + count)]
+        gc = np.array([cx, cy, cz], np.longdouble)
+        assert (np.sqrt(((m[:, :3] - gc) ** 2).sum(1)) + np.abs(m[:, 3]) <= np.longdouble(rg)).all()
+        assert float(ty(rg)) == rg                          # (the radius is a value of the scalar type)
+        pos += int(count)
+    assert pos == n
+    if shape != "wide_radii":
+        assert nloose == 0
+    again = _group(sph, f32)
+    assert np.array_equal(order, again[0]) and np.array_equal(groups, again[2])
+
+
+def test_groups_leave_a_sky_sphere_loose_and_refuse_non_finite_lists():
+    rng = np.random.default_rng(5)
+    sph = np.column_stack([rng.uniform(-6, 6, (60, 3)), rng.uniform(0.2, 0.4, 60)])
+    sph[17] = [0, 0, 0, 30.0]                               # a sphere around the whole scene: would blow its group's bounding sphere up
+    order, nloose, groups = _group(sph)
+    assert nloose == 1 and order[0] == 17 and len(groups) >= 8 and groups[:, 3].max() < 8
+    # neighbours end up together: the groups' bounding spheres are far smaller than the cloud
+    assert np.median(groups[:, 3]) < 4.5
+    for bad in (np.nan, np.inf):
+        broken = sph.copy()
+        broken[3, 1] = bad
+        assert len(_group(broken)[2]) == 0
+    assert len(_group(sph[:15])[2]) == 0                    # fewer than two full groups: none
