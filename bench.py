@@ -1084,9 +1084,9 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
     except Exception as e:  # noqa: BLE001
         ex["variants"]["user_sphere_ks_ref0_2048"] = {"error": repr(e)}
     # What a LONGER OBJECT LIST costs (round-5 review item 1: `objs::Vector{Object{T}}` has no length limit, src/RayTraceGR.jl:433-441):
-    # example2 at 2048² with its three objects, with 16 (the kernels' argument block full) and with 64 (48 of them in the device
-    # table).  Per step every object costs one reach test in the FAR pass and nine distances in a scanned NEAR step; the slope is
-    # read off the hardware's instruction counter (SQ_INSTS_VALU per wave-step, live) and off the pass times.
+    # example2 at 2048² with its three objects, with 16 (the kernels' argument block full), with 64 and with 256 (a device table; their
+    # spheres in groups of neighbours whose bounding spheres the FAR pass's reach test asks first).  The slope is read
+    # off the hardware's instruction counter (SQ_INSTS_VALU per wave-step, live) and off the pass times.
     try:
         base = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 10, 2, live_on=False)
         if a.live_counters:    # (the three-object frame's instruction count at THIS size, one counter pass)
@@ -1097,9 +1097,10 @@ def run_extras(a, rt, host_pass, pixels_pass, device_s):
             if lv:
                 base["roofline"]["valu_per_wave_step"], base["roofline"]["counters"] = lv["valu_per_wave_step"], "live"
         rows = {3: base}
-        for nobj in (16, 64):
-            rows[nobj] = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 6 if nobj == 16 else 3, 1, live_on=bool(a.live_counters), nobj=nobj)
-        for nobj in (16, 64):
+        for nobj in (16, 64, 256):   # (256: time only — where the groups of a long list and the resolve kernel's selection decide)
+            rows[nobj] = time_variant(rt, "ks_ref0", 2048, "f64", "closed", 6 if nobj == 16 else 3, 1,
+                                      live_on=bool(a.live_counters) and nobj <= 64, nobj=nobj)
+        for nobj in (16, 64, 256):
             r, b = rows[nobj], rows[3]
             e = {"workload": r["workload"], "ms_per_pass": r["ms_per_pass"], "three_objects_ms_per_pass": b["ms_per_pass"],
                  "over_three_objects": r["ms_per_pass"] / b["ms_per_pass"],

@@ -22,6 +22,10 @@
 
 namespace rtgr {
 
+#ifndef RTGR_F32_SPLIT_FROM
+#define RTGR_F32_SPLIT_FROM 32
+#endif
+
 // One lane = one ray.  A wave owns an 8x8 pixel tile (lock-step efficiency 0.90 vs 0.45 for 64 consecutive
 // pixels); a 256-thread workgroup owns 4 horizontally adjacent tiles.  The simple variant (knob tile = 1):
 // whole adaptive loop + event finder + colouring inline — an independent formulation kept for A/B and cross-checks.
@@ -259,11 +263,14 @@ static int launch_trace(LaunchEnv& E, const TraceArgs<R>& A, hipStream_t st) {
     cur += align256(chunk);
     uint32_t* hist = (uint32_t*)cur;  // 256 bins + 256 running offsets
     cur += 4096;
-    // Float32 rays last ~20 steps: one FULL pass wins (measured 5-6 %)
+    // Float32 rays last ~20 steps: one FULL pass wins (measured 5-6 %) — with a short list.  The FULL pass pays 9 distances per object
+    // and accepted step, the FAR pass one reach test (and, with groups, not even that): from RTGR_F32_SPLIT_FROM objects on Float32
+    // runs FAR + NEAR too (2048², 64 objects: a = 0 17.6 -> 11.1 ms, a = 0.8 14.9 -> 13.6; 256 objects 49.0 -> 22.1, 41.1 -> 25.7:
+    // profiles/r06/f32_objects_split.log)
     // (a user unit carries Float32 twins of the FULL pass only)
     // (… and a unit whose objects come without a reach bound has nothing to decide a hand-over by: every accepted step is
     //  scanned, as the reference does — the single FULL pass; include/rtgr.h "user objects")
-    bool split = (K.split >= 0 ? K.split != 0 : sizeof(R) == 8) && !(USER && sizeof(R) == 4);
+    bool split = (K.split >= 0 ? K.split != 0 : (sizeof(R) == 8 || A.sc.nobj >= (uint32_t)RTGR_F32_SPLIT_FROM)) && !(USER && sizeof(R) == 4);
     if constexpr (USER) if (E.user->has_objects && !E.user->has_reach) split = false;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = (n - off) < chunk ? (n - off) : chunk;

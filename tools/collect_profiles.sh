@@ -18,5 +18,6 @@ tools/prof.sh ${R}_userks_true08 --steps 3 --warmup 1 --rhs user_ks --size 2048 
 fi
 if [[ $PART == *c* ]]; then
 tools/prof.sh ${R}_user_sphere --steps 5 --warmup 1 --size 2048 --user-sphere > /dev/null 2>&1; echo done user_sphere "(example2 with its small sphere as a user-defined object: a unit of objects for the built-in metric)"
-tools/prof.sh ${R}_objects64 --steps 3 --warmup 1 --size 2048 --objects 64 > /dev/null 2>&1; echo done objects64 "(example2 + 61 small spheres: 48 of the 64 objects in the device table, two hand-back rounds)"
+tools/prof.sh ${R}_objects64 --steps 3 --warmup 1 --size 2048 --objects 64 > /dev/null 2>&1; echo done objects64 "(example2 + 61 small spheres: a device table, the spheres in 8 groups, two hand-back rounds)"
+tools/prof.sh ${R}_objects256 --steps 3 --warmup 1 --size 2048 --objects 256 > /dev/null 2>&1; echo done objects256 "(example2 + 253 small spheres: 32 groups, one round)"
 fi
