@@ -227,7 +227,8 @@ int rtgr_device_info(rtgr_context* ctx, int index, char* name, uint64_t name_len
  * "scene_check" (default 1): the automatic first-trace check of scenes with user objects (see "user objects" below); 0 = off.
  * "groups" (default 1): object lists longer than RTGR_MAX_OBJECTS have their spheres sorted into groups of neighbours, each with a
  * bounding sphere that the per-step reach test asks first, and the event root-find narrows the list to the objects the event's step
- * can meet; 0 = every object is asked every time (A/B and tests: the frames are equal bit for bit).  In Float64 no option changes
+ * can meet; 0 = every object is asked every time (A/B and tests: the frames are equal bit for bit); a value >= 2 = that many spheres
+ * per group at most instead of 8 (experiments: 8 is the measured optimum for 32-256 objects).  In Float64 no option changes
  * a result bit except "tile" / "pack"; in Float32 "split" (and "groups", "rounds" through it) selects kernels whose compiled
  * arithmetic differs in the last bit, as "pack" does — Float32 lists of 32 objects and more run the FAR + NEAR pair by default.
  * Two options govern how run-time units are LOADED: "unit_audit" (default 1; 0 = skip the audit of the code object for the

@@ -338,7 +338,8 @@ struct SphereGroup { uint32_t first, count; };   // positions in the device list
 // tree's leaves, <= RTGR_GROUP_MAX members each; a sphere much larger than the list's typical one (a sky sphere around the scene) would
 // make its group's bounding sphere as large as itself and stays loose.  Lists with fewer than two full groups, or with a non-finite
 // centre or radius among the spheres, get no groups.  Deterministic: ties are broken by the caller's index.
-static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order, uint32_t* nloose, std::vector<SphereGroup>& groups) {
+static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order, uint32_t* nloose, std::vector<SphereGroup>& groups,
+                          size_t leaf = RTGR_GROUP_MAX) {
     *nloose = 0;
     groups.clear();
     const size_t n = order.size();
@@ -359,7 +360,7 @@ static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order,
     while (!todo.empty()) {
         const auto [lo, hi] = todo.back();
         todo.pop_back();
-        if (hi - lo <= (size_t)RTGR_GROUP_MAX) { leaves.push_back({lo, hi}); continue; }
+        if (hi - lo <= leaf) { leaves.push_back({lo, hi}); continue; }
         double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
         for (size_t k = lo; k < hi; k++)
             for (int q = 0; q < 3; q++) { mn[q] = std::min(mn[q], objs[rest[k]].p[1 + q]); mx[q] = std::max(mx[q], objs[rest[k]].p[1 + q]); }
@@ -457,8 +458,9 @@ int convert_scene(DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserM
     d.nsph = (uint32_t)order.size();
     // … and the spheres of a LONG list in groups of neighbours (DevScene: GROUPS)
     std::vector<SphereGroup> groups;
-    if (s->nobj > n0 && (tl_knobs_override ? tl_knobs_override->groups : D.knobs.groups))
-        group_spheres(objs, order, &d.nloose, groups);
+    const long kg = tl_knobs_override ? tl_knobs_override->groups : D.knobs.groups;   // (0: off; 1: on; >= 2: on, with that many spheres per group at most — experiments)
+    if (s->nobj > n0 && kg)
+        group_spheres(objs, order, &d.nloose, groups, kg >= 2 ? (size_t)kg : (size_t)RTGR_GROUP_MAX);
     for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind != RTGR_SPHERE) order.push_back(o);
     for (uint32_t k = 0; k < n0; k++) {
         if ((rc = convert_object<R>(objs[order[k]], d.obj[k]))) return rc;

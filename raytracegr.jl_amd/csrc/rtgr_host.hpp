@@ -77,7 +77,8 @@ struct Knobs {
     long unit_audit = 1;          // … and audit the code object for the compiler's EXEC-flip fault before loading it; 0 = skip
                                   // (a test hook: the probe must catch a faulty unit on its own)
     long groups = 1;              // object lists beyond the argument block: 1 = their spheres are sorted into groups of neighbours with a bounding
-                                  // sphere each, which the FAR pass's reach test asks first (DevScene, rtgr_args.hpp); 0 = every object is asked
+                                  // sphere each, which the FAR pass's reach test asks first (DevScene, rtgr_args.hpp); 0 = every object is asked; >= 2: on, with
+                                  // that many spheres per group at most (experiments; 8 = RTGR_GROUP_MAX is the measured optimum)
     long scene_check = 1;         // scenes whose USER OBJECTS bring their own reach bound: the first trace of each (unit, object list, metric
                                   // parameters, solver, camera) runs rtgr_scene_check's comparison on a coarse sample of the call's own rays and
                                   // refuses a scene whose FAR + NEAR passes lose what the FULL pass finds (rtgr_units.hip: auto_scene_check); 0 = off
