@@ -390,6 +390,43 @@ def test_object_lists_of_any_length_match_oracle(lib, name, n, nobj):
             assert np.array_equal(g[k], other[k], equal_nan=True), (knobs, k)
 
 
+@pytest.mark.parametrize("nsph", [10, 34])
+def test_long_lists_of_mixed_kinds_match_oracle(lib, nsph):
+    """A long list is not only spheres: concentric rings (disks) and several planes in time among them, in an order that interleaves
+    the kinds — the device list regroups them (spheres first; with 34 spheres also into groups), the colour rule must still see the
+    CALLER's order (first-smaller-wins, omin / length(objs)).  10 spheres: 21 objects, no groups, the rest of the list behind the
+    argument block; 34 spheres: groups + the other kinds from the table.  Against the oracle, and bit for bit against the pass
+    structures that ask everything."""
+    rng = np.random.default_rng(11)
+    camera = np.array([4.0, -2.0, 0.0])
+    spheres = []
+    while len(spheres) < nsph:
+        c = rng.normal(size=3) * 3.5
+        r = rng.uniform(0.15, 0.5)
+        if np.linalg.norm(c - camera) < r + 0.3 or np.linalg.norm(c) < 2.5 + r or abs(c[2]) < r + 0.2:
+            continue
+        spheres.append(rt.Sphere((0, *c), (1, 0, 0, 0), r))
+    others = [rt.Disk(0.05, 6.0, 7.0), rt.Plane(-25.0), rt.Disk(0.04, 7.5, 8.5), rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -12.0), rt.Disk(0.05, 9.0, 9.8),
+              rt.Plane(-40.0), rt.Disk(0.03, 10.2, 10.6), rt.Plane(-60.0), rt.Disk(0.05, 2.6, 3.2), rt.Plane(-80.0), rt.Disk(0.02, 5.0, 5.5)]
+    objs = []
+    for k in range(max(len(spheres), len(others))):    # interleaved: sphere, other, sphere, other, …
+        objs += spheres[k:k + 1] + others[k:k + 1]
+    sc, cam = rt.make_scene(rt.KerrSchild(1, 0.8), objs), rt.make_camera(**rt.example2_scene()[2])
+    assert sc.nobj == nsph + len(others) > abi.RTGR_MAX_OBJECTS
+    opt = rt.solver_defaults()
+    n = 48
+    g = hip_trace(lib, sc, opt, n, n, cam=cam)
+    r = O.trace(sc, opt, n, n, cam=cam)
+    kinds = {objs[h - 1].kind for h in np.unique(r["hit"]) if h}
+    assert kinds == {abi.SPHERE, abi.DISK, abi.PLANE}, kinds
+    compare(g, r, sc=sc, max_class_flips=6, max_step_diff=2, rel_step_diff=0.015)
+    for knobs in (dict(split=0), dict(groups=0), dict(rounds=2)):
+        with abi.options(lib, **knobs):
+            other = hip_trace(lib, sc, opt, n, n, cam=cam)
+        for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            assert np.array_equal(g[k], other[k], equal_nan=True), (knobs, k)
+
+
 @pytest.mark.parametrize("metric", ["ks_ref0", "ks_true08"])
 @pytest.mark.parametrize("seed,nsph,spread,rmax", [(1, 40, 6.0, 0.5), (2, 150, 7.0, 0.3), (3, 90, 3.5, 0.8), (4, 200, 9.0, 0.12)])
 def test_grouped_lists_give_the_frame_of_the_full_scan(lib, metric, seed, nsph, spread, rmax):
