@@ -450,6 +450,43 @@ def test_workspace_growth_and_stream_capture(lib):
     abi.check(lib, lib.rtgr_trim(None))   # frees retired buffers (graph `g` must not be replayed afterwards)
 
 
+def test_a_long_object_list_and_stream_capture(lib):
+    """A list beyond the argument block lives in a device table that is uploaded the first time the list is seen (hipMalloc + a blocking
+    copy: neither can be captured).  First sight DURING a capture is an error that says what to do; a list that has been traced once
+    is captured and replayed like any scene — the table is found again by content, nothing is allocated."""
+    import torch
+    from raytracegr_jl_amd import sharded
+    hip = _hip_runtime()
+    sc, cam = scene_variant("ks_ref0_many64")
+    opt = rt.solver_defaults()
+    ni = nj = 96
+    side = torch.cuda.Stream()
+    out = {"rgb": torch.zeros((3, ni * nj), dtype=torch.float64, device="cuda")}
+    abi.check(lib, lib.rtgr_reserve_workspace(None, out["rgb"].data_ptr(), side.cuda_stream, ni * nj, 0, 0))
+    with abi.options(lib, groups=5):     # (a layout of the list no other test has asked for: its table does not exist yet)
+        graph = C.c_void_p(None)
+        assert hip.hipStreamBeginCapture(C.c_void_p(side.cuda_stream), 2) == 0
+        rc = lib.rtgr_trace_device_f64(None, C.byref(sc), C.byref(opt), None, C.byref(cam), ni, nj, 0, nj, out["rgb"].data_ptr(), None, None,
+                                       side.cuda_stream)
+        msg = lib.rtgr_last_error()
+        assert hip.hipStreamEndCapture(C.c_void_p(side.cuda_stream), C.byref(graph)) == 0
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        assert rc == abi.ERR_BAD_ARG and b"trace the scene once" in msg, msg
+        eager = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj)["rgb"].clone()     # first sight: the table is uploaded
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj, out=out)
+        out["rgb"].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out["rgb"], eager) and len(torch.unique(out["rgb"][2])) > 3
+    again = sharded.trace_slab_torch(sc, opt, cam, ni, nj, 0, nj)["rgb"]          # (and the default layout gives the same frame)
+    torch.cuda.synchronize()
+    assert torch.equal(again, eager)
+
+
 # ---- the reference's OWN call shape over every device of a context (SURVEY §8b/§8e; src/RayTraceGR.jl:483-536, :596) -------
 def _golden(name):
     from raytracegr_jl_amd.png import read_png
