@@ -1,0 +1,96 @@
+"""Long object lists, fuzzed: the groups of a long list's spheres, the NEAR pass's scan mask per block of neighbours
+and the resolve kernel's selection each only skip a question whose answer is known — so the frame must equal, BIT FOR BIT, the frame of
+the pass structure that asks every object at every accepted step as the reference does (split = 0: one FULL pass, no reach test, no
+groups in the integrate kernels) and the frame of the FAR + NEAR pair without groups and without the selection (groups = 0).
+
+Seeded lists of 17-400 objects built to be unkind: clusters, lattices, duplicates, nested and overlapping spheres, near-zero and
+negative (inside-out) radii among the grouped ones, spheres that contain the camera, a far shell, rings and planes interleaved in the
+caller's order; flat space, Kerr-Schild as written, textbook Kerr-Schild with random spin, the generic dual-number path; the
+reference's tolerance and a loose one; odd canvas sizes.  The FULL pass itself is held against the oracle elsewhere
+(tests/test_gpu_parity.py); a sample of the seeds is held against it here too."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from scenes import rt
+from test_gpu_parity import compare, hip_trace, lib  # noqa: F401  (lib: fixture)
+
+pytestmark = pytest.mark.gpu
+abi = rt._abi
+KEYS = ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject")
+
+
+def fuzz_scene(seed):
+    rng = np.random.default_rng(1000 + seed)
+    camera = np.array([4.0, -2.0, 0.0]) + rng.normal(size=3) * (0.0 if seed % 3 else 0.4)
+    nsph = int(rng.choice([17, 20, 31, 48, 64, 65, 100, 129, 200, 257, 400]))
+    layout = rng.choice(["cloud", "clusters", "lattice", "shell", "line"])
+    rmax = float(rng.choice([0.1, 0.3, 0.6, 1.2]))
+    centres = []
+    if layout == "clusters":
+        hubs = rng.normal(size=(int(rng.integers(2, 9)), 3)) * 5.0
+    while len(centres) < nsph:
+        if layout == "cloud":
+            c = rng.normal(size=3) * rng.choice([2.5, 5.0, 9.0])
+        elif layout == "clusters":
+            c = hubs[rng.integers(len(hubs))] + rng.normal(size=3) * 0.6
+        elif layout == "lattice":
+            c = (rng.integers(-4, 5, size=3) * 1.5).astype(float) + np.array([0.25, 0.1, 0.0])
+        elif layout == "shell":
+            d = rng.normal(size=3)
+            c = d / np.linalg.norm(d) * 6.0
+        else:
+            c = np.array([1.0, 0.5, 0.2]) * rng.uniform(-9, 9) + np.array([0.0, 3.0, 0.0])
+        centres.append(c)
+    objs = []
+    for k, c in enumerate(centres):
+        r = float(rng.uniform(0.02, rmax))
+        kind = rng.integers(0, 40)
+        if kind == 0:
+            r = 1e-9                                    # a point
+        elif kind == 1:
+            r = -r                                      # inside-out (sign(R) * (|x − c|² − R²), :415-419)
+        elif kind == 2 and objs:
+            c = np.array(objs[-1].pos[1:])              # a duplicate centre: nested or identical spheres
+        elif kind == 3:
+            c, r = camera + rng.normal(size=3) * 0.1, float(rng.uniform(0.5, 2.0))   # contains the camera
+        if np.linalg.norm(c) < 2.2 + abs(r) and kind != 3:
+            c = c / max(np.linalg.norm(c), 1e-3) * (2.4 + abs(r))                     # keep the horizon's neighbourhood clear
+        objs.append(rt.Sphere((0, *c), (1, 0, 0, 0), r))
+    extras = [rt.Sphere((0, 0, 0, 0), (1, 0, 0, 0), -float(rng.uniform(11, 16))), rt.Plane(-float(rng.uniform(20, 40)))]
+    if rng.integers(2):
+        extras += [rt.Disk(0.05, 6.0, 7.0), rt.Plane(-55.0), rt.Disk(0.02, 2.7, 3.1)]
+    for e in extras:                                     # the other kinds somewhere in the caller's order
+        objs.insert(int(rng.integers(0, len(objs) + 1)), e)
+    which = int(rng.integers(0, 4))
+    metric = [rt.minkowski, rt.kerr_schild, rt.KerrSchild(1, float(rng.uniform(0.05, 0.95))),
+              rt.KerrSchild(1, 0.0, textbook=False, generic=True)][which]
+    cam = rt.make_camera(pos=(0, *camera), widthx=(0, 1, 0, 0), widthy=(0, 0, 0, 1), normal=(0, 0, 1, 0))
+    # (a step cap: a captured ray that no plane ends would otherwise hover above the horizon for the default 100000 steps)
+    opt = rt.solver_defaults(max_steps=3000) if rng.integers(3) else rt.solver_defaults(reltol=1e-6, abstol=1e-6, max_steps=3000)
+    tol = float(opt.reltol)
+    ni, nj = int(rng.choice([24, 33, 40])), int(rng.choice([17, 32]))
+    return rt.make_scene(metric, objs), cam, opt, ni, nj, dict(nsph=nsph, layout=str(layout), rmax=rmax, metric=which, nobj=len(objs), tol=tol)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTGR_FUZZ_SEEDS", "72"))))   # (profiles/r06/fuzz_long_lists.log: 1000 seeds)
+def test_fuzzed_long_list_equals_the_ask_everything_frames(lib, seed):
+    sc, cam, opt, ni, nj, what = fuzz_scene(seed)
+    g = hip_trace(lib, sc, opt, ni, nj, cam=cam)
+    assert g["counters"]["rays"] == ni * nj
+    for knobs in (dict(split=0), dict(groups=0), dict(rounds=3 if seed % 2 else 1)):
+        with abi.options(lib, **knobs):
+            other = hip_trace(lib, sc, opt, ni, nj, cam=cam)
+        for k in KEYS:
+            assert np.array_equal(g[k], other[k], equal_nan=True), (seed, what, knobs, k, int((g[k] != other[k]).sum()))
+    if seed % 4 == 0 and what["metric"] != 0 and what["tol"] < 1e-9 and what["nsph"] <= 129:
+        # … and a sample against the oracle, on the rays that stay signal-dominated (fewer than 400 step attempts: the captured
+        # ones that circle the hole until a late plane ends them follow the RHS formulation's rounding noise, INTEGRATION.md "Where
+        # parity ends"), at the many-object tests' bars
+        r = O.trace(sc, opt, ni, nj, cam=cam)
+        plain = (r["n_accept"] + r["n_reject"]) < 400
+        assert plain.mean() > 0.4
+        sub = lambda d: {k: (v[..., plain] if k == "rgb" else v[plain]) for k, v in d.items() if k in KEYS}   # noqa: E731
+        compare(sub(g), sub(r), sc=sc, max_class_flips=max(4, ni * nj // 200), max_step_diff=3, rel_step_diff=0.02)
