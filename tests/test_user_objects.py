@@ -288,6 +288,34 @@ def test_scenes_with_user_objects_match_the_oracle(lib, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("metric_name", ["ks_ref0", "ks_true08"])
+def test_user_objects_in_a_long_list_match_the_oracle(lib, metric_name):
+    """New `Object` subtypes among the 60 objects of a long list: the unit's kernels walk the device table like the library's own —
+    the spheres in groups, the user objects behind them with the other kinds, their reach bound asked per step and their distance
+    bounds (distance ± reach over the event's step) in the resolve kernel's selection — and the colour rule sees the caller's order.
+    Against the oracle at the north_star bar, and bit for bit against the pass structures that ask everything."""
+    from scenes import many_objects, user_shapes
+    from test_gpu_parity import compare, hip_trace
+    metric = {"ks_ref0": rt.kerr_schild, "ks_true08": rt.KerrSchild(1, 0.8)}[metric_name]
+    spheres = many_objects(57)                                   # sky sphere, far plane, 55 small spheres
+    shapes = user_shapes(True)[1]
+    objs = spheres[:20] + shapes[:1] + spheres[20:40] + shapes[1:] + spheres[40:]
+    sc, cam = rt.make_scene(metric, objs), rt.make_camera(**rt.example2_scene()[2])
+    assert sc.nobj == 60 and _info(sc)["has_reach"] == 1
+    opt = rt.solver_defaults()
+    ref = O.trace(sc, opt, 56, 56, cam=cam)
+    user_hits = {21, 42, 43}                                     # the shapes' places in the caller's list (1-based)
+    assert user_hits <= set(np.unique(ref["hit"])) and len(np.unique(ref["hit"])) > 12
+    got = hip_trace(lib, sc, opt, 56, 56, cam=cam)
+    compare(got, ref, sc=sc, max_class_flips=4, max_step_diff=2, rel_step_diff=0.015)
+    for knobs in (dict(split=0), dict(groups=0)):
+        with abi.options(lib, **knobs):
+            other = hip_trace(lib, sc, opt, 56, 56, cam=cam)
+        for k in ("rgb", "hit", "status", "n_accept", "n_reject", "state_end", "lambda_end"):
+            assert np.array_equal(got[k], other[k], equal_nan=got[k].dtype.kind == "f"), (knobs, k)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ks_ref0_shapes", "ks_true08_shapes"])
 def test_user_objects_in_float32_match_the_float32_oracle(lib, name):
     """T = Float32 (`Object{T}` is generic in T, src/RayTraceGR.jl:375): the unit's Float32 kernels against the Float32 oracle at the
