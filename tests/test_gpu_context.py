@@ -533,6 +533,26 @@ def test_trace_rays_drop_in_entry_uses_every_device_of_the_context(lib, ndev):
         abi.check(lib, lib.rtgr_destroy(ctx))
 
 
+def test_a_long_object_list_over_every_device_of_a_context(lib):
+    """The device table of a long list (and its groups) is per device: a three-device context deals the rows of a 64-object scene
+    cyclically, every device uploads its own table on first sight, and the canvas equals the single-device one bit for bit — Float64
+    and Float32 (which runs FAR + NEAR from 32 objects on), and again on the second call, when the tables are found by content."""
+    from scenes import many_objects
+    metric, _, cam = rt.example2_scene()
+    objs = many_objects(64)
+    ctx = abi.create_context(lib, _devices(3))
+    try:
+        for dtype in (np.float64, np.float32):
+            canvas = rt.make_canvas(metric, cam["pos"], cam["widthx"], cam["widthy"], cam["normal"], 96, 77, dtype=dtype)
+            single = rt.trace_rays(metric, objs, canvas)
+            for _ in range(2):
+                multi, info = rt.trace_rays(metric, objs, canvas, return_info=True, ctx=ctx)
+                assert multi.pixels.tobytes() == single.pixels.tobytes() and info["rays"] == 96 * 77
+            assert len(np.unique(single.pixels["rgb"][..., 2])) > 8      # (the blue channel is omin / 64: many objects on screen)
+    finally:
+        abi.check(lib, lib.rtgr_destroy(ctx))
+
+
 @pytest.mark.parametrize("ndev", [2, 4])
 def test_host_entry_with_caller_rays_and_every_output_over_all_devices(lib, ndev):
     """rtgr_trace_f64 with caller-supplied states (`input_func(i)`, :492-496) and a row slab [j0, j1), every per-ray
