@@ -339,7 +339,7 @@ struct SphereGroup { uint32_t first, count; };   // positions in the device list
 // make its group's bounding sphere as large as itself and stays loose.  Lists with fewer than two full groups, or with a non-finite
 // centre or radius among the spheres, get no groups.  Deterministic: ties are broken by the caller's index.
 static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order, uint32_t* nloose, std::vector<SphereGroup>& groups,
-                          size_t leaf = RTGR_GROUP_MAX) {
+                          size_t leaf = RTGR_GROUP_MAX, double limit = std::numeric_limits<double>::max()) {
     *nloose = 0;
     groups.clear();
     const size_t n = order.size();
@@ -347,7 +347,8 @@ static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order,
     std::vector<double> radii(n);
     for (size_t k = 0; k < n; k++) {
         const rtgr_object& o = objs[order[k]];
-        if (!std::isfinite(o.p[1]) || !std::isfinite(o.p[2]) || !std::isfinite(o.p[3]) || !std::isfinite(o.p[8])) return;
+        // (finite in the kernels' scalar type too: `limit` is its largest value — a centre that becomes inf there has no bounding sphere)
+        if (!(std::fabs(o.p[1]) <= limit) || !(std::fabs(o.p[2]) <= limit) || !(std::fabs(o.p[3]) <= limit) || !(std::fabs(o.p[8]) <= limit)) return;
         radii[k] = std::fabs(o.p[8]);
     }
     std::vector<double> sorted = radii;
@@ -460,7 +461,7 @@ int convert_scene(DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserM
     std::vector<SphereGroup> groups;
     const long kg = tl_knobs_override ? tl_knobs_override->groups : D.knobs.groups;   // (0: off; 1: on; >= 2: on, with that many spheres per group at most — experiments)
     if (s->nobj > n0 && kg)
-        group_spheres(objs, order, &d.nloose, groups, kg >= 2 ? (size_t)kg : (size_t)RTGR_GROUP_MAX);
+        group_spheres(objs, order, &d.nloose, groups, kg >= 2 ? (size_t)kg : (size_t)RTGR_GROUP_MAX, (double)std::numeric_limits<R>::max());
     for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind != RTGR_SPHERE) order.push_back(o);
     for (uint32_t k = 0; k < n0; k++) {
         if ((rc = convert_object<R>(objs[order[k]], d.obj[k]))) return rc;
@@ -854,7 +855,7 @@ extern "C" int rtgr_testhook_group_spheres(const rtgr_object* objs, uint32_t n, 
     std::vector<uint32_t> order(n);
     for (uint32_t k = 0; k < n; k++) order[k] = k;
     std::vector<SphereGroup> groups;
-    group_spheres(objs, order, nloose, groups);
+    group_spheres(objs, order, nloose, groups, RTGR_GROUP_MAX, is_f32 ? (double)std::numeric_limits<float>::max() : std::numeric_limits<double>::max());
     for (uint32_t k = 0; k < n; k++) order_out[k] = order[k];
     if (groups.size() > cap) return -1;
     auto fill = [&](auto zero) {

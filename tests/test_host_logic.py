@@ -139,3 +139,6 @@ def test_groups_leave_a_sky_sphere_loose_and_refuse_non_finite_lists():
         broken[3, 1] = bad
         assert len(_group(broken)[2]) == 0
     assert len(_group(sph[:15])[2]) == 0                    # fewer than two full groups: none
+    far = sph.copy()
+    far[5, 0] = 1e39                                        # finite in Float64, inf in Float32: groups there, none here
+    assert len(_group(far)[2]) > 0 and len(_group(far, f32=True)[2]) == 0
