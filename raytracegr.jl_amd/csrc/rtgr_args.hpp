@@ -36,7 +36,7 @@ struct DevScene {
     DevObject<R> obj[RTGR_MAX_OBJECTS];
     const DevObject<R>* more;   // objects RTGR_MAX_OBJECTS .. nobj-1 (the table holds the WHOLE list: table = more - RTGR_MAX_OBJECTS)
     uint32_t nloose;    // (ngroups > 0) spheres [0, nloose) belong to no group
-    uint32_t pad_;
+    uint32_t nsuper;    // > 0: the groups themselves come in that many runs of neighbouring groups with a bounding sphere each (a second level)
 };
 // GROUPS (long lists: DESIGN.md §4.7).  The FAR pass's reach test asks of every object, every step, "can this step reach you?"; of a
 // list of 64 small spheres the answer is no for all but one or two.  The host therefore sorts the spheres of a long list into groups of
@@ -44,7 +44,9 @@ struct DevScene {
 // that provably stays outside a group's bounding sphere cannot change the sign of any member's distance, and the members are only
 // asked when some lane of the wave cannot prove that.  A group is a DevObject in sphere form — p[1..3] the centre, p[8] the radius,
 // `type` the position of its first member in the device list, `orig` their number — and the groups follow the objects in the table:
-// groups = table + nobj.  Same results bit for bit with and without (the bound is a bound; FULL == FAR + NEAR is under test with
+// groups = table + nobj.  Lists of a few hundred spheres get a second level the same way: runs of ~8 neighbouring groups (a subtree of the
+// same median splits) with a bounding sphere over all their members, asked before their groups — supers = groups + ngroups, `type` the
+// first GROUP of the run, `orig` their number.  Same results bit for bit with and without (the bound is a bound; FULL == FAR + NEAR is under test with
 // grouped lists); option groups = 0 switches them off (A/B, tests).
 #define RTGR_GROUP_MAX 8
 

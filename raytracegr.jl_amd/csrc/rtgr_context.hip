@@ -338,10 +338,14 @@ struct SphereGroup { uint32_t first, count; };   // positions in the device list
 // tree's leaves, <= RTGR_GROUP_MAX members each; a sphere much larger than the list's typical one (a sky sphere around the scene) would
 // make its group's bounding sphere as large as itself and stays loose.  Lists with fewer than two full groups, or with a non-finite
 // centre or radius among the spheres, get no groups.  Deterministic: ties are broken by the caller's index.
+// `supers`: the second level — runs of neighbouring groups (first / count are GROUP indices): the nodes of the same split tree that hold
+// at most 8 leaves' worth of spheres; only lists of RTGR_SUPER_FROM groups and more get them.
+constexpr size_t RTGR_SUPER_FROM = 24;
 static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order, uint32_t* nloose, std::vector<SphereGroup>& groups,
-                          size_t leaf = RTGR_GROUP_MAX, double limit = std::numeric_limits<double>::max()) {
+                          std::vector<SphereGroup>& supers, size_t leaf = RTGR_GROUP_MAX, double limit = std::numeric_limits<double>::max()) {
     *nloose = 0;
     groups.clear();
+    supers.clear();
     const size_t n = order.size();
     if (n < 2 * (size_t)RTGR_GROUP_MAX) return;
     std::vector<double> radii(n);
@@ -355,7 +359,8 @@ static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order,
     std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
     const double big = 4.0 * sorted[n / 2];
     std::vector<uint32_t> loose, rest;
-    for (size_t k = 0; k < n; k++) (radii[k] > big ? loose : rest).push_back(order[k]);
+    // (… and an inside-out sphere, R < 0: the resolve kernel's bound for a group's members — select_objects — wants R >= 0)
+    for (size_t k = 0; k < n; k++) ((radii[k] > big || objs[order[k]].p[8] < 0) ? loose : rest).push_back(order[k]);
     if (rest.size() < 2 * (size_t)RTGR_GROUP_MAX) return;
     std::vector<std::pair<size_t, size_t>> todo{{0, rest.size()}}, leaves;
     while (!todo.empty()) {
@@ -381,6 +386,25 @@ static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order,
     order = loose;
     order.insert(order.end(), rest.begin(), rest.end());
     for (auto& lf : leaves) groups.push_back({(uint32_t)(loose.size() + lf.first), (uint32_t)(lf.second - lf.first)});
+    if (leaves.size() < RTGR_SUPER_FROM) return;
+    // the second level: the same tree (the splits above cut every range at lo + (hi - lo) / 2), stopped at nodes of <= 8 leaves' worth
+    std::vector<std::pair<size_t, size_t>> nodes;
+    todo.assign(1, {0, rest.size()});
+    while (!todo.empty()) {
+        const auto [lo, hi] = todo.back();
+        todo.pop_back();
+        if (hi - lo <= 8 * leaf) { nodes.push_back({lo, hi}); continue; }
+        const size_t mid = lo + (hi - lo) / 2;
+        todo.push_back({mid, hi});
+        todo.push_back({lo, mid});
+    }
+    std::sort(nodes.begin(), nodes.end());
+    size_t g = 0;
+    for (auto& nd : nodes) {   // (leaves are sorted by position and nest in the nodes)
+        const size_t g0 = g;
+        while (g < leaves.size() && leaves[g].first < nd.second) g++;
+        supers.push_back({(uint32_t)g0, (uint32_t)(g - g0)});
+    }
 }
 // … and a group's bounding sphere from its members AS THE KERNELS SEE THEM (the scalar type's values): centre = the middle of the
 // centres' box, radius = max (|c_i − C| + |r_i|), evaluated in double and rounded UP into R with a margin of 64 ulp — what the reach
@@ -405,6 +429,15 @@ static void bounding_sphere(const DevObject<R>* t, const SphereGroup& g, DevObje
     R r = (R)rad;
     if ((double)r < rad) r = std::nextafter(r, std::numeric_limits<R>::infinity());
     out.p[8] = r;
+}
+// … and a run of groups' bounding sphere: over ALL the members of its groups (they are neighbours in the device list too)
+template <class R>
+static void super_sphere(const DevObject<R>* t, const std::vector<SphereGroup>& groups, const SphereGroup& run, DevObject<R>& out) {
+    const SphereGroup& a = groups[run.first];
+    const SphereGroup& b = groups[run.first + run.count - 1];
+    bounding_sphere<R>(t, SphereGroup{a.first, b.first + b.count - a.first}, out);
+    out.type = run.first;
+    out.orig = run.count;
 }
 
 template <class R>
@@ -458,24 +491,26 @@ int convert_scene(DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserM
     for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind == RTGR_SPHERE) order.push_back(o);
     d.nsph = (uint32_t)order.size();
     // … and the spheres of a LONG list in groups of neighbours (DevScene: GROUPS)
-    std::vector<SphereGroup> groups;
+    std::vector<SphereGroup> groups, supers;
     const long kg = tl_knobs_override ? tl_knobs_override->groups : D.knobs.groups;   // (0: off; 1: on; >= 2: on, with that many spheres per group at most — experiments)
     if (s->nobj > n0 && kg)
-        group_spheres(objs, order, &d.nloose, groups, kg >= 2 ? (size_t)kg : (size_t)RTGR_GROUP_MAX, (double)std::numeric_limits<R>::max());
+        group_spheres(objs, order, &d.nloose, groups, supers, kg >= 2 ? (size_t)kg : (size_t)RTGR_GROUP_MAX, (double)std::numeric_limits<R>::max());
     for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind != RTGR_SPHERE) order.push_back(o);
     for (uint32_t k = 0; k < n0; k++) {
         if ((rc = convert_object<R>(objs[order[k]], d.obj[k]))) return rc;
         d.obj[k].orig = order[k];
     }
     if (s->nobj > n0) {   // a long list: a device table of ALL of it (+ its groups), shared by every call with the same list
-        std::vector<char> content((size_t)(s->nobj + groups.size()) * sizeof(DevObject<R>), 0);
+        std::vector<char> content((size_t)(s->nobj + groups.size() + supers.size()) * sizeof(DevObject<R>), 0);
         DevObject<R>* t = (DevObject<R>*)content.data();
         for (uint32_t k = 0; k < s->nobj; k++) {
             if ((rc = convert_object<R>(objs[order[k]], t[k]))) return rc;
             t[k].orig = order[k];
         }
         for (size_t g = 0; g < groups.size(); g++) bounding_sphere<R>(t, groups[g], t[s->nobj + g]);
+        for (size_t u = 0; u < supers.size(); u++) super_sphere<R>(t, groups, supers[u], t[s->nobj + groups.size() + u]);
         d.ngroups = (uint32_t)groups.size();
+        d.nsuper = (uint32_t)supers.size();
         const void* dev = nullptr;
         if ((rc = object_table(D, content, st, &dev))) return rc;
         d.more = (const DevObject<R>*)dev + n0;
@@ -848,16 +883,18 @@ int api::trace_rows_device_f32(rtgr_context* ctx, const rtgr_scene* scene, const
 // A test hook, not part of include/rtgr.h (tests/test_host_logic.py; host code only — runs without a GPU): how convert_scene lays a
 // list's SPHERES out — `order` (n entries: indices into objs, loose spheres first, then the groups' members), the number of loose
 // ones, and per group {centre x, y, z, radius, first position, count} as the kernels of the scalar type get them.  objs[] must all be
-// RTGR_SPHEREs.  Returns the number of groups (0: the list gets none), or -1 when `cap` groups do not hold them.
+// RTGR_SPHEREs.  Returns the number of groups (0: the list gets none), or -1 when `cap` rows do not hold them; *nsuper rows of runs of
+// groups follow the groups' rows (first / count: group indices).
 extern "C" int rtgr_testhook_group_spheres(const rtgr_object* objs, uint32_t n, int is_f32, uint32_t* order_out, uint32_t* nloose,
-                                           double* groups_out, uint32_t cap) {
+                                           double* groups_out, uint32_t cap, uint32_t* nsuper) {
     using namespace rtgr;
     std::vector<uint32_t> order(n);
     for (uint32_t k = 0; k < n; k++) order[k] = k;
-    std::vector<SphereGroup> groups;
-    group_spheres(objs, order, nloose, groups, RTGR_GROUP_MAX, is_f32 ? (double)std::numeric_limits<float>::max() : std::numeric_limits<double>::max());
+    std::vector<SphereGroup> groups, supers;
+    group_spheres(objs, order, nloose, groups, supers, RTGR_GROUP_MAX, is_f32 ? (double)std::numeric_limits<float>::max() : std::numeric_limits<double>::max());
     for (uint32_t k = 0; k < n; k++) order_out[k] = order[k];
-    if (groups.size() > cap) return -1;
+    if (groups.size() + supers.size() > cap) return -1;
+    if (nsuper) *nsuper = (uint32_t)supers.size();
     auto fill = [&](auto zero) {
         typedef decltype(zero) R;
         std::vector<DevObject<R>> t(n);
@@ -866,6 +903,12 @@ extern "C" int rtgr_testhook_group_spheres(const rtgr_object* objs, uint32_t n, 
             DevObject<R> G;
             bounding_sphere<R>(t.data(), groups[g], G);
             double* o = groups_out + 6 * g;
+            o[0] = (double)G.p[1]; o[1] = (double)G.p[2]; o[2] = (double)G.p[3]; o[3] = (double)G.p[8]; o[4] = G.type; o[5] = G.orig;
+        }
+        for (size_t u = 0; u < supers.size(); u++) {   // (the runs of groups follow the groups; first / count are group indices)
+            DevObject<R> G;
+            super_sphere<R>(t.data(), groups, supers[u], G);
+            double* o = groups_out + 6 * (groups.size() + u);
             o[0] = (double)G.p[1]; o[1] = (double)G.p[2]; o[2] = (double)G.p[3]; o[3] = (double)G.p[8]; o[4] = G.type; o[5] = G.orig;
         }
     };

@@ -284,16 +284,18 @@ RTGR_DEV uint32_t colour_pixel(const DevScene<R>& sc, const DevSolver<R>& opt, c
     R dmin = opt.hit_threshold;                                                       // :519
     // (the device list is regrouped — spheres first, DevScene —: "the first object with the smallest distance wins" (:520-526) is
     //  the smallest distance and, among equal ones, the smallest ORIGINAL index)
-    for_each_object<R>(sc, [&](const DevObject<R>& o_, uint32_t o) {                  // :520-526
-        if constexpr (SEL) { if (!sel.has(o)) return; }   // (left out: provably farther than the nearest object, select_objects)
+    auto nearest = [&](const DevObject<R>& o_, uint32_t o) {                          // :520-526
         const R d = obj_distance<R>(o_, x);
         if (d < dmin || (d == dmin && omin != 0u && o_.orig + 1u < omin)) { omin = o_.orig + 1u; pmin = o; dmin = d; }
-    });
+    };
+    if constexpr (SEL) for_each_selected<R>(sc, sel, nearest);   // (the rest: provably farther than the nearest object, select_objects)
+    else for_each_object<R>(sc, nearest);
     if (omin == 0) {                                                                  // :527-528
         col[0] = opt.miss_rgb[0]; col[1] = opt.miss_rgb[1]; col[2] = opt.miss_rgb[2];
         return 0;
     }
-    const DevObject<R>& ob = object_at<R>(sc, pmin);
+    // (a selection exists for lists beyond the argument block only: their table holds the whole list)
+    const DevObject<R>& ob = SEL ? (sc.more - (uint32_t)RTGR_MAX_OBJECTS)[pmin] : object_at<R>(sc, pmin);
     const R pi = R(3.14159265358979323846264338327950288L);
     if (ob.kind == RTGR_PLANE) {                                                      // :402-404
         col[0] = R(0); col[1] = R(0.5); col[2] = R(0);

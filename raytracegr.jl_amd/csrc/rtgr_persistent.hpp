@@ -536,9 +536,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             };
                             // (a lane that has ruled a whole GROUP of spheres out — see below — has ruled its members out: what the
                             //  members' own tests say for that lane, asked because another lane needs them, does not count)
-                            bool group_out = false;
+                            bool group_out = false, run_out = false;
                             for_each_within_reach<R>(A.sc,
-                              [&](const DevObject<R>& G) -> bool {        // a group of a long list (DevScene): its bounding sphere
+                              [&](const DevObject<R>& G, int level) -> bool {   // a group of a long list (level 0), or a run of groups (1): its bounding sphere
                                 // OUTSIDE the bounding sphere now, and for the whole step (the sphere test below without the absolute
                                 // value): then outside every member, by at least the same margin, for the whole step — no member's
                                 // distance changes sign.  The floor keeps that margin above the rounding noise of the members' own
@@ -548,7 +548,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 const R B = rfma(dl[1], rfma(R(2), rabs(X0), dl[1]),
                                                  rfma(dl[2], rfma(R(2), rabs(X1), dl[2]), dl[3] * rfma(R(2), rabs(X2), dl[3])));
                                 const R mag = rabs(D0) + R(2) * Rr * Rr;
-                                group_out = D0 > rfma(guard, B, R(256) * eps * mag);
+                                const bool out = D0 > rfma(guard, B, R(256) * eps * mag);
+                                if (level != 0) { run_out = out; group_out = out; }   // (a lane that has ruled the run out has ruled its groups out)
+                                else group_out = run_out || out;
                                 return __ballot(run && !group_out) != 0ull;
                               },
                               [&](const DevObject<R>& ob, uint32_t o) {   // the spheres of the list: no dispatch, one batch of scalar loads each
@@ -1128,17 +1130,56 @@ RTGR_DEV ObjSel select_objects(const DevScene<R>& sc, const R x0[4], const R c[4
 #pragma unroll
     for (int q = 0; q < 4; q++) dl[q] = top * rfma(top, rfma(top, rfma(top, rabs(c[3][q]), rabs(c[2][q])), rabs(c[1][q])), rabs(c[0][q]));
     R U = R(__builtin_huge_val());
-    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t) {
+    auto upper = [&](const DevObject<R>& ob, uint32_t) {
         R lo, up;
         distance_bounds<R>(ob, x0, dl, &lo, &up);
         U = up < U ? up : U;
-    });
-    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) {
+    };
+    if (sc.ngroups == 0u) {   // a list without groups: every object twice
+        for_each_object<R>(sc, upper);
+        for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) {
+            R lo, up;
+            distance_bounds<R>(ob, x0, dl, &lo, &up);
+            if (__ballot(event && !(lo > U)) != 0ull) sel.mask |= 1ull << (o >> sel.shift);
+        });
+        return sel;
+    }
+    // A grouped list (DevScene): the bound U may come from ANY objects — from a sample first (one member of every group, the loose
+    // spheres, the other kinds).  A group whose bounding sphere stays farther than sqrt(U) away for the whole step holds no member
+    // that can be the minimum: with m = |X_g| − R_g − |δ| > sqrt(U) >= 0 every member has |X_i(θ)| − r_i >= m, so its distance
+    // (|X_i| − r_i)(|X_i| + r_i) >= m² > U (members have r_i >= 0: the host leaves inside-out spheres loose).  Such groups — and
+    // runs of groups — are passed over when every lane agrees; the members that remain tighten the bound (U2: the minimum over the
+    // sample AND over everything that passed, which holds the object the full list's bound comes from), and a last walk over what
+    // passed keeps what the tight bound cannot leave out: the same selection as two walks over the whole list give.
+    for_each_sample<R>(sc, upper);
+    const R eps = sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7);
+    const R guard = R(1) + R(1e-6);
+    const R reach = guard * (rsqrt_(rfma(dl[1], dl[1], rfma(dl[2], dl[2], dl[3] * dl[3]))) + (U > R(0) ? rsqrt_(U) : R(0)));
+    R U2 = U;
+    auto member = [&](const DevObject<R>& ob, uint32_t o) {
         R lo, up;
         distance_bounds<R>(ob, x0, dl, &lo, &up);
-        if (__ballot(event && !(lo > U)) != 0ull) sel.mask |= 1ull << (o >> sel.shift);
+        const bool in = !(lo > U);
+        U2 = (in && up < U2) ? up : U2;
+        if (__ballot(event && in) != 0ull) sel.mask |= 1ull << (o >> sel.shift);
+    };
+    for_each_within_reach<R>(sc,
+        [&](const DevObject<R>& G, int) -> bool {
+            const R X0 = x0[1] - G.p[1], X1 = x0[2] - G.p[2], X2 = x0[3] - G.p[3];
+            const R S = rfma(X0, X0, rfma(X1, X1, X2 * X2));
+            const R t = G.p[8] + reach;
+            const R rhs = t * t;
+            const bool far_away = S > rfma(guard, rhs, R(256) * eps * (S + rhs));
+            return __ballot(event && !far_away) != 0ull;
+        },
+        member, member);
+    ObjSel fin{0ull, sel.shift};
+    for_each_selected<R>(sc, sel, [&](const DevObject<R>& ob, uint32_t o) {
+        R lo, up;
+        distance_bounds<R>(ob, x0, dl, &lo, &up);
+        if (__ballot(event && !(lo > U2)) != 0ull) fin.mask |= 1ull << (o >> fin.shift);
     });
-    return sel;
+    return fin;
 }
 
 // Bracketed root of g(θ) = ps·cond(x(θ)) on [0, top], g(0) > 0 >= g(top).  Ridders' method: every iterate stays inside

@@ -932,8 +932,9 @@ RTGR_DEV void for_each_by_kind(const DevScene<R>& sc, FS&& fs, FO&& fo) {
 #endif
 }
 // The reach test's walk (rtgr_persistent.hpp): as for_each_by_kind, but a list with GROUPS (DevScene, rtgr_args.hpp) is walked group
-// by group — fg(group) -> wave-uniform "some lane cannot rule this group out"; only then its members are handed to fs.  The whole
-// walk of a grouped list reads the device table (scalar loads through the constant address space, as above) and is cold code for
+// by group — fg(group, level) -> wave-uniform "some lane cannot rule this group out"; only then its members are handed to fs.  With a
+// second level (nsuper > 0) the runs of groups are asked first (level 1), their groups (level 0) only when a run is not ruled out.  The
+// whole walk of a grouped list reads the device table (scalar loads through the constant address space, as above) and is cold code for
 // every list without groups.
 template <class R, class FG, class FS, class FO>
 RTGR_DEV void for_each_within_reach(const DevScene<R>& sc, FG&& fg, FS&& fs, FO&& fo) {
@@ -942,12 +943,23 @@ RTGR_DEV void for_each_within_reach(const DevScene<R>& sc, FG&& fg, FS&& fs, FO&
         typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
         const ConstTable table = (ConstTable)(unsigned long long)(sc.more - (uint32_t)RTGR_MAX_OBJECTS);
         const ConstTable groups = table + sc.nobj;
+        const ConstTable supers = groups + sc.ngroups;
         for (uint32_t o = 0; o < sc.nloose; o++) fs(*(const DevObject<R>*)(table + o), o);
-        for (uint32_t g = 0; g < sc.ngroups; g++) {
-            const DevObject<R>& G = *(const DevObject<R>*)(groups + g);
-            if (fg(G)) {
-                const uint32_t o1 = G.type + G.orig;
-                for (uint32_t o = G.type; o < o1; o++) fs(*(const DevObject<R>*)(table + o), o);
+        const uint32_t runs = sc.nsuper != 0u ? sc.nsuper : 1u;
+        for (uint32_t s = 0; s < runs; s++) {
+            uint32_t g0 = 0u, g1 = sc.ngroups;
+            if (sc.nsuper != 0u) {
+                const DevObject<R>& S = *(const DevObject<R>*)(supers + s);
+                if (!fg(S, 1)) continue;
+                g0 = S.type;
+                g1 = S.type + S.orig;
+            }
+            for (uint32_t g = g0; g < g1; g++) {
+                const DevObject<R>& G = *(const DevObject<R>*)(groups + g);
+                if (fg(G, 0)) {
+                    const uint32_t o1 = G.type + G.orig;
+                    for (uint32_t o = G.type; o < o1; o++) fs(*(const DevObject<R>*)(table + o), o);
+                }
             }
         }
         for (uint32_t o = sc.nsph; o < sc.nobj; o++) fo(*(const DevObject<R>*)(table + o), o);
@@ -955,6 +967,19 @@ RTGR_DEV void for_each_within_reach(const DevScene<R>& sc, FG&& fg, FS&& fs, FO&
     }
 #endif
     for_each_by_kind<R>(sc, fs, fo);
+}
+// A SAMPLE of a grouped list (ngroups > 0): the loose spheres, ONE member of every group, the other kinds — f(object, position).
+template <class R, class F>
+RTGR_DEV void for_each_sample(const DevScene<R>& sc, F&& f) {
+    typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
+    const ConstTable table = (ConstTable)(unsigned long long)(sc.more - (uint32_t)RTGR_MAX_OBJECTS);
+    const ConstTable groups = table + sc.nobj;
+    for (uint32_t o = 0; o < sc.nloose; o++) f(*(const DevObject<R>*)(table + o), o);
+    for (uint32_t g = 0; g < sc.ngroups; g++) {
+        const uint32_t o = ((const DevObject<R>*)(groups + g))->type;
+        f(*(const DevObject<R>*)(table + o), o);
+    }
+    for (uint32_t o = sc.nsph; o < sc.nobj; o++) f(*(const DevObject<R>*)(table + o), o);
 }
 // … and one object by (per-lane) POSITION in the regrouped list
 template <class R>
@@ -973,14 +998,32 @@ RTGR_DEV uint32_t objsel_shift(uint32_t nobj) {   // the smallest shift with (no
     return nobj > 64u ? 32u - (uint32_t)__builtin_clz((nobj - 1u) >> 6) : 0u;
 }
 
+// The objects of a selection, in list order — f(object, position) —, found by the mask's set bits (a list of 1024 objects is not walked
+// to find the three that are selected).  Lists beyond the argument block only: the device table holds the whole list.
+template <class R, class F>
+RTGR_DEV void for_each_selected(const DevScene<R>& sc, ObjSel sel, F&& f) {
+    typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
+    const ConstTable table = (ConstTable)(unsigned long long)(sc.more - (uint32_t)RTGR_MAX_OBJECTS);
+    unsigned long long m = sel.mask;
+    while (m != 0ull) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t o0 = b << sel.shift;
+        uint32_t o1 = o0 + (1u << sel.shift);
+        o1 = o1 < sc.nobj ? o1 : sc.nobj;
+        for (uint32_t o = o0; o < o1; o++) f(*(const DevObject<R>*)(table + o), o);
+    }
+}
+
 template <class R, bool SEL = false>
 RTGR_DEV R min_distance(const DevScene<R>& sc, const R pos[4], ObjSel sel = ObjSel{}) {   // :433-441
     R dmin = R(__builtin_huge_val());
-    for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) {
-        if constexpr (SEL) { if (!sel.has(o)) return; }
+    auto fold = [&](const DevObject<R>& ob, uint32_t) {
         const R d = obj_distance<R>(ob, pos);
         dmin = (d < dmin || d != d) ? d : dmin;
-    });
+    };
+    if constexpr (SEL) for_each_selected<R>(sc, sel, fold);
+    else for_each_object<R>(sc, fold);
     return dmin;
 }
 

@@ -209,6 +209,42 @@ def test_the_kernels_the_library_ships_are_free_of_the_exec_flip_fault():
     assert n == 0, report
 
 
+def test_no_kernel_of_the_library_keeps_its_arguments_in_scratch(tmp_path):
+    """A kernel's argument block (ResolveArgs / IntegrateArgs with the scene's 16 inline objects: 1.4 KB) is read with scalar loads
+    from the kernarg segment.  One unlucky access pattern — a per-lane index into the inline objects next to a walk over the device
+    table — and the compiler copies the whole block into every lane's scratch memory first: the resolve kernel of a three-object
+    scene went from 0.38 to 2.5 ms that way (round 6, caught by the cost table only).  So: no kernel the library ships holds more
+    than the few spill slots the hot kernels are known to have (<= 64 bytes per lane, RTGR_USER_MAX_SCRATCH's bar for units)."""
+    import re
+    import struct
+    from scenes import rt
+    blob = open(rt._abi.LIB_PATH, "rb").read()
+    sizes = {}
+    for k, m in enumerate(re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)):
+        o = m.start()
+        n = struct.unpack_from("<Q", blob, o + 24)[0]
+        p = o + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "amdgcn" in triple and size:
+                co = tmp_path / f"{k}.hsaco"
+                co.write_bytes(blob[o + off:o + off + size])
+                txt = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", str(co)], capture_output=True, text=True, check=True).stdout
+                cur = None
+                for line in txt.splitlines():
+                    mm = re.match(r"\s+\.name:\s+(\S+)", line)
+                    if mm:
+                        cur = mm.group(1)
+                    mm = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+                    if mm and cur:
+                        sizes[cur] = int(mm.group(1))
+    assert len(sizes) > 40 and any("resolve_kernel" in k for k in sizes) and any("integrate" in k for k in sizes)
+    fat = {k: v for k, v in sizes.items() if v > 64}
+    assert not fat, fat
+
+
 def _build_module(name="rtgr_build_t2"):
     import importlib.util
     spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "raytracegr.jl_amd", "build.py"))

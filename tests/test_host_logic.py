@@ -86,9 +86,11 @@ def _group(spheres, f32=False):
     groups = np.zeros((n + 1, 6))
     fn = lib.rtgr_testhook_group_spheres
     fn.restype = C.c_int
-    fn.argtypes = [C.POINTER(abi.rtgr_object), C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32]
-    ng = fn(objs, n, int(f32), order.ctypes.data, C.byref(nloose), groups.ctypes.data, n + 1)
+    fn.argtypes = [C.POINTER(abi.rtgr_object), C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    nsuper = C.c_uint32(0)
+    ng = fn(objs, n, int(f32), order.ctypes.data, C.byref(nloose), groups.ctypes.data, n + 1, C.byref(nsuper))
     assert ng >= 0
+    _group.runs = groups[ng:ng + nsuper.value]              # (the second level of the last call: runs of groups)
     return order, nloose.value, groups[:ng]
 
 
@@ -122,6 +124,19 @@ def test_groups_of_a_long_list_contain_their_members(n, seed, f32, shape):
     assert pos == n
     if shape != "wide_radii":
         assert nloose == 0
+    # the second level (lists of 24 groups and more): runs of groups that tile the groups, each with a bounding sphere around ALL the
+    # members of its groups
+    runs = _group.runs
+    assert (len(runs) > 0) == (len(groups) >= 24)
+    nxt = 0
+    for cx, cy, cz, rr, g0, cnt in runs:
+        assert g0 == nxt and 1 <= cnt <= 16
+        first = int(groups[int(g0)][4])
+        last = int(groups[int(g0 + cnt) - 1][4] + groups[int(g0 + cnt) - 1][5])
+        m = seen[first:last]
+        assert (np.sqrt(((m[:, :3] - np.array([cx, cy, cz], np.longdouble)) ** 2).sum(1)) + np.abs(m[:, 3]) <= np.longdouble(rr)).all()
+        nxt += int(cnt)
+    assert nxt == (len(groups) if len(runs) else 0)
     again = _group(sph, f32)
     assert np.array_equal(order, again[0]) and np.array_equal(groups, again[2])
 
@@ -130,8 +145,9 @@ def test_groups_leave_a_sky_sphere_loose_and_refuse_non_finite_lists():
     rng = np.random.default_rng(5)
     sph = np.column_stack([rng.uniform(-6, 6, (60, 3)), rng.uniform(0.2, 0.4, 60)])
     sph[17] = [0, 0, 0, 30.0]                               # a sphere around the whole scene: would blow its group's bounding sphere up
+    sph[33, 3] = -0.3                                       # an inside-out sphere (sign(R) * (|x − c|² − R²), :415-419): loose too
     order, nloose, groups = _group(sph)
-    assert nloose == 1 and order[0] == 17 and len(groups) >= 8 and groups[:, 3].max() < 8
+    assert nloose == 2 and sorted(order[:2].tolist()) == [17, 33] and len(groups) >= 8 and groups[:, 3].max() < 8
     # neighbours end up together: the groups' bounding spheres are far smaller than the cloud
     assert np.median(groups[:, 3]) < 4.5
     for bad in (np.nan, np.inf):
