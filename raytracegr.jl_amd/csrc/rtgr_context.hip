@@ -335,14 +335,14 @@ static int object_table(DeviceCtx& D, const std::vector<char>& content, hipStrea
 struct SphereGroup { uint32_t first, count; };   // positions in the device list
 // `order` holds the spheres in the caller's order; on return: [0, *nloose) the spheres that join no group, then the groups' members,
 // group by group (`groups`: their positions).  Groups are the leaves of median splits of the centres along the widest axis — a k-d
-// tree's leaves, <= RTGR_GROUP_MAX members each; a sphere much larger than the list's typical one (a sky sphere around the scene) would
+// tree's leaves, <= RTGR_GROUP_MAX members each (half that for lists of fewer than 36 spheres); a sphere much larger than the list's typical one (a sky sphere around the scene) would
 // make its group's bounding sphere as large as itself and stays loose.  Lists with fewer than two full groups, or with a non-finite
 // centre or radius among the spheres, get no groups.  Deterministic: ties are broken by the caller's index.
 // `supers`: the second level — runs of neighbouring groups (first / count are GROUP indices): the nodes of the same split tree that hold
 // at most 8 leaves' worth of spheres; only lists of RTGR_SUPER_FROM groups and more get them.
 constexpr size_t RTGR_SUPER_FROM = 24;
 static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order, uint32_t* nloose, std::vector<SphereGroup>& groups,
-                          std::vector<SphereGroup>& supers, size_t leaf = RTGR_GROUP_MAX, double limit = std::numeric_limits<double>::max()) {
+                          std::vector<SphereGroup>& supers, size_t leaf = 0, double limit = std::numeric_limits<double>::max()) {
     *nloose = 0;
     groups.clear();
     supers.clear();
@@ -362,6 +362,9 @@ static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order,
     // (… and an inside-out sphere, R < 0: the resolve kernel's bound for a group's members — select_objects — wants R >= 0)
     for (size_t k = 0; k < n; k++) ((radii[k] > big || objs[order[k]].p[8] < 0) ? loose : rest).push_back(order[k]);
     if (rest.size() < 2 * (size_t)RTGR_GROUP_MAX) return;
+    // (leaf = 0: automatic — a few dozen spheres spread over a scene make better groups of <= 4: 2048², 24 objects 35.5 -> 33.8 ms, 32:
+    //  42.4 -> 41.4, but 40: 43.9 -> 45.7; profiles/r06/groups_small_lists.log)
+    if (leaf == 0) leaf = rest.size() < 36 ? RTGR_GROUP_MAX / 2 : RTGR_GROUP_MAX;
     std::vector<std::pair<size_t, size_t>> todo{{0, rest.size()}}, leaves;
     while (!todo.empty()) {
         const auto [lo, hi] = todo.back();
@@ -494,7 +497,7 @@ int convert_scene(DeviceCtx& D, const rtgr_scene* s, DevScene<R>& d, const UserM
     std::vector<SphereGroup> groups, supers;
     const long kg = tl_knobs_override ? tl_knobs_override->groups : D.knobs.groups;   // (0: off; 1: on; >= 2: on, with that many spheres per group at most — experiments)
     if (s->nobj > n0 && kg)
-        group_spheres(objs, order, &d.nloose, groups, supers, kg >= 2 ? (size_t)kg : (size_t)RTGR_GROUP_MAX, (double)std::numeric_limits<R>::max());
+        group_spheres(objs, order, &d.nloose, groups, supers, kg >= 2 ? (size_t)kg : (size_t)0, (double)std::numeric_limits<R>::max());
     for (uint32_t o = 0; o < s->nobj; o++) if (objs[o].kind != RTGR_SPHERE) order.push_back(o);
     for (uint32_t k = 0; k < n0; k++) {
         if ((rc = convert_object<R>(objs[order[k]], d.obj[k]))) return rc;
@@ -891,7 +894,7 @@ extern "C" int rtgr_testhook_group_spheres(const rtgr_object* objs, uint32_t n, 
     std::vector<uint32_t> order(n);
     for (uint32_t k = 0; k < n; k++) order[k] = k;
     std::vector<SphereGroup> groups, supers;
-    group_spheres(objs, order, nloose, groups, supers, RTGR_GROUP_MAX, is_f32 ? (double)std::numeric_limits<float>::max() : std::numeric_limits<double>::max());
+    group_spheres(objs, order, nloose, groups, supers, 0, is_f32 ? (double)std::numeric_limits<float>::max() : std::numeric_limits<double>::max());
     for (uint32_t k = 0; k < n; k++) order_out[k] = order[k];
     if (groups.size() + supers.size() > cap) return -1;
     if (nsuper) *nsuper = (uint32_t)supers.size();
