@@ -211,6 +211,8 @@ int rtgr_init(int device);
 /* Destroy the default context. */
 int rtgr_shutdown(void);
 const char* rtgr_last_error(void);
+/* (The library also exports `rtgr_testhook_*` symbols — host-only probes of internal layouts for the CPU tests, e.g. how a long object
+ * list's spheres are grouped — and, in debug builds, `rtgr_debug_*`: neither is part of this ABI; nothing outside tests/ may bind them.) */
 int rtgr_abi_version(void);
 /* Fill `s` with the reference's constants for T = Float64 (is_f32 = 0) or Float32 (is_f32 = 1). */
 int rtgr_solver_defaults(rtgr_solver* s, int is_f32);
