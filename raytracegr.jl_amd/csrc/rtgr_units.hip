@@ -206,6 +206,9 @@ static int probe_unit(DeviceCtx& D, const UserModule& U, std::string* why) {
 #ifndef RTGR_HEADER_HASH
 #define RTGR_HEADER_HASH 0ull   // (build.py passes the FNV-1a of the device headers the library's kernels were built from)
 #endif
+// A test hook, not part of include/rtgr.h (tests/test_build_checks.py): the hash of the device headers this library's kernels were built from
+// — a library left over from before an edit of the headers refuses every unit built after it, and the CPU suite should say so first.
+extern "C" unsigned long long rtgr_testhook_header_hash(void) { return RTGR_HEADER_HASH; }
 
 // load a gfx950 code object image into every device of the context; its id is a hash of the image
 static int load_module_image(rtgr_context* c, const std::vector<char>& image, const std::string& what, uint64_t* id_out) {

@@ -209,6 +209,18 @@ def test_the_kernels_the_library_ships_are_free_of_the_exec_flip_fault():
     assert n == 0, report
 
 
+def test_the_library_in_the_tree_was_built_from_the_headers_in_the_tree():
+    """librtgr_hip.so is git-ignored but travels to the GPU box as it lies; a library left over from before an edit of a device header
+    (or of include/rtgr.h, which they include) refuses every run-time unit built afterwards ("built from other device headers") — on the
+    GPU box, minutes later.  Say so here: the hash compiled into the library equals the hash of the headers on disk."""
+    import ctypes as C
+    from scenes import rt
+    lib = rt._abi.load()
+    fn = lib.rtgr_testhook_header_hash
+    fn.restype = C.c_ulonglong
+    assert fn() == _build_module("rtgr_build_t3").header_hash(), "stale librtgr_hip.so: python -c 'import __graft_entry__ as g; g.build()'"
+
+
 def test_no_kernel_of_the_library_keeps_its_arguments_in_scratch(tmp_path):
     """A kernel's argument block (ResolveArgs / IntegrateArgs with the scene's 16 inline objects: 1.4 KB) is read with scalar loads
     from the kernarg segment.  One unlucky access pattern — a per-lane index into the inline objects next to a walk over the device
