@@ -157,6 +157,7 @@ void free_device_state(DeviceCtx& d, bool all) {
     }
     for (auto& kv : d.object_tables) (void)hipFree(kv.second.dev);   // (the device is idle: synchronised above)
     d.object_tables.clear();
+    d.object_table_bytes = 0;
     if (all) { d.staging.reset(); d.staging2.reset(); }   // (rtgr_trim releases the staging BUFFERS separately, under the staging's own mutex)
     if (all) {
         d.streams.clear();
@@ -316,16 +317,19 @@ static int object_table(DeviceCtx& D, const std::vector<char>& content, hipStrea
     if (st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(RTGR_ERR_BAD_ARG, "a scene of more than RTGR_MAX_OBJECTS objects is seen for the first time while the stream is being captured "
                                       "(its object table must be uploaded): trace the scene once before hipStreamBeginCapture");
-    if (D.object_tables.size() >= OBJECT_TABLES_MAX) {   // a caller that animates a long list: start over (nothing in flight may read a freed table)
+    if (D.object_tables.size() >= OBJECT_TABLES_MAX || D.object_table_bytes + content.size() > OBJECT_TABLES_BYTES) {
+        // a caller that animates a long list: start over (nothing in flight may read a freed table)
         HIP_TRY(hipDeviceSynchronize());
         for (auto& kv : D.object_tables) (void)hipFree(kv.second.dev);
         D.object_tables.clear();
+        D.object_table_bytes = 0;
     }
     ObjectTable t;
     HIP_TRY(hipMalloc(&t.dev, content.size()));
     const hipError_t e = hipMemcpy(t.dev, content.data(), content.size(), hipMemcpyHostToDevice);   // blocking: complete before any launch
     if (e != hipSuccess) { (void)hipFree(t.dev); return fail(RTGR_ERR_HIP, std::string("hipMemcpy(object table): ") + hipGetErrorString(e)); }
     t.content = content;
+    D.object_table_bytes += content.size();
     *dev = t.dev;
     D.object_tables.emplace(key, std::move(t));
     return RTGR_OK;

@@ -110,12 +110,14 @@ struct UserModule {
 
 struct TimedLaunch { hipEvent_t a, b; int which; };
 
-// Objects RTGR_MAX_OBJECTS .. nobj-1 of a scene whose list is longer than the kernels' argument block holds (DevScene::more): one
-// immutable device table per distinct (scalar type, list) a device has seen, found again by content.  Immutable, so a kernel in
-// flight — or a hipGraph captured earlier — never sees it change; freed by rtgr_trim / rtgr_destroy (or all at once, behind a
-// device synchronisation, when a caller has gone through OBJECT_TABLES_MAX distinct lists).
+// A scene whose list is longer than the kernels' argument block holds (DevScene::more): the whole list, its groups and runs of groups in
+// one immutable device table per distinct (scalar type, list, layout) a device has seen, found again by content.  Immutable, so a
+// kernel in flight — or a hipGraph captured earlier — never sees it change; freed by rtgr_trim / rtgr_destroy (or all at once, behind
+// a device synchronisation, when a caller has gone through OBJECT_TABLES_MAX distinct lists or OBJECT_TABLES_BYTES of them: an
+// animation of a 100000-object list is 9 MB a frame, on the device and in the host copy the lookup compares with).
 struct ObjectTable { std::vector<char> content; void* dev = nullptr; };
 constexpr size_t OBJECT_TABLES_MAX = 512;
+constexpr size_t OBJECT_TABLES_BYTES = (size_t)1 << 30;
 
 // pipeline workspace of one (device, stream)
 struct StreamState {
@@ -135,6 +137,7 @@ struct DeviceCtx {
     std::unordered_map<hipStream_t, StreamState> streams;
     std::vector<UserModule> modules;
     std::unordered_multimap<uint64_t, ObjectTable> object_tables;   // by FNV-1a of the content
+    size_t object_table_bytes = 0;                                   // … and what they hold together
     std::unordered_map<uint64_t, int> checked_scenes;                // auto_scene_check: key of a scene -> the verdict it got (RTGR_OK or the refusal)
     Knobs knobs;
     // optional per-kernel timing (bench.py's roofline leg): hipEvents around each kernel of the pipeline

@@ -533,6 +533,31 @@ def test_trace_rays_drop_in_entry_uses_every_device_of_the_context(lib, ndev):
         abi.check(lib, lib.rtgr_destroy(ctx))
 
 
+def test_an_animated_long_list_starts_its_tables_over(lib):
+    """Every distinct list leaves a device table (and the host copy it is found again by) behind until rtgr_trim: a caller that moves
+    one object per frame piles them up.  Past OBJECT_TABLES_MAX lists (512) — or OBJECT_TABLES_BYTES (1 GiB: the same branch) — the
+    device is synchronised and the tables start over; the frames do not notice.  600 frames of a 41-object list whose last object
+    moves where no ray goes: every frame equals the first, bit for bit."""
+    from scenes import many_objects
+    metric, _, cam = rt.example2_scene()
+    objs = many_objects(40)
+    camera = rt.make_camera(**cam)
+    opt = rt.solver_defaults()
+    frames = []
+    for k in range(600):
+        sc = rt.make_scene(metric, objs + [rt.Sphere((0, 0.0, -400.0 - k, 0.0), (1, 0, 0, 0), 0.5)])   # outside the sky sphere: never seen
+        rgb = np.zeros((3, 12 * 12))
+        hit = np.zeros(144, np.uint8)
+        o = abi.rtgr_ray_outputs()
+        o.hit = hit.ctypes.data
+        abi.check(lib, lib.rtgr_trace_f64(None, C.byref(sc), C.byref(opt), None, C.byref(camera), 12, 12, 0, 12, rgb.ctypes.data, C.byref(o), None))
+        frames.append((rgb, hit))
+    for rgb, hit in frames[1:]:
+        assert np.array_equal(rgb, frames[0][0]) and np.array_equal(hit, frames[0][1])
+    assert len(np.unique(frames[0][1])) > 4 and (frames[0][1] > 0).all() and int(frames[0][1].max()) <= 40
+    abi.check(lib, lib.rtgr_trim(None))
+
+
 def test_a_long_object_list_over_every_device_of_a_context(lib):
     """The device table of a long list (and its groups) is per device: a three-device context deals the rows of a 64-object scene
     cyclically, every device uploads its own table on first sight, and the canvas equals the single-device one bit for bit — Float64
