@@ -394,13 +394,16 @@ static void group_spheres(const rtgr_object* objs, std::vector<uint32_t>& order,
     order.insert(order.end(), rest.begin(), rest.end());
     for (auto& lf : leaves) groups.push_back({(uint32_t)(loose.size() + lf.first), (uint32_t)(lf.second - lf.first)});
     if (leaves.size() < RTGR_SUPER_FROM) return;
-    // the second level: the same tree (the splits above cut every range at lo + (hi - lo) / 2), stopped at nodes of <= 8 leaves' worth
+    // the second level: the same tree (the splits above cut every range at lo + (hi - lo) / 2), stopped at nodes of <= 8 leaves' worth —
+    // more for very long lists: with G groups in runs of r, a step asks G / r runs + r groups of every run it cannot rule out (a few),
+    // least for r ~ sqrt(G / 3) (8 up to ~1500 spheres; 70 for 120000)
+    const size_t per_run = std::max<size_t>(8, (size_t)std::sqrt((double)leaves.size() / 3.0));
     std::vector<std::pair<size_t, size_t>> nodes;
     todo.assign(1, {0, rest.size()});
     while (!todo.empty()) {
         const auto [lo, hi] = todo.back();
         todo.pop_back();
-        if (hi - lo <= 8 * leaf) { nodes.push_back({lo, hi}); continue; }
+        if (hi - lo <= per_run * leaf) { nodes.push_back({lo, hi}); continue; }
         const size_t mid = lo + (hi - lo) / 2;
         todo.push_back({mid, hi});
         todo.push_back({lo, mid});

@@ -506,6 +506,10 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                     // per scanned step and 9 x the one or two spheres a ray is passing (2048², 64 objects, NEAR pass
                     // 65.9 -> see there).  Same results bit for bit: FULL == FAR + NEAR is under test with long lists too.
                     unsigned long long scan_mask = ~0ull;
+                    // … and, for lists beyond 64 objects (where a bit stands for 2, 4, … 2048 neighbours), the positions themselves: up to
+                    // RTGR_EARLY_BUF of them in the wave's LDS (the early list's buffer, idle in this pass); more than that — or "every
+                    // object" — and the scan walks the mask's blocks instead
+                    uint32_t ncand = RTGR_EARLY_BUF + 1u;
                     if constexpr (MODE == MODE_FAR || MODE == MODE_NEAR) {
                         if (EEst2 <= 1.0f) {
                             // ---- can ANY object's distance change sign anywhere in this step?  |x_q(θ) − x_q| <= δ_q for all
@@ -525,13 +529,20 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 // a lane INSIDE an object (ps < 0: the minimum is that object's negative distance and changes sign when
                                 // the ray leaves it), or without a sign yet (ps == 0), needs every object: no selection for this wave-step
                                 scan_mask = __ballot(run && !(ps > R(0))) != 0ull ? ~0ull : 0ull;
+                                ncand = scan_mask != 0ull ? RTGR_EARLY_BUF + 1u : 0u;
                             }
                             // (+ an absolute floor of a few hundred ulp of the operands: a distance that is itself rounding noise must go
                             //  through the real scan)
                             auto note = [&](bool safe_o, uint32_t o) {
                                 safe = safe && safe_o;
                                 if constexpr (MODE == MODE_NEAR) {
-                                    if (__ballot(run && !safe_o) != 0ull) scan_mask |= 1ull << (o >> mask_shift);
+                                    if (__ballot(run && !safe_o) != 0ull) {
+                                        scan_mask |= 1ull << (o >> mask_shift);
+                                        if (__builtin_expect(mask_shift != 0u, 0)) {
+                                            if (ncand < RTGR_EARLY_BUF) early_buf[ncand] = o;   // (every lane that is here writes the same word)
+                                            ncand++;
+                                        }
+                                    }
                                 }
                             };
                             // (a lane that has ruled a whole GROUP of spheres out — see below — has ruled its members out: what the
@@ -604,6 +615,7 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                             //  and make it wave-uniform for the compiler too, so that the scan's per-object branches are scalar)
                             const unsigned long long m_acc = __ballot(EEst2 <= 1.0f);
                             scan_mask = uniform64(__shfl(scan_mask, m_acc != 0ull ? (int)__builtin_ctzll(m_acc) : 0, 64));
+                            ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)ncand, m_acc != 0ull ? (int)__builtin_ctzll(m_acc) : 0, 64));
                         }
                     }
         // [budget: hand over]
@@ -648,6 +660,23 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                         }
                         bool found = false;
                         R nextc;
+                        // the objects of this step's scan: by the list of positions where there is one (NEAR, lists beyond 64 objects),
+                        // else by the mask (for_each_masked_by_kind: bit tests for a list in the argument block, set bits beyond)
+                        auto scan_objects = [&](auto&& fs, auto&& fo) {
+                            if constexpr (MODE == MODE_NEAR) {
+                                if (__builtin_expect(mask_shift != 0u && ncand <= RTGR_EARLY_BUF, 0)) {
+                                    typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
+                                    const ConstTable table = (ConstTable)(unsigned long long)(A.sc.more - (uint32_t)RTGR_MAX_OBJECTS);
+                                    for (uint32_t c_ = 0; c_ < ncand; c_++) {
+                                        const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)early_buf[c_]);
+                                        if (o < A.sc.nsph) fs(*(const DevObject<R>*)(table + o), o);
+                                        else fo(*(const DevObject<R>*)(table + o), o);
+                                    }
+                                    return;
+                                }
+                            }
+                            for_each_masked_by_kind<R>(A.sc, scan_mask, mask_shift, fs, fo);
+                        };
                         if constexpr (NPTS10) {
                             // two blocks (θ = 1/9…5/9, then 6/9…8/9 + the end point) keep the live set inside the
                             // 256-register budget; each object's parameters are fetched once per block
@@ -661,9 +690,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                     for (int q = 0; q < 4; q++)
                                         pos[j][q] = rfma(th, rfma(th, rfma(th, rfma(th, cc[3][q], cc[2][q]), cc[1][q]), cc[0][q]), x[q]);
                                 }
-                                for_each_by_kind<R>(A.sc,
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_sphere<R, 5>(ob, pos, dmin); },
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_distances<R, 5>(ob, pos, dmin); });
+                                scan_objects(
+                                    [&](const DevObject<R>& ob, uint32_t) { fold_sphere<R, 5>(ob, pos, dmin); },
+                                    [&](const DevObject<R>& ob, uint32_t) { fold_distances<R, 5>(ob, pos, dmin); });
 #pragma unroll
                                 for (int j = 0; j < 5; j++) {
                                     const bool hit = (ps * dmin[j] < R(0)) && !found;
@@ -684,9 +713,9 @@ RTGR_DEV void integrate_body(const IntegrateArgs<R>& A) {
                                 dmin[3] = R(__builtin_huge_val());
 #pragma unroll
                                 for (int q = 0; q < 4; q++) pos[3][q] = xn[q];
-                                for_each_by_kind<R>(A.sc,
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_sphere<R, 4>(ob, pos, dmin); },
-                                    [&](const DevObject<R>& ob, uint32_t o) { if ((scan_mask >> (o >> mask_shift)) & 1ull) fold_distances<R, 4>(ob, pos, dmin); });
+                                scan_objects(
+                                    [&](const DevObject<R>& ob, uint32_t) { fold_sphere<R, 4>(ob, pos, dmin); },
+                                    [&](const DevObject<R>& ob, uint32_t) { fold_distances<R, 4>(ob, pos, dmin); });
                                 nextc = dmin[3];
 #pragma unroll
                                 for (int j = 0; j < 3; j++) {
@@ -1125,7 +1154,7 @@ RTGR_DEV void distance_bounds(const DevObject<R>& ob, const R x[4], const R dl[4
 }
 template <class R>
 RTGR_DEV ObjSel select_objects(const DevScene<R>& sc, const R x0[4], const R c[4][4], R top, bool event) {
-    ObjSel sel{0ull, objsel_shift(sc.nobj)};
+    ObjSel sel{0ull, objsel_shift(sc.nobj), 0u, 0u};
     R dl[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) dl[q] = top * rfma(top, rfma(top, rfma(top, rabs(c[3][q]), rabs(c[2][q])), rabs(c[1][q])), rabs(c[0][q]));
@@ -1140,7 +1169,7 @@ RTGR_DEV ObjSel select_objects(const DevScene<R>& sc, const R x0[4], const R c[4
         for_each_object<R>(sc, [&](const DevObject<R>& ob, uint32_t o) {
             R lo, up;
             distance_bounds<R>(ob, x0, dl, &lo, &up);
-            if (__ballot(event && !(lo > U)) != 0ull) sel.mask |= 1ull << (o >> sel.shift);
+            if (__ballot(event && !(lo > U)) != 0ull) sel.add(o);
         });
         return sel;
     }
@@ -1161,7 +1190,7 @@ RTGR_DEV ObjSel select_objects(const DevScene<R>& sc, const R x0[4], const R c[4
         distance_bounds<R>(ob, x0, dl, &lo, &up);
         const bool in = !(lo > U);
         U2 = (in && up < U2) ? up : U2;
-        if (__ballot(event && in) != 0ull) sel.mask |= 1ull << (o >> sel.shift);
+        if (__ballot(event && in) != 0ull) sel.add(o);
     };
     for_each_within_reach<R>(sc,
         [&](const DevObject<R>& G, int) -> bool {
@@ -1173,11 +1202,11 @@ RTGR_DEV ObjSel select_objects(const DevScene<R>& sc, const R x0[4], const R c[4
             return __ballot(event && !far_away) != 0ull;
         },
         member, member);
-    ObjSel fin{0ull, sel.shift};
+    ObjSel fin{0ull, sel.shift, 0u, 0u};
     for_each_selected<R>(sc, sel, [&](const DevObject<R>& ob, uint32_t o) {
         R lo, up;
         distance_bounds<R>(ob, x0, dl, &lo, &up);
-        if (__ballot(event && !(lo > U2)) != 0ull) fin.mask |= 1ull << (o >> fin.shift);
+        if (__ballot(event && !(lo > U2)) != 0ull) fin.add(o);
     });
     return fin;
 }
@@ -1364,7 +1393,7 @@ RTGR_DEV void resolve_body_selected(const ResolveArgs<R>& A) {
             xe[q] = rfma(Theta, rfma(Theta, rfma(Theta, rfma(Theta, c[3][q], c[2][q]), c[1][q]), c[0][q]), x0[q]);
     }
     // (a ray without an event is coloured where it stopped: nothing is known about that point — every object is asked)
-    if (__ballot(!event) != 0ull) sel.mask = ~0ull;
+    if (__ballot(!event) != 0ull) { sel.mask = ~0ull; sel.count = 65u; }
     R col[3];
     const uint32_t hit = colour_pixel<R, true>(A.sc, A.opt, xe, col, sel);
     if (live) resolve_store<R>(A, w, rec, xe, Theta, t, h, col, hit, ps, root_iters);

@@ -931,6 +931,36 @@ RTGR_DEV void for_each_by_kind(const DevScene<R>& sc, FS&& fs, FO&& fo) {
     }
 #endif
 }
+// The sample-point scan's walk (rtgr_persistent.hpp): the objects whose bit — bit (position >> shift) — is set in `mask`, spheres to fs,
+// the other kinds to fo.  A list in the argument block is walked object by object with the bit tested on the way (the hot loop's
+// stream); a longer one BY THE SET BITS, through the device table: the scan of a step that can meet three of 100000 objects is not
+// a walk over 100000 bits.
+template <class R, class FS, class FO>
+RTGR_DEV void for_each_masked_by_kind(const DevScene<R>& sc, unsigned long long mask, uint32_t shift, FS&& fs, FO&& fo) {
+#ifndef RTGR_INLINE_OBJECTS_ONLY
+    if (__builtin_expect(sc.nobj > (uint32_t)RTGR_MAX_OBJECTS, 0)) {
+        typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
+        const ConstTable table = (ConstTable)(unsigned long long)(sc.more - (uint32_t)RTGR_MAX_OBJECTS);
+        unsigned long long m = mask;
+        while (m != 0ull) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t o0 = b << shift;
+            uint32_t o1 = o0 + (1u << shift);
+            o1 = o1 < sc.nobj ? o1 : sc.nobj;
+            for (uint32_t o = o0; o < o1; o++) {
+                if (o < sc.nsph) fs(*(const DevObject<R>*)(table + o), o);
+                else fo(*(const DevObject<R>*)(table + o), o);
+            }
+        }
+        return;
+    }
+#endif
+    const uint32_t n0 = sc.nobj < (uint32_t)RTGR_MAX_OBJECTS ? sc.nobj : (uint32_t)RTGR_MAX_OBJECTS;   // (such a list has one bit per object: shift = 0)
+    const uint32_t s0 = sc.nsph < n0 ? sc.nsph : n0;
+    for (uint32_t o = 0; o < s0; o++) if ((mask >> o) & 1ull) fs(sc.obj[o], o);
+    for (uint32_t o = s0; o < n0; o++) if ((mask >> o) & 1ull) fo(sc.obj[o], o);
+}
 // The reach test's walk (rtgr_persistent.hpp): as for_each_by_kind, but a list with GROUPS (DevScene, rtgr_args.hpp) is walked group
 // by group — fg(group, level) -> wave-uniform "some lane cannot rule this group out"; only then its members are handed to fs.  With a
 // second level (nsuper > 0) the runs of groups are asked first (level 1), their groups (level 0) only when a run is not ruled out.  The
@@ -968,16 +998,26 @@ RTGR_DEV void for_each_within_reach(const DevScene<R>& sc, FG&& fg, FS&& fs, FO&
 #endif
     for_each_by_kind<R>(sc, fs, fo);
 }
-// A SAMPLE of a grouped list (ngroups > 0): the loose spheres, ONE member of every group, the other kinds — f(object, position).
+// A SAMPLE of a grouped list (ngroups > 0): the loose spheres, ONE member of every group (of every run of groups, where there are
+// runs), the other kinds — f(object, position).
 template <class R, class F>
 RTGR_DEV void for_each_sample(const DevScene<R>& sc, F&& f) {
     typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
     const ConstTable table = (ConstTable)(unsigned long long)(sc.more - (uint32_t)RTGR_MAX_OBJECTS);
     const ConstTable groups = table + sc.nobj;
     for (uint32_t o = 0; o < sc.nloose; o++) f(*(const DevObject<R>*)(table + o), o);
-    for (uint32_t g = 0; g < sc.ngroups; g++) {
-        const uint32_t o = ((const DevObject<R>*)(groups + g))->type;
-        f(*(const DevObject<R>*)(table + o), o);
+    if (sc.nsuper != 0u) {   // (with a second level: one member of every RUN of groups — the bound only has to be a bound)
+        const ConstTable supers = groups + sc.ngroups;
+        for (uint32_t s = 0; s < sc.nsuper; s++) {
+            const uint32_t g = ((const DevObject<R>*)(supers + s))->type;
+            const uint32_t o = ((const DevObject<R>*)(groups + g))->type;
+            f(*(const DevObject<R>*)(table + o), o);
+        }
+    } else {
+        for (uint32_t g = 0; g < sc.ngroups; g++) {
+            const uint32_t o = ((const DevObject<R>*)(groups + g))->type;
+            f(*(const DevObject<R>*)(table + o), o);
+        }
     }
     for (uint32_t o = sc.nsph; o < sc.nobj; o++) f(*(const DevObject<R>*)(table + o), o);
 }
@@ -992,7 +1032,18 @@ RTGR_DEV const DevObject<R>& object_at(const DevScene<R>& sc, uint32_t o) {
 struct ObjSel {
     unsigned long long mask;
     uint32_t shift;
+    // lists beyond 64 objects (a bit is 2, 4, … 2048 neighbours): the selected positions themselves, entry k in lane k of `list`
+    // (read with v_readlane, which ignores EXEC), `count` of them; count > 64: too many, walk the mask's blocks
+    uint32_t list;
+    uint32_t count;
     RTGR_DEV bool has(uint32_t o) const { return ((mask >> (o >> shift)) & 1ull) != 0ull; }
+    RTGR_DEV void add(uint32_t o) {   // wave-uniform o
+        mask |= 1ull << (o >> shift);
+        if (shift != 0u) {
+            if (count < 64u) list = ((threadIdx.x & 63u) == count) ? o : list;   // (called with every lane of the wave active: select_objects)
+            count++;
+        }
+    }
 };
 RTGR_DEV uint32_t objsel_shift(uint32_t nobj) {   // the smallest shift with (nobj − 1) >> shift <= 63
     return nobj > 64u ? 32u - (uint32_t)__builtin_clz((nobj - 1u) >> 6) : 0u;
@@ -1004,6 +1055,13 @@ template <class R, class F>
 RTGR_DEV void for_each_selected(const DevScene<R>& sc, ObjSel sel, F&& f) {
     typedef const DevObject<R> __attribute__((address_space(4))) * ConstTable;
     const ConstTable table = (ConstTable)(unsigned long long)(sc.more - (uint32_t)RTGR_MAX_OBJECTS);
+    if (sel.shift != 0u && sel.count <= 64u) {   // by the list of positions
+        for (uint32_t k = 0; k < sel.count; k++) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)sel.list, (int)k);
+            f(*(const DevObject<R>*)(table + o), o);
+        }
+        return;
+    }
     unsigned long long m = sel.mask;
     while (m != 0ull) {
         const uint32_t b = (uint32_t)__builtin_ctzll(m);

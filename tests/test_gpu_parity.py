@@ -390,6 +390,38 @@ def test_object_lists_of_any_length_match_oracle(lib, name, n, nobj):
             assert np.array_equal(g[k], other[k], equal_nan=True), (knobs, k)
 
 
+def test_ten_thousand_objects(lib):
+    """A list of 10000 small spheres (a cloud around the hole; through rtgr_scene.objects as a packed array): groups of <= 8, runs of
+    ~58 groups (the run length grows with the list: rtgr_context.hip), hit32.  Bit for bit the frames of the pass structures that ask
+    every one of the 10000 at every step, and the wide hit map holds indices beyond 255 and beyond 2^13."""
+    rng = np.random.default_rng(21)
+    n = 10000
+    c = rng.normal(size=(n, 3)) * 4.0
+    keep = np.linalg.norm(c, axis=1) > 2.8
+    c[~keep] *= (3.0 / np.linalg.norm(c[~keep], axis=1))[:, None]
+    metric, objs3, cam = rt.example2_scene()
+    sc0 = rt.make_scene(rt.KerrSchild(1, 0.6), objs3[:2])           # sky sphere, far plane
+    arr = (abi.rtgr_object * (n + 2))()
+    arr[0], arr[1] = sc0.obj[0], sc0.obj[1]
+    view = np.frombuffer(arr, dtype=np.float64).reshape(n + 2, C.sizeof(abi.rtgr_object) // 8)
+    kinds = np.frombuffer(arr, dtype=np.uint32).reshape(n + 2, C.sizeof(abi.rtgr_object) // 4)
+    p0 = abi.rtgr_object.p.offset // 8
+    kinds[2:, abi.rtgr_object.kind.offset // 4] = abi.SPHERE
+    view[2:, p0 + 1:p0 + 4] = c
+    view[2:, p0 + 8] = rng.uniform(0.02, 0.09, n)
+    sc = sc0.clone()
+    sc.objects, sc.nobj = C.cast(arr, C.POINTER(abi.rtgr_object)), n + 2
+    opt = rt.solver_defaults()
+    camera = rt.make_camera(**cam)
+    g = hip_trace(lib, sc, opt, 24, 24, cam=camera)
+    assert g["hit"].dtype == np.uint32 and int(g["hit"].max()) > 8192 and len(np.unique(g["hit"])) > 50
+    for knobs in (dict(groups=0), dict(split=0)):
+        with abi.options(lib, **knobs):
+            other = hip_trace(lib, sc, opt, 24, 24, cam=camera)
+        for k in ("rgb", "state_end", "lambda_end", "status", "hit", "n_accept", "n_reject"):
+            assert np.array_equal(g[k], other[k], equal_nan=True), (knobs, k)
+
+
 @pytest.mark.parametrize("nsph", [10, 34])
 def test_long_lists_of_mixed_kinds_match_oracle(lib, nsph):
     """A long list is not only spheres: concentric rings (disks) and several planes in time among them, in an order that interleaves

@@ -95,7 +95,7 @@ def _group(spheres, f32=False):
 
 
 @settings(max_examples=40, deadline=None)
-@given(st.integers(16, 400), st.integers(0, 2**31 - 1), st.booleans(), st.sampled_from(["cloud", "line", "same", "wide_radii"]))
+@given(st.one_of(st.integers(16, 400), st.integers(3000, 6000)), st.integers(0, 2**31 - 1), st.booleans(), st.sampled_from(["cloud", "line", "same", "wide_radii"]))
 def test_groups_of_a_long_list_contain_their_members(n, seed, f32, shape):
     """What the FAR pass's group test rests on: the groups' member ranges tile the spheres behind the loose ones, no sphere is lost or
     listed twice, and every member — as the kernels of the scalar type see it — lies INSIDE its group's bounding sphere
@@ -130,7 +130,7 @@ def test_groups_of_a_long_list_contain_their_members(n, seed, f32, shape):
     assert (len(runs) > 0) == (len(groups) >= 24)
     nxt = 0
     for cx, cy, cz, rr, g0, cnt in runs:
-        assert g0 == nxt and 1 <= cnt <= 16
+        assert g0 == nxt and 1 <= cnt <= 2 * max(8, int((len(groups) / 3.0) ** 0.5))
         first = int(groups[int(g0)][4])
         last = int(groups[int(g0 + cnt) - 1][4] + groups[int(g0 + cnt) - 1][5])
         m = seen[first:last]
