@@ -129,7 +129,7 @@ typedef struct rtgr_scene {
                              the context keeps per distinct list (uploaded when a list is first seen — blocking, microseconds; a
                              first sight during hipGraph capture is refused: trace the scene once before capturing), its spheres
                              sorted into groups of neighbours that the kernels ask before their members (option "groups").  Cost:
-                             64 objects ~1.8 x, 256 objects ~1.9 x the 3-object frame. */
+                             64 objects ~1.8 x, 256-512 objects ~1.5-1.85 x the 3-object frame. */
 } rtgr_scene;
 
 /* ---- solver constants (src/RayTraceGR.jl:485, :497, :510-511, :519, :528; OrdinaryDiffEq 5.38 defaults) -- */

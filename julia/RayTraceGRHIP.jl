@@ -445,7 +445,7 @@ node work on the canvas (rows dealt cyclically); the result does not depend on t
 `metric`: `minkowski`, `kerr_schild`, `KerrSchild(M, a)`, a `DeviceMetric`; anything else runs the reference's CPU path.
 `objs`: `Plane`, `Sphere`, `Disk`, `DeviceObject`s, in any number (the reference's `Vector{Object{T}}` has no length limit, :433-441,
 and neither has the device: the first 16 travel in the kernels' argument block, a longer list in a device table with its spheres
-sorted into groups of neighbours that are asked first — 64 objects cost ≈ 1.8 ×, 256 ≈ 1.9 × the 3-object frame); any other `Object` subtype runs the reference's CPU path.  Every fall-back says so once (`@warn`).
+sorted into groups of neighbours that are asked first — 64 objects cost ≈ 1.8 ×, 256 … 512 ≈ 1.5–1.85 × the 3-object frame); any other `Object` subtype runs the reference's CPU path.  Every fall-back says so once (`@warn`).
 
 Where parity ends: on rays that are CAPTURED with |u^t| ≳ 10⁶ the step sequence follows the rounding noise of the RHS formulation;
 the closed-form kernels (`kerr_schild`, `KerrSchild(M, a)`) then take up to 27 % fewer steps than the reference and end such rays with
