@@ -238,5 +238,6 @@ int misc_place_rows_f32(const float* d_part, uint64_t ni, uint64_t nj, uint64_t 
                         float* d_full, hipStream_t st);
 int misc_place_rows_u8(const uint8_t* d_part, uint64_t ni, uint64_t nj, uint64_t rank, uint64_t nranks, uint64_t elem,
                        uint8_t* d_full, hipStream_t st);
+int misc_poison_registers(int n_cu, unsigned pattern, hipStream_t st);   // the load-time probe's scrubber (rtgr_misc.hip)
 
 }  // namespace rtgr

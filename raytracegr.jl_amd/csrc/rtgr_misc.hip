@@ -229,4 +229,33 @@ int misc_redshift_f32(const DevScene<float>& sc, const DevCamera<float>& cam, co
     CHECK_LAUNCH();
     return RTGR_OK;
 }
+// The load-time probe's scrubber (rtgr_units.hip: probe_trace).  The compiler fault the probe exists for makes a kernel read registers it
+// never wrote for some lanes — whatever the wave that had the SIMD before left there.  When that was an identical run of the same frame,
+// the stale values are the RIGHT ones and the fault hides (round 6: the probe passed or refused a faulty unit depending on which tests
+// had run before it).  So every probe run starts from registers that hold a pattern of ITS OWN: one wave per launch slot that owns a
+// SIMD's whole register file (256 VGPRs + 256 AGPRs x 64 lanes = 128 KB) and writes the pattern into all of it; eight waves per SIMD
+// of the device, so that every SIMD is visited.
+__global__ __launch_bounds__(64) void poison_registers_kernel(unsigned pattern) {
+    // (… and 64 KB of the CU's LDS with it: a skipped LDS store finds the previous run's value just the same)
+    __shared__ unsigned lds[16384];
+    for (unsigned k = threadIdx.x; k < 16384u; k += 64u) ((volatile unsigned*)lds)[k] = pattern;
+    asm volatile(
+        ".set rtgr_poison_i, 0\n"
+        ".rept 256\n"
+        "v_mov_b32 v[rtgr_poison_i], %0\n"
+        "s_nop 1\n"
+        "v_accvgpr_write_b32 a[rtgr_poison_i], v[rtgr_poison_i]\n"
+        ".set rtgr_poison_i, rtgr_poison_i + 1\n"
+        ".endr\n"
+        "s_nop 4\n"
+        :
+        : "s"(pattern)
+        : "v255", "a255", "memory");
+}
+int misc_poison_registers(int n_cu, unsigned pattern, hipStream_t st) {
+    hipLaunchKernelGGL(poison_registers_kernel, dim3((unsigned)(n_cu > 0 ? n_cu : 256) * 4u * 8u), dim3(64), 0, st, pattern);
+    CHECK_LAUNCH();
+    return RTGR_OK;
+}
+
 }  // namespace rtgr

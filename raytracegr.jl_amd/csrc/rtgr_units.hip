@@ -89,6 +89,24 @@ static int probe_trace(DeviceCtx& D, const rtgr_scene& sc, long split, ProbeFram
         struct Clear { ~Clear() { tl_probe_forces_unit = false; tl_knobs_override = nullptr; } } clear;
         tl_probe_forces_unit = force_unit;
         tl_knobs_override = &mine;
+        // (every probe run starts from registers holding a pattern of its own: a kernel that reads what it never wrote must not find
+        //  the previous, identical run's values there — rtgr_misc.hip: poison_registers_kernel)
+        // … and from a WORKSPACE that does: a store the fault skips for some lanes leaves the record of the previous probe run in place,
+        // and when that was the same frame of the same source the record is right (round 6: a faulty unit was refused by the first probe
+        // of a process and passed every later one)
+        static std::atomic<unsigned> probe_runs{0};
+        const unsigned pattern = 0x7ff4a5a5u + 0x01010101u * (probe_runs++ & 0x3fu);
+        {
+            DeviceGuard guard(D.dev);
+            if ((rc = misc_poison_registers(D.num_cu, pattern, nullptr))) return rc;
+            std::lock_guard<std::mutex> lk(D.mu);
+            StreamState* ss = nullptr;
+            if ((rc = stream_state(D, nullptr, &ss))) return rc;
+            const size_t bytes = workspace_bytes<R>(N, true);
+            if ((rc = ensure_workspace(D, *ss, bytes, nullptr))) return rc;
+            const size_t scrub = ss->ws_bytes < ((size_t)256 << 20) ? ss->ws_bytes : ((size_t)256 << 20);   // (the probe's 1024 rays live in its head)
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ss->ws, (int)pattern, scrub / 4, nullptr));
+        }
         rc = trace_device<R>(D, &sc, &opt, d_state0, d_state0 ? nullptr : &cam, NI, NJ, 0, NJ, (R*)base, &out, nullptr, nullptr);
     }
     if (rc) return rc;
