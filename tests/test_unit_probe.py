@@ -60,56 +60,36 @@ def lib():
     return lib
 
 
-_FIRST_CONTACT = """
-import sys
-sys.path.insert(0, {tests!r})
-import conftest
-conftest.load_package()
-from raytracegr_jl_amd import user_metric as um, _abi as abi
-lib = abi.load()
-abi.check(lib, lib.rtgr_init(-1))
-with abi.options(lib, unit_audit=0):
-    try:
-        um.load({raw!r})
-        print("LOADED")
-    except abi.RtgrError as e:
-        print("REFUSED:", e)
-"""
-
-
 @pytest.mark.gpu
 def test_probe_alone_refuses_a_unit_with_the_fault(lib, zoo_raw):
-    """The fault injected AFTER the audit (option unit_audit = 0 is the hook): with the audit on, both the bare code object and the
-    bundle are refused by the audit; with it off, the probe refuses the unit on its symptom and the unit is not left resident.
-    The symptom is a kernel reading state it never wrote for some lanes, so what it shows depends on what was there: the probe scrubs
-    registers, LDS and the workspace before every run, and still (round 6, the kernels with object groups) a process's FIRST probe of
-    this unit refuses it every time while later probes of the same image in the same process have let it pass — state we could not
-    name.  So the probe's verdict is asserted where it is deterministic, at first contact in a fresh process; in this process it is
-    asserted that a probe RAN whenever the library says it did."""
+    """The fault injected AFTER the audit (option unit_audit = 0 is the hook): the probe refuses the unit on its symptom, the unit
+    is not left resident, and with the audit on both the bare code object and the bundle are refused by the audit.
+    The symptom is a kernel reading state it never wrote for some lanes, so what it shows depends on what was there.  Round 6 (the
+    kernels with object groups): the first probe of a process refused this unit and every later one let it pass — left-overs of the
+    previous, identical probe run are the RIGHT values; and registers scrubbed with a NaN made every run end the same rays "NaN",
+    reproducibly.  The probe now scrubs registers, LDS and workspace before every run, alternately with a NaN and an ordinary number:
+    refused every time, here five times in a row."""
     raw, bundle = zoo_raw
     for path in (raw, bundle):
         with pytest.raises(abi.RtgrError, match="FLOW block"):
             um.load(path)
-    res = subprocess.run([sys.executable, "-c", _FIRST_CONTACT.format(tests=os.path.join(ROOT, "tests"), raw=raw)], capture_output=True, text=True, timeout=600)
-    assert "REFUSED:" in res.stdout and "refused by the load-time probe" in res.stdout, res.stdout + res.stderr
-    assert "differ" in res.stdout or "disagree" in res.stdout or "apart" in res.stdout
+    for _ in range(5):
+        with abi.options(lib, unit_audit=0):
+            with pytest.raises(abi.RtgrError, match="refused by the load-time probe") as e:
+                um.load(raw)
+        assert "differ" in str(e.value) or "disagree" in str(e.value) or "apart" in str(e.value)
+    assert lib.rtgr_user_metric_loaded(None, 0) in (0, 1)          # (other tests' units may be resident; this one must not be:)
     with abi.options(lib, unit_audit=0, unit_probe=0):             # both checks off: it loads — that is what the options mean
         mid = um.load(raw)
         assert um.unit_info(mid)["probe_ok"] == 0
         um._ids.clear()
     assert lib.rtgr_user_metric_loaded(None, mid) == 1
-    # asked for again with the probe back on: a resident copy that was never probed is probed NOW — refused and gone, or passed and
-    # marked as probed; never left resident and unprobed
+    # asked for again with the probe back on: a resident copy that was never probed is probed NOW — refused, and gone
     with abi.options(lib, unit_audit=0):
-        try:
-            again = um.load(raw)
-            assert again == mid and um.unit_info(mid)["probe_ok"] == 1
-        except abi.RtgrError as e:
-            assert "refused by the load-time probe" in str(e)
-            assert lib.rtgr_user_metric_loaded(None, mid) == 0
+        with pytest.raises(abi.RtgrError, match="refused by the load-time probe"):
+            um.load(raw)
     um._ids.clear()
-    if lib.rtgr_user_metric_loaded(None, mid) == 1:
-        abi.check(lib, lib.rtgr_user_metric_unload(None, mid))
+    assert lib.rtgr_user_metric_loaded(None, mid) == 0
 
 
 @pytest.mark.gpu
