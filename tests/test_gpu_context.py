@@ -750,6 +750,24 @@ def test_frames_in_flight_are_the_single_frames(lib, ndev):
             abi.check(lib, lib.rtgr_destroy(ctx))
 
 
+def test_frames_in_flight_of_a_long_object_list(lib):
+    """Two frames in flight run on two host threads inside the library: both convert the same 64-object list, find (or, the first of
+    them, upload) its one device table under the device's lock, and trace.  Five frames of five cameras equal the five single calls."""
+    from scenes import many_objects
+    from test_gpu_parity import hip_trace
+    metric, _, _ = rt.example2_scene()
+    objs = many_objects(64, seed=12)                     # (a list no other test has traced: its table is uploaded inside this call)
+    cams = _cameras(5)
+    frames = rt.trace_frames(metric, objs, cams, 80, 64, details=True)
+    sc, opt = rt.make_scene(metric, objs), rt.solver_defaults()
+    for k, f in enumerate(frames):
+        single = hip_trace(lib, sc, opt, 80, 64, cam=rt.make_camera(**cams[k]))
+        for key in OUT_KEYS:
+            assert np.array_equal(f[key], single[key], equal_nan=True), (k, key)
+        assert f["counters"] == single["counters"], k
+    assert len(np.unique(frames[0]["hit"])) > 8
+
+
 def test_frames_of_pixel_arrays_and_the_error_path(lib):
     """The _pixels twin takes the reference's own Array{Pixel{T},2} per frame (src/RayTraceGR.jl:446-450, :532) — three canvases of three
     cameras in one call equal three trace_rays calls; a frame with a NULL array is refused with its number before anything runs."""
