@@ -75,7 +75,7 @@ def fuzz_scene(seed):
     return rt.make_scene(metric, objs), cam, opt, ni, nj, dict(nsph=nsph, layout=str(layout), rmax=rmax, metric=which, nobj=len(objs), tol=tol)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RTGR_FUZZ_SEEDS", "72"))))   # (profiles/r06/fuzz_long_lists.log: 1000 seeds)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTGR_FUZZ_SEEDS", "72"))))   # (profiles/r06/fuzz_long_lists.log: 4000 seeds)
 def test_fuzzed_long_list_equals_the_ask_everything_frames(lib, seed):
     sc, cam, opt, ni, nj, what = fuzz_scene(seed)
     g = hip_trace(lib, sc, opt, ni, nj, cam=cam)
